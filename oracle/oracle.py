@@ -1,0 +1,353 @@
+"""ctypes binding of the CPU oracle (oracle/sdb_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Nothing under semadb_amd/ does.  See sdb_oracle.h for what the oracle restates and how it is
+pinned ("restatement-pinned": the Go reference cannot be built in this image).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsdb_oracle.so")
+
+METRICS = {"euclidean": 0, "cosine": 1, "dot": 2}
+IMPL_ASM, IMPL_AVX2, IMPL_PURE = 0, 1, 2
+STARTID = 1
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "sdb_oracle.c")
+    hdr = os.path.join(_HERE, "sdb_oracle.h")
+    if (force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsdb_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class Trace(C.Structure):
+    _fields_ = [("n_dist", C.c_uint64), ("n_hop", C.c_uint64), ("n_edges", C.c_uint64),
+                ("n_visit_written", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    f32p, u64p, i32p, u8p = (C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int),
+                             C.POINTER(C.c_uint8))
+    L.orc_dot.restype = C.c_float
+    L.orc_dot.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
+    L.orc_sqeuclid.restype = C.c_float
+    L.orc_sqeuclid.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
+    L.orc_distance.restype = C.c_float
+    L.orc_distance.argtypes = [f32p, f32p, C.c_size_t, C.c_int, C.c_int]
+    L.orc_distance_matrix.restype = None
+    L.orc_distance_matrix.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, f32p]
+    L.orc_distset_script.restype = C.c_int
+    L.orc_distset_script.argtypes = [C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int, u64p, i32p, u64p, C.c_int]
+    L.orc_index_new.restype = C.c_void_p
+    L.orc_index_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.orc_index_free.argtypes = [C.c_void_p]
+    L.orc_index_set_start.argtypes = [C.c_void_p, f32p]
+    L.orc_index_insert.argtypes = [C.c_void_p, C.c_uint64, f32p]
+    L.orc_index_load.argtypes = [C.c_void_p, C.c_uint64, u64p, f32p, u64p, u64p]
+    L.orc_index_size.restype = C.c_uint64
+    L.orc_index_size.argtypes = [C.c_void_p]
+    L.orc_index_num_edges.restype = C.c_uint64
+    L.orc_index_num_edges.argtypes = [C.c_void_p]
+    L.orc_index_export.argtypes = [C.c_void_p, u64p, f32p, u64p, u64p]
+    L.orc_index_search.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, u64p, C.c_int, u64p, f32p, i32p,
+                                   u64p, C.c_int, C.POINTER(Trace)]
+    L.orc_index_search_batch.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, u64p, f32p, i32p,
+                                         C.POINTER(Trace), C.c_int]
+    L.orc_index_visited_sorted.argtypes = [C.c_void_p, f32p, C.c_int, u64p, f32p, C.c_int]
+    L.orc_kmeans_fit.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, f32p, u8p, i32p]
+    L.orc_pq_new.restype = C.c_void_p
+    L.orc_pq_new.argtypes = [C.c_int] * 5
+    L.orc_pq_free.argtypes = [C.c_void_p]
+    L.orc_pq_fit.argtypes = [C.c_void_p, f32p, C.c_int, i32p, C.c_int, u8p]
+    L.orc_pq_set_codebook.argtypes = [C.c_void_p, f32p]
+    L.orc_pq_flat_centroids.restype = f32p
+    L.orc_pq_flat_centroids.argtypes = [C.c_void_p]
+    L.orc_pq_centroid_dists.restype = f32p
+    L.orc_pq_centroid_dists.argtypes = [C.c_void_p]
+    L.orc_pq_encode.restype = None
+    L.orc_pq_encode.argtypes = [C.c_void_p, f32p, u8p]
+    L.orc_pq_lut.restype = None
+    L.orc_pq_lut.argtypes = [C.c_void_p, f32p, f32p]
+    L.orc_pq_dist_lut.restype = C.c_float
+    L.orc_pq_dist_lut.argtypes = [C.c_void_p, f32p, u8p]
+    L.orc_pq_dist_sym.restype = C.c_float
+    L.orc_pq_dist_sym.argtypes = [C.c_void_p, u8p, u8p]
+    L.orc_index_attach_pq.argtypes = [C.c_void_p, C.c_void_p, u8p]
+    L.orc_shard_limit.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_cluster_merge.argtypes = [C.c_int, i32p, u64p, f32p, C.c_int, C.c_float, C.c_int, u64p, f32p, i32p]
+    _lib = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def dot(x, y, impl=IMPL_ASM):
+    x, y = _f32(x), _f32(y)
+    return np.float32(lib().orc_dot(_p(x, C.c_float), _p(y, C.c_float), x.size, impl))
+
+
+def sqeuclid(x, y, impl=IMPL_ASM):
+    x, y = _f32(x), _f32(y)
+    return np.float32(lib().orc_sqeuclid(_p(x, C.c_float), _p(y, C.c_float), x.size, impl))
+
+
+def distance(x, y, metric, impl=IMPL_ASM):
+    x, y = _f32(x), _f32(y)
+    return np.float32(lib().orc_distance(_p(x, C.c_float), _p(y, C.c_float), x.size, METRICS[metric], impl))
+
+
+def distance_matrix(q, c, metric, impl=IMPL_ASM):
+    q, c = _f32(q), _f32(c)
+    out = np.empty((q.shape[0], c.shape[0]), dtype=np.float32)
+    lib().orc_distance_matrix(_p(q, C.c_float), q.shape[0], _p(c, C.c_float), c.shape[0], q.shape[1],
+                              METRICS[metric], impl, _p(out, C.c_float))
+    return out
+
+
+def distset_script(capacity, dists, script, use_bitset=False):
+    """script: list of ("add"|"limit"|"sort", [ids])."""
+    dists = _f32(dists)
+    opmap = {"add": 0, "limit": 1, "sort": 2}
+    ops = np.array([opmap[s[0]] for s in script], dtype=np.int32)
+    args, off = [], [0]
+    for s in script:
+        args.extend(s[1] if len(s) > 1 else [])
+        off.append(len(args))
+    args = np.array(args if args else [0], dtype=np.uint64)
+    off = np.array(off, dtype=np.int32)
+    out = np.zeros(max(len(args) + 8, 16), dtype=np.uint64)
+    n = lib().orc_distset_script(capacity, int(use_bitset), _p(dists, C.c_float), dists.size,
+                                 _p(ops, C.c_int), len(script), _p(args, C.c_uint64), _p(off, C.c_int),
+                                 _p(out, C.c_uint64), out.size)
+    return [int(v) for v in out[:n]]
+
+
+class Index:
+    """Oracle counterpart of vamana.IndexVamana (shard/index/vamana/vamana.go:36-52)."""
+
+    def __init__(self, dim, metric="euclidean", degree_bound=64, search_size=75, alpha=1.2, impl=IMPL_ASM):
+        self.dim, self.metric = dim, metric
+        self._h = lib().orc_index_new(dim, METRICS[metric], impl, degree_bound, search_size, C.c_float(alpha))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_index_free(self._h)
+            self._h = None
+
+    def set_start(self, vec):
+        vec = _f32(vec)
+        assert vec.size == self.dim
+        return lib().orc_index_set_start(self._h, _p(vec, C.c_float))
+
+    def insert(self, node_id, vec):
+        vec = _f32(vec)
+        assert vec.size == self.dim
+        return lib().orc_index_insert(self._h, int(node_id), _p(vec, C.c_float))
+
+    def load(self, ids, vectors, offsets, edges):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        vectors = _f32(vectors)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        edges = np.ascontiguousarray(edges if len(edges) else [0], dtype=np.uint64)
+        return lib().orc_index_load(self._h, ids.size, _p(ids, C.c_uint64), _p(vectors, C.c_float),
+                                    _p(offsets, C.c_uint64), _p(edges, C.c_uint64))
+
+    @property
+    def size(self):
+        return int(lib().orc_index_size(self._h))
+
+    def export(self, with_vectors=True):
+        n, ne = self.size, int(lib().orc_index_num_edges(self._h))
+        ids = np.zeros(n, dtype=np.uint64)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        edges = np.zeros(max(ne, 1), dtype=np.uint64)
+        vecs = np.zeros((n, self.dim), dtype=np.float32) if with_vectors else None
+        lib().orc_index_export(self._h, _p(ids, C.c_uint64),
+                               _p(vecs, C.c_float) if with_vectors else None, _p(offsets, C.c_uint64),
+                               _p(edges, C.c_uint64))
+        return ids, vecs, offsets, edges[:ne]
+
+    def search(self, query, limit, search_size, filter_ids=None, visit_cap=4096):
+        """IndexVamana.Search (vamana.go:278-310). Returns (ids, dists, visit_order, trace) or raises."""
+        query = _f32(query)
+        out_ids = np.zeros(max(limit, 1), dtype=np.uint64)
+        out_d = np.zeros(max(limit, 1), dtype=np.float32)
+        cnt = C.c_int(0)
+        visit = np.zeros(visit_cap, dtype=np.uint64)
+        tr = Trace()
+        fptr, nf = None, 0
+        if filter_ids is not None:
+            f = np.ascontiguousarray(sorted(int(v) for v in filter_ids), dtype=np.uint64)
+            if f.size == 0:
+                f = np.zeros(1, dtype=np.uint64)
+                nf = 0
+            else:
+                nf = f.size
+            fptr = _p(f, C.c_uint64)
+        rc = lib().orc_index_search(self._h, _p(query, C.c_float), limit, search_size, fptr, nf,
+                                    _p(out_ids, C.c_uint64), _p(out_d, C.c_float), C.byref(cnt),
+                                    _p(visit, C.c_uint64), visit_cap, C.byref(tr))
+        if rc == -1:
+            raise ValueError("searchSize (%d) must be greater than k (%d)" % (search_size, limit))
+        if rc != 0:
+            raise RuntimeError("oracle search failed rc=%d" % rc)
+        n = cnt.value
+        return out_ids[:n].copy(), out_d[:n].copy(), visit[:tr.n_visit_written].copy(), tr
+
+    def search_batch(self, queries, limit, search_size, n_threads=0):
+        queries = _f32(queries)
+        nq = queries.shape[0]
+        out_ids = np.zeros((nq, limit), dtype=np.uint64)
+        out_d = np.zeros((nq, limit), dtype=np.float32)
+        cnts = np.zeros(nq, dtype=np.int32)
+        traces = (Trace * nq)()
+        rc = lib().orc_index_search_batch(self._h, _p(queries, C.c_float), nq, limit, search_size,
+                                          _p(out_ids, C.c_uint64), _p(out_d, C.c_float), _p(cnts, C.c_int),
+                                          traces, n_threads)
+        if rc:
+            raise RuntimeError("oracle batch search failed rc=%d" % rc)
+        n_dist = np.array([t.n_dist for t in traces], dtype=np.uint64)
+        n_hop = np.array([t.n_hop for t in traces], dtype=np.uint64)
+        n_edges = np.array([t.n_edges for t in traces], dtype=np.uint64)
+        return out_ids, out_d, cnts, n_dist, n_hop, n_edges
+
+    def visited_sorted(self, query, search_size, cap=8192):
+        query = _f32(query)
+        ids = np.zeros(cap, dtype=np.uint64)
+        d = np.zeros(cap, dtype=np.float32)
+        n = lib().orc_index_visited_sorted(self._h, _p(query, C.c_float), search_size, _p(ids, C.c_uint64),
+                                           _p(d, C.c_float), cap)
+        if n < 0:
+            raise RuntimeError("rc=%d" % n)
+        return ids[:n].copy(), d[:n].copy()
+
+    def attach_pq(self, pq, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self._pq = pq
+        return lib().orc_index_attach_pq(self._h, pq._h, _p(codes, C.c_uint8))
+
+
+def kmeans_fit(X, offset, length, K, max_iter=100, first_idx=0, alias=True, impl=IMPL_ASM):
+    """utils.KMeans.Fit (utils/kmeans.go:34-150).  X (n, stride) float32 is modified in place when
+    alias=True (the reference's centroid/data aliasing).  Returns (centroids, labels, iters)."""
+    assert X.dtype == np.float32 and X.flags.c_contiguous
+    n, stride = X.shape
+    cent = np.zeros((K, length), dtype=np.float32)
+    labels = np.zeros(n, dtype=np.uint8)
+    iters = C.c_int(0)
+    rc = lib().orc_kmeans_fit(_p(X, C.c_float), n, stride, offset, length, K, max_iter, first_idx,
+                              int(alias), impl, _p(cent, C.c_float), _p(labels, C.c_uint8), C.byref(iters))
+    if rc:
+        raise RuntimeError("kmeans rc=%d" % rc)
+    return cent, labels, iters.value
+
+
+class PQ:
+    """Oracle counterpart of productQuantizer (shard/vectorstore/product.go:28-40)."""
+
+    def __init__(self, dim, metric, num_subvectors, num_centroids, impl=IMPL_ASM):
+        self.dim, self.M, self.K = dim, num_subvectors, num_centroids
+        self._h = lib().orc_pq_new(dim, METRICS[metric], impl, num_subvectors, num_centroids)
+        if not self._h:
+            raise ValueError("invalid product quantizer parameters")
+        self.sub_len = dim // num_subvectors
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_pq_free(self._h)
+            self._h = None
+
+    def fit(self, X, first_idx, alias=True):
+        assert X.dtype == np.float32 and X.flags.c_contiguous and X.shape[1] == self.dim
+        fi = np.ascontiguousarray(first_idx, dtype=np.int32)
+        codes = np.zeros((X.shape[0], self.M), dtype=np.uint8)
+        rc = lib().orc_pq_fit(self._h, _p(X, C.c_float), X.shape[0], _p(fi, C.c_int), int(alias),
+                              _p(codes, C.c_uint8))
+        if rc:
+            raise RuntimeError("pq fit rc=%d" % rc)
+        return codes
+
+    def set_codebook(self, flat):
+        flat = _f32(flat)
+        assert flat.size == self.M * self.K * self.sub_len
+        lib().orc_pq_set_codebook(self._h, _p(flat, C.c_float))
+
+    @property
+    def flat_centroids(self):
+        p = lib().orc_pq_flat_centroids(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.M, self.K, self.sub_len)).copy()
+
+    @property
+    def centroid_dists(self):
+        p = lib().orc_pq_centroid_dists(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.M, self.K, self.K)).copy()
+
+    def encode(self, vec):
+        vec = _f32(vec)
+        codes = np.zeros(self.M, dtype=np.uint8)
+        lib().orc_pq_encode(self._h, _p(vec, C.c_float), _p(codes, C.c_uint8))
+        return codes
+
+    def lut(self, q):
+        q = _f32(q)
+        out = np.zeros((self.M, self.K), dtype=np.float32)
+        lib().orc_pq_lut(self._h, _p(q, C.c_float), _p(out, C.c_float))
+        return out
+
+    def dist_lut(self, lut, codes):
+        lut = _f32(lut)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        return np.float32(lib().orc_pq_dist_lut(self._h, _p(lut, C.c_float), _p(codes, C.c_uint8)))
+
+    def dist_sym(self, cx, cy):
+        cx = np.ascontiguousarray(cx, dtype=np.uint8)
+        cy = np.ascontiguousarray(cy, dtype=np.uint8)
+        return np.float32(lib().orc_pq_dist_sym(self._h, _p(cx, C.c_uint8), _p(cy, C.c_uint8)))
+
+
+def shard_limit(limit, n_shards, max_search_limit=75):
+    return lib().orc_shard_limit(limit, n_shards, max_search_limit)
+
+
+def cluster_merge(ids, dists, counts, limit, weight=1.0):
+    """ids/dists: (n_shards, cap); counts (n_shards,). Returns (ids, dists, shards)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    dists = _f32(dists)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    ns, cap = ids.shape
+    o_ids = np.zeros(limit, dtype=np.uint64)
+    o_d = np.zeros(limit, dtype=np.float32)
+    o_s = np.zeros(limit, dtype=np.int32)
+    n = lib().orc_cluster_merge(ns, _p(counts, C.c_int), _p(ids, C.c_uint64), _p(dists, C.c_float), cap,
+                                C.c_float(weight), limit, _p(o_ids, C.c_uint64), _p(o_d, C.c_float),
+                                _p(o_s, C.c_int))
+    return o_ids[:n], o_d[:n], o_s[:n]
+
+
+def has_avx2():
+    return bool(lib().orc_has_avx2())
+
+
+def max_threads():
+    return int(lib().orc_max_threads())

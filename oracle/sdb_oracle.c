@@ -1,0 +1,1009 @@
+/*
+ * sdb_oracle.c -- CPU ORACLE for the SemaDB Vamana hot path.  TEST INFRASTRUCTURE ONLY.
+ * See sdb_oracle.h for the scope statement and the parity status ("restatement-pinned").
+ *
+ * Build: gcc -O2 -std=c11 -mavx2 -mfma -ffp-contract=off -fopenmp -fPIC -shared
+ * (-ffp-contract=off matters: the reference's pure-Go path is unfused and the asm path fuses
+ *  only where the assembly says VFMADD231).
+ */
+#define _GNU_SOURCE
+#include "sdb_oracle.h"
+
+#include <float.h>
+#include <immintrin.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* =====================================================================================
+ * 1. Raw distances
+ * ===================================================================================== */
+
+/* distance/asm/dot.s:7-55.  acc[8*j+l] is lane l of YMM accumulator j (Y0..Y3). */
+static float dot_asm_model(const float *x, const float *y, size_t n) {
+  float acc[32];
+  for (int i = 0; i < 32; i++) acc[i] = 0.0f; /* VXORPS dot.s:11-14 */
+  size_t i = 0;
+  for (; n - i >= 32; i += 32) /* blockloop dot.s:16-30 */
+    for (int L = 0; L < 32; L++) acc[L] = fmaf(x[i + L], y[i + L], acc[L]); /* VFMADD231PS */
+  float t[4] = {0.0f, 0.0f, 0.0f, 0.0f}; /* X4, dot.s:33 */
+  for (; i < n; i++) t[0] = fmaf(x[i], y[i], t[0]); /* VFMADD231SS dot.s:35-43 */
+  float s[8], r[4];
+  for (int l = 0; l < 8; l++) s[l] = ((acc[l] + acc[8 + l]) + acc[16 + l]) + acc[24 + l]; /* :46-48 */
+  for (int l = 0; l < 4; l++) r[l] = s[l] + s[l + 4]; /* VEXTRACTF128 + VADDPS :49-50 */
+  for (int l = 0; l < 4; l++) r[l] = r[l] + t[l];     /* VADDPS X0,X4,X0 :51 */
+  return (r[0] + r[1]) + (r[2] + r[3]);               /* 2x VHADDPS :52-53 */
+}
+
+/* distance/asm/euclidean.s:7-65.  Accumulators are Y0,Y2,Y3,Y4 (Y1 is the diff scratch). */
+static float l2_asm_model(const float *x, const float *y, size_t n) {
+  float acc[32];
+  for (int i = 0; i < 32; i++) acc[i] = 0.0f;
+  size_t i = 0;
+  for (; n - i >= 32; i += 32) /* blockloop euclidean.s:20-38 */
+    for (int L = 0; L < 32; L++) {
+      float d = x[i + L] - y[i + L]; /* VSUBPS: separately rounded :27,29,31,33 */
+      acc[L] = fmaf(d, d, acc[L]);   /* VFMADD231PS :28,30,32,34 */
+    }
+  float t[4] = {0.0f, 0.0f, 0.0f, 0.0f}; /* X1 :41 */
+  for (; i < n; i++) {                   /* tailloop :44-53 */
+    float d = x[i] - y[i];               /* VSUBSS */
+    t[0] = fmaf(d, d, t[0]);             /* VFMADD231SS */
+  }
+  float s[8], r[4];
+  for (int l = 0; l < 8; l++) s[l] = ((acc[l] + acc[8 + l]) + acc[16 + l]) + acc[24 + l]; /* :56-58 */
+  for (int l = 0; l < 4; l++) r[l] = s[l] + s[l + 4]; /* :59-60 */
+  for (int l = 0; l < 4; l++) r[l] = r[l] + t[l];     /* :61 */
+  return (r[0] + r[1]) + (r[2] + r[3]);               /* :62-63 */
+}
+
+/* The same two routines, instruction for instruction, with AVX2/FMA intrinsics. */
+__attribute__((target("avx2,fma"))) static float dot_avx2(const float *x, const float *y, size_t n) {
+  __m256 y0 = _mm256_setzero_ps(), y1 = y0, y2 = y0, y3 = y0;
+  while (n >= 32) {
+    __m256 a0 = _mm256_loadu_ps(x), a1 = _mm256_loadu_ps(x + 8);
+    __m256 a2 = _mm256_loadu_ps(x + 16), a3 = _mm256_loadu_ps(x + 24);
+    y0 = _mm256_fmadd_ps(a0, _mm256_loadu_ps(y), y0);
+    y1 = _mm256_fmadd_ps(a1, _mm256_loadu_ps(y + 8), y1);
+    y2 = _mm256_fmadd_ps(a2, _mm256_loadu_ps(y + 16), y2);
+    y3 = _mm256_fmadd_ps(a3, _mm256_loadu_ps(y + 24), y3);
+    x += 32, y += 32, n -= 32;
+  }
+  __m128 x4 = _mm_setzero_ps();
+  while (n != 0) {
+    x4 = _mm_fmadd_ss(_mm_load_ss(x), _mm_load_ss(y), x4);
+    x++, y++, n--;
+  }
+  y0 = _mm256_add_ps(y1, y0);
+  y0 = _mm256_add_ps(y2, y0);
+  y0 = _mm256_add_ps(y3, y0);
+  __m128 x1 = _mm256_extractf128_ps(y0, 1);
+  __m128 x0 = _mm_add_ps(x1, _mm256_castps256_ps128(y0));
+  x0 = _mm_add_ps(x4, x0);
+  x0 = _mm_hadd_ps(x0, x0);
+  x0 = _mm_hadd_ps(x0, x0);
+  return _mm_cvtss_f32(x0);
+}
+
+__attribute__((target("avx2,fma"))) static float l2_avx2(const float *x, const float *y, size_t n) {
+  __m256 y0 = _mm256_setzero_ps(), y2 = y0, y3 = y0, y4 = y0, y1;
+  while (n >= 32) {
+    y1 = _mm256_sub_ps(_mm256_loadu_ps(x), _mm256_loadu_ps(y));
+    y0 = _mm256_fmadd_ps(y1, y1, y0);
+    y1 = _mm256_sub_ps(_mm256_loadu_ps(x + 8), _mm256_loadu_ps(y + 8));
+    y2 = _mm256_fmadd_ps(y1, y1, y2);
+    y1 = _mm256_sub_ps(_mm256_loadu_ps(x + 16), _mm256_loadu_ps(y + 16));
+    y3 = _mm256_fmadd_ps(y1, y1, y3);
+    y1 = _mm256_sub_ps(_mm256_loadu_ps(x + 24), _mm256_loadu_ps(y + 24));
+    y4 = _mm256_fmadd_ps(y1, y1, y4);
+    x += 32, y += 32, n -= 32;
+  }
+  __m128 x1 = _mm_setzero_ps();
+  while (n != 0) {
+    __m128 x5 = _mm_sub_ss(_mm_load_ss(x), _mm_load_ss(y));
+    x1 = _mm_fmadd_ss(x5, x5, x1);
+    x++, y++, n--;
+  }
+  y0 = _mm256_add_ps(y2, y0);
+  y0 = _mm256_add_ps(y3, y0);
+  y0 = _mm256_add_ps(y4, y0);
+  __m128 x2 = _mm256_extractf128_ps(y0, 1);
+  __m128 x0 = _mm_add_ps(x2, _mm256_castps256_ps128(y0));
+  x0 = _mm_add_ps(x1, x0);
+  x0 = _mm_hadd_ps(x0, x0);
+  x0 = _mm_hadd_ps(x0, x0);
+  return _mm_cvtss_f32(x0);
+}
+
+/* distance/puredist.go:12-18 */
+static float dot_pure(const float *x, const float *y, size_t n) {
+  float sum = 0.0f;
+  for (size_t i = 0; i < n; i++) sum += x[i] * y[i];
+  return sum;
+}
+
+/* distance/puredist.go:3-10 */
+static float l2_pure(const float *x, const float *y, size_t n) {
+  float sum = 0.0f;
+  for (size_t i = 0; i < n; i++) {
+    float diff = x[i] - y[i];
+    sum += diff * diff;
+  }
+  return sum;
+}
+
+int orc_has_avx2(void) { return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"); }
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+float orc_dot(const float *x, const float *y, size_t n, int impl) {
+  switch (impl) {
+    case ORC_IMPL_AVX2: return dot_avx2(x, y, n);
+    case ORC_IMPL_PURE: return dot_pure(x, y, n);
+    default: return dot_asm_model(x, y, n);
+  }
+}
+
+float orc_sqeuclid(const float *x, const float *y, size_t n, int impl) {
+  switch (impl) {
+    case ORC_IMPL_AVX2: return l2_avx2(x, y, n);
+    case ORC_IMPL_PURE: return l2_pure(x, y, n);
+    default: return l2_asm_model(x, y, n);
+  }
+}
+
+/* distance/distance.go:19-25 and :70-83 */
+float orc_distance(const float *x, const float *y, size_t n, int metric, int impl) {
+  switch (metric) {
+    case ORC_METRIC_EUCLIDEAN: return orc_sqeuclid(x, y, n, impl);
+    case ORC_METRIC_DOT: return -orc_dot(x, y, n, impl);
+    default: return 1 - orc_dot(x, y, n, impl);
+  }
+}
+
+void orc_distance_matrix(const float *q, size_t nq, const float *c, size_t nc, size_t d, int metric,
+                         int impl, float *out) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)nq; i++)
+    for (size_t j = 0; j < nc; j++) out[i * nc + j] = orc_distance(q + i * d, c + j * d, d, metric, impl);
+}
+
+/* =====================================================================================
+ * 2. Product quantizer state (declared early: the index's distance closures use it)
+ * ===================================================================================== */
+struct orc_pq {
+  int dim, M, K, sub_len, metric, impl;
+  float *flat_centroids; /* [M][K][sub_len]  product.go:37 */
+  float *centroid_dists; /* [M][K][K]        product.go:36 */
+  int fitted;
+};
+
+/* =====================================================================================
+ * 3. DistSet (shard/index/vamana/distset.go)
+ * ===================================================================================== */
+typedef struct {
+  uint32_t slot;
+  float dist;
+  uint8_t visited;
+  uint8_t removed; /* pruneRemoved distset.go:124 */
+} ds_elem;
+
+enum { DF_TABLE, DF_FLOAT_PLAIN, DF_POINT_PLAIN, DF_FLOAT_PQ, DF_POINT_PQ };
+
+/* vectorstore.PointIdDistFn (vectorstore.go:21): a bound left-hand side */
+typedef struct {
+  int kind;
+  const orc_index *ix;
+  const float *x;     /* plain: query / point vector */
+  const float *table; /* KAT: dists[id] */
+  const float *lut;   /* pq asymmetric table */
+  const uint8_t *cx;  /* pq symmetric: codes of the bound point */
+  uint64_t n_eval;
+} distfn;
+
+typedef struct {
+  ds_elem *items;
+  int len, cap, alloc;
+  int sorted_until;
+  /* visitedSet interface distset.go:66-69: bitset or map */
+  int use_bitset;
+  uint64_t *bits;
+  size_t nwords;
+  int bits_owned;
+  uint32_t *hkeys; /* slot+1, 0 = empty */
+  uint32_t hcap, hcount;
+  distfn *df;
+} distset;
+
+struct orc_index {
+  int dim, metric, impl, R, L;
+  float alpha;
+  uint64_t n, cap;
+  float *vectors;
+  uint64_t *ids;
+  uint32_t **edges;
+  uint32_t *deg, *ecap;
+  /* id -> slot */
+  uint64_t *mkeys;
+  uint32_t *mvals;
+  uint64_t mcap;
+  int64_t start_slot;
+  uint64_t max_node_id; /* vamana.go:47 */
+  const orc_pq *pq;
+  uint8_t *codes;
+};
+
+static float distfn_eval(distfn *f, uint32_t slot) {
+  f->n_eval++;
+  switch (f->kind) {
+    case DF_TABLE: return f->table[slot];
+    case DF_FLOAT_PLAIN: /* plain.go:76-85 */
+    case DF_POINT_PLAIN: /* plain.go:87-97 */
+      return orc_distance(f->x, f->ix->vectors + (size_t)slot * f->ix->dim, f->ix->dim, f->ix->metric,
+                          f->ix->impl);
+    case DF_FLOAT_PQ: /* product.go:264-276 */
+      return orc_pq_dist_lut(f->ix->pq, f->lut, f->ix->codes + (size_t)slot * f->ix->pq->M);
+    default: /* product.go:293-304 */
+      return orc_pq_dist_sym(f->ix->pq, f->cx, f->ix->codes + (size_t)slot * f->ix->pq->M);
+  }
+}
+
+static void ds_hash_grow(distset *ds) {
+  uint32_t ncap = ds->hcap ? ds->hcap * 2 : 64;
+  uint32_t *nk = calloc(ncap, sizeof(uint32_t));
+  for (uint32_t i = 0; i < ds->hcap; i++)
+    if (ds->hkeys[i]) {
+      uint32_t h = (ds->hkeys[i] * 2654435761u) & (ncap - 1);
+      while (nk[h]) h = (h + 1) & (ncap - 1);
+      nk[h] = ds->hkeys[i];
+    }
+  free(ds->hkeys);
+  ds->hkeys = nk;
+  ds->hcap = ncap;
+}
+
+/* visitedSet.CheckAndVisit distset.go:81-87 (map) and :105-111 (bitset) */
+static int ds_check_and_visit(distset *ds, uint32_t slot) {
+  if (ds->use_bitset) {
+    uint64_t w = ds->bits[slot >> 6], b = 1ull << (slot & 63);
+    if (w & b) return 1;
+    ds->bits[slot >> 6] = w | b;
+    return 0;
+  }
+  if ((ds->hcount + 1) * 2 > ds->hcap) ds_hash_grow(ds);
+  uint32_t key = slot + 1, h = (key * 2654435761u) & (ds->hcap - 1);
+  while (ds->hkeys[h]) {
+    if (ds->hkeys[h] == key) return 1;
+    h = (h + 1) & (ds->hcap - 1);
+  }
+  ds->hkeys[h] = key;
+  ds->hcount++;
+  return 0;
+}
+
+/* NewDistSet distset.go:140-155.  nbits > 0 -> VisitedBitSet (cleared: ClearAll :101),
+ * nbits == 0 -> VisitedMap.  ext_bits lets a caller lend a pooled bitset (sync.Pool :46). */
+static void ds_init(distset *ds, int capacity, size_t nbits, uint64_t *ext_bits, distfn *df) {
+  memset(ds, 0, sizeof(*ds));
+  ds->cap = capacity;
+  ds->alloc = capacity > 4 ? capacity : 4;
+  ds->items = malloc(sizeof(ds_elem) * ds->alloc);
+  ds->df = df;
+  if (nbits) {
+    ds->use_bitset = 1;
+    ds->nwords = (nbits + 63) / 64;
+    if (ext_bits) {
+      ds->bits = ext_bits;
+    } else {
+      ds->bits = malloc(ds->nwords * 8);
+      ds->bits_owned = 1;
+    }
+    memset(ds->bits, 0, ds->nwords * 8);
+  }
+}
+
+static void ds_free(distset *ds) {
+  free(ds->items);
+  if (ds->bits_owned) free(ds->bits);
+  free(ds->hkeys);
+  memset(ds, 0, sizeof(*ds));
+}
+
+static void ds_push(distset *ds, ds_elem e) {
+  if (ds->len == ds->alloc) {
+    ds->alloc *= 2;
+    ds->items = realloc(ds->items, sizeof(ds_elem) * ds->alloc);
+  }
+  ds->items[ds->len++] = e;
+}
+
+/* DistSet.AddWithLimit distset.go:166-200.  `cap` is the construction capacity; the reference
+ * reads cap(ds.items), which only differs if Add has overflowed the slice first -- never the
+ * case on the search path (search.go:42-50 adds at most searchSize points). */
+static void ds_add_with_limit(distset *ds, const uint32_t *slots, int n) {
+  for (int p = 0; p < n; p++) {
+    if (ds_check_and_visit(ds, slots[p])) continue; /* :174 -- marks before any test */
+    float distance = distfn_eval(ds->df, slots[p]); /* :179 */
+    int limit = ds->cap;
+    if (ds->len == limit && distance > ds->items[limit - 1].dist) continue; /* :184 strict > */
+    ds_elem ne = {slots[p], distance, 0, 0};
+    if (ds->len < limit) { /* :189-191 */
+      ds_push(ds, ne);
+      ds->sorted_until++;
+    } else {
+      ds->items[ds->len - 1] = ne; /* :193 tail evicted */
+    }
+    for (int i = ds->len - 1; i > 0 && ds->items[i].dist < ds->items[i - 1].dist; i--) { /* :196-198 */
+      ds_elem tmp = ds->items[i];
+      ds->items[i] = ds->items[i - 1];
+      ds->items[i - 1] = tmp;
+    }
+  }
+}
+
+/* DistSet.Add distset.go:203-211 */
+static void ds_add(distset *ds, const uint32_t *slots, int n) {
+  for (int p = 0; p < n; p++) {
+    if (ds_check_and_visit(ds, slots[p])) continue;
+    float distance = distfn_eval(ds->df, slots[p]);
+    ds_elem ne = {slots[p], distance, 0, 0};
+    ds_push(ds, ne);
+  }
+}
+
+/* DistSet.Sort distset.go:223-238: insertion sort from sortedUntil, ascending, stable */
+static void ds_sort(distset *ds) {
+  for (int i = ds->sorted_until; i < ds->len; i++)
+    for (int j = i; j > 0 && ds->items[j].dist < ds->items[j - 1].dist; j--) {
+      ds_elem tmp = ds->items[j];
+      ds->items[j] = ds->items[j - 1];
+      ds->items[j - 1] = tmp;
+    }
+  ds->sorted_until = ds->len;
+}
+
+int orc_distset_script(int capacity, int use_bitset, const float *dists, int n_dists, const int *ops,
+                       int n_ops, const uint64_t *args, const int *arg_off, uint64_t *out_ids,
+                       int out_cap) {
+  distfn df = {0};
+  df.kind = DF_TABLE;
+  df.table = dists;
+  distset ds;
+  ds_init(&ds, capacity, use_bitset ? (size_t)n_dists + 64 : 0, NULL, &df);
+  for (int i = 0; i < n_ops; i++) {
+    int na = arg_off[i + 1] - arg_off[i];
+    uint32_t *slots = malloc(sizeof(uint32_t) * (na > 0 ? na : 1));
+    for (int j = 0; j < na; j++) slots[j] = (uint32_t)args[arg_off[i] + j];
+    if (ops[i] == 0) ds_add(&ds, slots, na);
+    else if (ops[i] == 1) ds_add_with_limit(&ds, slots, na);
+    else ds_sort(&ds);
+    free(slots);
+  }
+  int n = ds.len < out_cap ? ds.len : out_cap;
+  for (int i = 0; i < n; i++) out_ids[i] = ds.items[i].slot;
+  int len = ds.len;
+  ds_free(&ds);
+  return len;
+}
+
+/* =====================================================================================
+ * 4. Index container (stands in for cache.ItemCache + plainStore + graphNode)
+ * ===================================================================================== */
+static uint64_t hash64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+static int64_t map_get(const orc_index *ix, uint64_t id) {
+  if (!ix->mcap) return -1;
+  uint64_t h = hash64(id) & (ix->mcap - 1);
+  while (ix->mkeys[h]) {
+    if (ix->mkeys[h] == id) return ix->mvals[h];
+    h = (h + 1) & (ix->mcap - 1);
+  }
+  return -1;
+}
+
+static void map_put_raw(uint64_t *keys, uint32_t *vals, uint64_t cap, uint64_t id, uint32_t v) {
+  uint64_t h = hash64(id) & (cap - 1);
+  while (keys[h]) h = (h + 1) & (cap - 1);
+  keys[h] = id;
+  vals[h] = v;
+}
+
+static void map_put(orc_index *ix, uint64_t id, uint32_t slot) {
+  if ((ix->n + 1) * 2 > ix->mcap) {
+    uint64_t ncap = ix->mcap ? ix->mcap * 2 : 1024;
+    uint64_t *nk = calloc(ncap, 8);
+    uint32_t *nv = calloc(ncap, 4);
+    for (uint64_t i = 0; i < ix->mcap; i++)
+      if (ix->mkeys[i]) map_put_raw(nk, nv, ncap, ix->mkeys[i], ix->mvals[i]);
+    free(ix->mkeys);
+    free(ix->mvals);
+    ix->mkeys = nk, ix->mvals = nv, ix->mcap = ncap;
+  }
+  map_put_raw(ix->mkeys, ix->mvals, ix->mcap, id, slot);
+}
+
+orc_index *orc_index_new(int dim, int metric, int impl, int degree_bound, int search_size, float alpha) {
+  orc_index *ix = calloc(1, sizeof(*ix));
+  ix->dim = dim, ix->metric = metric, ix->impl = impl;
+  ix->R = degree_bound, ix->L = search_size, ix->alpha = alpha;
+  ix->start_slot = -1;
+  return ix;
+}
+
+void orc_index_free(orc_index *ix) {
+  if (!ix) return;
+  for (uint64_t i = 0; i < ix->n; i++) free(ix->edges[i]);
+  free(ix->edges), free(ix->deg), free(ix->ecap), free(ix->vectors), free(ix->ids);
+  free(ix->mkeys), free(ix->mvals), free(ix->codes);
+  free(ix);
+}
+
+static void index_reserve(orc_index *ix, uint64_t want) {
+  if (want <= ix->cap) return;
+  uint64_t ncap = ix->cap ? ix->cap : 1024;
+  while (ncap < want) ncap *= 2;
+  ix->vectors = realloc(ix->vectors, sizeof(float) * ncap * ix->dim);
+  ix->ids = realloc(ix->ids, 8 * ncap);
+  ix->edges = realloc(ix->edges, sizeof(uint32_t *) * ncap);
+  ix->deg = realloc(ix->deg, 4 * ncap);
+  ix->ecap = realloc(ix->ecap, 4 * ncap);
+  ix->cap = ncap;
+}
+
+/* vecStore.Set (plain.go:58-65) + nodeStore.Put: returns the slot */
+static uint32_t index_add_node(orc_index *ix, uint64_t id, const float *vec) {
+  index_reserve(ix, ix->n + 1);
+  uint32_t s = (uint32_t)ix->n;
+  memcpy(ix->vectors + (size_t)s * ix->dim, vec, sizeof(float) * ix->dim);
+  ix->ids[s] = id;
+  ix->edges[s] = NULL, ix->deg[s] = 0, ix->ecap[s] = 0;
+  map_put(ix, id, s);
+  ix->n++;
+  if (id > ix->max_node_id) ix->max_node_id = id; /* vamana.go:166-168 */
+  return s;
+}
+
+/* graphNode.AddNeighbour node.go:66-71 */
+static int node_add_neighbour(orc_index *ix, uint32_t s, uint32_t nb) {
+  if (ix->deg[s] == ix->ecap[s]) {
+    ix->ecap[s] = ix->ecap[s] ? ix->ecap[s] * 2 : (uint32_t)(ix->R > 0 ? ix->R + 1 : 8);
+    ix->edges[s] = realloc(ix->edges[s], 4 * ix->ecap[s]);
+  }
+  ix->edges[s][ix->deg[s]++] = nb;
+  return (int)ix->deg[s];
+}
+
+int orc_index_set_start(orc_index *ix, const float *vec) {
+  if (ix->start_slot >= 0) return 0; /* vamana.go:95-97 */
+  ix->start_slot = index_add_node(ix, ORC_STARTID, vec);
+  ix->max_node_id = 0; /* the start node does not move maxNodeId */
+  return 0;
+}
+
+uint64_t orc_index_size(const orc_index *ix) { return ix->n; }
+
+uint64_t orc_index_num_edges(const orc_index *ix) {
+  uint64_t t = 0;
+  for (uint64_t i = 0; i < ix->n; i++) t += ix->deg[i];
+  return t;
+}
+
+int orc_index_load(orc_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
+                   const uint64_t *offsets, const uint64_t *edges) {
+  if (ix->n != 0) return -1;
+  index_reserve(ix, n);
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t s = index_add_node(ix, ids[i], vectors + (size_t)i * ix->dim);
+    if (ids[i] == ORC_STARTID) ix->start_slot = s;
+  }
+  if (ix->start_slot < 0) return -2;
+  for (uint64_t i = 0; i < n; i++)
+    for (uint64_t e = offsets[i]; e < offsets[i + 1]; e++) {
+      int64_t t = map_get(ix, edges[e]);
+      if (t < 0) continue; /* GetMany skips unknown ids, itemcache.go:109-128 */
+      node_add_neighbour(ix, (uint32_t)i, (uint32_t)t);
+    }
+  return 0;
+}
+
+int orc_index_export(const orc_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets,
+                     uint64_t *edges) {
+  uint64_t o = 0;
+  for (uint64_t i = 0; i < ix->n; i++) {
+    if (ids) ids[i] = ix->ids[i];
+    if (offsets) offsets[i] = o;
+    for (uint32_t e = 0; e < ix->deg[i]; e++, o++)
+      if (edges) edges[o] = ix->ids[ix->edges[i][e]];
+  }
+  if (offsets) offsets[ix->n] = o;
+  if (vectors) memcpy(vectors, ix->vectors, sizeof(float) * ix->n * ix->dim);
+  return 0;
+}
+
+int orc_index_attach_pq(orc_index *ix, const orc_pq *pq, const uint8_t *codes) {
+  if (!pq->fitted || pq->dim != ix->dim) return -1;
+  ix->pq = pq;
+  free(ix->codes);
+  ix->codes = malloc((size_t)ix->n * pq->M);
+  memcpy(ix->codes, codes, (size_t)ix->n * pq->M);
+  return 0;
+}
+
+/* vecStore.DistanceFromFloat: plain.go:76-85 / product.go:238-277 */
+static void bind_from_float(const orc_index *ix, const float *q, distfn *df, float **lut_owned) {
+  memset(df, 0, sizeof(*df));
+  df->ix = ix;
+  *lut_owned = NULL;
+  if (ix->pq) {
+    float *lut = malloc(sizeof(float) * ix->pq->M * ix->pq->K);
+    orc_pq_lut(ix->pq, q, lut);
+    df->kind = DF_FLOAT_PQ, df->lut = lut, *lut_owned = lut;
+  } else {
+    df->kind = DF_FLOAT_PLAIN, df->x = q;
+  }
+}
+
+/* vecStore.DistanceFromPoint: plain.go:87-97 / product.go:279-305 */
+static void bind_from_point(const orc_index *ix, uint32_t slot, distfn *df) {
+  memset(df, 0, sizeof(*df));
+  df->ix = ix;
+  if (ix->pq) {
+    df->kind = DF_POINT_PQ, df->cx = ix->codes + (size_t)slot * ix->pq->M;
+  } else {
+    df->kind = DF_POINT_PLAIN, df->x = ix->vectors + (size_t)slot * ix->dim;
+  }
+}
+
+/* =====================================================================================
+ * 5. greedySearch (shard/index/vamana/search.go:9-102)
+ * ===================================================================================== */
+static int filter_contains(const uint64_t *f, int n, uint64_t id) { /* roaring Contains */
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    int mid = (lo + hi) / 2;
+    if (f[mid] == id) return 1;
+    if (f[mid] < id) lo = mid + 1;
+    else hi = mid - 1;
+  }
+  return 0;
+}
+
+/* On return *result points at search_set or result_set (search.go:26,36); visited is sorted.
+ * bits_a/bits_b: caller-lent bitsets of >= ix->n bits (the sync.Pool stand-in) or NULL. */
+static int greedy_search(const orc_index *ix, distfn *df, int k, int search_size, const uint64_t *filter,
+                         int n_filter, uint64_t *bits_a, uint64_t *bits_b, distset *search_set,
+                         distset *result_set, distset **result, distset *visited, uint64_t *visit_ids,
+                         int visit_cap, orc_trace *tr) {
+  /* The reference sizes the bitset by maxNodeId and falls back to a map above 10.5M ids
+   * (distset.go:41,140-153); both are exact sets, so one exact bitset over slots is equivalent. */
+  ds_init(search_set, search_size, ix->n, bits_a, df);   /* search.go:13 */
+  ds_init(visited, search_size * 2, 0, NULL, df);        /* search.go:21 */
+  memset(result_set, 0, sizeof(*result_set));
+  *result = search_set;
+  if (search_size < k) return -1;                        /* search.go:23-25 */
+  if (filter) {                                          /* search.go:33-51 */
+    ds_init(result_set, k, ix->n, bits_b, df);
+    *result = result_set;
+    uint32_t *fp = malloc(sizeof(uint32_t) * (search_size > 0 ? search_size : 1));
+    int nfp = 0;
+    for (int i = 0; i < search_size && i < n_filter; i++) { /* first searchSize ids, ascending */
+      int64_t s = map_get(ix, filter[i]);
+      if (s >= 0) fp[nfp++] = (uint32_t)s; /* GetMany skips missing */
+    }
+    ds_add(search_set, fp, nfp);            /* :49 unbounded Add, unsorted */
+    ds_add_with_limit(result_set, fp, nfp); /* :50 */
+    free(fp);
+  }
+  uint32_t sn = (uint32_t)ix->start_slot;
+  ds_add_with_limit(search_set, &sn, 1); /* search.go:57-61 */
+  uint64_t n_hop = 0, n_edges = 0, n_vw = 0;
+  for (int i = 0; i < (search_set->len < search_size ? search_set->len : search_size);) { /* :65 */
+    ds_elem e = search_set->items[i];
+    if (e.visited) {
+      i++;
+      continue;
+    }
+    ds_push(visited, e);            /* AddAlreadyUnique :73 */
+    search_set->items[i].visited = 1; /* :74 */
+    if (visit_ids && (int)n_vw < visit_cap) visit_ids[n_vw++] = ix->ids[e.slot];
+    n_hop++;
+    n_edges += ix->deg[e.slot];
+    ds_add_with_limit(search_set, ix->edges[e.slot], (int)ix->deg[e.slot]); /* :77-91 */
+    if (filter && filter_contains(filter, n_filter, ix->ids[e.slot]))       /* :93-95 */
+      ds_add_with_limit(result_set, &e.slot, 1);
+    i = 0; /* :97 */
+  }
+  ds_sort(visited); /* :100 */
+  if (tr) {
+    tr->n_dist = df->n_eval;
+    tr->n_hop = n_hop;
+    tr->n_edges = n_edges;
+    tr->n_visit_written = n_vw;
+  }
+  return 0;
+}
+
+/* IndexVamana.Search vamana.go:278-310 */
+static int search_one(const orc_index *ix, const float *query, int limit, int search_size,
+                      const uint64_t *filter_ids, int n_filter, uint64_t *bits_a, uint64_t *bits_b,
+                      uint64_t *out_ids, float *out_dists, int *out_count, uint64_t *visit_ids,
+                      int visit_cap, orc_trace *trace) {
+  distfn df;
+  float *lut;
+  bind_from_float(ix, query, &df, &lut);
+  distset ss, rs, vs, *res;
+  int rc = greedy_search(ix, &df, limit, search_size, filter_ids, n_filter, bits_a, bits_b, &ss, &rs, &res,
+                         &vs, visit_ids, visit_cap, trace);
+  int cnt = 0;
+  if (rc == 0) {
+    for (int i = 0; i < res->len; i++) {
+      if (ix->ids[res->items[i].slot] == ORC_STARTID) continue; /* vamana.go:294-296 */
+      if (cnt >= limit) break;                                  /* :297-299 */
+      out_ids[cnt] = ix->ids[res->items[i].slot];
+      out_dists[cnt] = res->items[i].dist;
+      cnt++;
+    }
+  }
+  *out_count = cnt;
+  ds_free(&ss), ds_free(&vs);
+  if (rs.items) ds_free(&rs);
+  free(lut);
+  return rc;
+}
+
+int orc_index_search(const orc_index *ix, const float *query, int limit, int search_size,
+                     const uint64_t *filter_ids, int n_filter, uint64_t *out_ids, float *out_dists,
+                     int *out_count, uint64_t *visit_ids, int visit_cap, orc_trace *trace) {
+  if (ix->start_slot < 0) return -2;
+  return search_one(ix, query, limit, search_size, filter_ids, filter_ids ? n_filter : 0, NULL, NULL,
+                    out_ids, out_dists, out_count, visit_ids, visit_cap, trace);
+}
+
+int orc_index_search_batch(const orc_index *ix, const float *queries, int nq, int limit,
+                           int search_size, uint64_t *out_ids, float *out_dists, int *out_counts,
+                           orc_trace *traces, int n_threads) {
+  if (ix->start_slot < 0) return -2;
+  int rc_all = 0;
+#ifdef _OPENMP
+  if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+  n_threads = 1;
+#endif
+  size_t nwords = (ix->n + 63) / 64;
+#pragma omp parallel num_threads(n_threads)
+  {
+    uint64_t *bits = malloc(nwords * 8); /* one pooled bitset per worker, distset.go:46-62 */
+#pragma omp for schedule(dynamic, 4)
+    for (int q = 0; q < nq; q++) {
+      orc_trace tr;
+      int rc = search_one(ix, queries + (size_t)q * ix->dim, limit, search_size, NULL, 0, bits, NULL,
+                          out_ids + (size_t)q * limit, out_dists + (size_t)q * limit, out_counts + q,
+                          NULL, 0, &tr);
+      if (traces) traces[q] = tr;
+      if (rc) {
+#pragma omp atomic write
+        rc_all = rc;
+      }
+    }
+    free(bits);
+  }
+  return rc_all;
+}
+
+int orc_index_visited_sorted(const orc_index *ix, const float *query, int search_size,
+                             uint64_t *out_ids, float *out_dists, int cap) {
+  distfn df;
+  float *lut;
+  bind_from_float(ix, query, &df, &lut);
+  distset ss, rs, vs, *res;
+  int rc = greedy_search(ix, &df, 1, search_size, NULL, 0, NULL, NULL, &ss, &rs, &res, &vs, NULL, 0, NULL);
+  int n = 0;
+  if (rc == 0)
+    for (; n < vs.len && n < cap; n++) {
+      out_ids[n] = ix->ids[vs.items[n].slot];
+      out_dists[n] = vs.items[n].dist;
+    }
+  ds_free(&ss), ds_free(&vs);
+  free(lut);
+  return rc ? rc : n;
+}
+
+/* =====================================================================================
+ * 6. robustPrune (search.go:106-138) and insertSinglePoint (insert.go:16-68)
+ * ===================================================================================== */
+static void robust_prune(orc_index *ix, uint32_t node, distset *cand) {
+  ix->deg[node] = 0; /* ClearNeighbours node.go:56-63 */
+  for (int i = 0; i < cand->len; i++) {
+    ds_elem closest = cand->items[i];
+    if (closest.removed || closest.slot == node) continue; /* :115-117 */
+    int edge_count = node_add_neighbour(ix, node, closest.slot); /* :118 */
+    if (edge_count >= ix->R) break;                              /* :119-121 */
+    distfn df;
+    bind_from_point(ix, closest.slot, &df); /* :124 */
+    for (int j = i + 1; j < cand->len; j++) {
+      if (cand->items[j].removed) continue;
+      if (ix->alpha * distfn_eval(&df, cand->items[j].slot) < cand->items[j].dist) /* :132 */
+        cand->items[j].removed = 1;
+    }
+  }
+}
+
+int orc_index_insert(orc_index *ix, uint64_t id, const float *vec) {
+  if (id == ORC_STARTID || id == 0) return -3; /* vamana.go:150-157 */
+  if (ix->start_slot < 0) return -2;
+  if (map_get(ix, id) >= 0) return -4; /* update path (vamana.go:170-174) is out of scope */
+  uint32_t a = index_add_node(ix, id, vec); /* vecStore.Set insert.go:17 */
+  /* the new vector is in the store but unreachable: no inbound edges yet */
+  const float *avec = ix->vectors + (size_t)a * ix->dim;
+  distfn df;
+  float *lut;
+  bind_from_float(ix, avec, &df, &lut);
+  distset ss, rs, vs, *res;
+  int rc = greedy_search(ix, &df, 1, ix->L, NULL, 0, NULL, NULL, &ss, &rs, &res, &vs, NULL, 0, NULL); /* :22 */
+  if (rc) {
+    ds_free(&ss), ds_free(&vs), free(lut);
+    return rc;
+  }
+  robust_prune(ix, a, &vs); /* :29-31 */
+  for (uint32_t e = 0; e < ix->deg[a]; e++) { /* :36 in A's edge order */
+    uint32_t b = ix->edges[a][e];
+    if ((int)ix->deg[b] + 1 > ix->R) { /* :47 */
+      distfn dfb;
+      bind_from_point(ix, b, &dfb); /* :49 */
+      distset c;
+      ds_init(&c, (int)ix->deg[b] + 1, 0, NULL, &dfb); /* :50 map-backed */
+      uint32_t *nb = malloc(4 * (ix->deg[b] + 1));
+      memcpy(nb, ix->edges[b], 4 * ix->deg[b]);
+      ds_add(&c, nb, (int)ix->deg[b]); /* :55 */
+      ds_add(&c, &a, 1);               /* :56 */
+      ds_sort(&c);                     /* :57 */
+      robust_prune(ix, b, &c);         /* :58 */
+      free(nb);
+      ds_free(&c);
+    } else {
+      node_add_neighbour(ix, b, a); /* :62 */
+    }
+  }
+  ds_free(&ss), ds_free(&vs), free(lut);
+  return 0;
+}
+
+/* =====================================================================================
+ * 7. k-means (utils/kmeans.go:34-150)
+ * ===================================================================================== */
+int orc_kmeans_fit(float *X, int n, int stride, int offset, int len, int K, int max_iter,
+                   int first_idx, int alias, int impl, float *centroids_out, uint8_t *labels,
+                   int *iters_out) {
+  if (n <= 0 || K <= 0 || K > 256) return -1;
+  float *min_dist = malloc(sizeof(float) * n);
+  for (int i = 0; i < n; i++) min_dist[i] = FLT_MAX; /* :56-58 */
+  /* Centroids[i] is a view: either into X (alias) or into the private copy */
+  float **cent = malloc(sizeof(float *) * K);
+  float *priv = alias ? NULL : malloc(sizeof(float) * (size_t)K * len);
+#define ROW(j) (X + (size_t)(j) * stride + offset)
+  int *chosen = malloc(sizeof(int) * K);
+  chosen[0] = first_idx; /* :61-63 */
+  for (int i = 1; i < K; i++) { /* :65-83 */
+    float furthest = 0.0f;
+    int furthest_id = 0;
+    const float *prev = ROW(chosen[i - 1]);
+    for (int j = 0; j < n; j++) {
+      if (j == first_idx) continue; /* alreadyCentroid only ever holds randId :60-62,68 */
+      float cd = orc_sqeuclid(ROW(j), prev, len, impl); /* euclidean always :45 */
+      if (cd < min_dist[j]) min_dist[j] = cd;
+      if (min_dist[j] > furthest) {
+        furthest = min_dist[j];
+        furthest_id = j;
+      }
+    }
+    chosen[i] = furthest_id;
+  }
+  for (int i = 0; i < K; i++) {
+    if (alias) {
+      cent[i] = ROW(chosen[i]);
+    } else {
+      cent[i] = priv + (size_t)i * len;
+      memcpy(cent[i], ROW(chosen[i]), sizeof(float) * len);
+    }
+  }
+  memset(labels, 0, n); /* :87 */
+  float *sums = calloc((size_t)K * len, sizeof(float));
+  int *counts = calloc(K, sizeof(int));
+  int iters = 0;
+  for (int iter = 0; iter < max_iter; iter++) { /* :96 */
+    iters++;
+    int change = 0;
+    for (int i = 0; i < n; i++) { /* :100-115 */
+      const float *sv = ROW(i);
+      float best = orc_sqeuclid(sv, cent[0], len, impl);
+      uint8_t best_id = 0;
+      for (int j = 1; j < K; j++) {
+        float dj = orc_sqeuclid(sv, cent[j], len, impl);
+        if (dj < best) best = dj, best_id = (uint8_t)j;
+      }
+      if (labels[i] != best_id) change++, labels[i] = best_id;
+    }
+    if (change == 0) break; /* :116-118 */
+    for (int i = 0; i < K; i++) counts[i] = 0;
+    for (int i = 0; i < n; i++) { /* :125-137 */
+      int lb = labels[i];
+      if (counts[lb] == 0)
+        for (int j = 0; j < len; j++) sums[(size_t)lb * len + j] = 0.0f;
+      counts[lb]++;
+      const float *sv = ROW(i);
+      for (int j = 0; j < len; j++) sums[(size_t)lb * len + j] += sv[j];
+    }
+    for (int i = 0; i < K; i++) { /* :139-146 -- writes through the alias into X */
+      if (counts[i] == 0) continue;
+      for (int j = 0; j < len; j++) cent[i][j] = sums[(size_t)i * len + j] / (float)counts[i];
+    }
+  }
+  for (int i = 0; i < K; i++) memcpy(centroids_out + (size_t)i * len, cent[i], sizeof(float) * len);
+  if (iters_out) *iters_out = iters;
+#undef ROW
+  free(min_dist), free(cent), free(priv), free(chosen), free(sums), free(counts);
+  return 0;
+}
+
+/* =====================================================================================
+ * 8. Product quantizer (shard/vectorstore/product.go)
+ * ===================================================================================== */
+orc_pq *orc_pq_new(int dim, int metric, int impl, int num_subvectors, int num_centroids) {
+  if (num_subvectors <= 0 || dim % num_subvectors != 0) return NULL; /* product.go:44-46 */
+  if (num_centroids > 256 || num_centroids < 1) return NULL;          /* :63-65 */
+  orc_pq *pq = calloc(1, sizeof(*pq));
+  pq->dim = dim, pq->M = num_subvectors, pq->K = num_centroids, pq->impl = impl;
+  pq->sub_len = dim / num_subvectors;
+  pq->metric = metric == ORC_METRIC_COSINE ? ORC_METRIC_EUCLIDEAN : metric; /* :52-61 */
+  pq->flat_centroids = calloc((size_t)pq->M * pq->K * pq->sub_len, sizeof(float));
+  pq->centroid_dists = calloc((size_t)pq->M * pq->K * pq->K, sizeof(float));
+  return pq;
+}
+
+void orc_pq_free(orc_pq *pq) {
+  if (!pq) return;
+  free(pq->flat_centroids), free(pq->centroid_dists), free(pq);
+}
+
+const float *orc_pq_flat_centroids(const orc_pq *pq) { return pq->flat_centroids; }
+const float *orc_pq_centroid_dists(const orc_pq *pq) { return pq->centroid_dists; }
+
+static void pq_fill_centroid_dists(orc_pq *pq) { /* product.go:225-230 */
+  for (int i = 0; i < pq->M; i++)
+    for (int j = 0; j < pq->K; j++)
+      for (int k = 0; k < pq->K; k++)
+        pq->centroid_dists[(size_t)i * pq->K * pq->K + (size_t)j * pq->K + k] =
+            orc_distance(pq->flat_centroids + ((size_t)i * pq->K + j) * pq->sub_len,
+                         pq->flat_centroids + ((size_t)i * pq->K + k) * pq->sub_len, pq->sub_len,
+                         pq->metric, pq->impl);
+}
+
+int orc_pq_set_codebook(orc_pq *pq, const float *flat_centroids) {
+  memcpy(pq->flat_centroids, flat_centroids, sizeof(float) * (size_t)pq->M * pq->K * pq->sub_len);
+  pq_fill_centroid_dists(pq);
+  pq->fitted = 1;
+  return 0;
+}
+
+int orc_pq_fit(orc_pq *pq, float *X, int n, const int *first_idx, int alias, uint8_t *codes_out) {
+  uint8_t *labels = malloc(n);
+  for (int i = 0; i < pq->M; i++) { /* one goroutine per sub-quantizer product.go:202-232 */
+    int rc = orc_kmeans_fit(X, n, pq->dim, i * pq->sub_len, pq->sub_len, pq->K, 100, first_idx[i], alias,
+                            pq->impl, pq->flat_centroids + (size_t)i * pq->K * pq->sub_len, labels, NULL);
+    if (rc) {
+      free(labels);
+      return rc;
+    }
+    if (codes_out)
+      for (int j = 0; j < n; j++) codes_out[(size_t)j * pq->M + i] = labels[j]; /* :216-218 */
+  }
+  free(labels);
+  pq_fill_centroid_dists(pq);
+  pq->fitted = 1;
+  return 0;
+}
+
+void orc_pq_encode(const orc_pq *pq, const float *vec, uint8_t *codes) { /* product.go:136-159 */
+  for (int i = 0; i < pq->M; i++) {
+    const float *sub = vec + (size_t)i * pq->sub_len;
+    float best = FLT_MAX;
+    int best_id = 0;
+    for (int j = 0; j < pq->K; j++) {
+      float dist = orc_distance(sub, pq->flat_centroids + ((size_t)i * pq->K + j) * pq->sub_len,
+                                pq->sub_len, pq->metric, pq->impl);
+      if (dist < best) best = dist, best_id = j;
+    }
+    codes[i] = (uint8_t)best_id;
+  }
+}
+
+void orc_pq_lut(const orc_pq *pq, const float *query, float *lut) { /* product.go:255-263 */
+  for (int i = 0; i < pq->M; i++)
+    for (int j = 0; j < pq->K; j++)
+      lut[(size_t)i * pq->K + j] =
+          orc_distance(query + (size_t)i * pq->sub_len,
+                       pq->flat_centroids + ((size_t)i * pq->K + j) * pq->sub_len, pq->sub_len,
+                       pq->metric, pq->impl);
+}
+
+float orc_pq_dist_lut(const orc_pq *pq, const float *lut, const uint8_t *codes) { /* :271-275 */
+  float dist = 0.0f;
+  for (int i = 0; i < pq->M; i++) dist += lut[(size_t)i * pq->K + codes[i]];
+  return dist;
+}
+
+float orc_pq_dist_sym(const orc_pq *pq, const uint8_t *cx, const uint8_t *cy) { /* :300-302 */
+  float dist = 0.0f;
+  for (int i = 0; i < pq->M; i++)
+    dist += pq->centroid_dists[(size_t)i * pq->K * pq->K + (size_t)cx[i] * pq->K + cy[i]];
+  return dist;
+}
+
+/* =====================================================================================
+ * 9. Cluster merge (cluster/actions.go:291-376)
+ * ===================================================================================== */
+int orc_shard_limit(int limit, int n_shards, int max_search_limit) {
+  /* actions.go:291-299: int(float32(limit)*(1/float32(nShards))*1.42 + 10.0); the untyped
+   * constants take float32 in that expression */
+  int target = (int)((float)limit * (1.0f / (float)n_shards) * 1.42f + 10.0f);
+  if (target > max_search_limit) target = max_search_limit;
+  if (target > limit) target = limit;
+  return target;
+}
+
+typedef struct {
+  float score;
+  float dist;
+  int shard;
+  uint64_t id;
+} merge_item;
+
+static int merge_cmp(const void *a, const void *b) {
+  const merge_item *x = a, *y = b;
+  if (x->score > y->score) return -1; /* cmp.Compare(b.HybridScore, a.HybridScore) :362-364 */
+  if (x->score < y->score) return 1;
+  if (x->shard != y->shard) return x->shard < y->shard ? -1 : 1;
+  if (x->id != y->id) return x->id < y->id ? -1 : 1;
+  return 0;
+}
+
+int orc_cluster_merge(int n_shards, const int *counts, const uint64_t *ids, const float *dists,
+                      int per_shard_cap, float weight, int limit, uint64_t *out_ids,
+                      float *out_dists, int *out_shards) {
+  int total = 0;
+  for (int s = 0; s < n_shards; s++) total += counts[s];
+  merge_item *it = malloc(sizeof(merge_item) * (total > 0 ? total : 1));
+  int n = 0;
+  for (int s = 0; s < n_shards; s++)
+    for (int i = 0; i < counts[s]; i++, n++) {
+      it[n].dist = dists[(size_t)s * per_shard_cap + i];
+      it[n].score = -1 * it[n].dist * weight; /* vamana.go:303 */
+      it[n].shard = s;
+      it[n].id = ids[(size_t)s * per_shard_cap + i];
+    }
+  if (n_shards > 1) qsort(it, n, sizeof(merge_item), merge_cmp); /* actions.go:357 */
+  if (n > limit) n = limit;                                       /* :372-374 */
+  for (int i = 0; i < n; i++) {
+    out_ids[i] = it[i].id;
+    out_dists[i] = it[i].dist;
+    if (out_shards) out_shards[i] = it[i].shard;
+  }
+  free(it);
+  return n;
+}

@@ -1,0 +1,341 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for the hot path
+(SURVEY.md section 8c).  Each test names the reference test it mirrors (file:line, relative to
+the reference repository).  CPU only."""
+import numpy as np
+import pytest
+
+F32MAX = np.finfo(np.float32).max
+
+# distance/distance_test.go:9-21 (vectorTable)
+VECTOR_TABLE = [
+    ("Zero", [0, 0, 0], [0, 0, 0], 0, 0),
+    ("One", [1, 1], [1, 1], 2, 0),
+    ("Two", [1, 2, 3], [4, 5, 6], 32, 27),
+    ("Negative", [-1, -2, -3], [-4, -5, -6], 32, 27),
+    ("Mixed", [-1, 2, 3], [4, -5, 6], 4, 83),
+]
+
+
+@pytest.mark.parametrize("name,x,y,want_dot,want_l2", VECTOR_TABLE)
+def test_pure_distances(oracle, name, x, y, want_dot, want_l2):
+    # TestPureDotProduct / TestPureSquaredEuclidean distance/distance_test.go:23-39
+    assert oracle.dot(x, y, oracle.IMPL_PURE) == np.float32(want_dot)
+    assert oracle.sqeuclid(x, y, oracle.IMPL_PURE) == np.float32(want_l2)
+
+
+@pytest.mark.parametrize("impl", ["IMPL_ASM", "IMPL_AVX2"])
+@pytest.mark.parametrize("name,x,y,want_dot,want_l2", VECTOR_TABLE)
+def test_asm_distances(oracle, impl, name, x, y, want_dot, want_l2):
+    # TestASMdotProduct distance/distance_amd64_test.go:12-19, TestASMSquaredEuclidean :21-27
+    impl = getattr(oracle, impl)
+    assert oracle.dot(x, y, impl) == np.float32(want_dot)
+    assert oracle.sqeuclid(x, y, impl) == np.float32(want_l2)
+
+
+def test_metric_wrappers(oracle):
+    # distance/distance.go:19-25: dot -> -dot ; cosine -> 1 - dot (no normalisation)
+    x, y = [1, 2, 3], [4, 5, 6]
+    assert oracle.distance(x, y, "dot") == np.float32(-32)
+    assert oracle.distance(x, y, "cosine") == np.float32(1 - 32)
+    assert oracle.distance(x, y, "euclidean") == np.float32(27)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 8, 31, 32, 33, 63, 64, 65, 96, 100, 128, 384, 385, 768, 1536, 4096])
+def test_lane_model_equals_avx2_transcription(oracle, d):
+    """The scalar 32-accumulator model and the AVX2 intrinsics transcription of dot.s / euclidean.s
+    agree bit for bit; sequential summation (puredist.go) generally does not."""
+    if not oracle.has_avx2():
+        pytest.skip("host has no AVX2/FMA")
+    rng = np.random.default_rng(1000 + d)
+    n_diff_pure = 0
+    for trial in range(200):
+        scale = np.float32(10.0 ** rng.integers(-3, 4))
+        x = (rng.standard_normal(d) * scale).astype(np.float32)
+        y = (rng.standard_normal(d) * scale).astype(np.float32)
+        a, b = oracle.dot(x, y, oracle.IMPL_ASM), oracle.dot(x, y, oracle.IMPL_AVX2)
+        assert a.view(np.uint32) == b.view(np.uint32)
+        a2, b2 = oracle.sqeuclid(x, y, oracle.IMPL_ASM), oracle.sqeuclid(x, y, oracle.IMPL_AVX2)
+        assert a2.view(np.uint32) == b2.view(np.uint32)
+        # bitwise symmetric in (x, y)
+        assert oracle.dot(y, x, oracle.IMPL_ASM).view(np.uint32) == a.view(np.uint32)
+        assert oracle.sqeuclid(y, x, oracle.IMPL_ASM).view(np.uint32) == a2.view(np.uint32)
+        n_diff_pure += int(oracle.dot(x, y, oracle.IMPL_PURE).view(np.uint32) != a.view(np.uint32))
+    if d >= 128:
+        assert n_diff_pure > 0  # the summation order matters: that is why the oracle models it
+
+
+def test_denormals_and_specials(oracle):
+    if not oracle.has_avx2():
+        pytest.skip("host has no AVX2/FMA")
+    tiny = np.float32(1e-39)  # denormal
+    x = np.full(70, tiny, dtype=np.float32)
+    y = np.full(70, np.float32(1.0), dtype=np.float32)
+    for fn in (oracle.dot, oracle.sqeuclid):
+        a, b = fn(x, y, oracle.IMPL_ASM), fn(x, y, oracle.IMPL_AVX2)
+        assert a.view(np.uint32) == b.view(np.uint32)
+    assert oracle.dot(x, y, oracle.IMPL_ASM) != 0  # no flush to zero
+
+
+# ---- DistSet: shard/index/vamana/distset_test.go:41-74 --------------------------------------
+def test_distset_add(oracle):
+    # TestDistSet_Add :41-48
+    assert oracle.distset_script(2, [0.5, 1.0, 0.2], [("add", [0, 1, 2])]) == [0, 1, 2]
+    assert oracle.distset_script(2, [0.5, 1.0, 0.2], [("add", [0, 1, 2]), ("sort",)]) == [2, 0, 1]
+
+
+def test_distset_add_bitset(oracle):
+    # TestDistSet_Add_Bitset :50-57
+    s = [("add", [0, 1, 2, 0])]
+    assert oracle.distset_script(2, [0.5, 1.0, 0.2], s, use_bitset=True) == [0, 1, 2]
+    assert oracle.distset_script(2, [0.5, 1.0, 0.2], s + [("sort",)], use_bitset=True) == [2, 0, 1]
+
+
+def test_distset_add_duplicate(oracle):
+    # TestDistSet_Add_Duplicate :59-66
+    s = [("add", [0, 1, 2]), ("add", [0])]
+    assert len(oracle.distset_script(3, [0.5, 1.0, 0.1], s)) == 3
+    assert oracle.distset_script(3, [0.5, 1.0, 0.1], s + [("sort",)]) == [2, 0, 1]
+
+
+def test_distset_add_with_limit(oracle):
+    # TestDistSet_AddWithLimit :68-74
+    d = [0.5, 1.0, 0.1, 1.2]
+    assert oracle.distset_script(2, d, [("limit", [0, 1, 2])]) == [2, 0]
+    assert oracle.distset_script(2, d, [("limit", [0, 1, 2]), ("limit", [3, 3])]) == [2, 0]
+
+
+def test_distset_tie_rules(oracle):
+    # distset.go:184 strict '>' (an equal distance replaces the tail) and :196 strict '<'
+    # (a new element lands after equal distances)
+    d = [1.0, 1.0, 1.0, 0.5]
+    assert oracle.distset_script(2, d, [("limit", [0, 1])]) == [0, 1]
+    assert oracle.distset_script(2, d, [("limit", [0, 1, 2])]) == [0, 2]
+    assert oracle.distset_script(2, d, [("limit", [0, 1, 2, 3])]) == [3, 0]
+
+
+# ---- Vamana on the deterministic data of shard/index/dispatch_test.go:66-89 -------------------
+def _deterministic_index(oracle, n=100, start=None):
+    ix = oracle.Index(2, "euclidean", degree_bound=64, search_size=75, alpha=1.2)
+    rng = np.random.default_rng(20250622)
+    if start is None:
+        start = rng.uniform(-1, 1, 2).astype(np.float32)
+        start = start * np.float32(1 / np.float32(np.sqrt(np.float64(np.sum(start * start, dtype=np.float32)))))
+    ix.set_start(start)
+    for i in range(n):
+        ii = i + 2
+        assert ix.insert(ii, [ii, ii + 1]) == 0
+    return ix
+
+
+def test_search_single(oracle):
+    # TestSearch_Single shard/index/search_test.go:89-144: limit 10 -> 10 results, first is 42
+    ix = _deterministic_index(oracle)
+    ids, dists, _, _ = ix.search([42, 43], 10, 75)
+    assert len(ids) == 10 and ids[0] == 42 and dists[0] == 0
+    assert np.all(np.diff(dists) >= 0)
+
+
+def test_search_or_vector_topk_set(oracle):
+    # TestSearch_OrVector :414-457: limit 5 -> ids {40..44}; HybridScore == -dist for weights 0.5+0.5
+    ix = _deterministic_index(oracle)
+    ids, dists, _, _ = ix.search([42, 43], 5, 75)
+    assert set(int(i) for i in ids) == {40, 41, 42, 43, 44}
+    w = np.float32(0.5)
+    for d in dists:
+        assert (np.float32(-1) * d * w) + (np.float32(-1) * d * w) == -d
+
+
+def test_search_filter_by_id(oracle):
+    # TestSearch_FilterById :196-244: filter {47} -> one result, distance exactly 50
+    ix = _deterministic_index(oracle)
+    ids, dists, _, _ = ix.search([42, 43], 10, 75, filter_ids=[47])
+    assert list(ids) == [47] and dists[0] == np.float32(50)
+
+
+def test_search_filter_specific(oracle):
+    # TestSearch_FilterSpecific :246-288: filter {42..46} -> exactly those five, first 42
+    ix = _deterministic_index(oracle)
+    ids, _, _, _ = ix.search([42, 43], 10, 75, filter_ids=[42, 43, 44, 45, 46])
+    assert sorted(int(i) for i in ids) == [42, 43, 44, 45, 46] and ids[0] == 42
+
+
+# ---- Vamana properties on random 2-D data: shard/index/vamana/vamana_test.go ---------------------
+def _random2d_index(oracle, n, seed):
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n, 2), dtype=np.float32)  # randPoints vamana_test.go:48-61
+    ix = oracle.Index(2, "euclidean", 64, 75, 1.2)
+    s = rng.uniform(-1, 1, 2).astype(np.float32)
+    ix.set_start(s / np.float32(np.linalg.norm(s)))
+    for i in range(n):
+        assert ix.insert(i + 2, pts[i]) == 0
+    return ix, pts
+
+
+def _reachable(ix):
+    ids, _, offsets, edges = ix.export(with_vectors=False)
+    pos = {int(v): i for i, v in enumerate(ids)}
+    seen, queue = set(), [1]
+    while queue:
+        v = queue.pop()
+        if v in seen:
+            continue
+        seen.add(v)
+        i = pos[v]
+        queue.extend(int(e) for e in edges[int(offsets[i]):int(offsets[i + 1])])
+    return len(seen) - 1
+
+
+@pytest.mark.parametrize("size", [1, 100, 4242])
+def test_insert_connectivity(oracle, size):
+    # Test_Insert vamana_test.go:63-75 (checkConnectivity :29-46)
+    ix, _ = _random2d_index(oracle, size, 7 + size)
+    assert _reachable(ix) == size
+    _, _, offsets, _ = ix.export(with_vectors=False)
+    assert int(np.max(np.diff(offsets.astype(np.int64)))) <= 64  # degree bound holds
+
+
+def test_invalid_id_insert(oracle):
+    # Test_InvalidIdInsert vamana_test.go:77-90
+    ix = oracle.Index(2, "euclidean")
+    ix.set_start([0.6, 0.8])
+    assert ix.insert(0, [0.5, 0.5]) != 0
+    assert ix.insert(1, [0.5, 0.5]) != 0
+
+
+def test_empty_search(oracle):
+    # Test_EmptySearch vamana_test.go:213-228
+    ix = oracle.Index(2, "euclidean")
+    ix.set_start([0.6, 0.8])
+    ids, _, _, _ = ix.search([0.5, 0.5], 10, 75)
+    assert len(ids) == 0
+
+
+def test_self_retrieval(oracle):
+    # Test_Search vamana_test.go:230-252: every point is its own nearest neighbour, 10 results
+    ix, pts = _random2d_index(oracle, 200, 99)
+    for i in range(200):
+        ids, dists, _, _ = ix.search(pts[i], 10, 75)
+        assert len(ids) == 10 and ids[0] == i + 2 and dists[0] == 0
+
+
+def test_filter_search(oracle):
+    # Test_FilterSearch vamana_test.go:254-276
+    ix, pts = _random2d_index(oracle, 200, 123)
+    ids, _, _, _ = ix.search(pts[0], 10, 75, filter_ids=[2, 3, 4])
+    assert len(ids) == 3 and ids[0] == 2
+
+
+def test_search_size_smaller_than_k(oracle):
+    # search.go:23-25
+    ix, pts = _random2d_index(oracle, 50, 5)
+    with pytest.raises(ValueError):
+        ix.search(pts[0], 30, 25)
+
+
+# ---- k-means: utils/kmeans_test.go ----------------------------------------------------------------
+@pytest.mark.parametrize("offset", [0, 2])
+@pytest.mark.parametrize("first", [0, 3, 5])
+def test_kmeans_fit(oracle, offset, first):
+    # TestKMeans_Fit utils/kmeans_test.go:15-68
+    rng = np.random.default_rng(3)
+    offs = np.array([[-1, -1, 1, 1], [-1, -1, 1, 1], [0, 0, -1, 1], [0, 0, -1, 1], [1, 1, 1, -1], [1, 1, 1, -1]],
+                    dtype=np.float32)
+    data = (offs * 10 + rng.random(offs.shape, dtype=np.float32)).astype(np.float32)
+    cent, labels, _ = oracle.kmeans_fit(data.copy(), offset, 2, 3, max_iter=10, first_idx=first)
+    assert cent.shape == (3, 2)
+    assert labels[0] == labels[1] and labels[0] != labels[2]
+    assert labels[2] == labels[3] and labels[2] != labels[4]
+    assert labels[4] == labels[5]
+
+
+def test_kmeans_large(oracle):
+    # TestKMeans_Large utils/kmeans_test.go:70-91 (1000 iterations there; the cap is what matters)
+    rng = np.random.default_rng(4)
+    data = rng.random((10000, 16), dtype=np.float32)
+    cent, labels, iters = oracle.kmeans_fit(data, 0, 16, 256, max_iter=20, first_idx=17,
+                                            impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    assert cent.shape == (256, 16) and labels.max() <= 255
+
+
+def test_kmeans_aliasing_overwrites_input(oracle):
+    # utils/kmeans.go:63,82,144: Centroids alias rows of X and the mean update writes through
+    rng = np.random.default_rng(5)
+    data = rng.random((64, 4), dtype=np.float32)
+    a = data.copy()
+    cent, _, _ = oracle.kmeans_fit(a, 0, 4, 4, max_iter=10, first_idx=0, alias=True)
+    assert not np.array_equal(a, data)
+    assert any(np.array_equal(a[i], cent[0]) for i in range(64))
+    b = data.copy()
+    oracle.kmeans_fit(b, 0, 4, 4, max_iter=10, first_idx=0, alias=False)
+    assert np.array_equal(b, data)
+
+
+# ---- vector stores: shard/vectorstore/vectorestore_test.go:112-154 -----------------------------------
+def _trigger_fit_pq(oracle):
+    # triggerFit :37-50 with storeTypes[2] (:17): K=256, M=2 on five 4-d points
+    X = np.array([[1, 2, 3, 4], [4, 5, 6, 7], [7, 8, 9, 10], [-10, -11, -12, -13], [-13, 14, -15, 16]],
+                 dtype=np.float32)
+    pq = oracle.PQ(4, "euclidean", 2, 256)
+    pq.fit(X, first_idx=[0, 0], alias=True)
+    return pq
+
+
+def test_pq_distance_from_float_fitted(oracle):
+    # Test_DistanceFromFloat (product/fit=true) :112-132
+    pq = _trigger_fit_pq(oracle)
+    c7, c8 = pq.encode([1, 2, 3, 4]), pq.encode([4, 5, 6, 7])
+    lut = pq.lut([1, 2, 3, 4])
+    assert pq.dist_lut(lut, c7) == 0
+    assert pq.dist_lut(lut, c7) < pq.dist_lut(lut, c8)
+
+
+def test_pq_distance_from_point_fitted(oracle):
+    # Test_DistanceFromPoint (product/fit=true) :134-154
+    pq = _trigger_fit_pq(oracle)
+    c7, c8 = pq.encode([1, 2, 3, 4]), pq.encode([4, 5, 6, 7])
+    assert pq.dist_sym(c7, c7) == 0
+    assert pq.dist_sym(c7, c7) < pq.dist_sym(c7, c8)
+
+
+def test_plain_distance_from_float(oracle):
+    # Test_DistanceFromFloat / Test_DistanceFromPoint (none) :112-154
+    assert oracle.distance([1, 2, 3, 4], [1, 2, 3, 4], "euclidean") == 0
+    assert oracle.distance([1, 2, 3, 4], [1, 2, 3, 4], "euclidean") < oracle.distance([1, 2, 3, 4], [4, 5, 6, 7],
+                                                                                     "euclidean")
+
+
+def test_pq_cosine_becomes_euclidean(oracle):
+    # product.go:52-61
+    pq_c = oracle.PQ(4, "cosine", 2, 4)
+    pq_e = oracle.PQ(4, "euclidean", 2, 4)
+    cb = np.arange(2 * 4 * 2, dtype=np.float32)
+    pq_c.set_codebook(cb)
+    pq_e.set_codebook(cb)
+    q = [0.5, 1.5, 2.5, 3.5]
+    assert np.array_equal(pq_c.lut(q), pq_e.lut(q))
+    assert np.array_equal(pq_c.encode(q), pq_e.encode(q))
+
+
+def test_pq_parameter_checks(oracle):
+    # product.go:44-46 (divisibility), :63-65 (<= 256 centroids)
+    with pytest.raises(ValueError):
+        oracle.PQ(10, "euclidean", 3, 16)
+    with pytest.raises(ValueError):
+        oracle.PQ(8, "euclidean", 2, 257)
+
+
+# ---- cluster merge: cluster/actions.go:291-376 -----------------------------------------------------------
+def test_shard_limit(oracle):
+    # actions.go:291-299: limit 10 on 8 shards -> min(10, 75, int(10/8*1.42+10)=11) = 10
+    assert oracle.shard_limit(10, 8) == 10
+    assert oracle.shard_limit(100, 5) == 38   # int(20*1.42+10)
+    assert oracle.shard_limit(75, 1) == 75
+    assert oracle.shard_limit(100, 1, 75) == 75
+
+
+def test_cluster_merge(oracle):
+    ids = np.array([[10, 11, 12], [20, 21, 22]], dtype=np.uint64)
+    d = np.array([[0.1, 0.4, 0.9], [0.2, 0.3, 0.95]], dtype=np.float32)
+    o_ids, o_d, o_s = oracle.cluster_merge(ids, d, [3, 3], 4)
+    assert list(o_ids) == [10, 20, 21, 11] and list(o_s) == [0, 1, 1, 0]
+    assert np.all(np.diff(o_d) >= 0)
