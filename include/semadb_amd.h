@@ -1,0 +1,219 @@
+/*
+ * semadb_amd.h -- C ABI of the MI355X-native Vamana search path for SemaDB.
+ *
+ * This is the drop-in boundary: the entry points a SemaDB maintainer binds from Go through cgo
+ * (INTEGRATION.md shows the shim) to put the hot path -- distance/, shard/vectorstore,
+ * shard/index/vamana search + insert, utils/kmeans + the product quantizer, and the cluster
+ * top-k merge -- on an MI355X.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Each function cites the reference interface it replaces (file:line relative to the reference
+ * repository Semafind/semadb).
+ *
+ * Conventions
+ *   - every function returns an sdb_status (0 = ok) and never aborts the process
+ *     (CONTRIBUTING.md:150 "no panics"); sdb_last_error() returns a thread-local message.
+ *   - `mem` says where caller buffers live: SDB_MEM_HOST (Go slices; the callee copies and never
+ *     retains the pointer, as cgo requires) or SDB_MEM_DEVICE (HBM pointers; the call is
+ *     asynchronous on `stream` and the caller synchronises).  Host calls synchronise before
+ *     returning.
+ *   - node ids are the reference's uint64 node ids (shard/idcounter.go); id 1 is the start node
+ *     (vamana.go:28) and ids 0/1 are rejected on write (vamana.go:150-157).
+ *   - vectors are row-major float32, `dim` floats per row (conversion.BytesToFloat32 layout).
+ *   - search calls may be issued concurrently from many threads on one index (the reference
+ *     serves searches from concurrent goroutines under an RLock, shard/cache/manager.go:163);
+ *     load/insert calls are exclusive, like its write lock.
+ */
+#ifndef SEMADB_AMD_H
+#define SEMADB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDB_ABI_VERSION 1
+
+typedef enum {
+  SDB_OK = 0,
+  SDB_ERR_INVALID = 1,   /* bad argument / parameter out of the reference's range        */
+  SDB_ERR_DEVICE = 2,    /* HIP runtime error (no GPU, launch failure, out of HBM)        */
+  SDB_ERR_STATE = 3,     /* call not valid in this state (e.g. search before start node)  */
+  SDB_ERR_NOT_FOUND = 4, /* unknown node id                                               */
+  SDB_ERR_EXISTS = 5     /* id already present (update path is host-side, not here)       */
+} sdb_status;
+
+/* models.Distance* names accepted by distance.GetFloatDistanceFn (distance/distance.go:70-83) */
+#define SDB_METRIC_EUCLIDEAN 0
+#define SDB_METRIC_COSINE 1
+#define SDB_METRIC_DOT 2
+
+#define SDB_MEM_HOST 0
+#define SDB_MEM_DEVICE 1
+
+#define SDB_STARTID 1ull /* vamana.go:28 */
+
+typedef struct sdb_index sdb_index;
+typedef struct sdb_pq sdb_pq;
+
+const char *sdb_last_error(void);
+int sdb_abi_version(void);
+/* number of visible MI355X devices; SDB_ERR_DEVICE if the HIP runtime finds none */
+int sdb_device_count(int *count);
+
+/* ---------------------------------------------------------------------------------------------
+ * distance/  (K1)
+ * ------------------------------------------------------------------------------------------- */
+/* Replaces distance.FloatDistFunc as obtained from GetFloatDistanceFn (distance/distance.go:11,
+ * 70-83) with the amd64 overrides installed (distance/distance_amd64.go:19-27): asm.Dot
+ * (distance/asm/dot.s:7-55) and asm.SquaredEuclideanDistance (distance/asm/euclidean.s:7-65),
+ * wrapped by dotProductDistance / cosineDistance (distance.go:19-25).  Results are bit-identical
+ * to that path: the kernel keeps the assembly's 32 partial sums, FMA order and reduce tree.
+ * Batched: out[q*nc + c] = dist(queries[q], candidates[c]); rows are `dim` floats. */
+int sdb_distance_batch(int metric, uint32_t dim, const float *queries, uint64_t nq,
+                       const float *candidates, uint64_t nc, float *out, int mem, int device,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * shard/index/vamana + shard/vectorstore (plain)  (K2, K3, K4)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t dim;          /* models.IndexVectorVamanaParameters.VectorSize  1..4096 (models/index.go:276) */
+  uint32_t metric;       /* DistanceMetric: SDB_METRIC_*                                         */
+  uint32_t search_size;  /* SearchSize used while inserting, 25..75 (models/index.go:278)        */
+  uint32_t degree_bound; /* DegreeBound 32..64 (models/index.go:279)                             */
+  float alpha;           /* Alpha 1.1..1.5 (models/index.go:280)                                 */
+  int32_t device;        /* HIP device ordinal that pins the slab and the graph                  */
+  uint64_t capacity;     /* rows to reserve in HBM up front (grows on demand); 0 = default       */
+  uint32_t strict;       /* != 0: enforce the reference's parameter ranges (models/index.go:284-313) */
+} sdb_index_params;
+
+/* vamana.NewIndexVamana (vamana.go:54-81) + vectorstore.New for the plain store (vectorstore.go:47-96).
+ * The HBM state is a cache of the bucket contents, like the reference's ItemCache. */
+int sdb_index_create(const sdb_index_params *params, sdb_index **out);
+int sdb_index_destroy(sdb_index *ix);
+
+/* setupStartNode (vamana.go:93-120).  The reference draws the start vector from an unseeded RNG;
+ * the caller supplies it (a Go shim passes the vector it read from / wrote to the bucket). */
+int sdb_index_set_start(sdb_index *ix, const float *vec, int mem);
+
+/* Bulk load of an existing graph: what the reference reads lazily from the bucket through
+ * plainPoint.ReadFrom (shard/vectorstore/plain.go:125-141) and graphNode.ReadFrom
+ * (shard/index/vamana/node.go:96-111).  CSR: offsets[n+1], edges hold uint64 node ids
+ * (conversion.BytesToEdgeList).  Edges to ids that are not loaded are dropped, the way
+ * ItemCache.GetMany skips them (shard/cache/itemcache.go:109-128); a repeated id inside one row
+ * keeps its first occurrence (later ones can never pass CheckAndVisit, distset.go:174).
+ * ids == NULL means row i has id i+1 (row 0 is the start node).  The start node (id 1) must be
+ * present.  vectors follow `mem`; ids/offsets/edges are always host memory. */
+int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
+                   const uint64_t *offsets, const uint64_t *edges, int mem);
+
+/* IndexVamana.InsertUpdateDelete, insert branch (vamana.go:127-201) -> insertSinglePoint
+ * (insert.go:16-68): greedySearch(vec, 1, SearchSize) -> robustPrune (search.go:106-138) ->
+ * back-edges with re-prune.  The reference runs NumCPU-1 inserts concurrently, so its graph
+ * depends on goroutine interleaving; here inserts run in deterministic rounds of `round_size`
+ * points that search one frozen snapshot (round_size = 1 reproduces a sequential
+ * insertSinglePoint loop exactly; 0 picks a default that grows with the index).
+ * ids == NULL assigns max_id+1.. in order.  ids 0 and 1 are rejected (vamana.go:150-157). */
+int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
+                           int mem, uint32_t round_size, void *stream);
+
+/* per-query search trace; every pointer may be NULL.  Arrays follow the same `mem` as the
+ * outputs of the call. */
+typedef struct {
+  uint32_t *n_dist;     /* [nq] distFn evaluations (distset.go:179)                           */
+  uint32_t *n_hop;      /* [nq] expanded nodes = len(visitedSet) (search.go:73)               */
+  uint32_t *n_edges;    /* [nq] edge ids read = sum deg(expanded)                             */
+  uint64_t *visit_ids;  /* [nq][visit_cap] node ids in expansion order                        */
+  uint32_t visit_cap;
+} sdb_search_trace;
+
+/* IndexVamana.Search (vamana.go:278-310) over greedySearch (search.go:9-102), for nq queries
+ * at once (the reference has no batch entry point: a host-side micro-batcher coalesces
+ * concurrent Search calls).  limit = query.Limit, search_size =
+ * query.SearchSize; search_size < limit is an error (search.go:23-25).
+ * Optional filter (the roaring bitmap argument): filter_offsets[nq+1] into filter_ids, each
+ * query's ids ascending; NULL = no filter.  Filter arrays are host memory.
+ * Outputs: out_ids[nq*limit], out_dists[nq*limit] (ascending distance, start node removed),
+ * out_counts[nq].  HybridScore = -1 * dist * weight is left to the caller (vamana.go:303). */
+int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
+                           uint32_t search_size, const uint64_t *filter_offsets,
+                           const uint64_t *filter_ids, uint64_t *out_ids, float *out_dists,
+                           uint32_t *out_counts, const sdb_search_trace *trace, int mem,
+                           void *stream);
+
+/* plainStore.DistanceFromFloat (shard/vectorstore/plain.go:76-85) batched: distances from each
+ * query to an explicit list of stored node ids (nc per query, cand_ids[nq*nc], host memory).
+ * Unknown ids give math.MaxFloat32, as the reference does for a foreign point type
+ * (plain.go:78-82).  out[nq*nc] follows `mem`. */
+int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, uint64_t nc,
+                             const uint64_t *cand_ids, float *out, int mem, void *stream);
+
+/* cache.Cachable.SizeInMemory (vamana.go:83-85): bytes of HBM held */
+int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes);
+/* number of nodes (start node included) / edges */
+int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id);
+/* Copy the graph back out in bucket order (what flush() writes, vamana.go:265-276): ids[n],
+ * vectors[n*dim] (NULL to skip), offsets[n+1], edges[n_edges] as node ids.  Host memory. */
+int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets,
+                     uint64_t *edges);
+
+/* ---------------------------------------------------------------------------------------------
+ * cluster fan-out merge  (C1's host half)
+ * ------------------------------------------------------------------------------------------- */
+/* ClusterNode.SearchPoints merge (cluster/actions.go:357-376): for each of nq queries take the
+ * n_shards per-shard result lists (shard-major: ids[s][q][per_shard], dists likewise,
+ * counts[s][q]) -- e.g. the buffer an RCCL all-gather produced -- sort by HybridScore
+ * descending (= distance ascending for weight > 0) and truncate to `limit`.  The reference's
+ * sort is unstable on arrival-ordered input; ties here break by (shard, id) ascending.
+ * out_shards (optional) receives the originating shard.  Buffers follow `mem`. */
+int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uint64_t *ids,
+                   const float *dists, const uint32_t *counts, uint32_t limit, uint64_t *out_ids,
+                   float *out_dists, uint32_t *out_shards, uint32_t *out_counts, int mem, int device,
+                   void *stream);
+/* per-shard limit rule, cluster/actions.go:291-299 */
+int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit, uint32_t *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * utils/kmeans.go + shard/vectorstore/product.go  (K5..K8)
+ * ------------------------------------------------------------------------------------------- */
+/* utils.KMeans.Fit (utils/kmeans.go:34-150) on X[n][stride] sub-vectors [offset, offset+len).
+ * first_idx replaces rand.IntN (kmeans.go:61).  alias != 0 keeps the reference's behaviour that
+ * centroids are views into X and the mean update overwrites those rows (kmeans.go:63,82,144);
+ * X is then modified in place.  centroids_out[K*len], labels_out[n].  Buffers follow `mem`. */
+int sdb_kmeans_fit(float *X, uint32_t n, uint32_t stride, uint32_t offset, uint32_t len, uint32_t K,
+                   uint32_t max_iter, uint32_t first_idx, int alias, float *centroids_out,
+                   uint8_t *labels_out, uint32_t *iters_out, int mem, int device, void *stream);
+
+/* newProductQuantizer (product.go:42-88): cosine is replaced by euclidean (:52-61). */
+int sdb_pq_create(uint32_t dim, uint32_t metric, uint32_t num_subvectors, uint32_t num_centroids,
+                  int device, sdb_pq **out);
+int sdb_pq_destroy(sdb_pq *pq);
+/* productQuantizer.Fit (product.go:175-236): k-means per sub-vector over X[n][dim] in the given
+ * row order, then the centroid-pair table (:225-230).  first_idx[M].  codes_out[n*M] (optional). */
+int sdb_pq_fit(sdb_pq *pq, float *X, uint32_t n, const uint32_t *first_idx, int alias,
+               uint8_t *codes_out, int mem, void *stream);
+/* install a codebook read from the bucket (product.go:79-86): flat_centroids[M][K][subLen] */
+int sdb_pq_set_codebook(sdb_pq *pq, const float *flat_centroids, int mem);
+int sdb_pq_get_codebook(const sdb_pq *pq, float *flat_centroids, float *centroid_dists);
+/* productQuantizer.encode (product.go:136-159) for n vectors: codes[n*M] */
+int sdb_pq_encode(const sdb_pq *pq, const float *vectors, uint64_t n, uint8_t *codes, int mem,
+                  void *stream);
+/* asymmetric distance (product.go:238-277): per query a LUT of M*K sub-distances (:255-263), then
+ * out[q*nc + c] = sum_i lut[i][codes[c][i]] in index order (:271-275).  codes[nc*M]. */
+int sdb_pq_lut_distance(const sdb_pq *pq, const float *queries, uint64_t nq, const uint8_t *codes,
+                        uint64_t nc, float *out, int mem, void *stream);
+/* symmetric distance via the centroid-pair table (product.go:279-305): out[i] for pairs
+ * (codes_x[i], codes_y[i]) */
+int sdb_pq_sym_distance(const sdb_pq *pq, const uint8_t *codes_x, const uint8_t *codes_y, uint64_t n,
+                        float *out, int mem, void *stream);
+/* switch an index to the fitted quantizer: its searches then use the LUT distance and its
+ * prunes the symmetric table, exactly as a fitted productQuantizer store does.  The index
+ * encodes every stored vector (product.go:161-169 Set -> encode). */
+int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMADB_AMD_H */

@@ -1,0 +1,65 @@
+// common.h -- shared host-side plumbing for the C ABI (error reporting, device guards).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/semadb_amd.h"
+
+namespace sdb {
+
+// thread-local last error (the C ABI never throws and never aborts)
+std::string &last_error_ref();
+int fail(int code, const char *fmt, ...);
+
+#define SDB_HIP(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return sdb::fail(SDB_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                       __FILE__, __LINE__);                                                  \
+  } while (0)
+
+#define SDB_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != SDB_OK) return _rc; \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// Row layout of the HBM vector slab (see DESIGN.md "Data layout"):
+//   [ ng groups of 128 floats ][ 32 tail floats if dim % 32 != 0 ]
+// group g, float L*4+k  <->  original element 32*(4g+k) + L   (zero when 4g+k >= dim/32)
+// so that a 16-byte load at lane L of a 32-lane half-wave yields four consecutive links of the
+// FMA chain of partial sum L of distance/asm/dot.s (block b = 4g+k, lane L).
+struct RowLayout {
+  uint32_t dim = 0, nblk = 0, ng = 0, tail = 0, ld = 0;
+  explicit RowLayout(uint32_t d = 0) {
+    dim = d;
+    nblk = d / 32;
+    ng = (nblk + 3) / 4;
+    tail = d % 32;
+    ld = ng * 128 + (tail ? 32 : 0);
+  }
+};
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace sdb

@@ -1,0 +1,89 @@
+// dist_core.h -- device-side distance arithmetic shared by every kernel.
+//
+// The reference's distance is asm.Dot / asm.SquaredEuclideanDistance (distance/asm/dot.s:7-55,
+// distance/asm/euclidean.s:7-65): 32 partial sums (4 YMM registers x 8 lanes), each an FMA chain
+// over the 32-float blocks in order, a sequential scalar chain for the n % 32 tail, and a fixed
+// reduce tree.  Identical result ids and visit order need identical float compares, so the
+// kernels reproduce exactly that arithmetic: a 32-lane half-wave owns one (query, candidate)
+// pair, lane L owns partial sum L, and the reduce tree is replayed with wave shuffles.
+// Compile with -ffp-contract=off: every fusion below is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/semadb_amd.h"
+
+namespace sdb {
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;  // adjacency padding / "unknown id"
+constexpr uint32_t kVisBit = 0x80000000u;  // DistSetElem.visited (distset.go:123) packed into the slot word
+
+// one link of partial sum L: VFMADD231PS (dot.s:24-27) or VSUBPS + VFMADD231PS (euclidean.s:27-34)
+template <bool L2>
+__device__ __forceinline__ float chain1(float acc, float x, float y) {
+  if constexpr (L2) {
+    float d = x - y;  // separately rounded subtract
+    return __builtin_fmaf(d, d, acc);
+  } else {
+    return __builtin_fmaf(x, y, acc);
+  }
+}
+
+// four consecutive blocks (b = 4g..4g+3) of partial sum L: the slab layout puts them in one float4
+template <bool L2>
+__device__ __forceinline__ float chain4(float acc, const float4 &x, const float4 &y) {
+  acc = chain1<L2>(acc, x.x, y.x);
+  acc = chain1<L2>(acc, x.y, y.y);
+  acc = chain1<L2>(acc, x.z, y.z);
+  acc = chain1<L2>(acc, x.w, y.w);
+  return acc;
+}
+
+// Sequential tail chain (dot.s:35-43 / euclidean.s:44-53).  Lane L of each half holds tail
+// element L of x and of y; every lane of the half replays the chain in element order.
+template <bool L2>
+__device__ __forceinline__ float tail_chain(float xt, float yt, uint32_t tail, int lane) {
+  float t = 0.0f;
+  const int hb = lane & 32;
+  for (uint32_t i = 0; i < tail; i++) {
+    float xi = __shfl(xt, hb + (int)i, 64);
+    float yi = __shfl(yt, hb + (int)i, 64);
+    t = chain1<L2>(t, xi, yi);
+  }
+  return t;
+}
+
+// The reduce tree (dot.s:45-53 / euclidean.s:55-63) inside each 32-lane half:
+//   s[l] = ((acc[l] + acc[8+l]) + acc[16+l]) + acc[24+l]   l = 0..7   three VADDPS
+//   r[l] = s[l] + s[l+4]                                   l = 0..3   VEXTRACTF128 + VADDPS
+//   r[l] = r[l] + t[l]   (t = {tail, 0, 0, 0})                        VADDPS X0, X4, X0
+//   result = (r[0] + r[1]) + (r[2] + r[3])                            two VHADDPS
+// The result is valid in lane 0 of each half (wave lanes 0 and 32).
+__device__ __forceinline__ float asm_reduce(float acc, float t, int lane) {
+  const int L = lane & 31;
+  float a8 = __shfl_down(acc, 8, 64);
+  float a16 = __shfl_down(acc, 16, 64);
+  float a24 = __shfl_down(acc, 24, 64);
+  float s = ((acc + a8) + a16) + a24;
+  float r = s + __shfl_down(s, 4, 64);
+  r = r + (L == 0 ? t : 0.0f);
+  float u = r + __shfl_down(r, 1, 64);
+  return u + __shfl_down(u, 2, 64);
+}
+
+// distance.go:19-25: euclidean -> as is, cosine -> 1 - dot, dot -> -dot (one more fp32 rounding)
+__device__ __forceinline__ float metric_finish(float raw, int metric) {
+  if (metric == SDB_METRIC_COSINE) return 1.0f - raw;
+  if (metric == SDB_METRIC_DOT) return -raw;
+  return raw;
+}
+
+// Query element for group g, slot k of lane L, read from an ORIGINAL-layout vector.
+__device__ __forceinline__ float q_elem(const float *__restrict__ q, uint32_t nblk, uint32_t g, uint32_t k,
+                                        int L) {
+  uint32_t b = 4 * g + k;
+  return b < nblk ? q[32 * b + L] : 0.0f;
+}
+
+}  // namespace sdb

@@ -1,0 +1,55 @@
+// index.h -- host-side state of one HBM-resident Vamana index (internal; the public surface is
+// include/semadb_amd.h).
+#pragma once
+#include <map>
+#include <unordered_map>
+
+#include "common.h"
+
+namespace sdb {
+
+constexpr uint32_t kAdjStride = 64;  // adjacency row stride in u32 (DegreeBound <= 64, models/index.go:279)
+
+// Everything one in-flight batch needs besides the index itself.  One per stream.
+struct Workspace {
+  int device = 0;
+  hipStream_t own_stream = nullptr;  // used by host-memory calls
+  uint32_t *bitsets = nullptr;       // [nq][words]: the per-search VisitedBitSet (distset.go:89-116)
+  size_t bitset_bytes = 0;
+  void *scratch = nullptr;  // staging for host-memory calls
+  size_t scratch_bytes = 0;
+  bool busy = false;
+  int ensure_bitsets(size_t bytes);
+  int ensure_scratch(size_t bytes);
+  void release();
+};
+
+struct PQState;  // pq.hip
+
+}  // namespace sdb
+
+struct sdb_index {
+  sdb_index_params P{};
+  sdb::RowLayout lay;
+  uint32_t n = 0;    // rows in use (slot ids are 0..n-1)
+  uint32_t cap = 0;  // rows allocated
+  int64_t start_slot = -1;
+  uint64_t max_node_id = 0;  // vamana.go:47
+  float *d_slab = nullptr;   // [cap][lay.ld] float32, permuted rows (common.h RowLayout)
+  uint32_t *d_adj = nullptr; // [cap][kAdjStride] neighbour slots, kNoSlot padded, edge order kept
+  uint32_t *d_deg = nullptr; // [cap]
+  uint64_t *d_ids = nullptr; // [cap] slot -> node id
+  std::vector<uint64_t> h_ids;
+  bool dense_ids = true;  // ids[i] == ids[0] + i  (then no hash map is needed)
+  std::unordered_map<uint64_t, uint32_t> id2slot;
+  // product quantizer attachment (product.go): codes per slot + tables
+  const sdb_pq *pq = nullptr;
+  uint8_t *d_codes = nullptr;
+  mutable std::mutex mu;
+  mutable std::vector<sdb::Workspace *> pool;
+
+  int64_t slot_of(uint64_t id) const;
+  int reserve(uint32_t rows);
+  sdb::Workspace *acquire_ws() const;
+  void release_ws(sdb::Workspace *ws) const;
+};

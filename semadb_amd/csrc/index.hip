@@ -1,0 +1,530 @@
+// index.hip -- K3 (HBM slab + adjacency loader) and the host side of K2 (search_batch).
+#include <algorithm>
+#include <cmath>
+
+#include "search_kernel.h"
+
+namespace sdb {
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+std::string &last_error_ref() {
+  static thread_local std::string e;
+  return e;
+}
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error_ref() = buf;
+  return code;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspaces
+// ------------------------------------------------------------------------------------------
+int Workspace::ensure_bitsets(size_t bytes) {
+  if (bytes <= bitset_bytes) return SDB_OK;
+  if (bitsets) SDB_HIP(hipFree(bitsets));
+  bitsets = nullptr, bitset_bytes = 0;
+  SDB_HIP(hipMalloc(&bitsets, bytes));
+  bitset_bytes = bytes;
+  return SDB_OK;
+}
+
+int Workspace::ensure_scratch(size_t bytes) {
+  if (bytes <= scratch_bytes) return SDB_OK;
+  if (scratch) SDB_HIP(hipFree(scratch));
+  scratch = nullptr, scratch_bytes = 0;
+  SDB_HIP(hipMalloc(&scratch, bytes));
+  scratch_bytes = bytes;
+  return SDB_OK;
+}
+
+void Workspace::release() {
+  if (bitsets) (void)hipFree(bitsets);
+  if (scratch) (void)hipFree(scratch);
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+  bitsets = nullptr, scratch = nullptr, own_stream = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout kernels
+// ------------------------------------------------------------------------------------------
+// original row-major [n][dim]  ->  slab rows [n][ld] (RowLayout in common.h)
+__global__ void k_permute_rows(const float *__restrict__ src, float *__restrict__ dst, uint32_t n,
+                               uint32_t dim, uint32_t nblk, uint32_t ng, uint32_t tail, uint32_t ld) {
+  const uint32_t row = blockIdx.x;
+  if (row >= n) return;
+  const float *s = src + (size_t)row * dim;
+  float *d = dst + (size_t)row * ld;
+  for (uint32_t t = threadIdx.x; t < ld; t += blockDim.x) {
+    float v = 0.0f;
+    if (t < ng * 128) {
+      uint32_t g = t / 128, r = t % 128, Lx = r / 4, k = r % 4, b = 4 * g + k;
+      if (b < nblk) v = s[32 * b + Lx];
+    } else {
+      uint32_t i = t - ng * 128;
+      if (i < tail) v = s[nblk * 32 + i];
+    }
+    d[t] = v;
+  }
+}
+
+__global__ void k_unpermute_rows(const float *__restrict__ src, float *__restrict__ dst, uint32_t n,
+                                 uint32_t dim, uint32_t nblk, uint32_t ng, uint32_t ld) {
+  const uint32_t row = blockIdx.x;
+  if (row >= n) return;
+  const float *s = src + (size_t)row * ld;
+  float *d = dst + (size_t)row * dim;
+  for (uint32_t e = threadIdx.x; e < dim; e += blockDim.x) {
+    uint32_t b = e / 32, Lx = e % 32;
+    d[e] = b < nblk ? s[(b / 4) * 128 + Lx * 4 + (b % 4)] : s[ng * 128 + Lx];
+  }
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// search launcher
+// ------------------------------------------------------------------------------------------
+template <int NG, bool L2>
+static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  size_t lds = NG < 0 ? (size_t)(a.ng * 128 + 32) * sizeof(float) : 0;
+  if (a.search_size <= 128)
+    hipLaunchKernelGGL((k_greedy_search<NG, L2, 2>), dim3(nq), dim3(64), lds, stream, a);
+  else
+    hipLaunchKernelGGL((k_greedy_search<NG, L2, 8>), dim3(nq), dim3(64), lds, stream, a);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
+template <bool L2>
+static int launch_ng(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  switch (a.ng) {
+    case 0: return launch_nreg<0, L2>(a, nq, stream);
+    case 1: return launch_nreg<1, L2>(a, nq, stream);
+    case 2: return launch_nreg<2, L2>(a, nq, stream);
+    case 3: return launch_nreg<3, L2>(a, nq, stream);
+    case 4: return launch_nreg<4, L2>(a, nq, stream);
+    case 6: return launch_nreg<6, L2>(a, nq, stream);
+    case 8: return launch_nreg<8, L2>(a, nq, stream);
+    default: return launch_nreg<-1, L2>(a, nq, stream);
+  }
+}
+
+int launch_greedy_search(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  if (nq == 0) return SDB_OK;
+  if (a.search_size == 0 || a.search_size > 512)
+    return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
+  if (a.metric == SDB_METRIC_EUCLIDEAN) return launch_ng<true>(a, nq, stream);
+  return launch_ng<false>(a, nq, stream);
+}
+
+}  // namespace sdb
+
+using namespace sdb;
+
+// ------------------------------------------------------------------------------------------
+// sdb_index methods
+// ------------------------------------------------------------------------------------------
+int64_t sdb_index::slot_of(uint64_t id) const {
+  if (n == 0) return -1;
+  if (dense_ids) {
+    uint64_t base = h_ids[0];
+    if (id < base || id - base >= n) return -1;
+    return (int64_t)(id - base);
+  }
+  auto it = id2slot.find(id);
+  return it == id2slot.end() ? -1 : (int64_t)it->second;
+}
+
+int sdb_index::reserve(uint32_t rows) {
+  if (rows <= cap) return SDB_OK;
+  uint32_t ncap = cap ? cap : 1024;
+  while (ncap < rows) ncap = ncap < (1u << 30) ? ncap * 2 : rows;
+  float *nslab = nullptr;
+  uint32_t *nadj = nullptr, *ndeg = nullptr;
+  uint64_t *nids = nullptr;
+  SDB_HIP(hipMalloc(&nslab, (size_t)ncap * lay.ld * sizeof(float)));
+  SDB_HIP(hipMalloc(&nadj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
+  SDB_HIP(hipMalloc(&ndeg, (size_t)ncap * sizeof(uint32_t)));
+  SDB_HIP(hipMalloc(&nids, (size_t)ncap * sizeof(uint64_t)));
+  SDB_HIP(hipMemset(nadj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
+  SDB_HIP(hipMemset(ndeg, 0, (size_t)ncap * sizeof(uint32_t)));
+  if (n) {
+    SDB_HIP(hipMemcpy(nslab, d_slab, (size_t)n * lay.ld * sizeof(float), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(nadj, d_adj, (size_t)n * kAdjStride * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(ndeg, d_deg, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(nids, d_ids, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+  }
+  if (d_slab) (void)hipFree(d_slab);
+  if (d_adj) (void)hipFree(d_adj);
+  if (d_deg) (void)hipFree(d_deg);
+  if (d_ids) (void)hipFree(d_ids);
+  d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_ids = nids, cap = ncap;
+  return SDB_OK;
+}
+
+Workspace *sdb_index::acquire_ws() const {
+  std::lock_guard<std::mutex> g(mu);
+  for (auto *w : pool)
+    if (!w->busy) {
+      w->busy = true;
+      return w;
+    }
+  auto *w = new Workspace();
+  w->device = P.device;
+  w->busy = true;
+  pool.push_back(w);
+  return w;
+}
+
+void sdb_index::release_ws(Workspace *ws) const {
+  std::lock_guard<std::mutex> g(mu);
+  ws->busy = false;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *sdb_last_error(void) { return last_error_ref().c_str(); }
+
+int sdb_abi_version(void) { return SDB_ABI_VERSION; }
+
+int sdb_device_count(int *count) {
+  if (!count) return fail(SDB_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    *count = 0;
+    return fail(SDB_ERR_DEVICE, "no HIP device visible: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return SDB_OK;
+}
+
+int sdb_index_create(const sdb_index_params *p, sdb_index **out) {
+  if (!p || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (p->dim < 1 || p->dim > 4096)  // models/index.go:285-287
+    return fail(SDB_ERR_INVALID, "vector size must be between 1 and 4096, got %u", p->dim);
+  if (p->metric > SDB_METRIC_DOT) return fail(SDB_ERR_INVALID, "unknown distance metric %u", p->metric);
+  if (p->degree_bound < 1 || p->degree_bound > kAdjStride)
+    return fail(SDB_ERR_INVALID, "degree bound must be between 1 and %u, got %u", kAdjStride, p->degree_bound);
+  if (p->search_size < 1 || p->search_size > 512)
+    return fail(SDB_ERR_INVALID, "search size must be between 1 and 512, got %u", p->search_size);
+  if (p->strict) {  // models/index.go:299-307
+    if (p->search_size < 25 || p->search_size > 75)
+      return fail(SDB_ERR_INVALID, "search size must be between 25 and 75, got %u", p->search_size);
+    if (p->degree_bound < 32 || p->degree_bound > 64)
+      return fail(SDB_ERR_INVALID, "degree bound must be between 32 and 64, got %u", p->degree_bound);
+    if (p->alpha < 1.1f || p->alpha > 1.5f)
+      return fail(SDB_ERR_INVALID, "alpha must be between 1.1 and 1.5, got %f", (double)p->alpha);
+  }
+  int ndev = 0;
+  SDB_TRY(sdb_device_count(&ndev));
+  if (p->device < 0 || p->device >= ndev) return fail(SDB_ERR_INVALID, "device %d out of range", p->device);
+  DeviceGuard dg(p->device);
+  if (!dg.ok) return fail(SDB_ERR_DEVICE, "hipSetDevice(%d) failed", p->device);
+  auto *ix = new sdb_index();
+  ix->P = *p;
+  ix->lay = RowLayout(p->dim);
+  int rc = ix->reserve((uint32_t)std::max<uint64_t>(p->capacity ? p->capacity : 1024, 16));
+  if (rc != SDB_OK) {
+    delete ix;
+    return rc;
+  }
+  *out = ix;
+  return SDB_OK;
+}
+
+int sdb_index_destroy(sdb_index *ix) {
+  if (!ix) return SDB_OK;
+  DeviceGuard dg(ix->P.device);
+  (void)hipDeviceSynchronize();
+  if (ix->d_slab) (void)hipFree(ix->d_slab);
+  if (ix->d_adj) (void)hipFree(ix->d_adj);
+  if (ix->d_deg) (void)hipFree(ix->d_deg);
+  if (ix->d_ids) (void)hipFree(ix->d_ids);
+  if (ix->d_codes) (void)hipFree(ix->d_codes);
+  for (auto *w : ix->pool) {
+    w->release();
+    delete w;
+  }
+  delete ix;
+  return SDB_OK;
+}
+
+// copies n original-layout rows (host or device) into slab rows [first, first+n)
+static int store_rows(sdb_index *ix, uint32_t first, uint32_t n, const float *vectors, int mem,
+                      hipStream_t stream) {
+  if (n == 0) return SDB_OK;
+  const RowLayout &l = ix->lay;
+  const float *src = vectors;
+  float *staging = nullptr;
+  if (mem == SDB_MEM_HOST) {
+    SDB_HIP(hipMalloc(&staging, (size_t)n * l.dim * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(staging, vectors, (size_t)n * l.dim * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) {
+      (void)hipFree(staging);
+      return fail(SDB_ERR_DEVICE, "H2D copy failed: %s", hipGetErrorString(e));
+    }
+    src = staging;
+  }
+  hipLaunchKernelGGL(k_permute_rows, dim3(n), dim3(128), 0, stream, src, ix->d_slab + (size_t)first * l.ld, n,
+                     l.dim, l.nblk, l.ng, l.tail, l.ld);
+  hipError_t e = hipGetLastError();
+  if (staging) {
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(staging);
+  }
+  if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "permute launch failed: %s", hipGetErrorString(e));
+  return SDB_OK;
+}
+
+int sdb_index_set_start(sdb_index *ix, const float *vec, int mem) {
+  if (!ix || !vec) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (ix->start_slot >= 0) return SDB_OK;  // vamana.go:95-97: already there
+  if (ix->n != 0) return fail(SDB_ERR_STATE, "start node must be the first node of an empty index");
+  DeviceGuard dg(ix->P.device);
+  SDB_TRY(ix->reserve(1));
+  SDB_TRY(store_rows(ix, 0, 1, vec, mem, nullptr));
+  uint64_t id = SDB_STARTID;
+  SDB_HIP(hipMemcpy(ix->d_ids, &id, sizeof(id), hipMemcpyHostToDevice));
+  SDB_HIP(hipDeviceSynchronize());
+  ix->h_ids.assign(1, id);
+  ix->dense_ids = true;
+  ix->n = 1;
+  ix->start_slot = 0;
+  return SDB_OK;
+}
+
+int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
+                   const uint64_t *offsets, const uint64_t *edges, int mem) {
+  if (!ix || !vectors || !offsets) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (ix->n != 0) return fail(SDB_ERR_STATE, "index is not empty");
+  if (n == 0 || n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "node count %llu out of range", (unsigned long long)n);
+  if (offsets[n] && !edges) return fail(SDB_ERR_INVALID, "edges is NULL");
+  DeviceGuard dg(ix->P.device);
+  SDB_TRY(ix->reserve((uint32_t)n));
+  // id table
+  ix->h_ids.resize(n);
+  bool dense = true;
+  for (uint64_t i = 0; i < n; i++) {
+    ix->h_ids[i] = ids ? ids[i] : i + 1;
+    if (i && ix->h_ids[i] != ix->h_ids[0] + i) dense = false;
+  }
+  ix->dense_ids = dense;
+  ix->id2slot.clear();
+  ix->start_slot = -1;
+  ix->max_node_id = 0;
+  if (!dense) ix->id2slot.reserve(n * 2);
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t id = ix->h_ids[i];
+    if (id == 0) {
+      ix->h_ids.clear();
+      return fail(SDB_ERR_INVALID, "invalid point id: 0");
+    }
+    if (!dense && !ix->id2slot.emplace(id, (uint32_t)i).second) {
+      ix->h_ids.clear();
+      return fail(SDB_ERR_INVALID, "duplicate node id %llu", (unsigned long long)id);
+    }
+    if (id == SDB_STARTID) ix->start_slot = (int64_t)i;
+    else if (id > ix->max_node_id) ix->max_node_id = id;
+  }
+  if (ix->start_slot < 0) {
+    ix->h_ids.clear();
+    ix->id2slot.clear();
+    return fail(SDB_ERR_INVALID, "start node (id %llu) is not among the loaded ids", SDB_STARTID);
+  }
+  ix->n = (uint32_t)n;  // slot_of works from here on
+  // adjacency rows: ids -> slots, unknown ids dropped, first occurrence kept, edge order kept
+  std::vector<uint32_t> adj((size_t)n * kAdjStride, kNoSlot), deg(n, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t *row = adj.data() + (size_t)i * kAdjStride;
+    uint32_t dcnt = 0;
+    for (uint64_t e = offsets[i]; e < offsets[i + 1]; e++) {
+      int64_t s = ix->slot_of(edges[e]);
+      if (s < 0) continue;  // itemcache.go:109-128
+      bool dup = false;
+      for (uint32_t k = 0; k < dcnt; k++) dup |= (row[k] == (uint32_t)s);
+      if (dup) continue;
+      if (dcnt == kAdjStride) {
+        ix->n = 0;
+        return fail(SDB_ERR_INVALID, "node %llu has more than %u edges", (unsigned long long)ix->h_ids[i], kAdjStride);
+      }
+      row[dcnt++] = (uint32_t)s;
+    }
+    deg[i] = dcnt;
+  }
+  SDB_HIP(hipMemcpy(ix->d_adj, adj.data(), adj.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SDB_HIP(hipMemcpy(ix->d_deg, deg.data(), deg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SDB_HIP(hipMemcpy(ix->d_ids, ix->h_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  int rc = store_rows(ix, 0, (uint32_t)n, vectors, mem, nullptr);
+  if (rc != SDB_OK) {
+    ix->n = 0;
+    return rc;
+  }
+  SDB_HIP(hipDeviceSynchronize());
+  return SDB_OK;
+}
+
+int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
+                           uint32_t search_size, const uint64_t *filter_offsets,
+                           const uint64_t *filter_ids, uint64_t *out_ids, float *out_dists,
+                           uint32_t *out_counts, const sdb_search_trace *trace, int mem, void *stream_) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (nq == 0) return SDB_OK;
+  if (!queries || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (limit < 1) return fail(SDB_ERR_INVALID, "invalid limit %u for vector query", limit);
+  if (search_size < limit)  // search.go:23-25
+    return fail(SDB_ERR_INVALID, "searchSize (%u) must be greater than k (%u)", search_size, limit);
+  if (ix->P.strict && (search_size < 25 || search_size > 75 || limit > 75))  // models/search.go:287-297
+    return fail(SDB_ERR_INVALID, "invalid searchSize %u / limit %u for vector query, expected 25-75 / 1-75",
+                search_size, limit);
+  if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
+  if (filter_offsets || filter_ids) return fail(SDB_ERR_INVALID, "filtered search is not on the device path yet");
+  if (nq > 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many queries");
+  DeviceGuard dg(ix->P.device);
+  Workspace *ws = ix->acquire_ws();
+  struct Rel {
+    const sdb_index *ix;
+    Workspace *ws;
+    ~Rel() { ix->release_ws(ws); }
+  } rel{ix, ws};
+  hipStream_t stream = as_stream(stream_);
+  if (mem == SDB_MEM_HOST) {
+    if (!ws->own_stream) SDB_HIP(hipStreamCreateWithFlags(&ws->own_stream, hipStreamNonBlocking));
+    stream = ws->own_stream;
+  }
+  const RowLayout &l = ix->lay;
+  const uint32_t words = ((ix->n + 31) / 32 + 31) & ~31u;  // per-query bitset, 128-byte multiple
+  SDB_TRY(ws->ensure_bitsets((size_t)nq * words * sizeof(uint32_t)));
+  SDB_HIP(hipMemsetAsync(ws->bitsets, 0, (size_t)nq * words * sizeof(uint32_t), stream));  // ClearAll distset.go:101
+
+  SearchArgs a{};
+  a.slab = ix->d_slab, a.adj = ix->d_adj, a.ids = ix->d_ids;
+  a.bitsets = ws->bitsets, a.words_per_query = words;
+  a.dim = l.dim, a.nblk = l.nblk, a.ng = l.ng, a.tail = l.tail, a.ld = l.ld;
+  a.start_slot = (uint32_t)ix->start_slot;
+  a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
+
+  const uint32_t vcap = trace ? trace->visit_cap : 0;
+  if (mem == SDB_MEM_DEVICE) {
+    a.queries = queries;
+    a.out_ids = out_ids, a.out_dists = out_dists, a.out_counts = out_counts;
+    if (trace) {
+      a.tr_ndist = trace->n_dist, a.tr_nhop = trace->n_hop, a.tr_nedges = trace->n_edges;
+      a.tr_visit = trace->visit_ids, a.visit_cap = trace->visit_ids ? vcap : 0;
+    }
+    return launch_greedy_search(a, (uint32_t)nq, stream);
+  }
+  // host memory: stage through one scratch allocation
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_q = carve(nq * l.dim * sizeof(float));
+  const size_t o_ids = carve(nq * limit * sizeof(uint64_t));
+  const size_t o_d = carve(nq * limit * sizeof(float));
+  const size_t o_c = carve(nq * sizeof(uint32_t));
+  const size_t o_nd = carve(nq * sizeof(uint32_t)), o_nh = carve(nq * sizeof(uint32_t)),
+               o_ne = carve(nq * sizeof(uint32_t));
+  const size_t o_v = carve((trace && trace->visit_ids) ? nq * vcap * sizeof(uint64_t) : 0);
+  SDB_TRY(ws->ensure_scratch(off));
+  char *base = static_cast<char *>(ws->scratch);
+  SDB_HIP(hipMemcpyAsync(base + o_q, queries, nq * l.dim * sizeof(float), hipMemcpyHostToDevice, stream));
+  a.queries = reinterpret_cast<float *>(base + o_q);
+  a.out_ids = reinterpret_cast<uint64_t *>(base + o_ids);
+  a.out_dists = reinterpret_cast<float *>(base + o_d);
+  a.out_counts = reinterpret_cast<uint32_t *>(base + o_c);
+  if (trace) {
+    a.tr_ndist = reinterpret_cast<uint32_t *>(base + o_nd);
+    a.tr_nhop = reinterpret_cast<uint32_t *>(base + o_nh);
+    a.tr_nedges = reinterpret_cast<uint32_t *>(base + o_ne);
+    if (trace->visit_ids) a.tr_visit = reinterpret_cast<uint64_t *>(base + o_v), a.visit_cap = vcap;
+  }
+  SDB_HIP(hipMemsetAsync(base + o_ids, 0, o_c - o_ids, stream));
+  SDB_TRY(launch_greedy_search(a, (uint32_t)nq, stream));
+  SDB_HIP(hipMemcpyAsync(out_ids, a.out_ids, nq * limit * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  SDB_HIP(hipMemcpyAsync(out_dists, a.out_dists, nq * limit * sizeof(float), hipMemcpyDeviceToHost, stream));
+  SDB_HIP(hipMemcpyAsync(out_counts, a.out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  if (trace) {
+    if (trace->n_dist) SDB_HIP(hipMemcpyAsync(trace->n_dist, a.tr_ndist, nq * 4, hipMemcpyDeviceToHost, stream));
+    if (trace->n_hop) SDB_HIP(hipMemcpyAsync(trace->n_hop, a.tr_nhop, nq * 4, hipMemcpyDeviceToHost, stream));
+    if (trace->n_edges) SDB_HIP(hipMemcpyAsync(trace->n_edges, a.tr_nedges, nq * 4, hipMemcpyDeviceToHost, stream));
+    if (trace->visit_ids)
+      SDB_HIP(hipMemcpyAsync(trace->visit_ids, a.tr_visit, nq * vcap * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  }
+  SDB_HIP(hipStreamSynchronize(stream));
+  return SDB_OK;
+}
+
+int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) {
+  if (!ix || !bytes) return fail(SDB_ERR_INVALID, "NULL argument");
+  // vecStore.SizeInMemory + nodeStore.SizeInMemory (vamana.go:83-85), as held in HBM
+  *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + kAdjStride * 4 + 4 + 8);
+  return SDB_OK;
+}
+
+int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (n_nodes) *n_nodes = ix->n;
+  if (max_node_id) *max_node_id = ix->max_node_id;
+  if (n_edges) {
+    DeviceGuard dg(ix->P.device);
+    std::vector<uint32_t> deg(ix->n);
+    if (ix->n) SDB_HIP(hipMemcpy(deg.data(), ix->d_deg, (size_t)ix->n * 4, hipMemcpyDeviceToHost));
+    uint64_t t = 0;
+    for (uint32_t d : deg) t += d;
+    *n_edges = t;
+  }
+  return SDB_OK;
+}
+
+int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets, uint64_t *edges) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  DeviceGuard dg(ix->P.device);
+  SDB_HIP(hipDeviceSynchronize());
+  const uint32_t n = ix->n;
+  if (ids)
+    for (uint32_t i = 0; i < n; i++) ids[i] = ix->h_ids[i];
+  if (offsets || edges) {
+    std::vector<uint32_t> adj((size_t)n * kAdjStride), deg(n);
+    if (n) {
+      SDB_HIP(hipMemcpy(adj.data(), ix->d_adj, adj.size() * 4, hipMemcpyDeviceToHost));
+      SDB_HIP(hipMemcpy(deg.data(), ix->d_deg, deg.size() * 4, hipMemcpyDeviceToHost));
+    }
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (offsets) offsets[i] = o;
+      for (uint32_t k = 0; k < deg[i]; k++, o++)
+        if (edges) edges[o] = ix->h_ids[adj[(size_t)i * kAdjStride + k]];
+    }
+    if (offsets) offsets[n] = o;
+  }
+  if (vectors && n) {
+    const RowLayout &l = ix->lay;
+    float *tmp = nullptr;
+    SDB_HIP(hipMalloc(&tmp, (size_t)n * l.dim * sizeof(float)));
+    hipLaunchKernelGGL(k_unpermute_rows, dim3(n), dim3(128), 0, nullptr, ix->d_slab, tmp, n, l.dim, l.nblk, l.ng, l.ld);
+    hipError_t e = hipMemcpy(vectors, tmp, (size_t)n * l.dim * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(e));
+  }
+  return SDB_OK;
+}
+
+}  // extern "C"

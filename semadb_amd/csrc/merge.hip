@@ -1,0 +1,135 @@
+// merge.hip -- the shard fan-out merge of ClusterNode.SearchPoints (cluster/actions.go:291-376).
+//
+// In the 8-GPU layout every GPU holds one shard and answers every query; the per-shard top-k
+// lists are all-gathered over xGMI (RCCL, driven by the host process) and merged here.
+#include "common.h"
+
+namespace sdb {
+
+constexpr int kMergeMaxItems = 2048;  // n_shards * per_shard
+
+// one 64-thread block per query; rank-by-counting under the total order (dist, shard, id)
+__global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard,
+                                                   const uint64_t *__restrict__ ids,
+                                                   const float *__restrict__ dists,
+                                                   const uint32_t *__restrict__ counts, uint32_t limit,
+                                                   uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
+                                                   uint32_t *__restrict__ out_shards,
+                                                   uint32_t *__restrict__ out_counts) {
+  __shared__ float s_d[kMergeMaxItems];
+  __shared__ uint64_t s_id[kMergeMaxItems];
+  __shared__ uint16_t s_sh[kMergeMaxItems];
+  __shared__ uint32_t s_off[65];
+  const uint64_t q = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    uint32_t o = 0;
+    for (uint32_t s = 0; s < n_shards; s++) {
+      s_off[s] = o;
+      uint32_t c = counts[(size_t)s * nq + q];
+      o += c < per_shard ? c : per_shard;
+    }
+    s_off[n_shards] = o;
+  }
+  __syncthreads();
+  const uint32_t total = s_off[n_shards];
+  for (uint32_t s = 0; s < n_shards; s++) {
+    const uint32_t c = s_off[s + 1] - s_off[s];
+    for (uint32_t i = t; i < c; i += 64) {
+      const size_t src = ((size_t)s * nq + q) * per_shard + i;
+      s_d[s_off[s] + i] = dists[src];
+      s_id[s_off[s] + i] = ids[src];
+      s_sh[s_off[s] + i] = (uint16_t)s;
+    }
+  }
+  __syncthreads();
+  // HybridScore = -dist * weight descending (actions.go:362-364) == dist ascending for weight > 0
+  for (uint32_t i = t; i < total; i += 64) {
+    const float d = s_d[i];
+    const uint64_t id = s_id[i];
+    const uint16_t sh = s_sh[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < total; j++) {
+      const float dj = s_d[j];
+      const bool before = dj < d || (dj == d && (s_sh[j] < sh || (s_sh[j] == sh && s_id[j] < id)));
+      rank += before ? 1u : 0u;
+    }
+    if (rank < limit) {  // truncate to the original limit (actions.go:372-374)
+      out_ids[q * limit + rank] = id;
+      out_dists[q * limit + rank] = d;
+      if (out_shards) out_shards[q * limit + rank] = sh;
+    }
+  }
+  if (t == 0) out_counts[q] = total < limit ? total : limit;
+}
+
+}  // namespace sdb
+
+using namespace sdb;
+
+extern "C" {
+
+int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit, uint32_t *out) {
+  if (!out || n_shards == 0) return fail(SDB_ERR_INVALID, "bad argument");
+  // actions.go:291-299: int(float32(limit) * (1/float32(nShards)) * 1.42 + 10)
+  int target = (int)((float)limit * (1.0f / (float)n_shards) * 1.42f + 10.0f);
+  if (target > (int)max_search_limit) target = (int)max_search_limit;
+  if (target > (int)limit) target = (int)limit;
+  *out = (uint32_t)target;
+  return SDB_OK;
+}
+
+int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uint64_t *ids, const float *dists,
+                   const uint32_t *counts, uint32_t limit, uint64_t *out_ids, float *out_dists,
+                   uint32_t *out_shards, uint32_t *out_counts, int mem, int device, void *stream_) {
+  if (nq == 0) return SDB_OK;
+  if (!ids || !dists || !counts || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (n_shards == 0 || n_shards > 64) return fail(SDB_ERR_INVALID, "n_shards must be 1..64, got %u", n_shards);
+  if (limit == 0 || per_shard == 0) return fail(SDB_ERR_INVALID, "limit and per_shard must be positive");
+  if ((uint64_t)n_shards * per_shard > kMergeMaxItems)
+    return fail(SDB_ERR_INVALID, "n_shards * per_shard = %llu exceeds %d", (unsigned long long)n_shards * per_shard,
+                kMergeMaxItems);
+  int ndev = 0;
+  SDB_TRY(sdb_device_count(&ndev));
+  if (device < 0 || device >= ndev) return fail(SDB_ERR_INVALID, "device %d out of range", device);
+  DeviceGuard dg(device);
+  hipStream_t stream = as_stream(stream_);
+  const size_t items = (size_t)n_shards * nq * per_shard;
+  if (mem == SDB_MEM_DEVICE) {
+    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(64), 0, stream, n_shards, nq, per_shard, ids, dists,
+                       counts, limit, out_ids, out_dists, out_shards, out_counts);
+    SDB_HIP(hipGetLastError());
+    return SDB_OK;
+  }
+  char *buf = nullptr;
+  const size_t b_ids = items * 8, b_d = items * 4, b_c = (size_t)n_shards * nq * 4;
+  const size_t b_oi = nq * limit * 8, b_od = nq * limit * 4, b_os = nq * limit * 4, b_oc = nq * 4;
+  SDB_HIP(hipMalloc(&buf, b_ids + b_d + b_c + b_oi + b_od + b_os + b_oc));
+  uint64_t *d_ids = (uint64_t *)buf;
+  uint64_t *d_oi = (uint64_t *)(buf + b_ids);
+  float *d_d = (float *)(buf + b_ids + b_oi);
+  uint32_t *d_c = (uint32_t *)(buf + b_ids + b_oi + b_d);
+  float *d_od = (float *)(buf + b_ids + b_oi + b_d + b_c);
+  uint32_t *d_os = (uint32_t *)(buf + b_ids + b_oi + b_d + b_c + b_od);
+  uint32_t *d_oc = (uint32_t *)(buf + b_ids + b_oi + b_d + b_c + b_od + b_os);
+  hipError_t e = hipMemcpyAsync(d_ids, ids, b_ids, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_d, dists, b_d, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_c, counts, b_c, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_oi, 0, b_oi, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_od, 0, b_od + b_os + b_oc, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(64), 0, stream, n_shards, nq, per_shard, d_ids, d_d,
+                       d_c, limit, d_oi, d_od, d_os, d_oc);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, b_oi, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_dists, d_od, b_od, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess && out_shards) e = hipMemcpyAsync(out_shards, d_os, b_os, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_oc, b_oc, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "topk_merge failed: %s", hipGetErrorString(e));
+  return SDB_OK;
+}
+
+}  // extern "C"

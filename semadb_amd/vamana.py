@@ -1,0 +1,211 @@
+"""Mirror of the reference's vamana package (shard/index/vamana/) over the C ABI.
+
+Same exported surface as the Go package a maintainer would swap out:
+STARTID (vamana.go:28), IndexVectorChange (vamana.go:122-125), NewIndexVamana (vamana.go:54),
+IndexVamana.Search (vamana.go:278), InsertUpdateDelete (vamana.go:127), SizeInMemory (vamana.go:83).
+The index state lives in HBM; this module only marshals.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _buf
+from ._lib import (IndexParams, MEM_DEVICE, MEM_HOST, METRICS, SearchTrace, SemaDBError, check, lib)
+
+STARTID = 1  # vamana.go:28
+
+
+@dataclass
+class IndexVectorVamanaParameters:
+    """models.IndexVectorVamanaParameters (models/index.go:275-282)."""
+    VectorSize: int
+    DistanceMetric: str
+    SearchSize: int = 75
+    DegreeBound: int = 64
+    Alpha: float = 1.2
+
+
+@dataclass
+class SearchVectorVamanaOptions:
+    """models.SearchVectorVamanaOptions (models/search.go:268-275)."""
+    Vector: object
+    SearchSize: int = 75
+    Limit: int = 10
+    Weight: Optional[float] = None
+
+
+@dataclass
+class SearchResult:
+    """models.SearchResult fields the index fills (vamana.go:300-304)."""
+    NodeId: int
+    Distance: np.float32
+    HybridScore: np.float32
+
+
+@dataclass
+class IndexVectorChange:
+    """vamana.IndexVectorChange (vamana.go:122-125); Vector None means delete."""
+    Id: int
+    Vector: object = None
+
+
+@dataclass
+class BatchTrace:
+    n_dist: np.ndarray
+    n_hop: np.ndarray
+    n_edges: np.ndarray
+    visit_ids: Optional[np.ndarray] = None
+
+
+class IndexVamana:
+    """vamana.IndexVamana (vamana.go:36-52) with its state pinned in one MI355X's HBM."""
+
+    def __init__(self, name, params: IndexVectorVamanaParameters, bucket=None, device=0, capacity=0, strict=True):
+        if params.DistanceMetric not in METRICS:
+            raise SemaDBError(1, "unknown distance metric %s" % params.DistanceMetric)
+        self.name, self.parameters, self.device = name, params, device
+        p = IndexParams(params.VectorSize, METRICS[params.DistanceMetric], params.SearchSize, params.DegreeBound,
+                        params.Alpha, device, capacity, 1 if strict else 0)
+        h = C.c_void_p()
+        check(lib().sdb_index_create(C.byref(p), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sdb_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setupStartNode vamana.go:93-120 ------------------------------------------------------
+    def set_start(self, vec):
+        k, p, mem, shape = _buf.as_f32(vec)
+        if int(np.prod(shape)) != self.parameters.VectorSize:
+            raise SemaDBError(1, "start vector has wrong length")
+        check(lib().sdb_index_set_start(self._h, p, mem))
+
+    # ---- bucket -> HBM -------------------------------------------------------------------------
+    def load(self, ids, vectors, offsets, edges):
+        k, vp, mem, shape = _buf.as_f32(vectors)
+        n = shape[0]
+        ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ed = np.ascontiguousarray(edges if len(edges) else [0], dtype=np.uint64)
+        check(lib().sdb_index_load(self._h, n, _buf.np_ptr(ids_a), vp, _buf.np_ptr(off), _buf.np_ptr(ed), mem))
+
+    def export(self, with_vectors=True):
+        n, ne, _ = self.stats()
+        ids = np.zeros(n, dtype=np.uint64)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        edges = np.zeros(max(ne, 1), dtype=np.uint64)
+        vecs = np.zeros((n, self.parameters.VectorSize), dtype=np.float32) if with_vectors else None
+        check(lib().sdb_index_export(self._h, _buf.np_ptr(ids), _buf.np_ptr(vecs), _buf.np_ptr(offsets),
+                                     _buf.np_ptr(edges)))
+        return ids, vecs, offsets, edges[:ne]
+
+    def stats(self):
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().sdb_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def SizeInMemory(self):
+        v = C.c_int64(0)
+        check(lib().sdb_index_size_in_memory(self._h, C.byref(v)))
+        return v.value
+
+    # ---- InsertUpdateDelete vamana.go:127-263 (insert branch on device) --------------------------
+    def InsertUpdateDelete(self, points, round_size=0):
+        """points: iterable of IndexVectorChange.  Inserts go to the device; updates and deletes are
+        the reference's host-side path (prune.go) and are rejected here."""
+        ids, vecs = [], []
+        for ch in points:
+            if ch.Id == STARTID:
+                raise SemaDBError(1, "cannot modify point with start id: %d" % STARTID)  # vamana.go:150-153
+            if ch.Id == 0:
+                raise SemaDBError(1, "invalid point id: %d" % ch.Id)  # vamana.go:154-157
+            if ch.Vector is None:
+                raise SemaDBError(3, "delete/update is not on the device path")
+            ids.append(ch.Id)
+            vecs.append(np.asarray(ch.Vector, dtype=np.float32))
+        if not ids:
+            return
+        self.insert_batch(np.array(ids, dtype=np.uint64), np.stack(vecs), round_size)
+
+    def insert_batch(self, ids, vectors, round_size=0):
+        k, vp, mem, shape = _buf.as_f32(vectors)
+        ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        check(lib().sdb_index_insert_batch(self._h, shape[0], _buf.np_ptr(ids_a), vp, mem, round_size,
+                                           _buf.current_stream(mem)))
+
+    # ---- Search vamana.go:278-310 -------------------------------------------------------------------
+    def Search(self, options: SearchVectorVamanaOptions, filter=None):
+        """Returns (set of node ids, [SearchResult]) like (*roaring64.Bitmap, []models.SearchResult)."""
+        vec = np.ascontiguousarray(options.Vector, dtype=np.float32).reshape(1, -1)
+        if vec.shape[1] != self.parameters.VectorSize:  # models/search.go:198-200 rejects this upstream
+            raise SemaDBError(1, "query vector length %d does not match index %d" %
+                              (vec.shape[1], self.parameters.VectorSize))
+        ids, dists, counts, _ = self.search_batch(vec, options.Limit, options.SearchSize,
+                                                  filters=None if filter is None else [filter])
+        weight = np.float32(1) if options.Weight is None else np.float32(options.Weight)
+        results = []
+        for i in range(int(counts[0])):
+            d = np.float32(dists[0, i])
+            results.append(SearchResult(int(ids[0, i]), d, np.float32(-1) * d * weight))  # vamana.go:303
+        return set(r.NodeId for r in results), results
+
+    def search_batch(self, queries, limit, search_size, filters=None, trace=False, visit_cap=0):
+        """nq queries at once.  numpy in -> numpy out (synchronous); torch CUDA in -> torch out, enqueued
+        on the current stream.  Returns (ids [nq,limit] uint64, dists, counts, BatchTrace|None)."""
+        k, qp, mem, shape = _buf.as_f32(queries)
+        if len(shape) != 2 or shape[1] != self.parameters.VectorSize:
+            raise SemaDBError(1, "query vector length must be %d" % self.parameters.VectorSize)
+        nq = shape[0]
+        f_off = f_ids = None
+        if filters is not None:
+            if len(filters) != nq:
+                raise SemaDBError(1, "one filter per query expected")
+            flat, off = [], [0]
+            for f in filters:
+                flat.extend(sorted(int(v) for v in f))
+                off.append(len(flat))
+            f_off = np.array(off, dtype=np.uint64)
+            f_ids = np.array(flat if flat else [0], dtype=np.uint64)
+        ids, idp = _buf.empty_like_mem(mem, (nq, limit), "uint64", self.device)
+        dists, dp = _buf.empty_like_mem(mem, (nq, limit), "float32", self.device)
+        counts, cp = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
+        tr_struct, tr_out = None, None
+        if trace:
+            nd, ndp = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
+            nh, nhp = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
+            ne, nep = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
+            vis, visp = (None, None)
+            if visit_cap:
+                vis, visp = _buf.empty_like_mem(mem, (nq, visit_cap), "uint64", self.device)
+            tr_struct = SearchTrace(ndp, nhp, nep, visp, visit_cap)
+            tr_out = BatchTrace(nd, nh, ne, vis)
+        check(lib().sdb_index_search_batch(self._h, nq, qp, limit, search_size, _buf.np_ptr(f_off),
+                                           _buf.np_ptr(f_ids), idp, dp, cp,
+                                           C.byref(tr_struct) if tr_struct is not None else None, mem,
+                                           _buf.current_stream(mem)))
+        return ids, dists, counts, tr_out
+
+    # ---- plainStore.DistanceFromFloat plain.go:76-85, batched ------------------------------------------
+    def distance_batch(self, queries, cand_ids):
+        k, qp, mem, shape = _buf.as_f32(queries)
+        cand = np.ascontiguousarray(cand_ids, dtype=np.uint64)
+        nq, nc = cand.shape
+        out, op = _buf.empty_like_mem(mem, (nq, nc), "float32", self.device)
+        check(lib().sdb_index_distance_batch(self._h, nq, qp, nc, _buf.np_ptr(cand), op, mem,
+                                             _buf.current_stream(mem)))
+        return out
+
+
+def NewIndexVamana(name, params, bucket=None, **kw):
+    """vamana.NewIndexVamana (vamana.go:54-81)."""
+    return IndexVamana(name, params, bucket, **kw)

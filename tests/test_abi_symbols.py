@@ -1,0 +1,68 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/semadb_amd.h declares, the
+Python signature table covers the same set, and calls fail loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "semadb_amd.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_functions():
+    names = declared_functions()
+    assert "sdb_index_search_batch" in names and "sdb_distance_batch" in names and len(names) >= 20
+
+
+def test_library_exports_every_declared_symbol():
+    from semadb_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = C.CDLL(_lib.SO_PATH)
+    missing = [n for n in declared_functions() if not hasattr(L, n)]
+    assert not missing, "not exported: %s" % missing
+
+
+def test_python_signature_table_matches_header():
+    from semadb_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+
+
+def test_abi_version_and_error_channel():
+    from semadb_amd import _lib
+    L = _lib.lib()
+    assert L.sdb_abi_version() == 1
+    out = C.c_uint32(0)
+    assert L.sdb_shard_limit(10, 8, 75, C.byref(out)) == 0 and out.value == 10  # actions.go:291-299
+    assert L.sdb_shard_limit(10, 0, 75, C.byref(out)) != 0
+    assert L.sdb_last_error()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without an MI355X every compute entry point must fail, never compute on the CPU."""
+    import numpy as np
+    from semadb_amd import _lib, distance, vamana
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.SemaDBError):
+        distance.distance_batch("euclidean", np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32))
+    with pytest.raises(_lib.SemaDBError):
+        vamana.NewIndexVamana("x", vamana.IndexVectorVamanaParameters(4, "euclidean"))
+
+
+def test_product_path_never_touches_the_oracle():
+    """semadb_amd/ must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "semadb_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "sdb_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

@@ -1,0 +1,75 @@
+"""K1 parity (GPU): batched distances are bit-identical to the oracle's AVX2-order arithmetic."""
+import numpy as np
+import pytest
+
+from tests.helpers import bits
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [1, 2, 3, 7, 31, 32, 33, 64, 96, 100, 128, 129, 384, 385, 768, 1536, 4096]
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+@pytest.mark.parametrize("d", DIMS)
+def test_distance_batch_bit_exact(oracle, metric, d):
+    from semadb_amd import distance
+    rng = np.random.default_rng(d * 7 + len(metric))
+    nq, nc = 5, 77
+    q = (rng.standard_normal((nq, d)) * 3).astype(np.float32)
+    c = (rng.standard_normal((nc, d)) * 3).astype(np.float32)
+    got = distance.distance_batch(metric, q, c)
+    want = oracle.distance_matrix(q, c, metric, oracle.IMPL_ASM)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_reference_vector_table():
+    # distance/distance_test.go:9-21 through the GPU seam (TestASMdotProduct distance_amd64_test.go:12-27)
+    from semadb_amd import distance
+    table = [([0, 0, 0], [0, 0, 0], 0, 0), ([1, 1], [1, 1], 2, 0), ([1, 2, 3], [4, 5, 6], 32, 27),
+             ([-1, -2, -3], [-4, -5, -6], 32, 27), ([-1, 2, 3], [4, -5, 6], 4, 83)]
+    dot = distance.GetFloatDistanceFn("dot")
+    l2 = distance.GetFloatDistanceFn("euclidean")
+    cos = distance.GetFloatDistanceFn("cosine")
+    for x, y, want_dot, want_l2 in table:
+        assert dot(x, y) == np.float32(-want_dot)       # dotProductDistance distance.go:19-21
+        assert l2(x, y) == np.float32(want_l2)
+        assert cos(x, y) == np.float32(1 - want_dot)    # cosineDistance distance.go:23-25
+
+
+def test_unknown_metric_is_an_error():
+    from semadb_amd import distance, SemaDBError
+    with pytest.raises(SemaDBError):
+        distance.GetFloatDistanceFn("manhattan")
+
+
+def test_adversarial_values(oracle):
+    """denormals, huge magnitudes, cancellation, signed zeros: still bit-identical."""
+    from semadb_amd import distance
+    rng = np.random.default_rng(5)
+    d = 384
+    q = rng.standard_normal((4, d)).astype(np.float32)
+    c = rng.standard_normal((6, d)).astype(np.float32)
+    q[0] *= np.float32(1e-38)      # denormal products
+    c[0] *= np.float32(1e-3)
+    q[1] *= np.float32(1e18)       # overflow to inf in L2
+    c[1] *= np.float32(1e18)
+    c[2] = q[2]                    # exact zero distance
+    c[3] = -q[2]
+    q[3, ::2] = 0.0
+    c[4, 1::2] = -0.0
+    for metric in ("euclidean", "cosine", "dot"):
+        got = distance.distance_batch(metric, q, c)
+        want = oracle.distance_matrix(q, c, metric, oracle.IMPL_ASM)
+        assert np.array_equal(bits(got), bits(want)), metric
+
+
+def test_device_memory_path(oracle):
+    import torch
+    from semadb_amd import distance
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal((3, 384)).astype(np.float32)
+    c = rng.standard_normal((130, 384)).astype(np.float32)
+    got = distance.distance_batch("cosine", torch.from_numpy(q).cuda(), torch.from_numpy(c).cuda())
+    torch.cuda.synchronize()
+    want = oracle.distance_matrix(q, c, "cosine", oracle.IMPL_ASM)
+    assert np.array_equal(bits(got.cpu().numpy()), bits(want))
