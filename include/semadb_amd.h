@@ -112,9 +112,10 @@ int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *
 /* IndexVamana.InsertUpdateDelete, insert branch (vamana.go:127-201) -> insertSinglePoint
  * (insert.go:16-68): greedySearch(vec, 1, SearchSize) -> robustPrune (search.go:106-138) ->
  * back-edges with re-prune.  The reference runs NumCPU-1 inserts concurrently, so its graph
- * depends on goroutine interleaving; here inserts run in deterministic rounds of `round_size`
- * points that search one frozen snapshot (round_size = 1 reproduces a sequential
- * insertSinglePoint loop exactly; 0 picks a default that grows with the index).
+ * depends on goroutine interleaving; here inserts run in deterministic rounds whose points search
+ * one frozen snapshot.  A round holds at most `round_size` points (0 = 16384) and never more than
+ * 2 % of the nodes already in the graph, so early rounds are sequential; round_size = 1 reproduces
+ * a sequential insertSinglePoint loop exactly.
  * ids == NULL assigns max_id+1.. in order.  ids 0 and 1 are rejected (vamana.go:150-157). */
 int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
                            int mem, uint32_t round_size, void *stream);

@@ -1,0 +1,470 @@
+// build.hip -- K4: batched Vamana insert (greedy search -> RobustPrune -> back-edges) on device.
+//
+// Restates insertSinglePoint (shard/index/vamana/insert.go:16-68) and robustPrune
+// (shard/index/vamana/search.go:106-138).  The reference runs NumCPU-1 insertSinglePoint workers
+// concurrently (vamana.go:190-196) so its graph depends on goroutine interleaving; here inserts are
+// applied in deterministic rounds: all points of a round search the same frozen snapshot, prune
+// their own candidate lists in parallel, and then every back-edge target B is updated by exactly
+// one wavefront, in insert order.  A round of one point is exactly a sequential insertSinglePoint.
+//
+// All distances use the reference's arithmetic (dist_core.h), so with round_size = 1 the graph is
+// identical, edge for edge, to the oracle's sequential build.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "search_kernel.h"
+
+namespace sdb {
+
+struct BuildArgs {
+  const float *slab;
+  uint32_t *adj;
+  uint32_t *deg;
+  uint32_t dim, nblk, ng, tail, ld;
+  int metric;
+  float alpha;
+  uint32_t R;
+  // round
+  uint32_t first_slot;  // slot of the round's first new node
+  uint32_t nnew;
+  const uint32_t *vis_slots;
+  const float *vis_dists;
+  const uint32_t *vis_count;
+  uint32_t vis_cap;
+  uint64_t *keys_in;   // [nnew*64] (target slot << 32 | a_idx << 6 | edge position)
+  uint64_t *keys_sorted;
+};
+
+constexpr uint64_t kNoKey = ~0ull;
+
+// Distance source for a bound point p (vecStore.DistanceFromPoint, plain.go:87-97): p's slab row in
+// registers (NG >= 0) or in LDS (NG == -1).
+template <int NG>
+struct PointRow {
+  float4 xq[NG > 0 ? NG : 1];
+  float xt;
+};
+
+// robustPrune (search.go:106-138) by one wavefront.
+//   in_slot/in_dist [nc]   candidates in arrival order (LDS)
+//   s_*                    LDS scratch for the sorted copy
+// The candidate list is first sorted by distance, stable (DistSet.Sort distset.go:223-238: insertion
+// sort with strict '<', so equal distances keep arrival order).  Then for each surviving candidate in
+// order: add it as an edge (:118), stop at DegreeBound (:119-121), and mark every later candidate j
+// with alpha * dist(p*, c_j) < c_j.Distance as removed (:132).
+template <int NG, bool L2>
+__device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc, const uint32_t *in_slot,
+                                  const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
+                                  float *qs, int lane) {
+  constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
+  const int L = lane & 31;
+  for (int i = lane; i < nc; i += 64) {
+    const float d = in_dist[i];
+    int rank = 0;
+    for (int j = 0; j < nc; j++) {
+      const float dj = in_dist[j];
+      rank += (dj < d || (dj == d && j < i)) ? 1 : 0;
+    }
+    s_slot[rank] = in_slot[i];
+    s_dist[rank] = d;
+    s_rem[rank] = 0;
+  }
+  __syncthreads();
+  uint32_t my_out = kNoSlot;  // lane e holds edge e of the new row
+  int cnt = 0;
+  int i = 0;
+  while (i < nc) {
+    int found = -1;
+    for (int base = i & ~63; base < nc && found < 0; base += 64) {
+      const int j = base + lane;
+      const bool ok = j >= i && j < nc && !s_rem[j] && s_slot[j] != self_slot;  // :115-117
+      const uint64_t m = __ballot(ok);
+      if (m) found = base + __ffsll((unsigned long long)m) - 1;
+    }
+    if (found < 0) break;
+    const uint32_t p = s_slot[found];
+    if (lane == cnt) my_out = p;  // node.AddNeighbour :118
+    cnt++;
+    if (cnt >= (int)a.R) break;  // :119-121
+    // bind p (DistanceFromPoint :124)
+    PointRow<NG> pr;
+    const float *prow = a.slab + (size_t)p * a.ld;
+    if constexpr (NG >= 0) {
+#pragma unroll
+      for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(prow)[g * 32 + L];
+      if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pr.xt = a.tail ? prow[NG * 128 + L] : 0.0f;
+    } else {
+      __syncthreads();
+      for (uint32_t t = lane; t < a.ld; t += 64) qs[t] = prow[t];
+      __syncthreads();
+    }
+    for (int base = (found + 1) & ~63; base < nc; base += 64) {
+      const int j = base + lane;
+      const bool live = j > found && j < nc && !s_rem[j];
+      const uint32_t cs = live ? s_slot[j] : 0u;
+      const float cdj = live ? s_dist[j] : 0.0f;
+      uint64_t todo = __ballot(live);
+      bool rm = false;
+      while (todo) {
+        int jj[2 * U];
+#pragma unroll
+        for (int k = 0; k < 2 * U; k++) {
+          if (todo) {
+            jj[k] = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+          } else {
+            jj[k] = jj[k > 0 ? k - 1 : 0];
+          }
+        }
+        uint32_t slot[U];
+        float res[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t s0 = rl(cs, jj[2 * u]), s1 = rl(cs, jj[2 * u + 1]);
+          slot[u] = lane < 32 ? s0 : s1;
+        }
+        if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+        else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, qs, slot, res, lane);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+          const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+          if (lane == jj[2 * u]) rm = a.alpha * d0 < cdj;  // :132
+          if (lane == jj[2 * u + 1]) rm = a.alpha * d1 < cdj;
+        }
+      }
+      if (live && rm) s_rem[j] = 1;
+    }
+    __syncthreads();
+    i = found + 1;
+  }
+  // node.edges of `self`, kNoSlot padded
+  a.adj[(size_t)self_slot * kAdjStride + lane] = lane < cnt ? my_out : kNoSlot;
+  if (lane == 0) a.deg[self_slot] = (uint32_t)cnt;
+}
+
+// dynamic LDS carve shared by both prune kernels
+struct PruneLds {
+  uint32_t *in_slot;
+  float *in_dist;
+  uint32_t *s_slot;
+  float *s_dist;
+  uint32_t *s_rem;
+  float *qs;
+  __device__ PruneLds(char *base, uint32_t cap) {
+    in_slot = reinterpret_cast<uint32_t *>(base);
+    in_dist = reinterpret_cast<float *>(in_slot + cap);
+    s_slot = reinterpret_cast<uint32_t *>(in_dist + cap);
+    s_dist = reinterpret_cast<float *>(s_slot + cap);
+    s_rem = reinterpret_cast<uint32_t *>(s_dist + cap);
+    qs = reinterpret_cast<float *>(s_rem + cap);
+  }
+};
+
+static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld) {
+  return (size_t)cap * 20 + (NG < 0 ? (size_t)ld * 4 + 16 : 0);
+}
+
+// robustPrune(nodeA, visitedSet) for every new node of the round (insert.go:29-31), then emit the
+// back-edge requests (insert.go:36) as sortable keys.
+template <int NG, bool L2>
+__global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  PruneLds l(lds_raw, a.vis_cap);
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const uint32_t self = a.first_slot + q;
+  uint32_t nc = a.vis_count[q];
+  if (nc > a.vis_cap) nc = a.vis_cap;
+  for (uint32_t i = lane; i < nc; i += 64) {
+    l.in_slot[i] = a.vis_slots[(size_t)q * a.vis_cap + i];
+    l.in_dist[i] = a.vis_dists[(size_t)q * a.vis_cap + i];
+  }
+  __syncthreads();
+  robust_prune_wave<NG, L2>(a, self, (int)nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane);
+  const uint32_t nb = a.adj[(size_t)self * kAdjStride + lane];  // this lane wrote it
+  a.keys_in[(size_t)q * 64 + lane] =
+      nb == kNoSlot ? kNoKey : ((uint64_t)nb << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
+}
+
+// One wavefront per sorted key; only the first key of each target B proceeds and applies all of B's
+// requests in insert order (insert.go:36-65).
+template <int NG, bool L2>
+__global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const uint32_t cap = 128;
+  PruneLds l(lds_raw, cap);
+  const int lane = threadIdx.x, L = lane & 31;
+  const size_t pos = blockIdx.x;
+  const size_t total = (size_t)a.nnew * 64;
+  const uint64_t key = a.keys_sorted[pos];
+  if (key == kNoKey) return;
+  const uint32_t b = (uint32_t)(key >> 32);
+  if (pos > 0 && (uint32_t)(a.keys_sorted[pos - 1] >> 32) == b) return;  // not the head of B's segment
+  constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
+  uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
+  uint32_t deg = a.deg[b];
+  bool row_dirty = false;
+  for (size_t k = pos; k < total; k++) {
+    const uint64_t kk = a.keys_sorted[k];
+    if (kk == kNoKey || (uint32_t)(kk >> 32) != b) break;
+    const uint32_t anew = a.first_slot + (uint32_t)((kk & 0xFFFFFFFFull) >> 6);
+    if (deg + 1 > a.R) {  // insert.go:47: B is full -> candidateSet = B's neighbours + A, re-prune
+      if (row_dirty) {
+        a.adj[(size_t)b * kAdjStride + lane] = row;
+        row_dirty = false;
+      }
+      // distances from B (distFn = DistanceFromPoint(nB) :49) to its neighbours and to A
+      PointRow<NG> pr;
+      const float *brow = a.slab + (size_t)b * a.ld;
+      if constexpr (NG >= 0) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(brow)[g * 32 + L];
+        if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pr.xt = a.tail ? brow[NG * 128 + L] : 0.0f;
+      } else {
+        __syncthreads();
+        for (uint32_t t = lane; t < a.ld; t += 64) l.qs[t] = brow[t];
+        __syncthreads();
+      }
+      // candidate c: c < deg -> row entry c (lane c), c == deg -> A   (:55-56; Add dedupes, and a new
+      // node can not already be a neighbour)
+      const int nc = (int)deg + 1;
+      for (int c0 = 0; c0 < nc; c0 += 2 * U) {
+        uint32_t slot[U];
+        float res[U];
+        int cidx[2 * U];
+#pragma unroll
+        for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int i0 = cidx[2 * u], i1 = cidx[2 * u + 1];
+          const uint32_t s0 = i0 < (int)deg ? rl(row, i0) : anew;
+          const uint32_t s1 = i1 < (int)deg ? rl(row, i1) : anew;
+          slot[u] = lane < 32 ? s0 : s1;
+        }
+        if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+        else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+          const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+          if (lane == 0) {
+            const int i0 = cidx[2 * u], i1 = cidx[2 * u + 1];
+            l.in_dist[i0] = d0;
+            l.in_dist[i1] = d1;
+          }
+        }
+      }
+      if (lane < (int)deg) l.in_slot[lane] = row;
+      if (lane == 0) l.in_slot[deg] = anew;
+      __syncthreads();
+      robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane);  // :57-58
+      __syncthreads();
+      row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
+      deg = 0;
+      {
+        const uint64_t m = __ballot(row != kNoSlot);
+        deg = (uint32_t)__popcll(m);
+      }
+    } else {  // insert.go:62 nodeB.AddNeighbour(vecA)
+      if (lane == (int)deg) row = anew;
+      deg++;
+      row_dirty = true;
+    }
+  }
+  if (row_dirty) {
+    a.adj[(size_t)b * kAdjStride + lane] = row;
+    if (lane == 0) a.deg[b] = deg;
+  }
+}
+
+template <int NG, bool L2>
+static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, size_t sort_tmp_bytes,
+                        int sort_end_bit) {
+  const size_t lds1 = prune_lds_bytes(a.vis_cap, NG, a.ld);
+  hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a);
+  SDB_HIP(hipGetLastError());
+  size_t tmp = sort_tmp_bytes;
+  SDB_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp, a.keys_in, a.keys_sorted, (int)((size_t)a.nnew * 64), 0,
+                                            sort_end_bit, stream));
+  const size_t lds2 = prune_lds_bytes(128, NG, a.ld);
+  hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
+template <bool L2>
+static int launch_round_ng(const BuildArgs &a, hipStream_t s, void *t, size_t tb, int eb) {
+  switch (a.ng) {
+    case 0: return launch_round<0, L2>(a, s, t, tb, eb);
+    case 1: return launch_round<1, L2>(a, s, t, tb, eb);
+    case 2: return launch_round<2, L2>(a, s, t, tb, eb);
+    case 3: return launch_round<3, L2>(a, s, t, tb, eb);
+    case 4: return launch_round<4, L2>(a, s, t, tb, eb);
+    case 6: return launch_round<6, L2>(a, s, t, tb, eb);
+    case 8: return launch_round<8, L2>(a, s, t, tb, eb);
+    default: return launch_round<-1, L2>(a, s, t, tb, eb);
+  }
+}
+
+__global__ void k_fill_u64(uint64_t *p, uint64_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace sdb
+
+using namespace sdb;
+
+// defined in index.hip
+extern "C" int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id);
+
+namespace sdb {
+int store_rows_public(sdb_index *ix, uint32_t first, uint32_t n, const float *dev_vectors, hipStream_t stream);
+}
+
+extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem,
+                                      uint32_t round_size, void *stream_) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (n == 0) return SDB_OK;
+  if (!vectors) return fail(SDB_ERR_INVALID, "vectors is NULL");
+  if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
+  if (ix->pq) return fail(SDB_ERR_STATE, "insert into a quantized index is not on the device path yet");
+  if ((uint64_t)ix->n + n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many nodes");
+  // ---- ids: vamana.go:150-157 rejects 0 and the start id; an existing id would be an update
+  std::vector<uint64_t> new_ids(n);
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t id = ids ? ids[i] : std::max<uint64_t>(ix->max_node_id, SDB_STARTID) + 1 + i;
+    if (id == SDB_STARTID) return fail(SDB_ERR_INVALID, "cannot modify point with start id: %llu", SDB_STARTID);
+    if (id == 0) return fail(SDB_ERR_INVALID, "invalid point id: 0");
+    new_ids[i] = id;
+  }
+  {
+    // duplicates inside the batch or against the index
+    std::vector<uint64_t> sorted(new_ids);
+    std::sort(sorted.begin(), sorted.end());
+    for (uint64_t i = 1; i < n; i++)
+      if (sorted[i] == sorted[i - 1]) return fail(SDB_ERR_EXISTS, "duplicate id %llu in batch", (unsigned long long)sorted[i]);
+    for (uint64_t i = 0; i < n; i++)
+      if (ix->slot_of(new_ids[i]) >= 0)
+        return fail(SDB_ERR_EXISTS, "point %llu exists: updates are not on the device path", (unsigned long long)new_ids[i]);
+  }
+  DeviceGuard dg(ix->P.device);
+  hipStream_t stream = as_stream(stream_);
+  const RowLayout &l = ix->lay;
+  const uint32_t n0 = ix->n;
+  SDB_TRY(ix->reserve(n0 + (uint32_t)n));
+  // ---- stage the vectors (original layout) on device; they double as the search queries
+  const float *dvec = vectors;
+  float *staging = nullptr;
+  if (mem == SDB_MEM_HOST) {
+    SDB_HIP(hipMalloc(&staging, n * l.dim * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(staging, vectors, n * l.dim * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) {
+      (void)hipFree(staging);
+      return fail(SDB_ERR_DEVICE, "H2D copy failed: %s", hipGetErrorString(e));
+    }
+    dvec = staging;
+  }
+  struct Cleanup {
+    std::vector<void *> ptrs;
+    hipStream_t s;
+    ~Cleanup() {
+      (void)hipStreamSynchronize(s);
+      for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    }
+  } cleanup{{staging}, stream};
+  // vecStore.Set for the whole batch (insert.go:17): rows are unreachable until they get in-edges
+  SDB_TRY(store_rows_public(ix, n0, (uint32_t)n, dvec, stream));
+  SDB_HIP(hipMemcpyAsync(ix->d_ids + n0, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+  // host-side id bookkeeping
+  {
+    bool dense = ix->dense_ids;
+    for (uint64_t i = 0; i < n; i++) {
+      if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
+        dense = false;  // switch to the hash map
+        ix->id2slot.reserve((ix->h_ids.size() + n) * 2);
+        for (size_t s = 0; s < ix->h_ids.size(); s++) ix->id2slot.emplace(ix->h_ids[s], (uint32_t)s);
+      }
+      if (!dense) ix->id2slot.emplace(new_ids[i], (uint32_t)ix->h_ids.size());
+      ix->h_ids.push_back(new_ids[i]);
+      if (new_ids[i] > ix->max_node_id) ix->max_node_id = new_ids[i];  // vamana.go:166-168
+    }
+    ix->dense_ids = dense;
+  }
+  // ---- per-round buffers, sized for the largest round
+  const uint32_t L = ix->P.search_size;
+  const uint32_t vis_cap = std::max<uint32_t>(1024, 4 * L);
+  uint32_t max_round = round_size ? round_size : 16384;
+  if (max_round > n) max_round = (uint32_t)n;
+  const uint32_t total_rows = n0 + (uint32_t)n;
+  const uint32_t words = ((total_rows + 31) / 32 + 31) & ~31u;
+  uint32_t *bitsets = nullptr, *vis_slots = nullptr, *vis_count = nullptr;
+  float *vis_dists = nullptr;
+  uint64_t *keys_in = nullptr, *keys_sorted = nullptr;
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int end_bit = 64;
+  {
+    int b = 32;
+    while (b < 64 && (total_rows >> (b - 32)) != 0) b++;
+    end_bit = b;
+  }
+  SDB_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                            (int)((size_t)max_round * 64), 0, end_bit, stream));
+  SDB_HIP(hipMalloc(&bitsets, (size_t)max_round * words * 4));
+  cleanup.ptrs.push_back(bitsets);
+  SDB_HIP(hipMalloc(&vis_slots, (size_t)max_round * vis_cap * 4));
+  cleanup.ptrs.push_back(vis_slots);
+  SDB_HIP(hipMalloc(&vis_dists, (size_t)max_round * vis_cap * 4));
+  cleanup.ptrs.push_back(vis_dists);
+  SDB_HIP(hipMalloc(&vis_count, (size_t)max_round * 4));
+  cleanup.ptrs.push_back(vis_count);
+  SDB_HIP(hipMalloc(&keys_in, (size_t)max_round * 64 * 8));
+  cleanup.ptrs.push_back(keys_in);
+  SDB_HIP(hipMalloc(&keys_sorted, (size_t)max_round * 64 * 8));
+  cleanup.ptrs.push_back(keys_sorted);
+  SDB_HIP(hipMalloc(&sort_tmp, sort_tmp_bytes ? sort_tmp_bytes : 16));
+  cleanup.ptrs.push_back(sort_tmp);
+
+  uint64_t done = 0;
+  while (done < n) {
+    const uint32_t cur = n0 + (uint32_t)done;  // nodes in the graph so far
+    // a round never exceeds 2 % of the nodes already in the graph (points of one round do not see each
+    // other, so early rounds are sequential and rounds grow with the graph); round_size caps it
+    uint32_t rs = (uint32_t)((double)cur * 0.02);
+    if (rs < 1) rs = 1;
+    if (rs > max_round) rs = max_round;
+    if (rs > n - done) rs = (uint32_t)(n - done);
+    // ---- greedySearch(vec, 1, SearchSize, nil) for every point of the round (insert.go:22)
+    SDB_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
+    SearchArgs sa{};
+    sa.slab = ix->d_slab, sa.adj = ix->d_adj, sa.ids = ix->d_ids;
+    sa.bitsets = bitsets, sa.words_per_query = words;
+    sa.queries = dvec + done * l.dim;
+    sa.dim = l.dim, sa.nblk = l.nblk, sa.ng = l.ng, sa.tail = l.tail, sa.ld = l.ld;
+    sa.start_slot = (uint32_t)ix->start_slot;
+    sa.search_size = L, sa.limit = 1, sa.metric = (int)ix->P.metric;
+    sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
+    SDB_TRY(launch_greedy_search(sa, rs, stream));
+    // ---- robustPrune + back-edges
+    BuildArgs ba{};
+    ba.slab = ix->d_slab, ba.adj = ix->d_adj, ba.deg = ix->d_deg;
+    ba.dim = l.dim, ba.nblk = l.nblk, ba.ng = l.ng, ba.tail = l.tail, ba.ld = l.ld;
+    ba.metric = (int)ix->P.metric, ba.alpha = ix->P.alpha, ba.R = ix->P.degree_bound;
+    ba.first_slot = cur, ba.nnew = rs;
+    ba.vis_slots = vis_slots, ba.vis_dists = vis_dists, ba.vis_count = vis_count, ba.vis_cap = vis_cap;
+    ba.keys_in = keys_in, ba.keys_sorted = keys_sorted;
+    int rc = ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
+                                                  : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit);
+    if (rc != SDB_OK) return rc;
+    done += rs;
+    ix->n = n0 + (uint32_t)done;
+  }
+  SDB_HIP(hipStreamSynchronize(stream));
+  return SDB_OK;
+}

@@ -266,6 +266,7 @@ int sdb_index_destroy(sdb_index *ix) {
 }
 
 // copies n original-layout rows (host or device) into slab rows [first, first+n)
+static int store_rows(sdb_index *ix, uint32_t first, uint32_t n, const float *vectors, int mem, hipStream_t stream);
 static int store_rows(sdb_index *ix, uint32_t first, uint32_t n, const float *vectors, int mem,
                       hipStream_t stream) {
   if (n == 0) return SDB_OK;
@@ -528,3 +529,9 @@ int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_
 }
 
 }  // extern "C"
+
+namespace sdb {
+int store_rows_public(sdb_index *ix, uint32_t first, uint32_t n, const float *dev_vectors, hipStream_t stream) {
+  return store_rows(ix, first, n, dev_vectors, SDB_MEM_DEVICE, stream);
+}
+}  // namespace sdb

@@ -2,9 +2,6 @@
 #include "common.h"
 using namespace sdb;
 extern "C" {
-int sdb_index_insert_batch(sdb_index *, uint64_t, const uint64_t *, const float *, int, uint32_t, void *) {
-  return fail(SDB_ERR_STATE, "insert_batch: not implemented yet");
-}
 int sdb_kmeans_fit(float *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, float *,
                    uint8_t *, uint32_t *, int, int, void *) {
   return fail(SDB_ERR_STATE, "kmeans_fit: not implemented yet");
