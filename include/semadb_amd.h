@@ -151,6 +151,15 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
 int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, uint64_t nc,
                              const uint64_t *cand_ids, float *out, int mem, void *stream);
 
+/* Measurement hook (the reference logs the greedy-search duration at debug level, vamana.go:284):
+ * when enabled, HIP events are recorded on the launch stream immediately around the K2 kernel of
+ * every search_batch (not thread-safe: a single measuring caller); sdb_index_last_search_ms waits for
+ * the most recent one and returns its duration in milliseconds. */
+int sdb_index_set_profiling(sdb_index *ix, int enabled);
+int sdb_index_last_search_ms(sdb_index *ix, float *ms);
+/* durations of the most recent profiled K2 launches (oldest first, at most 256 kept); resets the log */
+int sdb_index_profile_read(sdb_index *ix, float *ms, uint32_t cap, uint32_t *n);
+
 /* cache.Cachable.SizeInMemory (vamana.go:83-85): bytes of HBM held */
 int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes);
 /* number of nodes (start node included) / edges */

@@ -1,0 +1,79 @@
+"""Mirror of the shard fan-out in ClusterNode.SearchPoints (cluster/actions.go:275-379).
+
+The reference scatters a query to every shard over msgpack net/rpc, gathers the per-shard results
+and sorts/truncates them (actions.go:316-376).  On one 8 x MI355X node the shards live one per GPU in
+one process per GPU; the gather step is a single RCCL all-gather over xGMI (torch.distributed backend
+"nccl") of the fixed-size per-shard top-k blocks, and the merge runs on device (merge.hip).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _buf
+from ._lib import MEM_DEVICE, SemaDBError, check, lib
+
+
+def shard_limit(limit, n_shards, max_search_limit=75):
+    """per-shard target limit, cluster/actions.go:291-299"""
+    out = C.c_uint32(0)
+    check(lib().sdb_shard_limit(limit, n_shards, max_search_limit, C.byref(out)))
+    return out.value
+
+
+def topk_merge(ids, dists, counts, limit, device=0):
+    """ids/dists [n_shards, nq, per_shard], counts [n_shards, nq] -> merged (ids, dists, shards, counts).
+
+    numpy in -> numpy out; torch CUDA in -> torch out on the current stream.  Ties break by
+    (shard, id) ascending (the reference's sort is unstable there, actions.go:357-364)."""
+    if _buf.is_torch_cuda(ids):
+        import torch
+        n_shards, nq, per = ids.shape
+        ids, dists, counts = ids.contiguous(), dists.contiguous(), counts.contiguous()
+        o_ids = torch.zeros((nq, limit), dtype=torch.int64, device=ids.device)
+        o_d = torch.zeros((nq, limit), dtype=torch.float32, device=ids.device)
+        o_s = torch.zeros((nq, limit), dtype=torch.int32, device=ids.device)
+        o_c = torch.zeros((nq,), dtype=torch.int32, device=ids.device)
+        check(lib().sdb_topk_merge(n_shards, nq, per, C.c_void_p(ids.data_ptr()), C.c_void_p(dists.data_ptr()),
+                                   C.c_void_p(counts.data_ptr()), limit, C.c_void_p(o_ids.data_ptr()),
+                                   C.c_void_p(o_d.data_ptr()), C.c_void_p(o_s.data_ptr()),
+                                   C.c_void_p(o_c.data_ptr()), MEM_DEVICE, device, _buf.current_stream(MEM_DEVICE)))
+        return o_ids, o_d, o_s, o_c
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    dists = np.ascontiguousarray(dists, dtype=np.float32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    n_shards, nq, per = ids.shape
+    o_ids = np.zeros((nq, limit), dtype=np.uint64)
+    o_d = np.zeros((nq, limit), dtype=np.float32)
+    o_s = np.zeros((nq, limit), dtype=np.uint32)
+    o_c = np.zeros((nq,), dtype=np.uint32)
+    check(lib().sdb_topk_merge(n_shards, nq, per, _buf.np_ptr(ids), _buf.np_ptr(dists), _buf.np_ptr(counts), limit,
+                               _buf.np_ptr(o_ids), _buf.np_ptr(o_d), _buf.np_ptr(o_s), _buf.np_ptr(o_c), 0, device,
+                               None))
+    return o_ids, o_d, o_s, o_c
+
+
+def allgather_topk(ids, dists, counts):
+    """The exchange step: every rank contributes its shard's [nq, per_shard] block and receives the
+    shard-major [world, nq, per_shard] buffers the merge consumes.  Works on any torch.distributed
+    backend (nccl = RCCL over xGMI on the GPU box, gloo for CPU tests).  Message size per rank:
+    nq * per_shard * 12 B + nq * 4 B (120 KB at 1024 x 10): latency-bound, one step."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    ids = ids.contiguous()
+    dists = dists.contiguous()
+    counts = counts.contiguous()
+    g_ids = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+    g_d = torch.empty((world,) + tuple(dists.shape), dtype=dists.dtype, device=dists.device)
+    g_c = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(g_ids, ids)
+    dist.all_gather_into_tensor(g_d, dists)
+    dist.all_gather_into_tensor(g_c, counts)
+    return g_ids, g_d, g_c
+
+
+def allgather_merge(ids, dists, counts, limit, device=0):
+    """all-gather the per-shard results and merge them on this rank's GPU (every rank ends up with the
+    merged answer, like every SemaDB server can answer the REST call)."""
+    g_ids, g_d, g_c = allgather_topk(ids, dists, counts)
+    return topk_merge(g_ids, g_d, g_c, limit, device=device)

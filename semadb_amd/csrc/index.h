@@ -45,6 +45,11 @@ struct sdb_index {
   // product quantizer attachment (product.go): codes per slot + tables
   const sdb_pq *pq = nullptr;
   uint8_t *d_codes = nullptr;
+  // measurement hook: events around the last K2 launch
+  bool profiling = false;
+  static constexpr uint32_t kProfRing = 256;
+  std::vector<hipEvent_t> ev0, ev1;  // ring of event pairs
+  uint64_t prof_count = 0;           // launches recorded since the last read
   mutable std::mutex mu;
   mutable std::vector<sdb::Workspace *> pool;
 

@@ -257,6 +257,10 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_deg) (void)hipFree(ix->d_deg);
   if (ix->d_ids) (void)hipFree(ix->d_ids);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
+  for (auto e : ix->ev0)
+    if (e) (void)hipEventDestroy(e);
+  for (auto e : ix->ev1)
+    if (e) (void)hipEventDestroy(e);
   for (auto *w : ix->pool) {
     w->release();
     delete w;
@@ -421,6 +425,17 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
+  auto launch = [&]() -> int {
+    const bool prof = ix->profiling && !ix->ev0.empty();
+    const uint32_t slot = (uint32_t)(ix->prof_count % sdb_index::kProfRing);
+    if (prof) (void)hipEventRecord(ix->ev0[slot], stream);
+    int rc = launch_greedy_search(a, (uint32_t)nq, stream);
+    if (prof) {
+      (void)hipEventRecord(ix->ev1[slot], stream);
+      ix->prof_count++;
+    }
+    return rc;
+  };
   if (mem == SDB_MEM_DEVICE) {
     a.queries = queries;
     a.out_ids = out_ids, a.out_dists = out_dists, a.out_counts = out_counts;
@@ -428,7 +443,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
       a.tr_ndist = trace->n_dist, a.tr_nhop = trace->n_hop, a.tr_nedges = trace->n_edges;
       a.tr_visit = trace->visit_ids, a.visit_cap = trace->visit_ids ? vcap : 0;
     }
-    return launch_greedy_search(a, (uint32_t)nq, stream);
+    return launch();
   }
   // host memory: stage through one scratch allocation
   size_t off = 0;
@@ -458,7 +473,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     if (trace->visit_ids) a.tr_visit = reinterpret_cast<uint64_t *>(base + o_v), a.visit_cap = vcap;
   }
   SDB_HIP(hipMemsetAsync(base + o_ids, 0, o_c - o_ids, stream));
-  SDB_TRY(launch_greedy_search(a, (uint32_t)nq, stream));
+  SDB_TRY(launch());
   SDB_HIP(hipMemcpyAsync(out_ids, a.out_ids, nq * limit * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   SDB_HIP(hipMemcpyAsync(out_dists, a.out_dists, nq * limit * sizeof(float), hipMemcpyDeviceToHost, stream));
   SDB_HIP(hipMemcpyAsync(out_counts, a.out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -470,6 +485,49 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
       SDB_HIP(hipMemcpyAsync(trace->visit_ids, a.tr_visit, nq * vcap * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   }
   SDB_HIP(hipStreamSynchronize(stream));
+  return SDB_OK;
+}
+
+int sdb_index_set_profiling(sdb_index *ix, int enabled) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  DeviceGuard dg(ix->P.device);
+  if (enabled && ix->ev0.empty()) {
+    ix->ev0.resize(sdb_index::kProfRing, nullptr);
+    ix->ev1.resize(sdb_index::kProfRing, nullptr);
+    for (uint32_t i = 0; i < sdb_index::kProfRing; i++) {
+      SDB_HIP(hipEventCreate(&ix->ev0[i]));
+      SDB_HIP(hipEventCreate(&ix->ev1[i]));
+    }
+  }
+  ix->profiling = enabled != 0;
+  ix->prof_count = 0;
+  return SDB_OK;
+}
+
+int sdb_index_profile_read(sdb_index *ix, float *ms, uint32_t cap, uint32_t *n) {
+  if (!ix || !ms || !n) return fail(SDB_ERR_INVALID, "NULL argument");
+  *n = 0;
+  if (ix->ev0.empty()) return fail(SDB_ERR_STATE, "profiling was never enabled");
+  DeviceGuard dg(ix->P.device);
+  uint64_t have = std::min<uint64_t>(ix->prof_count, sdb_index::kProfRing);
+  if (have > cap) have = cap;
+  for (uint64_t k = 0; k < have; k++) {
+    const uint32_t slot = (uint32_t)((ix->prof_count - have + k) % sdb_index::kProfRing);
+    SDB_HIP(hipEventSynchronize(ix->ev1[slot]));
+    SDB_HIP(hipEventElapsedTime(&ms[k], ix->ev0[slot], ix->ev1[slot]));
+  }
+  *n = (uint32_t)have;
+  ix->prof_count = 0;
+  return SDB_OK;
+}
+
+int sdb_index_last_search_ms(sdb_index *ix, float *ms) {
+  if (!ix || !ms) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (!ix->profiling || ix->prof_count == 0) return fail(SDB_ERR_STATE, "no profiled search_batch yet");
+  DeviceGuard dg(ix->P.device);
+  const uint32_t slot = (uint32_t)((ix->prof_count - 1) % sdb_index::kProfRing);
+  SDB_HIP(hipEventSynchronize(ix->ev1[slot]));
+  SDB_HIP(hipEventElapsedTime(ms, ix->ev0[slot], ix->ev1[slot]));
   return SDB_OK;
 }
 

@@ -114,6 +114,21 @@ class IndexVamana:
         check(lib().sdb_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def set_profiling(self, enabled=True):
+        check(lib().sdb_index_set_profiling(self._h, 1 if enabled else 0))
+
+    def last_search_ms(self):
+        v = C.c_float(0)
+        check(lib().sdb_index_last_search_ms(self._h, C.byref(v)))
+        return v.value
+
+    def profile_read(self):
+        """kernel durations (ms) of the profiled K2 launches since the last read, oldest first"""
+        buf = np.zeros(256, dtype=np.float32)
+        n = C.c_uint32(0)
+        check(lib().sdb_index_profile_read(self._h, _buf.np_ptr(buf), 256, C.byref(n)))
+        return buf[:n.value].copy()
+
     def SizeInMemory(self):
         v = C.c_int64(0)
         check(lib().sdb_index_size_in_memory(self._h, C.byref(v)))
