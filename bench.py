@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--dist", default="latent:24")
     ap.add_argument("--query-batches", type=int, default=10, help="distinct query batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-repeat", type=int, default=4)
+    ap.add_argument("--cpu-repeat", type=int, default=2)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -285,7 +285,7 @@ def cpu_baseline(a, ix, queries, k, L):
     log("cpu baseline: graph exported and loaded into the oracle in %.1fs" % (time.time() - t0))
     qb = queries.cpu().numpy()
     nb, nq, d = qb.shape
-    threads = orc.max_threads()
+    threads = orc.effective_cpus()  # affinity capped by the cgroup quota
     # all cores, one query per thread (goroutine-per-request); bounded sample = the distinct batches, repeated
     sample = np.concatenate([qb.reshape(nb * nq, d)] * a.cpu_repeat)
     o.search_batch(sample[:nq], k, L, n_threads=threads)  # warm

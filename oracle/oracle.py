@@ -351,3 +351,24 @@ def has_avx2():
 
 def max_threads():
     return int(lib().orc_max_threads())
+
+
+def effective_cpus():
+    """cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a container
+    can see 256 CPUs and be allowed 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)

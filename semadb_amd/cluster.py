@@ -66,9 +66,10 @@ def allgather_topk(ids, dists, counts):
     g_ids = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
     g_d = torch.empty((world,) + tuple(dists.shape), dtype=dists.dtype, device=dists.device)
     g_c = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(g_ids, ids)
-    dist.all_gather_into_tensor(g_d, dists)
-    dist.all_gather_into_tensor(g_c, counts)
+    # concatenated-along-dim-0 views of the shard-major buffers (the form every backend accepts)
+    dist.all_gather_into_tensor(g_ids.view((-1,) + tuple(ids.shape[1:])), ids)
+    dist.all_gather_into_tensor(g_d.view((-1,) + tuple(dists.shape[1:])), dists)
+    dist.all_gather_into_tensor(g_c.view((-1,) + tuple(counts.shape[1:])), counts)
     return g_ids, g_d, g_c
 
 

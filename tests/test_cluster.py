@@ -1,0 +1,131 @@
+"""Multi-shard path: the exchange step on 2 ranks over gloo (CPU), and the device merge kernel against
+the oracle's restatement of cluster/actions.go:357-376 (GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_results(rank, nq, per):
+    """deterministic per-shard top-k lists: ascending distances, ids unique per shard"""
+    rng = np.random.default_rng(100 + rank)
+    d = np.sort(rng.random((nq, per)).astype(np.float32), axis=1)
+    ids = (rng.permutation(nq * per).reshape(nq, per) + 2).astype(np.int64)
+    counts = np.full(nq, per, dtype=np.int32)
+    counts[rank] = per - 3  # one ragged query per shard
+    return ids, d, counts
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semadb_amd import cluster
+    nq, per = 16, 10
+    ids, d, c = _shard_results(rank, nq, per)
+    g_ids, g_d, g_c = cluster.allgather_topk(torch.from_numpy(ids), torch.from_numpy(d), torch.from_numpy(c))
+    q.put((rank, g_ids.numpy(), g_d.numpy(), g_c.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_exchange_two_ranks_gloo(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, nq, per, limit = 2, 16, 10, 10
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [_shard_results(r, nq, per) for r in range(world)]
+    for rank, g_ids, g_d, g_c in got:
+        # shard-major layout [world, nq, per], identical on every rank
+        for s in range(world):
+            assert np.array_equal(g_ids[s], expect[s][0]) and np.array_equal(g_d[s], expect[s][1])
+            assert np.array_equal(g_c[s], expect[s][2])
+        # merging the gathered buffer with the reference's rule gives the global top-k
+        for qi in range(nq):
+            m_ids, m_d, m_s = oracle.cluster_merge(g_ids[:, qi, :].astype(np.uint64), g_d[:, qi, :], g_c[:, qi], limit)
+            pool = sorted((float(expect[s][1][qi, j]), s, int(expect[s][0][qi, j]))
+                          for s in range(world) for j in range(int(expect[s][2][qi])))[:limit]
+            assert [p[2] for p in pool] == [int(v) for v in m_ids]
+            assert [p[1] for p in pool] == [int(v) for v in m_s]
+
+
+def test_shard_limit_rule():
+    # cluster/actions.go:291-299 through the C ABI (pure host arithmetic, no GPU needed)
+    from semadb_amd import cluster
+    assert cluster.shard_limit(10, 8) == 10
+    assert cluster.shard_limit(100, 5) == 38
+    assert cluster.shard_limit(75, 1) == 75
+    assert cluster.shard_limit(100, 1, 75) == 75
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards,per,limit", [(1, 10, 10), (2, 10, 10), (8, 10, 10), (8, 75, 75), (5, 38, 100)])
+def test_topk_merge_matches_reference_rule(oracle, n_shards, per, limit):
+    from semadb_amd import cluster
+    rng = np.random.default_rng(n_shards * 100 + per)
+    nq = 37
+    d = np.sort(rng.integers(0, 50, size=(n_shards, nq, per)).astype(np.float32) / 8, axis=2)  # many ties
+    ids = rng.integers(2, 10 ** 6, size=(n_shards, nq, per)).astype(np.uint64)
+    counts = rng.integers(0, per + 1, size=(n_shards, nq)).astype(np.uint32)
+    o_ids, o_d, o_s, o_c = cluster.topk_merge(ids, d, counts, limit)
+    for q in range(nq):
+        w_ids, w_d, w_s = oracle.cluster_merge(ids[:, q, :], d[:, q, :], counts[:, q].astype(np.int32), limit)
+        n = len(w_ids)
+        assert int(o_c[q]) == n
+        assert np.array_equal(o_ids[q, :n], w_ids) and np.array_equal(o_d[q, :n], w_d)
+        assert np.array_equal(o_s[q, :n].astype(np.int32), w_s)
+
+
+@pytest.mark.gpu
+def test_sharded_search_equals_single_index_union(oracle):
+    """Two shards on one GPU, merged with the cluster rule, against brute force over the union: the
+    fan-out path end to end (device tensors, as bench.py drives it)."""
+    import torch
+    from semadb_amd import cluster, vamana
+    from tests.helpers import start_vector, unit_rows
+    rng = np.random.default_rng(2)
+    d, n = 32, 2000
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    def rows(m):
+        x = rng.standard_normal((m, 8)).astype(np.float32) @ lat
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    shards = [rows(n), rows(n)]
+    q = rows(64)
+    res = []
+    for s, base in enumerate(shards):
+        ix = vamana.NewIndexVamana("s%d" % s, vamana.IndexVectorVamanaParameters(d, "cosine", 75, 64, 1.2))
+        ix.set_start(start_vector(rng, d))
+        ix.insert_batch(None, base)
+        ids, dist, cnt, _ = ix.search_batch(torch.from_numpy(q).cuda(), 10, 75)
+        res.append((ids, dist, cnt))
+        ix.close()
+    g_ids = torch.stack([r[0] for r in res]); g_d = torch.stack([r[1] for r in res]); g_c = torch.stack([r[2] for r in res])
+    m_ids, m_d, m_s, m_c = cluster.topk_merge(g_ids, g_d, g_c, 10)
+    torch.cuda.synchronize()
+    m_ids, m_s = m_ids.cpu().numpy(), m_s.cpu().numpy()
+    hits = 0
+    for i in range(64):
+        sims = np.concatenate([q[i] @ shards[0].T, q[i] @ shards[1].T])
+        top = np.argsort(-sims)[:10]
+        truth = set((int(t // n), int(t % n) + 2) for t in top)
+        hits += len(truth & set((int(m_s[i, j]), int(m_ids[i, j])) for j in range(10)))
+    assert hits / 640 >= 0.95
