@@ -18,7 +18,10 @@ struct Workspace {
   size_t bitset_bytes = 0;
   void *scratch = nullptr;  // staging for host-memory calls
   size_t scratch_bytes = 0;
+  float *lut = nullptr;  // [nq][M*K] product-quantizer distance tables of the batch
+  size_t lut_bytes = 0;
   bool busy = false;
+  int ensure_lut(size_t bytes);
   int ensure_bitsets(size_t bytes);
   int ensure_scratch(size_t bytes);
   void release();

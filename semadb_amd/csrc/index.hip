@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "pq.h"
 #include "search_kernel.h"
 
 namespace sdb {
@@ -45,7 +46,18 @@ int Workspace::ensure_scratch(size_t bytes) {
   return SDB_OK;
 }
 
+int Workspace::ensure_lut(size_t bytes) {
+  if (bytes <= lut_bytes) return SDB_OK;
+  if (lut) SDB_HIP(hipFree(lut));
+  lut = nullptr, lut_bytes = 0;
+  SDB_HIP(hipMalloc(&lut, bytes));
+  lut_bytes = bytes;
+  return SDB_OK;
+}
+
 void Workspace::release() {
+  if (lut) (void)hipFree(lut);
+  lut = nullptr;
   if (bitsets) (void)hipFree(bitsets);
   if (scratch) (void)hipFree(scratch);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -95,28 +107,28 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // ------------------------------------------------------------------------------------------
 // search launcher
 // ------------------------------------------------------------------------------------------
-template <int NG, bool L2>
-static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
-  size_t lds = NG < 0 ? (size_t)(a.ng * 128 + 32) * sizeof(float) : 0;
+template <class Dist>
+static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, size_t lds) {
   if (a.search_size <= 128)
-    hipLaunchKernelGGL((k_greedy_search<NG, L2, 2>), dim3(nq), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((k_greedy_search<Dist, 2>), dim3(nq), dim3(64), lds, stream, a);
   else
-    hipLaunchKernelGGL((k_greedy_search<NG, L2, 8>), dim3(nq), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((k_greedy_search<Dist, 8>), dim3(nq), dim3(64), lds, stream, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }
 
 template <bool L2>
 static int launch_ng(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  const size_t lds = (size_t)(a.ng * 128 + 32) * sizeof(float);
   switch (a.ng) {
-    case 0: return launch_nreg<0, L2>(a, nq, stream);
-    case 1: return launch_nreg<1, L2>(a, nq, stream);
-    case 2: return launch_nreg<2, L2>(a, nq, stream);
-    case 3: return launch_nreg<3, L2>(a, nq, stream);
-    case 4: return launch_nreg<4, L2>(a, nq, stream);
-    case 6: return launch_nreg<6, L2>(a, nq, stream);
-    case 8: return launch_nreg<8, L2>(a, nq, stream);
-    default: return launch_nreg<-1, L2>(a, nq, stream);
+    case 0: return launch_nreg<PlainDist<0, L2>>(a, nq, stream, 0);
+    case 1: return launch_nreg<PlainDist<1, L2>>(a, nq, stream, 0);
+    case 2: return launch_nreg<PlainDist<2, L2>>(a, nq, stream, 0);
+    case 3: return launch_nreg<PlainDist<3, L2>>(a, nq, stream, 0);
+    case 4: return launch_nreg<PlainDist<4, L2>>(a, nq, stream, 0);
+    case 6: return launch_nreg<PlainDist<6, L2>>(a, nq, stream, 0);
+    case 8: return launch_nreg<PlainDist<8, L2>>(a, nq, stream, 0);
+    default: return launch_nreg<PlainDist<-1, L2>>(a, nq, stream, lds);
   }
 }
 
@@ -124,6 +136,10 @@ int launch_greedy_search(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   if (nq == 0) return SDB_OK;
   if (a.search_size == 0 || a.search_size > 512)
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
+  if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
+    const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
+    return launch_nreg<PQDist>(a, nq, stream, lds);
+  }
   if (a.metric == SDB_METRIC_EUCLIDEAN) return launch_ng<true>(a, nq, stream);
   return launch_ng<false>(a, nq, stream);
 }
@@ -426,6 +442,13 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
+    if (ix->pq) {  // fitted quantizer: DistanceFromFloat builds the M x K table first (product.go:255-263)
+      const sdb_pq *pq = ix->pq;
+      SDB_TRY(ws->ensure_lut((size_t)nq * pq->M * pq->K * sizeof(float)));
+      SDB_TRY(pq_build_lut(pq, a.queries, nq, ws->lut, stream));
+      a.pq_lut = ws->lut, a.pq_codes = ix->d_codes, a.pq_M = pq->M, a.pq_K = pq->K;
+      a.pq_lut_in_lds = ((size_t)pq->M * pq->K * sizeof(float) <= 64 * 1024) ? 1u : 0u;
+    }
     const bool prof = ix->profiling && !ix->ev0.empty();
     const uint32_t slot = (uint32_t)(ix->prof_count % sdb_index::kProfRing);
     if (prof) (void)hipEventRecord(ix->ev0[slot], stream);
@@ -593,3 +616,47 @@ int store_rows_public(sdb_index *ix, uint32_t first, uint32_t n, const float *de
   return store_rows(ix, first, n, dev_vectors, SDB_MEM_DEVICE, stream);
 }
 }  // namespace sdb
+
+namespace sdb {
+int unpermute_rows_public(const sdb_index *ix, uint32_t first, uint32_t n, float *dst, hipStream_t stream) {
+  if (n == 0) return SDB_OK;
+  const RowLayout &l = ix->lay;
+  hipLaunchKernelGGL(k_unpermute_rows, dim3(n), dim3(128), 0, stream, ix->d_slab + (size_t)first * l.ld, dst, n, l.dim,
+                     l.nblk, l.ng, l.ld);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+}  // namespace sdb
+
+// productQuantizer.Set -> encode for every stored vector (product.go:161-169), then searches use the
+// LUT distance (product.go:250-277).
+extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream_) {
+  if (!ix || !pq) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");
+  if (pq->dim != ix->lay.dim) return fail(SDB_ERR_INVALID, "quantizer dim %u != index dim %u", pq->dim, ix->lay.dim);
+  if (pq->device != ix->P.device) return fail(SDB_ERR_INVALID, "quantizer and index live on different devices");
+  {
+    // the reference swaps cosine for euclidean inside the quantizer only (product.go:52-61); any other
+    // mismatch between the index metric and the quantizer metric is a configuration error
+    const int want = ix->P.metric == SDB_METRIC_COSINE ? SDB_METRIC_EUCLIDEAN : (int)ix->P.metric;
+    if (pq->metric != want) return fail(SDB_ERR_INVALID, "quantizer metric does not match the index metric");
+  }
+  DeviceGuard dg(ix->P.device);
+  hipStream_t stream = as_stream(stream_);
+  if (ix->d_codes) (void)hipFree(ix->d_codes);
+  ix->d_codes = nullptr;
+  SDB_HIP(hipMalloc(&ix->d_codes, (size_t)ix->cap * pq->M));
+  const uint32_t chunk = 1u << 18;
+  float *tmp = nullptr;
+  SDB_HIP(hipMalloc(&tmp, (size_t)std::min<uint32_t>(chunk, std::max<uint32_t>(ix->n, 1)) * ix->lay.dim * sizeof(float)));
+  int rc = SDB_OK;
+  for (uint32_t first = 0; first < ix->n && rc == SDB_OK; first += chunk) {
+    const uint32_t m = std::min<uint32_t>(chunk, ix->n - first);
+    rc = unpermute_rows_public(ix, first, m, tmp, stream);
+    if (rc == SDB_OK) rc = pq_encode_device(pq, tmp, m, ix->d_codes + (size_t)first * pq->M, stream);
+  }
+  (void)hipStreamSynchronize(stream);
+  (void)hipFree(tmp);
+  if (rc == SDB_OK) ix->pq = pq;
+  return rc;
+}

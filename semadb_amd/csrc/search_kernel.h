@@ -43,6 +43,11 @@ struct SearchArgs {
   float *vis_dists;
   uint32_t *vis_count;
   uint32_t vis_cap;
+  // product-quantized store (product.go:238-277): per-query LUT [nq][M*K] and per-slot codes [n][M]
+  const float *pq_lut;
+  const uint8_t *pq_codes;
+  uint32_t pq_M, pq_K;
+  uint32_t pq_lut_in_lds;  // != 0: the kernel copies its LUT into LDS first
 };
 
 template <int NG>
@@ -116,35 +121,123 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
   }
 }
 
-// NG >= 0: compile-time group count, query in registers.  NG == -1: run-time ng, query in LDS.
-template <int NG, bool L2, int NREG>
-__global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
-  constexpr int NGR = NG > 0 ? NG : 1;
-  constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
-  const int lane = threadIdx.x;
-  const int L = lane & 31;
-  const uint32_t q = blockIdx.x;
-  const float *__restrict__ qv = a.queries + (size_t)q * a.dim;
-  const uint32_t tail = a.tail;
+// ---- distance policies: what vecStore.DistanceFromFloat(query) binds (plain.go:76-85 / product.go:238-277)
 
-  extern __shared__ float qs[];  // only used when NG == -1
+// Full-precision store.  NG >= 0: compile-time group count, query in registers.  NG == -1: run-time
+// ng, query tile in LDS.
+template <int NG, bool L2>
+struct PlainDist {
+  static constexpr int NGR = NG > 0 ? NG : 1;
+  static constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
   float4 xq[NGR];
-  float xt = 0.0f;
-  if constexpr (NG >= 0) {
+  float xt;
+  float *qs;
+
+  __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
+    const int L = lane & 31;
+    const float *__restrict__ qv = a.queries + (size_t)q * a.dim;
+    qs = lds;
+    xt = 0.0f;
+    if constexpr (NG >= 0) {
 #pragma unroll
-    for (int g = 0; g < NG; g++)
-      xq[g] = make_float4(q_elem(qv, a.nblk, g, 0, L), q_elem(qv, a.nblk, g, 1, L),
-                          q_elem(qv, a.nblk, g, 2, L), q_elem(qv, a.nblk, g, 3, L));
-    if (NG == 0) xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    xt = (tail && (uint32_t)L < tail) ? qv[a.nblk * 32 + L] : 0.0f;
-  } else {
-    for (uint32_t i = lane; i < a.ng * 128; i += 64) {
-      uint32_t g = i / 128, r = i % 128;
-      qs[i] = q_elem(qv, a.nblk, g, r % 4, (int)(r / 4));
+      for (int g = 0; g < NG; g++)
+        xq[g] = make_float4(q_elem(qv, a.nblk, g, 0, L), q_elem(qv, a.nblk, g, 1, L),
+                            q_elem(qv, a.nblk, g, 2, L), q_elem(qv, a.nblk, g, 3, L));
+      if (NG == 0) xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      xt = (a.tail && (uint32_t)L < a.tail) ? qv[a.nblk * 32 + L] : 0.0f;
+    } else {
+      for (uint32_t i = lane; i < a.ng * 128; i += 64) {
+        uint32_t g = i / 128, r = i % 128;
+        qs[i] = q_elem(qv, a.nblk, g, r % 4, (int)(r / 4));
+      }
+      if (a.tail && lane < 32) qs[a.ng * 128 + lane] = (uint32_t)lane < a.tail ? qv[a.nblk * 32 + lane] : 0.0f;
+      __syncthreads();
     }
-    if (tail && lane < 32) qs[a.ng * 128 + lane] = (uint32_t)lane < tail ? qv[a.nblk * 32 + lane] : 0.0f;
-    __syncthreads();
   }
+
+  __device__ __forceinline__ void chunk(const SearchArgs &a, const uint32_t (&slot)[U], float (&res)[U], int lane) {
+    if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, xq, xt, slot, res, lane);
+    else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, qs, slot, res, lane);
+  }
+
+  // distance to one row (wave-uniform result)
+  __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) {
+    uint32_t slot[U];
+    float res[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) slot[u] = s;
+    chunk(a, slot, res, lane);
+    return metric_finish(rlf(res[0], 0), a.metric);
+  }
+
+  // distances of the new neighbours of one hop: lane j (bit j of pend) gets dist(query, row nb_j)
+  __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    float mydist = 0.0f;
+    uint64_t todo = pend;
+    while (todo) {
+      int jj[2 * U];
+#pragma unroll
+      for (int i = 0; i < 2 * U; i++) {
+        if (todo) {
+          jj[i] = __ffsll((unsigned long long)todo) - 1;
+          todo &= todo - 1;
+        } else {
+          jj[i] = jj[i > 0 ? i - 1 : 0];
+        }
+      }
+      uint32_t slot[U];
+      float res[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        uint32_t s0 = rl(nb, jj[2 * u]), s1 = rl(nb, jj[2 * u + 1]);
+        slot[u] = lane < 32 ? s0 : s1;
+      }
+      chunk(a, slot, res, lane);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float d0 = metric_finish(rlf(res[u], 0), a.metric);
+        float d1 = metric_finish(rlf(res[u], 32), a.metric);
+        if (lane == jj[2 * u]) mydist = d0;
+        if (lane == jj[2 * u + 1]) mydist = d1;
+      }
+    }
+    return mydist;
+  }
+};
+
+// Fitted product quantizer: dist = sum_i lut[i*K + code_i], plain fp32 adds in index order
+// (product.go:271-275).  One lane per neighbour: all new neighbours of a hop in one pass.
+struct PQDist {
+  const float *lut;  // this query's [M][K] table, in LDS or in global memory
+  __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
+    const float *g = a.pq_lut + (size_t)q * a.pq_M * a.pq_K;
+    if (a.pq_lut_in_lds) {
+      for (uint32_t i = lane; i < a.pq_M * a.pq_K; i += 64) lds[i] = g[i];
+      __syncthreads();
+      lut = lds;
+    } else {
+      lut = g;
+    }
+  }
+  __device__ __forceinline__ float sum(const SearchArgs &a, uint32_t slot) const {
+    const uint8_t *__restrict__ c = a.pq_codes + (size_t)slot * a.pq_M;
+    float dist = 0.0f;
+    for (uint32_t i = 0; i < a.pq_M; i++) dist += lut[i * a.pq_K + c[i]];
+    return dist;
+  }
+  __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
+  __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    return ((pend >> lane) & 1ull) ? sum(a, nb) : 0.0f;
+  }
+};
+
+template <class Dist, int NREG>
+__global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  Dist dist;
+  dist.init(a, q, lane, lds_f);
 
   uint32_t *__restrict__ bits = a.bitsets + (size_t)q * a.words_per_query;
   uint32_t cid[NREG];
@@ -154,11 +247,6 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   int len = 0;
   const int cap = (int)a.search_size;
   uint32_t n_dist = 0, n_hop = 0, n_edges = 0;
-
-  auto dist_chunk = [&](const uint32_t(&slot)[U], float(&res)[U]) {
-    if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, tail, xq, xt, slot, res, lane);
-    else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, tail, qs, slot, res, lane);
-  };
 
   // DistSet.AddWithLimit for one point whose distance is known (distset.go:184-198).
   auto insert = [&](uint32_t id, float d) {
@@ -191,12 +279,7 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   {
     const uint32_t s = a.start_slot;
     if (lane == 0) atomicOr(&bits[s >> 5], 1u << (s & 31));
-    uint32_t slot[U];
-    float res[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) slot[u] = s;
-    dist_chunk(slot, res);
-    float d = metric_finish(rlf(res[0], 0), a.metric);
+    const float d = dist.one(a, s, lane);
     n_dist = 1;
     insert(s, d);
   }
@@ -242,35 +325,7 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
     if (!pend) continue;
     n_dist += (uint32_t)__popcll(pend);
 
-    float mydist = 0.0f;  // lane j: distance of edge j
-    uint64_t todo = pend;
-    while (todo) {
-      int jj[2 * U];
-#pragma unroll
-      for (int i = 0; i < 2 * U; i++) {
-        if (todo) {
-          jj[i] = __ffsll((unsigned long long)todo) - 1;
-          todo &= todo - 1;
-        } else {
-          jj[i] = jj[i > 0 ? i - 1 : 0];
-        }
-      }
-      uint32_t slot[U];
-      float res[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        uint32_t s0 = rl(nb, jj[2 * u]), s1 = rl(nb, jj[2 * u + 1]);
-        slot[u] = lane < 32 ? s0 : s1;
-      }
-      dist_chunk(slot, res);
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        float d0 = metric_finish(rlf(res[u], 0), a.metric);
-        float d1 = metric_finish(rlf(res[u], 32), a.metric);
-        if (lane == jj[2 * u]) mydist = d0;
-        if (lane == jj[2 * u + 1]) mydist = d1;
-      }
-    }
+    const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
 
     // AddWithLimit over the new neighbours, in edge order distset.go:184-198
     uint64_t pd = pend;

@@ -1,0 +1,140 @@
+"""K5-K8 parity (GPU): k-means, product quantizer fit/encode/LUT/symmetric distance and the PQ-backed
+greedy search are bit-identical to the oracle's restatement of utils/kmeans.go and
+shard/vectorstore/product.go."""
+import numpy as np
+import pytest
+
+from tests.helpers import bits, build_oracle_index, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,stride,offset,length,K", [(6, 4, 0, 2, 3), (6, 4, 2, 2, 3), (500, 16, 4, 8, 16),
+                                                      (1000, 96, 32, 48, 32), (300, 8, 0, 4, 256), (5, 4, 2, 2, 256)])
+@pytest.mark.parametrize("alias", [True, False])
+def test_kmeans_matches_oracle(oracle, n, stride, offset, length, K, alias):
+    from semadb_amd.kmeans import KMeans
+    rng = np.random.default_rng(n + K)
+    X = rng.standard_normal((n, stride)).astype(np.float32)
+    first = int(rng.integers(0, n))
+    xo = X.copy()
+    o_cent, o_lab, o_it = oracle.kmeans_fit(xo, offset, length, K, max_iter=25, first_idx=first, alias=alias)
+    xg = X.copy()
+    km = KMeans(K, 25, offset, length, first_idx=first, alias=alias).Fit(xg)
+    assert np.array_equal(km.Labels, o_lab)
+    assert np.array_equal(bits(km.Centroids), bits(o_cent))
+    assert km.iters == o_it
+    assert np.array_equal(bits(xg), bits(xo))  # aliasing writes through to the caller's rows (or not at all)
+
+
+def test_kmeans_reference_kat():
+    # TestKMeans_Fit utils/kmeans_test.go:15-68
+    from semadb_amd.kmeans import KMeans
+    rng = np.random.default_rng(3)
+    offs = np.array([[-1, -1, 1, 1], [-1, -1, 1, 1], [0, 0, -1, 1], [0, 0, -1, 1], [1, 1, 1, -1], [1, 1, 1, -1]],
+                    dtype=np.float32)
+    for off in (0, 2):
+        data = (offs * 10 + rng.random(offs.shape, dtype=np.float32)).astype(np.float32)
+        km = KMeans(3, 10, off, 2, first_idx=1).Fit(data)
+        lb = km.Labels
+        assert km.Centroids.shape == (3, 2)
+        assert lb[0] == lb[1] and lb[0] != lb[2] and lb[2] == lb[3] and lb[2] != lb[4] and lb[4] == lb[5]
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+@pytest.mark.parametrize("d,M,K,n", [(4, 2, 256, 5), (32, 8, 16, 600), (96, 2, 32, 400), (768, 8, 64, 700),
+                                     (64, 16, 256, 1200)])
+def test_pq_matches_oracle(oracle, metric, d, M, K, n):
+    from semadb_amd import vectorstore as vs
+    rng = np.random.default_rng(d + M + K)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    first = rng.integers(0, n, M)
+    xo, xg = X.copy(), X.copy()
+    opq = oracle.PQ(d, metric, M, K)
+    o_codes = opq.fit(xo, first, alias=True)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    g_codes = gpq.Fit(xg, first, alias=True)
+    assert np.array_equal(g_codes, o_codes)
+    fc, cd = gpq.codebook()
+    assert np.array_equal(bits(fc), bits(opq.flat_centroids))
+    assert np.array_equal(bits(cd), bits(opq.centroid_dists))
+    assert np.array_equal(bits(xg), bits(xo))
+    # encode (product.go:136-159)
+    V = rng.standard_normal((50, d)).astype(np.float32)
+    ge = gpq.encode(V)
+    assert np.array_equal(ge, np.stack([opq.encode(v) for v in V]))
+    # asymmetric LUT distance (product.go:250-277)
+    Q = rng.standard_normal((7, d)).astype(np.float32)
+    got = gpq.lut_distance(Q, ge)
+    want = np.array([[opq.dist_lut(opq.lut(q), c) for c in ge] for q in Q], dtype=np.float32)
+    assert np.array_equal(bits(got), bits(want))
+    # symmetric distance (product.go:293-304)
+    perm = rng.permutation(50)
+    gs = gpq.sym_distance(ge, ge[perm])
+    ws = np.array([opq.dist_sym(ge[i], ge[perm[i]]) for i in range(50)], dtype=np.float32)
+    assert np.array_equal(bits(gs), bits(ws))
+    gpq.close()
+
+
+def test_pq_reference_contract():
+    # Test_DistanceFromFloat / Test_DistanceFromPoint, product store, fit=true
+    # (shard/vectorstore/vectorestore_test.go:17,37-50,112-154)
+    from semadb_amd import vectorstore as vs
+    X = np.array([[1, 2, 3, 4], [4, 5, 6, 7], [7, 8, 9, 10], [-10, -11, -12, -13], [-13, 14, -15, 16]], dtype=np.float32)
+    pq = vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(256, 2, 5), 4)
+    pq.Fit(X.copy(), [0, 0])
+    c = pq.encode(np.array([[1, 2, 3, 4], [4, 5, 6, 7]], dtype=np.float32))
+    d = pq.lut_distance(np.array([[1, 2, 3, 4]], dtype=np.float32), c)
+    assert d[0, 0] == 0 and d[0, 0] < d[0, 1]
+    s = pq.sym_distance(c[[0, 0]], c[[0, 1]])
+    assert s[0] == 0 and s[0] < s[1]
+    pq.close()
+
+
+def test_pq_parameter_errors():
+    # product.go:44-46,63-65
+    from semadb_amd import vectorstore as vs, SemaDBError
+    with pytest.raises(SemaDBError):
+        vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(16, 3), 10)
+    with pytest.raises(SemaDBError):
+        vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(257, 2), 8)
+    with pytest.raises(SemaDBError):
+        vs.ProductQuantizer("hamming", vs.ProductQuantizerParameters(16, 2), 8)
+    pq = vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(16, 2), 8)
+    with pytest.raises(SemaDBError):  # unfitted: encode returns nil in the reference (product.go:137-139)
+        pq.encode(np.zeros((1, 8), np.float32))
+    pq.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+@pytest.mark.parametrize("d,M,K", [(32, 8, 16), (96, 8, 256), (64, 32, 64)])
+def test_pq_search_parity(oracle, metric, d, M, K):
+    """greedy search over a quantized store: LUT distances (product.go:250-277) drive the same walk"""
+    from semadb_amd import vamana, vectorstore as vs
+    rng = np.random.default_rng(d * M + K)
+    n = 1500
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, metric, R=32, L=50)
+    ids, vecs, off, edges = o.export()
+    train = vecs[1:701].copy()
+    first = rng.integers(0, 700, M)
+    opq = oracle.PQ(d, metric, M, K)
+    opq.fit(train.copy(), first, alias=True)
+    codes = np.stack([opq.encode(v) for v in vecs])
+    assert o.attach_pq(opq, codes) == 0
+    ix = vamana.NewIndexVamana("pq", vamana.IndexVectorVamanaParameters(d, metric, 50, 32, 1.2), strict=False)
+    ix.load(ids, vecs, off, edges)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(train.copy(), first, alias=True)
+    vs.attach(ix, gpq)
+    q = unit_rows(rng, 32, d)
+    g_ids, g_d, g_c, tr = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
+    for k in range(32):
+        o_ids, o_d, o_vis, o_tr = o.search(q[k], 10, 50)
+        assert int(g_c[k]) == len(o_ids)
+        assert np.array_equal(g_ids[k, :len(o_ids)], o_ids)
+        assert np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d))
+        assert int(tr.n_hop[k]) == o_tr.n_hop and int(tr.n_dist[k]) == o_tr.n_dist
+        assert np.array_equal(tr.visit_ids[k, :o_tr.n_hop], o_vis)
+    ix.close()
+    gpq.close()
