@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libsemadb_amd.so")
+SO_PATH = os.environ.get("SEMADB_AMD_LIB") or os.path.join(_HERE, "libsemadb_amd.so")
 
 SDB_OK = 0
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -20,7 +20,10 @@ struct Workspace {
   size_t scratch_bytes = 0;
   float *lut = nullptr;  // [nq][M*K] product-quantizer distance tables of the batch
   size_t lut_bytes = 0;
+  void *filter = nullptr;  // seeds / filter slot lists of a filtered batch
+  size_t filter_bytes = 0;
   bool busy = false;
+  int ensure_filter(size_t bytes);
   int ensure_lut(size_t bytes);
   int ensure_bitsets(size_t bytes);
   int ensure_scratch(size_t bytes);

@@ -46,6 +46,15 @@ int Workspace::ensure_scratch(size_t bytes) {
   return SDB_OK;
 }
 
+int Workspace::ensure_filter(size_t bytes) {
+  if (bytes <= filter_bytes) return SDB_OK;
+  if (filter) SDB_HIP(hipFree(filter));
+  filter = nullptr, filter_bytes = 0;
+  SDB_HIP(hipMalloc(&filter, bytes));
+  filter_bytes = bytes;
+  return SDB_OK;
+}
+
 int Workspace::ensure_lut(size_t bytes) {
   if (bytes <= lut_bytes) return SDB_OK;
   if (lut) SDB_HIP(hipFree(lut));
@@ -56,6 +65,8 @@ int Workspace::ensure_lut(size_t bytes) {
 }
 
 void Workspace::release() {
+  if (filter) (void)hipFree(filter);
+  filter = nullptr;
   if (lut) (void)hipFree(lut);
   lut = nullptr;
   if (bitsets) (void)hipFree(bitsets);
@@ -109,10 +120,14 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // ------------------------------------------------------------------------------------------
 template <class Dist>
 static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, size_t lds) {
-  if (a.search_size <= 128)
-    hipLaunchKernelGGL((k_greedy_search<Dist, 2>), dim3(nq), dim3(64), lds, stream, a);
-  else
-    hipLaunchKernelGGL((k_greedy_search<Dist, 8>), dim3(nq), dim3(64), lds, stream, a);
+  const bool filt = a.filt_off != nullptr;
+  if (a.search_size <= 128) {
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true>), dim3(nq), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false>), dim3(nq), dim3(64), lds, stream, a);
+  } else {
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 8, true>), dim3(nq), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 8, false>), dim3(nq), dim3(64), lds, stream, a);
+  }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }
@@ -414,7 +429,8 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     return fail(SDB_ERR_INVALID, "invalid searchSize %u / limit %u for vector query, expected 25-75 / 1-75",
                 search_size, limit);
   if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
-  if (filter_offsets || filter_ids) return fail(SDB_ERR_INVALID, "filtered search is not on the device path yet");
+  const bool filtered = filter_offsets != nullptr;
+  if (filtered && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
   if (nq > 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many queries");
   DeviceGuard dg(ix->P.device);
   Workspace *ws = ix->acquire_ws();
@@ -430,12 +446,48 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   }
   const RowLayout &l = ix->lay;
   const uint32_t words = ((ix->n + 31) / 32 + 31) & ~31u;  // per-query bitset, 128-byte multiple
-  SDB_TRY(ws->ensure_bitsets((size_t)nq * words * sizeof(uint32_t)));
-  SDB_HIP(hipMemsetAsync(ws->bitsets, 0, (size_t)nq * words * sizeof(uint32_t), stream));  // ClearAll distset.go:101
+  const size_t bs_bytes = (size_t)nq * words * sizeof(uint32_t);
+  SDB_TRY(ws->ensure_bitsets(filtered ? 2 * bs_bytes : bs_bytes));
+  SDB_HIP(hipMemsetAsync(ws->bitsets, 0, filtered ? 2 * bs_bytes : bs_bytes, stream));  // ClearAll distset.go:101
 
   SearchArgs a{};
   a.slab = ix->d_slab, a.adj = ix->d_adj, a.ids = ix->d_ids;
   a.bitsets = ws->bitsets, a.words_per_query = words;
+  if (filtered) {
+    // search.go:41-48: seeds = the first <= searchSize filter ids (ascending) that exist; Contains (:93) is
+    // answered from the whole filter as ascending slots.  Filter arrays are host memory (header).
+    std::vector<uint32_t> off_seed(nq + 1, 0), off_filt(nq + 1, 0), seeds, fslots;
+    for (uint64_t q = 0; q < nq; q++) {
+      const uint64_t b = filter_offsets[q], e = filter_offsets[q + 1];
+      if (e < b) return fail(SDB_ERR_INVALID, "filter_offsets must be non-decreasing");
+      const size_t f0 = fslots.size();
+      for (uint64_t i = b; i < e; i++) {
+        if (i > b && filter_ids[i] <= filter_ids[i - 1])
+          return fail(SDB_ERR_INVALID, "filter ids of query %llu are not strictly ascending", (unsigned long long)q);
+        const int64_t s = ix->slot_of(filter_ids[i]);
+        if (s < 0) continue;  // GetMany skips unknown ids (itemcache.go:109-128)
+        if (i - b < search_size) seeds.push_back((uint32_t)s);
+        fslots.push_back((uint32_t)s);
+      }
+      std::sort(fslots.begin() + f0, fslots.end());
+      off_seed[q + 1] = (uint32_t)seeds.size();
+      off_filt[q + 1] = (uint32_t)fslots.size();
+    }
+    const size_t b_off = (nq + 1) * 4, b_seeds = seeds.size() * 4, b_f = fslots.size() * 4;
+    SDB_TRY(ws->ensure_filter(2 * ((b_off + 255) & ~(size_t)255) + ((b_seeds + 255) & ~(size_t)255) + b_f + 256));
+    char *fb = static_cast<char *>(ws->filter);
+    uint32_t *d_so = (uint32_t *)fb;
+    uint32_t *d_fo = (uint32_t *)(fb + ((b_off + 255) & ~(size_t)255));
+    uint32_t *d_seeds = (uint32_t *)(fb + 2 * ((b_off + 255) & ~(size_t)255));
+    uint32_t *d_f = (uint32_t *)((char *)d_seeds + ((b_seeds + 255) & ~(size_t)255));
+    SDB_HIP(hipMemcpyAsync(d_so, off_seed.data(), b_off, hipMemcpyHostToDevice, stream));
+    SDB_HIP(hipMemcpyAsync(d_fo, off_filt.data(), b_off, hipMemcpyHostToDevice, stream));
+    if (b_seeds) SDB_HIP(hipMemcpyAsync(d_seeds, seeds.data(), b_seeds, hipMemcpyHostToDevice, stream));
+    if (b_f) SDB_HIP(hipMemcpyAsync(d_f, fslots.data(), b_f, hipMemcpyHostToDevice, stream));
+    SDB_HIP(hipStreamSynchronize(stream));  // the staging vectors die with this scope
+    a.seed_off = d_so, a.filt_off = d_fo, a.seeds = d_seeds, a.filt_slots = d_f;
+    a.rbitsets = ws->bitsets + (size_t)nq * words;
+  }
   a.dim = l.dim, a.nblk = l.nblk, a.ng = l.ng, a.tail = l.tail, a.ld = l.ld;
   a.start_slot = (uint32_t)ix->start_slot;
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;

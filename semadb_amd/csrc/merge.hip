@@ -51,7 +51,9 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
     uint32_t rank = 0;
     for (uint32_t j = 0; j < total; j++) {
       const float dj = s_d[j];
-      const bool before = dj < d || (dj == d && (s_sh[j] < sh || (s_sh[j] == sh && s_id[j] < id)));
+      // a single shard is not re-sorted at all (actions.go:357: `if len(col.ShardIds) > 1`)
+      const bool before = n_shards == 1 ? (j < i)
+                                        : (dj < d || (dj == d && (s_sh[j] < sh || (s_sh[j] == sh && s_id[j] < id))));
       rank += before ? 1u : 0u;
     }
     if (rank < limit) {  // truncate to the original limit (actions.go:372-374)

@@ -48,12 +48,19 @@ struct SearchArgs {
   const uint8_t *pq_codes;
   uint32_t pq_M, pq_K;
   uint32_t pq_lut_in_lds;  // != 0: the kernel copies its LUT into LDS first
+  // filtered search (search.go:33-51,93-95): per query CSR of seeds (<= searchSize slots, ascending id
+  // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
+  const uint32_t *seed_off, *seeds, *filt_off, *filt_slots;
+  uint32_t *rbitsets;
 };
 
 template <int NG>
 struct ChunkPairs {
   // pairs of rows kept in flight per wave: ~96 VGPRs of loads
-  static constexpr int value = NG <= 1 ? 8 : (NG <= 3 ? 8 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3)));
+#ifndef SDB_PAIRS_NG3
+#define SDB_PAIRS_NG3 8
+#endif
+  static constexpr int value = NG <= 1 ? 8 : (NG <= 3 ? SDB_PAIRS_NG3 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3)));
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -231,7 +238,85 @@ struct PQDist {
   }
 };
 
-template <class Dist, int NREG>
+// ---- the candidate array (DistSet.items, distset.go:133-138) held in registers -------------------------
+// entry e lives in lane e % 64 of register e / 64; bit 31 of the slot word is the `visited` flag.
+
+// bubble position + shift of DistSet.AddWithLimit (distset.go:189-198) for one accepted point
+template <int NREG>
+__device__ __forceinline__ void list_insert(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap, uint32_t id,
+                                            float d, int lane) {
+  const bool full = (len == cap);
+  const int newlen = full ? len : len + 1;  // :189-194 append, or overwrite the tail
+  const int range = newlen - 1;             // entries the bubble loop compares against
+  int pos = 0;                              // :196-198 stops at the first i with !(d < items[i-1])
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    uint64_t m = __ballot((r * 64 + lane) < range && !(d < cd[r]));
+    if (m) pos = r * 64 + 64 - __clzll(m);
+  }
+#pragma unroll
+  for (int r = NREG - 1; r >= 0; r--) {
+    uint32_t up_id = __shfl_up(cid[r], 1, 64);
+    float up_d = __shfl_up(cd[r], 1, 64);
+    if (r > 0) {
+      uint32_t c_id = rl(cid[r - 1], 63);
+      float c_d = rlf(cd[r - 1], 63);
+      if (lane == 0) up_id = c_id, up_d = c_d;
+    }
+    const int e = r * 64 + lane;
+    if (e > pos && e < newlen) cid[r] = up_id, cd[r] = up_d;
+    else if (e == pos) cid[r] = id, cd[r] = d;
+  }
+  len = newlen;
+}
+
+template <int NREG>
+__device__ __forceinline__ float list_tail(const float (&cd)[NREG], int cap) {
+  float t = 0.0f;
+#pragma unroll
+  for (int r = 0; r < NREG; r++)
+    if (((cap - 1) >> 6) == r) t = rlf(cd[r], (cap - 1) & 63);
+  return t;
+}
+
+// AddWithLimit (distset.go:184-198) over the lanes in `pd`, IN LANE ORDER, each lane holding (idreg,
+// mydist).  Only points that beat the current tail are replayed: the tail only shrinks, so a point that
+// fails the current threshold can never pass a later one.
+template <int NREG>
+__device__ __forceinline__ void add_with_limit_lanes(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap,
+                                                     uint32_t idreg, float mydist, uint64_t pd, int lane) {
+  while (pd) {
+    bool ok = true;
+    if (len == cap) ok = !(mydist > list_tail(cd, cap));  // :184 strict '>'
+    const uint64_t am = __ballot(ok) & pd;
+    if (!am) break;
+    const int j = __ffsll((unsigned long long)am) - 1;
+    const float d = rlf(mydist, j);
+    const uint32_t id = rl(idreg, j);
+    pd = (j == 63) ? 0ull : ((pd >> (j + 1)) << (j + 1));
+    list_insert(cid, cd, len, cap, id, d, lane);
+  }
+}
+
+// roaring Contains on this query's ascending slot list: 64-ary search, all lanes probe at once
+__device__ __forceinline__ bool filter_contains(const uint32_t *__restrict__ arr, uint32_t n, uint32_t target,
+                                                int lane) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 64) {
+    const uint32_t step = (hi - lo + 63) / 64;
+    const uint32_t idx = lo + (uint32_t)lane * step;
+    const uint32_t v = idx < hi ? arr[idx] : 0xFFFFFFFFu;
+    const uint64_t m = __ballot(idx < hi && v <= target);
+    if (!m) return false;  // target below the first pivot
+    const uint32_t k = (uint32_t)__popcll(m);
+    lo = lo + (k - 1) * step;
+    hi = (lo + step < hi) ? lo + step : hi;
+  }
+  const uint32_t v = (lo + (uint32_t)lane < hi) ? arr[lo + lane] : 0xFFFFFFFFu;
+  return __ballot(lo + (uint32_t)lane < hi && v == target) != 0ull;
+}
+
+template <class Dist, int NREG, bool FILT>
 __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
@@ -248,44 +333,86 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   const int cap = (int)a.search_size;
   uint32_t n_dist = 0, n_hop = 0, n_edges = 0;
 
-  // DistSet.AddWithLimit for one point whose distance is known (distset.go:184-198).
-  auto insert = [&](uint32_t id, float d) {
-    const bool full = (len == cap);
-    const int newlen = full ? len : len + 1;  // :189-194 append, or overwrite the tail
-    const int range = newlen - 1;             // entries that the bubble loop compares against
-    int pos = 0;                              // :196-198 stop at the first i with !(d < items[i-1])
+  // filtered search (search.go:33-51): resultSet = DistSet(cap k) with its own visited set
+  uint32_t rid[FILT ? NREG : 1];
+  float rd[FILT ? NREG : 1];
+  int rlen = 0;
+  const int rcap = (int)a.limit;
+  uint32_t *__restrict__ rbits = nullptr;
+  const uint32_t *__restrict__ fsorted = nullptr;
+  uint32_t nfilt = 0;
+  if constexpr (FILT) {
 #pragma unroll
-    for (int r = 0; r < NREG; r++) {
-      uint64_t m = __ballot((r * 64 + lane) < range && !(d < cd[r]));
-      if (m) pos = r * 64 + 64 - __clzll(m);
-    }
-#pragma unroll
-    for (int r = NREG - 1; r >= 0; r--) {
-      uint32_t up_id = __shfl_up(cid[r], 1, 64);
-      float up_d = __shfl_up(cd[r], 1, 64);
-      if (r > 0) {
-        uint32_t c_id = rl(cid[r - 1], 63);
-        float c_d = rlf(cd[r - 1], 63);
-        if (lane == 0) up_id = c_id, up_d = c_d;
+    for (int r = 0; r < NREG; r++) rid[r] = kNoSlot, rd[r] = 0.0f;
+    rbits = a.rbitsets + (size_t)q * a.words_per_query;
+    fsorted = a.filt_slots + a.filt_off[q];
+    nfilt = a.filt_off[q + 1] - a.filt_off[q];
+    // seeds: the first <= searchSize filter ids in ascending id order that exist (:41-48)
+    const uint32_t s0 = a.seed_off[q], ns = a.seed_off[q + 1] - s0;
+    for (uint32_t base = 0; base < ns; base += 64) {
+      const uint32_t j = base + lane;
+      const bool has = j < ns;
+      const uint32_t slot = has ? a.seeds[s0 + j] : kNoSlot;
+      bool isnew = false;
+      if (has) {  // searchSet.Add (:49): CheckAndVisit, distance, plain append -- NOT sorted
+        const uint32_t bit = 1u << (slot & 31);
+        isnew = !(atomicOr(&bits[slot >> 5], bit) & bit);
       }
-      const int e = r * 64 + lane;
-      if (e > pos && e < newlen) cid[r] = up_id, cd[r] = up_d;
-      else if (e == pos) cid[r] = id, cd[r] = d;
+      const uint64_t pend = __ballot(isnew);
+      n_dist += (uint32_t)__popcll(pend);
+      const float mydist = dist.hop(a, slot, pend, lane);
+      for (uint64_t t = pend; t; t &= t - 1) {
+        const int j0 = __ffsll((unsigned long long)t) - 1;
+        const uint32_t id = rl(slot, j0);
+        const float d = rlf(mydist, j0);
+#pragma unroll
+        for (int r = 0; r < NREG; r++)
+          if ((len >> 6) == r && lane == (len & 63)) cid[r] = id, cd[r] = d;
+        len++;
+      }
+      // resultSet.AddWithLimit(filterPoints...) (:50): its own CheckAndVisit, distances evaluated again
+      bool rnew = false;
+      if (has) {
+        const uint32_t bit = 1u << (slot & 31);
+        rnew = !(atomicOr(&rbits[slot >> 5], bit) & bit);
+      }
+      const uint64_t rpend = __ballot(rnew);
+      n_dist += (uint32_t)__popcll(rpend);
+      add_with_limit_lanes(rid, rd, rlen, rcap, slot, mydist, rpend, lane);
     }
-    len = newlen;
-  };
+  }
 
   // ---- searchSet.AddWithLimit(startNode)  search.go:57-61
   {
     const uint32_t s = a.start_slot;
-    if (lane == 0) atomicOr(&bits[s >> 5], 1u << (s & 31));
-    const float d = dist.one(a, s, lane);
-    n_dist = 1;
-    insert(s, d);
+    uint32_t old = 0;
+    if (lane == 0) old = atomicOr(&bits[s >> 5], 1u << (s & 31));
+    old = rl(old, 0);
+    if (!(old & (1u << (s & 31)))) {
+      const float d = dist.one(a, s, lane);
+      n_dist++;
+      if (!(len == cap && d > list_tail(cd, cap))) list_insert(cid, cd, len, cap, s, d, lane);
+    }
   }
 
+#ifdef SDB_STAMPS  // diagnostic build only: where does a hop spend its cycles (never in the shipped library)
+  unsigned long long st_adj = 0, st_atom = 0, st_vec = 0, st_ins = 0, st_t0 = 0;
+#define SDB_STAMP(acc)                                              \
+  {                                                                 \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    acc += _t - st_t0;                                              \
+    st_t0 = _t;                                                     \
+  }
+#else
+#define SDB_STAMP(acc)
+#endif
   // ---- main loop search.go:65-98
   while (true) {
+#ifdef SDB_STAMPS
+    st_t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     int sel = -1;
 #pragma unroll
     for (int r = 0; r < NREG; r++) {
@@ -303,7 +430,9 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
         if (lane == (sel & 63)) cid[r] |= kVisBit;  // :74
       }
     if (lane == 0) {  // visitedSet.AddAlreadyUnique :73
+#ifndef SDB_STAMPS
       if (a.tr_visit && n_hop < a.visit_cap) a.tr_visit[(size_t)q * a.visit_cap + n_hop] = a.ids[pid];
+#endif
       if (a.vis_slots && n_hop < a.vis_cap) {
         a.vis_slots[(size_t)q * a.vis_cap + n_hop] = pid;
         a.vis_dists[(size_t)q * a.vis_cap + n_hop] = pdist;
@@ -315,6 +444,7 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
     const uint32_t nb = a.adj[(size_t)pid * kAdjStride + lane];
     const bool valid = nb != kNoSlot;
     n_edges += (uint32_t)__popcll(__ballot(valid));
+    SDB_STAMP(st_adj)
     bool isnew = false;
     if (valid) {  // CheckAndVisit distset.go:174 -- marks before any distance test
       const uint32_t bit = 1u << (nb & 31);
@@ -322,44 +452,53 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
       isnew = !(old & bit);
     }
     const uint64_t pend = __ballot(isnew);
-    if (!pend) continue;
-    n_dist += (uint32_t)__popcll(pend);
-
-    const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
-
-    // AddWithLimit over the new neighbours, in edge order distset.go:184-198
-    uint64_t pd = pend;
-    while (pd) {
-      bool ok = true;
-      if (len == cap) {
-        float tail_d = 0.0f;
-#pragma unroll
-        for (int r = 0; r < NREG; r++)
-          if (((cap - 1) >> 6) == r) tail_d = rlf(cd[r], (cap - 1) & 63);
-        ok = !(mydist > tail_d);  // :184 strict '>'
+    SDB_STAMP(st_atom)
+    if (pend) {
+      n_dist += (uint32_t)__popcll(pend);
+      const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
+#ifdef SDB_STAMPS
+      asm volatile("" ::"v"(mydist));
+#endif
+      SDB_STAMP(st_vec)
+      // AddWithLimit over the new neighbours, in edge order distset.go:184-198
+      add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);
+      SDB_STAMP(st_ins)
+    }
+    if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
+      if (filter_contains(fsorted, nfilt, pid, lane)) {
+        uint32_t old = 0;
+        if (lane == 0) old = atomicOr(&rbits[pid >> 5], 1u << (pid & 31));
+        old = rl(old, 0);
+        if (!(old & (1u << (pid & 31)))) {
+          n_dist++;  // distFn is evaluated again by the reference; same inputs, same bits as pdist
+          if (!(rlen == rcap && pdist > list_tail(rd, rcap))) list_insert(rid, rd, rlen, rcap, pid, pdist, lane);
+        }
       }
-      const uint64_t am = __ballot(ok) & pd;
-      if (!am) break;
-      const int j = __ffsll((unsigned long long)am) - 1;
-      const float d = rlf(mydist, j);
-      const uint32_t id = rl(nb, j);
-      pd = (j == 63) ? 0ull : ((pd >> (j + 1)) << (j + 1));
-      insert(id, d);
     }
   }
+#ifdef SDB_STAMPS
+  if (lane == 0 && a.tr_visit && a.visit_cap >= 4) {
+    a.tr_visit[(size_t)q * a.visit_cap + 0] = st_adj;
+    a.tr_visit[(size_t)q * a.visit_cap + 1] = st_atom;
+    a.tr_visit[(size_t)q * a.visit_cap + 2] = st_vec;
+    a.tr_visit[(size_t)q * a.visit_cap + 3] = st_ins;
+  }
+#endif
 
-  // ---- IndexVamana.Search result copy vamana.go:293-307
+  // ---- IndexVamana.Search result copy vamana.go:293-307 (from resultSet when filtered, search.go:36)
   if (a.out_ids) {
     int base = 0;
+    const int olen = FILT ? rlen : len;
 #pragma unroll
     for (int r = 0; r < NREG; r++) {
-      const uint32_t s = cid[r] & ~kVisBit;
-      const bool ok = (r * 64 + lane) < len && s != a.start_slot;  // :294-296
+      const uint32_t s = (FILT ? rid[FILT ? r : 0] : cid[r]) & ~kVisBit;
+      const float dd = FILT ? rd[FILT ? r : 0] : cd[r];
+      const bool ok = (r * 64 + lane) < olen && s != a.start_slot;  // :294-296
       const uint64_t m = __ballot(ok);
       const int rank = base + __popcll(m & ((1ull << lane) - 1));
       if (ok && rank < (int)a.limit) {  // :297-299
         a.out_ids[(size_t)q * a.limit + rank] = a.ids[s];
-        a.out_dists[(size_t)q * a.limit + rank] = cd[r];
+        a.out_dists[(size_t)q * a.limit + rank] = dd;
       }
       base += __popcll(m);
     }

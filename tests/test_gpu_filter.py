@@ -1,0 +1,98 @@
+"""Filtered greedy search on device (search.go:33-51,93-95): seeds, unsorted Add, result set with its own
+visited set -- identical ids, distance bits, visit order and n_dist to the oracle."""
+import numpy as np
+import pytest
+
+from tests.helpers import bits, build_oracle_index, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(o, d, metric, R, L):
+    from semadb_amd import vamana
+    ids, vecs, off, edges = o.export()
+    ix = vamana.NewIndexVamana("f", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.2), strict=False)
+    ix.load(ids, vecs, off, edges)
+    return ix
+
+
+def test_reference_filter_kats(oracle):
+    # shard/index/search_test.go:196-244 (filter {47} -> one result, distance exactly 50) and
+    # :246-288 (filter {42..46} -> exactly those five, first 42) on the dispatch_test.go:66-89 data
+    from semadb_amd import vamana
+    base = np.array([[ii, ii + 1] for ii in range(2, 102)], dtype=np.float32)
+    o = build_oracle_index(oracle, base, "euclidean", R=64, L=75)
+    ix = _gpu(o, 2, "euclidean", 64, 75)
+    rset, res = ix.Search(vamana.SearchVectorVamanaOptions([42, 43], 75, 10), filter={47})
+    assert rset == {47} and len(res) == 1 and res[0].Distance == np.float32(50)
+    rset, res = ix.Search(vamana.SearchVectorVamanaOptions([42, 43], 75, 10), filter={42, 43, 44, 45, 46})
+    assert rset == {42, 43, 44, 45, 46} and len(res) == 5 and res[0].NodeId == 42
+    ix.close()
+
+
+def test_filter_search_property(oracle):
+    # Test_FilterSearch vamana_test.go:254-276: filter of 3 ids -> 3 results, first is the query point
+    from semadb_amd import vamana
+    rng = np.random.default_rng(123)
+    pts = rng.random((200, 2), dtype=np.float32)
+    o = build_oracle_index(oracle, pts, "euclidean", R=64, L=75)
+    ix = _gpu(o, 2, "euclidean", 64, 75)
+    rset, res = ix.Search(vamana.SearchVectorVamanaOptions(pts[0], 75, 10), filter={2, 3, 4})
+    assert len(res) == 3 and res[0].NodeId == 2
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("d,n,L,k", [(32, 1200, 50, 10), (96, 900, 30, 30), (384, 600, 75, 10)])
+def test_filtered_batch_parity(oracle, metric, d, n, L, k):
+    rng = np.random.default_rng(d + n + L)
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, metric, R=32, L=50)
+    ix = _gpu(o, d, metric, 32, 50)
+    nq = 24
+    q = unit_rows(rng, nq, d)
+    all_ids = np.arange(2, n + 2)
+    filters = []
+    for i in range(nq):
+        kind = i % 6
+        if kind == 0:
+            f = rng.choice(all_ids, size=5, replace=False)            # tiny: fewer than k
+        elif kind == 1:
+            f = rng.choice(all_ids, size=L, replace=False)            # exactly searchSize seeds
+        elif kind == 2:
+            f = rng.choice(all_ids, size=n // 2, replace=False)       # large: most seeds ignored
+        elif kind == 3:
+            f = np.concatenate([rng.choice(all_ids, size=40, replace=False), [10 ** 7 + i, 10 ** 8]])  # unknown ids
+        elif kind == 4:
+            f = np.concatenate([[1], rng.choice(all_ids, size=20, replace=False)])  # contains the start id
+        else:
+            f = np.array([], dtype=np.int64)                          # empty filter (not nil): no results
+        filters.append(set(int(v) for v in f))
+    g_ids, g_d, g_c, tr = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+    for i in range(nq):
+        o_ids, o_d, o_vis, o_tr = o.search(q[i], k, L, filter_ids=sorted(filters[i]))
+        assert int(g_c[i]) == len(o_ids), (i, g_c[i], len(o_ids))
+        assert np.array_equal(g_ids[i, :len(o_ids)], o_ids), i
+        assert np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d)), i
+        assert int(tr.n_hop[i]) == o_tr.n_hop and int(tr.n_dist[i]) == o_tr.n_dist, i
+        assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), i
+        assert set(int(v) for v in o_ids) <= filters[i]
+    ix.close()
+
+
+def test_filter_argument_errors(oracle):
+    from semadb_amd import vamana, SemaDBError, _lib
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    base = unit_rows(rng, 100, 16)
+    o = build_oracle_index(oracle, base, "euclidean", R=16, L=30)
+    ix = _gpu(o, 16, "euclidean", 16, 30)
+    q = unit_rows(rng, 1, 16)
+    off = np.array([0, 3], dtype=np.uint64)
+    bad = np.array([5, 4, 9], dtype=np.uint64)  # not ascending
+    ids = np.zeros((1, 5), np.uint64); d = np.zeros((1, 5), np.float32); c = np.zeros(1, np.uint32)
+    rc = _lib.lib().sdb_index_search_batch(ix._h, 1, q.ctypes.data_as(C.c_void_p), 5, 30, off.ctypes.data_as(C.c_void_p),
+                                           bad.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                           d.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), None, 0, None)
+    assert rc != 0 and b"ascending" in _lib.lib().sdb_last_error()
+    ix.close()
