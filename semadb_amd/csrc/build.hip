@@ -441,7 +441,6 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     if (rs > max_round) rs = max_round;
     if (rs > n - done) rs = (uint32_t)(n - done);
     // ---- greedySearch(vec, 1, SearchSize, nil) for every point of the round (insert.go:22)
-    SDB_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
     SearchArgs sa{};
     sa.slab = ix->d_slab, sa.adj = ix->d_adj, sa.ids = ix->d_ids;
     sa.bitsets = bitsets, sa.words_per_query = words;
@@ -450,6 +449,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.start_slot = (uint32_t)ix->start_slot;
     sa.search_size = L, sa.limit = 1, sa.metric = (int)ix->P.metric;
     sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
+    if (!search_uses_hash(sa, rs)) SDB_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
     SDB_TRY(launch_greedy_search(sa, rs, stream));
     // ---- robustPrune + back-edges
     BuildArgs ba{};

@@ -1,6 +1,7 @@
 // index.hip -- K3 (HBM slab + adjacency loader) and the host side of K2 (search_batch).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "pq.h"
 #include "search_kernel.h"
@@ -118,42 +119,70 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // ------------------------------------------------------------------------------------------
 // search launcher
 // ------------------------------------------------------------------------------------------
-template <class Dist>
+// LDS hash visited set: plain store with the query in registers, unfiltered, reference-range search size,
+// and a batch small enough that LDS (4 waves per CU) is not what limits occupancy.
+bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
+  if (a.pq_codes || a.filt_off || a.prefer_bitset) return false;
+  if (a.search_size > 96 || nq > 4096) return false;
+  switch (a.ng) {
+    case 0: case 1: case 2: case 3: case 4: case 6: case 8: return true;
+    default: return false;
+  }
+}
+
+template <class Dist, bool HASH>
 static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, size_t lds) {
   const bool filt = a.filt_off != nullptr;
-  if (a.search_size <= 128) {
-    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true>), dim3(nq), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false>), dim3(nq), dim3(64), lds, stream, a);
+  if constexpr (HASH) {
+    hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, true>), dim3(nq), dim3(64), kHashCap * sizeof(uint32_t), stream, a);
+  } else if (a.search_size <= 128) {
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true, false>), dim3(nq), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, false>), dim3(nq), dim3(64), lds, stream, a);
   } else {
-    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 8, true>), dim3(nq), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL((k_greedy_search<Dist, 8, false>), dim3(nq), dim3(64), lds, stream, a);
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 8, true, false>), dim3(nq), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 8, false, false>), dim3(nq), dim3(64), lds, stream, a);
   }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
+}
+
+template <int NG, bool L2>
+static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  if (search_uses_hash(a, nq)) return launch_nreg<PlainDist<NG, L2>, true>(a, nq, stream, 0);
+  return launch_nreg<PlainDist<NG, L2>, false>(a, nq, stream, 0);
 }
 
 template <bool L2>
 static int launch_ng(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   const size_t lds = (size_t)(a.ng * 128 + 32) * sizeof(float);
   switch (a.ng) {
-    case 0: return launch_nreg<PlainDist<0, L2>>(a, nq, stream, 0);
-    case 1: return launch_nreg<PlainDist<1, L2>>(a, nq, stream, 0);
-    case 2: return launch_nreg<PlainDist<2, L2>>(a, nq, stream, 0);
-    case 3: return launch_nreg<PlainDist<3, L2>>(a, nq, stream, 0);
-    case 4: return launch_nreg<PlainDist<4, L2>>(a, nq, stream, 0);
-    case 6: return launch_nreg<PlainDist<6, L2>>(a, nq, stream, 0);
-    case 8: return launch_nreg<PlainDist<8, L2>>(a, nq, stream, 0);
-    default: return launch_nreg<PlainDist<-1, L2>>(a, nq, stream, lds);
+    case 0: return launch_plain<0, L2>(a, nq, stream);
+    case 1: return launch_plain<1, L2>(a, nq, stream);
+    case 2: return launch_plain<2, L2>(a, nq, stream);
+    case 3: return launch_plain<3, L2>(a, nq, stream);
+    case 4: return launch_plain<4, L2>(a, nq, stream);
+    case 6: return launch_plain<6, L2>(a, nq, stream);
+    case 8: return launch_plain<8, L2>(a, nq, stream);
+    default: return launch_nreg<PlainDist<-1, L2>, false>(a, nq, stream, lds);
   }
 }
 
-int launch_greedy_search(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream) {
   if (nq == 0) return SDB_OK;
+  SearchArgs a = a_in;
+  if (a.hash_limit == 0 || a.hash_limit > kHashLimit) {
+    a.hash_limit = kHashLimit;
+    // test hook: a tiny limit forces the bitset fallback for every query (tests/test_gpu_search.py)
+    if (const char *e = getenv("SDB_HASH_LIMIT")) {
+      long v = atol(e);
+      if (v > 0 && v < (long)kHashLimit) a.hash_limit = (uint32_t)v;
+    }
+  }
   if (a.search_size == 0 || a.search_size > 512)
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
-    return launch_nreg<PQDist>(a, nq, stream, lds);
+    return launch_nreg<PQDist, false>(a, nq, stream, lds);
   }
   if (a.metric == SDB_METRIC_EUCLIDEAN) return launch_ng<true>(a, nq, stream);
   return launch_ng<false>(a, nq, stream);
@@ -448,7 +477,6 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   const uint32_t words = ((ix->n + 31) / 32 + 31) & ~31u;  // per-query bitset, 128-byte multiple
   const size_t bs_bytes = (size_t)nq * words * sizeof(uint32_t);
   SDB_TRY(ws->ensure_bitsets(filtered ? 2 * bs_bytes : bs_bytes));
-  SDB_HIP(hipMemsetAsync(ws->bitsets, 0, filtered ? 2 * bs_bytes : bs_bytes, stream));  // ClearAll distset.go:101
 
   SearchArgs a{};
   a.slab = ix->d_slab, a.adj = ix->d_adj, a.ids = ix->d_ids;
@@ -501,6 +529,9 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
       a.pq_lut = ws->lut, a.pq_codes = ix->d_codes, a.pq_M = pq->M, a.pq_K = pq->K;
       a.pq_lut_in_lds = ((size_t)pq->M * pq->K * sizeof(float) <= 64 * 1024) ? 1u : 0u;
     }
+    // ClearAll (distset.go:101); the LDS hash variant clears a bitset only for a query that overflows it
+    if (!search_uses_hash(a, (uint32_t)nq))
+      SDB_HIP(hipMemsetAsync(ws->bitsets, 0, filtered ? 2 * bs_bytes : bs_bytes, stream));
     const bool prof = ix->profiling && !ix->ev0.empty();
     const uint32_t slot = (uint32_t)(ix->prof_count % sdb_index::kProfRing);
     if (prof) (void)hipEventRecord(ix->ev0[slot], stream);

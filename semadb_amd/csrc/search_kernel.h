@@ -52,6 +52,8 @@ struct SearchArgs {
   // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
   const uint32_t *seed_off, *seeds, *filt_off, *filt_slots;
   uint32_t *rbitsets;
+  uint32_t prefer_bitset;  // != 0: never use the LDS hash visited set (large build rounds)
+  uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
 
 template <int NG>
@@ -256,13 +258,14 @@ __device__ __forceinline__ void list_insert(uint32_t (&cid)[NREG], float (&cd)[N
   }
 #pragma unroll
   for (int r = NREG - 1; r >= 0; r--) {
-    uint32_t up_id = __shfl_up(cid[r], 1, 64);
-    float up_d = __shfl_up(cd[r], 1, 64);
-    if (r > 0) {
-      uint32_t c_id = rl(cid[r - 1], 63);
-      float c_d = rlf(cd[r - 1], 63);
-      if (lane == 0) up_id = c_id, up_d = c_d;
-    }
+    // entry e-1 -> e: one v_mov_b32_dpp wave_shr:1 per register; lane 0 takes the carry (lane 63 of the
+    // previous register) through the DPP `old` operand
+    uint32_t c_id = 0;
+    float c_d = 0.0f;
+    if (r > 0) c_id = rl(cid[r - 1], 63), c_d = rlf(cd[r - 1], 63);
+    const uint32_t up_id = (uint32_t)__builtin_amdgcn_update_dpp((int)c_id, (int)cid[r], 0x138, 0xf, 0xf, false);
+    const float up_d =
+        __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(c_d), __float_as_int(cd[r]), 0x138, 0xf, 0xf, false));
     const int e = r * 64 + lane;
     if (e > pos && e < newlen) cid[r] = up_id, cd[r] = up_d;
     else if (e == pos) cid[r] = id, cd[r] = d;
@@ -316,15 +319,58 @@ __device__ __forceinline__ bool filter_contains(const uint32_t *__restrict__ arr
   return __ballot(lo + (uint32_t)lane < hi && v == target) != 0ull;
 }
 
-template <class Dist, int NREG, bool FILT>
-__global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
-  const int lane = threadIdx.x;
-  const uint32_t q = blockIdx.x;
-  extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  Dist dist;
-  dist.init(a, q, lane, lds_f);
+// ---- visited-set policies (the visitedSet interface, distset.go:66-69) -----------------------------------
 
-  uint32_t *__restrict__ bits = a.bitsets + (size_t)q * a.words_per_query;
+// VisitedBitSet (distset.go:89-116): one bit per slot in HBM, test-and-set with a returning atomicOr.
+struct BitVisited {
+  uint32_t *__restrict__ bits;
+  __device__ __forceinline__ bool test_and_set(bool active, uint32_t slot, int lane) {
+    if (!active) return false;
+    const uint32_t bit = 1u << (slot & 31);
+    return !(atomicOr(&bits[slot >> 5], bit) & bit);
+  }
+  __device__ __forceinline__ bool overflowed() const { return false; }
+};
+
+// VisitedMap (distset.go:71-87) as an exact open-addressing hash set in LDS: a query marks a few thousand
+// ids, so the set fits next to the wave and CheckAndVisit costs an LDS atomic instead of an HBM round
+// trip.  Keys inserted by one instruction are distinct (rows are deduplicated), so the CAS loop only
+// resolves slot collisions.  When it fills past kHashLimit the query is rerun on the bitset.
+constexpr uint32_t kHashCap = 8192;  // 32 KB per wave -> 4 waves per CU
+constexpr uint32_t kHashLimit = 6000;
+struct HashVisited {
+  uint32_t *tab;
+  uint32_t count, limit;
+  __device__ __forceinline__ void init(uint32_t *lds, int lane, uint32_t lim) {
+    tab = lds;
+    count = 0;
+    limit = lim;
+    uint4 *t4 = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = lane; i < kHashCap / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
+    __syncthreads();
+  }
+  __device__ __forceinline__ bool test_and_set(bool active, uint32_t slot, int lane) {
+    bool isnew = false, done = !active;
+    uint32_t h = (slot * 2654435761u) >> (32 - 13);
+    while (__ballot(!done)) {
+      if (!done) {
+        const uint32_t old = atomicCAS(&tab[h], kNoSlot, slot);
+        if (old == kNoSlot) isnew = true, done = true;
+        else if (old == slot) done = true;
+        else h = (h + 1) & (kHashCap - 1);
+      }
+    }
+    count += (uint32_t)__popcll(__ballot(isnew));
+    return isnew;
+  }
+  __device__ __forceinline__ bool overflowed() const { return count > limit; }
+};
+
+// greedySearch for one query by one wavefront.  Returns false only when the LDS hash set overflowed
+// (the caller then reruns the query on the HBM bitset).
+template <class Dist, int NREG, bool FILT, class Visited>
+__device__ __forceinline__ bool search_body(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist,
+                                            Visited &vis) {
   uint32_t cid[NREG];
   float cd[NREG];
 #pragma unroll
@@ -353,11 +399,8 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
       const uint32_t j = base + lane;
       const bool has = j < ns;
       const uint32_t slot = has ? a.seeds[s0 + j] : kNoSlot;
-      bool isnew = false;
-      if (has) {  // searchSet.Add (:49): CheckAndVisit, distance, plain append -- NOT sorted
-        const uint32_t bit = 1u << (slot & 31);
-        isnew = !(atomicOr(&bits[slot >> 5], bit) & bit);
-      }
+      // searchSet.Add (:49): CheckAndVisit, distance, plain append -- NOT sorted
+      const bool isnew = vis.test_and_set(has, slot, lane);
       const uint64_t pend = __ballot(isnew);
       n_dist += (uint32_t)__popcll(pend);
       const float mydist = dist.hop(a, slot, pend, lane);
@@ -385,10 +428,8 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   // ---- searchSet.AddWithLimit(startNode)  search.go:57-61
   {
     const uint32_t s = a.start_slot;
-    uint32_t old = 0;
-    if (lane == 0) old = atomicOr(&bits[s >> 5], 1u << (s & 31));
-    old = rl(old, 0);
-    if (!(old & (1u << (s & 31)))) {
+    const bool snew = vis.test_and_set(lane == 0, s, lane);
+    if (__ballot(snew)) {
       const float d = dist.one(a, s, lane);
       n_dist++;
       if (!(len == cap && d > list_tail(cd, cap))) list_insert(cid, cd, len, cap, s, d, lane);
@@ -445,12 +486,9 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
     const bool valid = nb != kNoSlot;
     n_edges += (uint32_t)__popcll(__ballot(valid));
     SDB_STAMP(st_adj)
-    bool isnew = false;
-    if (valid) {  // CheckAndVisit distset.go:174 -- marks before any distance test
-      const uint32_t bit = 1u << (nb & 31);
-      const uint32_t old = atomicOr(&bits[nb >> 5], bit);
-      isnew = !(old & bit);
-    }
+    // CheckAndVisit distset.go:174 -- marks before any distance test
+    const bool isnew = vis.test_and_set(valid, nb, lane);
+    if (vis.overflowed()) return false;
     const uint64_t pend = __ballot(isnew);
     SDB_STAMP(st_atom)
     if (pend) {
@@ -510,9 +548,34 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
     if (a.tr_nedges) a.tr_nedges[q] = n_edges;
     if (a.vis_count) a.vis_count[q] = n_hop;
   }
+  return true;
+}
+
+
+// HASH: visited set in LDS with bitset fallback (plain store, unfiltered); otherwise the HBM bitset.
+template <class Dist, int NREG, bool FILT, bool HASH>
+__global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  Dist dist;
+  dist.init(a, q, lane, lds_f);
+  uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
+  if constexpr (HASH) {
+    HashVisited hv;
+    hv.init(reinterpret_cast<uint32_t *>(lds_f), lane, a.hash_limit);
+    if (search_body<Dist, NREG, FILT>(a, q, lane, dist, hv)) return;
+    // overflow (rare): clear this query's bitset and run the identical walk on it
+    for (uint32_t i = lane; i < a.words_per_query; i += 64) bits[i] = 0u;
+    __threadfence();
+  }
+  BitVisited bv{bits};
+  search_body<Dist, NREG, FILT>(a, q, lane, dist, bv);
 }
 
 // host-side launcher: picks the instantiation for (ng, metric, search_size)
 int launch_greedy_search(const SearchArgs &a, uint32_t nq, hipStream_t stream);
+// true when launch_greedy_search will use the LDS hash visited set (then the bitsets need no clearing)
+bool search_uses_hash(const SearchArgs &a, uint32_t nq);
 
 }  // namespace sdb

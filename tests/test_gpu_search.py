@@ -173,3 +173,19 @@ def test_sparse_ids_and_device_queries(oracle):
     assert np.array_equal(bits(got[:, :2]), bits(want))
     assert np.all(got[:, 3] == np.finfo(np.float32).max)
     ix.close()
+
+
+def test_hash_set_overflow_falls_back_to_bitset(oracle, monkeypatch):
+    """The LDS hash visited set is exact; when it fills, the query reruns on the HBM bitset.  A tiny
+    limit forces that path for every query: results must not change."""
+    rng = np.random.default_rng(77)
+    base = unit_rows(rng, 3000, 96)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ix = _gpu_index(o, 96, "cosine", 32, 50)
+    q = unit_rows(rng, 32, 96)
+    _check_batch(o, ix, q, 10, 50)            # hash path
+    monkeypatch.setenv("SDB_HASH_LIMIT", "40")
+    _check_batch(o, ix, q, 10, 50)            # every query overflows -> bitset rerun
+    monkeypatch.setenv("SDB_HASH_LIMIT", "700")
+    _check_batch(o, ix, q, 10, 50)            # a mix of both
+    ix.close()
