@@ -57,7 +57,7 @@ template <int NG, bool L2>
 __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc, const uint32_t *in_slot,
                                   const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
                                   float *qs, int lane) {
-  constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
+  constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
   for (int i = lane; i < nc; i += 64) {
     const float d = in_dist[i];
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
   if (key == kNoKey) return;
   const uint32_t b = (uint32_t)(key >> 32);
   if (pos > 0 && (uint32_t)(a.keys_sorted[pos - 1] >> 32) == b) return;  // not the head of B's segment
-  constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
+  constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
   uint32_t deg = a.deg[b];
   bool row_dirty = false;

@@ -148,8 +148,8 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 
 template <int NG, bool L2>
 static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
-  if (search_uses_hash(a, nq)) return launch_nreg<PlainDist<NG, L2>, true>(a, nq, stream, 0);
-  return launch_nreg<PlainDist<NG, L2>, false>(a, nq, stream, 0);
+  if (search_uses_hash(a, nq)) return launch_nreg<PlainDist<NG, L2, true>, true>(a, nq, stream, 0);
+  return launch_nreg<PlainDist<NG, L2, false>, false>(a, nq, stream, 0);
 }
 
 template <bool L2>

@@ -56,13 +56,13 @@ struct SearchArgs {
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
 
-template <int NG>
+// pairs of candidate rows a wave keeps in flight per chunk.  DEEP (one wave per SIMD, the batch-search
+// configuration: 4 waves per CU, the whole 512-entry register file available): ~190 VGPRs of loads;
+// otherwise ~96 so that three waves per SIMD still fit (large build rounds).
+template <int NG, bool DEEP>
 struct ChunkPairs {
-  // pairs of rows kept in flight per wave: ~96 VGPRs of loads
-#ifndef SDB_PAIRS_NG3
-#define SDB_PAIRS_NG3 8
-#endif
-  static constexpr int value = NG <= 1 ? 8 : (NG <= 3 ? SDB_PAIRS_NG3 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3)));
+  static constexpr int base = NG <= 3 ? 8 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3));
+  static constexpr int value = DEEP ? 2 * base : base;
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -134,10 +134,10 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
 
 // Full-precision store.  NG >= 0: compile-time group count, query in registers.  NG == -1: run-time
 // ng, query tile in LDS.
-template <int NG, bool L2>
+template <int NG, bool L2, bool DEEP = false>
 struct PlainDist {
   static constexpr int NGR = NG > 0 ? NG : 1;
-  static constexpr int U = NG >= 0 ? ChunkPairs<NG>::value : 4;
+  static constexpr int U = NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4;
   float4 xq[NGR];
   float xt;
   float *qs;
@@ -351,13 +351,16 @@ struct HashVisited {
   }
   __device__ __forceinline__ bool test_and_set(bool active, uint32_t slot, int lane) {
     bool isnew = false, done = !active;
+    // double hashing: the probe stride is odd (coprime with the table size), so every slot is reached and
+    // probe chains of different keys do not pile up the way linear probing clusters
     uint32_t h = (slot * 2654435761u) >> (32 - 13);
+    const uint32_t step = ((slot * 0x9E3779B1u) >> 19) | 1u;
     while (__ballot(!done)) {
       if (!done) {
         const uint32_t old = atomicCAS(&tab[h], kNoSlot, slot);
         if (old == kNoSlot) isnew = true, done = true;
         else if (old == slot) done = true;
-        else h = (h + 1) & (kHashCap - 1);
+        else h = (h + step) & (kHashCap - 1);
       }
     }
     count += (uint32_t)__popcll(__ballot(isnew));
