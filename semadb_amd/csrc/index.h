@@ -22,7 +22,10 @@ struct Workspace {
   size_t lut_bytes = 0;
   void *filter = nullptr;  // seeds / filter slot lists of a filtered batch
   size_t filter_bytes = 0;
-  bool busy = false;
+  bool busy = false;               // held by a call that has not returned yet
+  bool pending = false;            // device work of an asynchronous call may still be running
+  hipStream_t bound_stream = nullptr;
+  hipEvent_t done = nullptr;
   int ensure_filter(size_t bytes);
   int ensure_lut(size_t bytes);
   int ensure_bitsets(size_t bytes);
@@ -61,6 +64,6 @@ struct sdb_index {
 
   int64_t slot_of(uint64_t id) const;
   int reserve(uint32_t rows);
-  sdb::Workspace *acquire_ws() const;
-  void release_ws(sdb::Workspace *ws) const;
+  sdb::Workspace *acquire_ws(hipStream_t stream, bool async) const;
+  void release_ws(sdb::Workspace *ws, hipStream_t stream, bool async) const;
 };

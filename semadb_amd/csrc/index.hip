@@ -73,6 +73,8 @@ void Workspace::release() {
   if (bitsets) (void)hipFree(bitsets);
   if (scratch) (void)hipFree(scratch);
   if (own_stream) (void)hipStreamDestroy(own_stream);
+  if (done) (void)hipEventDestroy(done);
+  done = nullptr;
   bitsets = nullptr, scratch = nullptr, own_stream = nullptr;
 }
 
@@ -233,13 +235,25 @@ int sdb_index::reserve(uint32_t rows) {
   return SDB_OK;
 }
 
-Workspace *sdb_index::acquire_ws() const {
+// A workspace (visited bitsets, staging, LUTs) belongs to one in-flight batch.  Host-memory calls hold it
+// until they have synchronised.  Device-memory calls return before the kernel runs, so the workspace
+// stays bound to the caller's stream: it is handed out again only to a call on the same stream (stream
+// order then serialises the reuse) or once its completion event has fired.
+Workspace *sdb_index::acquire_ws(hipStream_t stream, bool async) const {
   std::lock_guard<std::mutex> g(mu);
-  for (auto *w : pool)
-    if (!w->busy) {
-      w->busy = true;
-      return w;
+  for (auto *w : pool) {
+    if (w->busy) continue;
+    if (w->pending) {
+      if (async && w->bound_stream == stream) {
+        w->busy = true;
+        return w;
+      }
+      if (hipEventQuery(w->done) != hipSuccess) continue;
+      w->pending = false;
     }
+    w->busy = true;
+    return w;
+  }
   auto *w = new Workspace();
   w->device = P.device;
   w->busy = true;
@@ -247,8 +261,15 @@ Workspace *sdb_index::acquire_ws() const {
   return w;
 }
 
-void sdb_index::release_ws(Workspace *ws) const {
+void sdb_index::release_ws(Workspace *ws, hipStream_t stream, bool async) const {
   std::lock_guard<std::mutex> g(mu);
+  if (async) {
+    if (!ws->done) (void)hipEventCreateWithFlags(&ws->done, hipEventDisableTiming);
+    if (ws->done && hipEventRecord(ws->done, stream) == hipSuccess) {
+      ws->pending = true;
+      ws->bound_stream = stream;
+    }
+  }
   ws->busy = false;
 }
 
@@ -462,13 +483,16 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   if (filtered && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
   if (nq > 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many queries");
   DeviceGuard dg(ix->P.device);
-  Workspace *ws = ix->acquire_ws();
+  hipStream_t stream = as_stream(stream_);
+  const bool async = mem == SDB_MEM_DEVICE;
+  Workspace *ws = ix->acquire_ws(stream, async);
   struct Rel {
     const sdb_index *ix;
     Workspace *ws;
-    ~Rel() { ix->release_ws(ws); }
-  } rel{ix, ws};
-  hipStream_t stream = as_stream(stream_);
+    hipStream_t stream;
+    bool async;
+    ~Rel() { ix->release_ws(ws, stream, async); }
+  } rel{ix, ws, stream, async};
   if (mem == SDB_MEM_HOST) {
     if (!ws->own_stream) SDB_HIP(hipStreamCreateWithFlags(&ws->own_stream, hipStreamNonBlocking));
     stream = ws->own_stream;

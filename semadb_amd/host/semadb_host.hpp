@@ -1,0 +1,492 @@
+// semadb_host.hpp -- C++ host-side mirror of the reference's Go interfaces for the hot path, on top of
+// the C ABI (include/semadb_amd.h).  The reference is Go; this image has no Go toolchain, so this header
+// is the compiled stand-in for the cgo shim of INTEGRATION.md: same package / type / method names,
+// same argument meaning, same error behaviour, so that host code and tests read like the reference's.
+//
+//   semadb::conversion   <-> conversion/            (NodeKey, float32 / edge-list byte codecs)
+//   semadb::diskstore    <-> diskstore/             (Bucket interface, MemBucket = NewMemBucket)
+//   semadb::distance     <-> distance/              (GetFloatDistanceFn)
+//   semadb::models       <-> models/                (IndexVectorVamanaParameters, SearchVectorVamanaOptions, SearchResult)
+//   semadb::vamana       <-> shard/index/vamana/    (STARTID, IndexVectorChange, NewIndexVamana, IndexVamana)
+//
+// IndexVamana keeps its state in HBM and treats the bucket as the source of truth exactly like the
+// reference's ItemCache: NewIndexVamana fills HBM from the 'n<id>v' / 'n<id>e' keys (plain.go:125-141,
+// node.go:96-111), InsertUpdateDelete flushes the touched rows back (vamana.go:265-276).  Search may be
+// called from many threads at once; a micro-batcher coalesces the calls into sdb_index_search_batch
+// (the reference has no batch entry point: one goroutine per request, shard/cache/manager.go:163).
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <set>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/semadb_amd.h"
+
+namespace semadb {
+
+// Go `error`: empty message == nil
+struct Error {
+  std::string msg;
+  Error() = default;
+  explicit Error(std::string m) : msg(std::move(m)) {}
+  explicit operator bool() const { return !msg.empty(); }
+  static Error wrap(const std::string &what, int rc) {
+    return Error(what + ": " + std::string(sdb_last_error()) + " (status " + std::to_string(rc) + ")");
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+namespace conversion {  // conversion/keys.go, conversion/conversion.go
+inline std::string NodeKey(uint64_t id, char suffix) {  // keys.go:6-12
+  std::string k(10, '\0');
+  k[0] = 'n';
+  for (int i = 0; i < 8; i++) k[1 + i] = (char)((id >> (8 * i)) & 0xFF);
+  k[9] = suffix;
+  return k;
+}
+inline bool NodeIdFromKey(const std::string &key, char suffix, uint64_t *id) {  // keys.go:15-20
+  if (key.size() != 10 || key[0] != 'n' || key[9] != suffix) return false;
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) v |= (uint64_t)(uint8_t)key[1 + i] << (8 * i);
+  *id = v;
+  return true;
+}
+inline std::string Uint64ToBytes(uint64_t v) {  // conversion.go:59-63
+  std::string b(8, '\0');
+  for (int i = 0; i < 8; i++) b[i] = (char)((v >> (8 * i)) & 0xFF);
+  return b;
+}
+inline uint64_t BytesToUint64(const std::string &b) {
+  uint64_t v = 0;
+  for (int i = 0; i < 8 && i < (int)b.size(); i++) v |= (uint64_t)(uint8_t)b[i] << (8 * i);
+  return v;
+}
+inline std::string Float32ToBytes(const float *f, size_t n) {  // raw little-endian, conversion.go:97-99
+  return std::string(reinterpret_cast<const char *>(f), n * 4);
+}
+inline std::vector<float> BytesToFloat32(const std::string &b) {  // conversion.go:101-108
+  std::vector<float> f(b.size() / 4);
+  if (!f.empty()) std::memcpy(f.data(), b.data(), f.size() * 4);
+  return f;
+}
+inline std::string EdgeListToBytes(const std::vector<uint64_t> &e) {  // conversion.go:110-116
+  std::string b;
+  b.reserve(e.size() * 8);
+  for (uint64_t v : e) b += Uint64ToBytes(v);
+  return b;
+}
+inline std::vector<uint64_t> BytesToEdgeList(const std::string &b) {  // conversion.go:118-124
+  std::vector<uint64_t> e(b.size() / 8);
+  for (size_t i = 0; i < e.size(); i++) e[i] = BytesToUint64(b.substr(i * 8, 8));
+  return e;
+}
+}  // namespace conversion
+
+// ---------------------------------------------------------------------------------------------------
+namespace diskstore {  // diskstore/diskstore.go:45-71
+class Bucket {
+ public:
+  virtual ~Bucket() = default;
+  virtual bool Get(const std::string &key, std::string *value) const = 0;
+  virtual Error Put(const std::string &key, const std::string &value) = 0;
+  virtual Error Delete(const std::string &key) = 0;
+  virtual Error ForEach(const std::function<Error(const std::string &, const std::string &)> &fn) const = 0;
+};
+// diskstore.NewMemBucket (diskstore/memstore.go:16): the reference's universal fake backend
+class MemBucket : public Bucket {
+  std::map<std::string, std::string> kv_;
+  mutable std::mutex mu_;
+
+ public:
+  bool Get(const std::string &key, std::string *value) const override {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = kv_.find(key);
+    if (it == kv_.end()) return false;
+    if (value) *value = it->second;
+    return true;
+  }
+  Error Put(const std::string &key, const std::string &value) override {
+    std::lock_guard<std::mutex> g(mu_);
+    kv_[key] = value;
+    return Error();
+  }
+  Error Delete(const std::string &key) override {
+    std::lock_guard<std::mutex> g(mu_);
+    kv_.erase(key);
+    return Error();
+  }
+  Error ForEach(const std::function<Error(const std::string &, const std::string &)> &fn) const override {
+    std::map<std::string, std::string> snap;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      snap = kv_;
+    }
+    for (auto &p : snap)
+      if (Error e = fn(p.first, p.second)) return e;
+    return Error();
+  }
+  size_t size() const {
+    std::lock_guard<std::mutex> g(mu_);
+    return kv_.size();
+  }
+};
+}  // namespace diskstore
+
+// ---------------------------------------------------------------------------------------------------
+namespace models {  // models/index.go:275-282, models/search.go:238-275
+constexpr const char *DistanceEuclidean = "euclidean";
+constexpr const char *DistanceCosine = "cosine";
+constexpr const char *DistanceDot = "dot";
+struct IndexVectorVamanaParameters {
+  uint32_t VectorSize = 0;
+  std::string DistanceMetric;
+  int SearchSize = 75;
+  int DegreeBound = 64;
+  float Alpha = 1.2f;
+};
+struct SearchVectorVamanaOptions {
+  std::vector<float> Vector;
+  int SearchSize = 75;
+  int Limit = 10;
+  std::optional<float> Weight;
+};
+struct SearchResult {
+  uint64_t NodeId = 0;
+  float Distance = 0;
+  float HybridScore = 0;
+};
+}  // namespace models
+
+inline int metric_code(const std::string &name) {
+  if (name == models::DistanceEuclidean) return SDB_METRIC_EUCLIDEAN;
+  if (name == models::DistanceCosine) return SDB_METRIC_COSINE;
+  if (name == models::DistanceDot) return SDB_METRIC_DOT;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+namespace distance {  // distance/distance.go:11,70-83
+using FloatDistFunc = std::function<float(const std::vector<float> &, const std::vector<float> &)>;
+inline Error GetFloatDistanceFn(const std::string &name, FloatDistFunc *out, int device = 0) {
+  const int mc = metric_code(name);
+  if (mc < 0) return Error("unknown float32 distance function: " + name);  // distance.go:81
+  *out = [mc, device](const std::vector<float> &x, const std::vector<float> &y) {
+    float d = 0;
+    // like asm.Dot the length comes from x only (dot.s:10)
+    sdb_distance_batch(mc, (uint32_t)x.size(), x.data(), 1, y.data(), 1, &d, SDB_MEM_HOST, device, nullptr);
+    return d;
+  };
+  return Error();
+}
+}  // namespace distance
+
+// ---------------------------------------------------------------------------------------------------
+namespace vamana {  // shard/index/vamana/vamana.go
+constexpr uint64_t STARTID = 1;                        // :28
+constexpr const char *MAXNODEIDKEY = "_vamanaMaxNodeId";  // :31
+struct IndexVectorChange {                             // :122-125 ; empty Vector == nil == delete
+  uint64_t Id = 0;
+  std::vector<float> Vector;
+};
+
+class IndexVamana {
+ public:
+  using Filter = std::set<uint64_t>;  // roaring64.Bitmap: ascending iteration, Contains
+  struct SearchReturn {
+    std::set<uint64_t> set;
+    std::vector<models::SearchResult> results;
+    Error err;
+  };
+
+  // vamana.NewIndexVamana (vamana.go:54-81)
+  static std::pair<std::unique_ptr<IndexVamana>, Error> NewIndexVamana(const std::string &name,
+                                                                      const models::IndexVectorVamanaParameters &params,
+                                                                      diskstore::Bucket *bucket, int device = 0,
+                                                                      const std::vector<float> *start_vector = nullptr) {
+    const int mc = metric_code(params.DistanceMetric);
+    if (mc < 0) return {nullptr, Error("could not create vector store: unknown float32 distance function: " + params.DistanceMetric)};
+    std::unique_ptr<IndexVamana> v(new IndexVamana());
+    v->name_ = name, v->parameters_ = params, v->bucket_ = bucket;
+    sdb_index_params p{};
+    p.dim = params.VectorSize, p.metric = (uint32_t)mc, p.search_size = (uint32_t)params.SearchSize;
+    p.degree_bound = (uint32_t)params.DegreeBound, p.alpha = params.Alpha, p.device = device, p.strict = 1;
+    if (int rc = sdb_index_create(&p, &v->h_)) return {nullptr, Error::wrap("could not create device index", rc)};
+    if (Error e = v->loadFromBucket(start_vector)) return {nullptr, e};
+    v->batcher_ = std::thread([raw = v.get()] { raw->batcherLoop(); });
+    return {std::move(v), Error()};
+  }
+
+  ~IndexVamana() {
+    {
+      std::lock_guard<std::mutex> g(qmu_);
+      stop_ = true;
+    }
+    qcv_.notify_all();
+    if (batcher_.joinable()) batcher_.join();
+    if (h_) sdb_index_destroy(h_);
+  }
+
+  int64_t SizeInMemory() const {  // vamana.go:83-85
+    int64_t b = 0;
+    sdb_index_size_in_memory(h_, &b);
+    return b;
+  }
+  void UpdateBucket(diskstore::Bucket *b) { bucket_ = b; }  // vamana.go:87-91
+  uint64_t maxNodeId() const {
+    uint64_t n = 0, e = 0, m = 0;
+    sdb_index_stats(h_, &n, &e, &m);
+    return m;
+  }
+
+  // IndexVamana.Search (vamana.go:278-310).  Thread-safe; concurrent calls share device batches.
+  SearchReturn Search(const models::SearchVectorVamanaOptions &q, const Filter *filter = nullptr) {
+    SearchReturn out;
+    if (q.Vector.size() != parameters_.VectorSize) {  // models/search.go:198-200 (rejected upstream)
+      out.err = Error("query vector length mismatch");
+      return out;
+    }
+    if (q.SearchSize < q.Limit) {  // search.go:23-25
+      out.err = Error("could not perform graph search: searchSize (" + std::to_string(q.SearchSize) +
+                      ") must be greater than k (" + std::to_string(q.Limit) + ")");
+      return out;
+    }
+    Request r;
+    r.q = &q, r.filter = filter;
+    {
+      std::lock_guard<std::mutex> g(qmu_);
+      queue_.push_back(&r);
+    }
+    qcv_.notify_all();
+    {
+      std::unique_lock<std::mutex> lk(r.mu);
+      r.cv.wait(lk, [&] { return r.done; });
+    }
+    if (r.err) {
+      out.err = Error("could not perform graph search: " + r.err.msg);
+      return out;
+    }
+    const float weight = q.Weight ? *q.Weight : 1.0f;  // vamana.go:289-292
+    for (size_t i = 0; i < r.ids.size(); i++) {
+      models::SearchResult sr;
+      sr.NodeId = r.ids[i], sr.Distance = r.dists[i];
+      sr.HybridScore = (-1 * r.dists[i] * weight);  // :303
+      out.results.push_back(sr);
+      out.set.insert(r.ids[i]);
+    }
+    return out;
+  }
+
+  // IndexVamana.InsertUpdateDelete (vamana.go:127-263), insert branch on device; the bucket is then
+  // brought up to date (flush, :265-276).  Updates/deletes stay on the reference's host path.
+  Error InsertUpdateDelete(const std::vector<IndexVectorChange> &points, uint32_t round_size = 0) {
+    std::lock_guard<std::mutex> wl(write_mu_);
+    std::vector<uint64_t> ids;
+    std::vector<float> vecs;
+    for (const auto &p : points) {
+      if (p.Id == STARTID) return Error("could not distribute or insert points: cannot modify point with start id: 1");
+      if (p.Id == 0) return Error("could not distribute or insert points: invalid point id: 0");
+      if (p.Vector.empty()) return Error("delete/update is not on the device path (prune.go)");
+      if (p.Vector.size() != parameters_.VectorSize) return Error("vector length mismatch");  // models/index.go:182-184
+      ids.push_back(p.Id);
+      vecs.insert(vecs.end(), p.Vector.begin(), p.Vector.end());  // copied: never retains caller memory
+    }
+    if (ids.empty()) return Error();
+    if (int rc = sdb_index_insert_batch(h_, ids.size(), ids.data(), vecs.data(), SDB_MEM_HOST, round_size, nullptr))
+      return Error::wrap("could not distribute or insert points", rc);
+    return flush();
+  }
+
+  // vamana.go:265-276: vectors -> 'n<id>v', edges -> 'n<id>e', max node id
+  Error flush() {
+    if (!bucket_) return Error();
+    uint64_t n = 0, ne = 0, mx = 0;
+    sdb_index_stats(h_, &n, &ne, &mx);
+    std::vector<uint64_t> ids(n), off(n + 1), edges(ne ? ne : 1);
+    std::vector<float> vecs(n * parameters_.VectorSize);
+    if (int rc = sdb_index_export(h_, ids.data(), vecs.data(), off.data(), edges.data()))
+      return Error::wrap("could not flush", rc);
+    const size_t d = parameters_.VectorSize;
+    for (uint64_t i = 0; i < n; i++) {
+      bucket_->Put(conversion::NodeKey(ids[i], 'v'), conversion::Float32ToBytes(vecs.data() + i * d, d));
+      std::vector<uint64_t> e(edges.begin() + off[i], edges.begin() + off[i + 1]);
+      bucket_->Put(conversion::NodeKey(ids[i], 'e'), conversion::EdgeListToBytes(e));
+    }
+    bucket_->Put(MAXNODEIDKEY, conversion::Uint64ToBytes(mx));
+    return Error();
+  }
+
+  // tuning knobs of the micro-batcher (not part of the reference surface)
+  void setBatching(size_t max_batch, std::chrono::microseconds window) {
+    std::lock_guard<std::mutex> g(qmu_);
+    max_batch_ = max_batch, window_ = window;
+  }
+  uint64_t deviceBatches() const { return n_batches_.load(); }
+
+ private:
+  IndexVamana() = default;
+  struct Request {
+    const models::SearchVectorVamanaOptions *q = nullptr;
+    const Filter *filter = nullptr;
+    std::vector<uint64_t> ids;
+    std::vector<float> dists;
+    Error err;
+    bool done = false;
+    std::mutex mu;
+    std::condition_variable cv;
+  };
+
+  // what plainPoint.ReadFrom / graphNode.ReadFrom read lazily (plain.go:125-141, node.go:96-111)
+  Error loadFromBucket(const std::vector<float> *start_vector) {
+    std::vector<uint64_t> ids, offsets{0}, edges;
+    std::vector<float> vectors;
+    const size_t d = parameters_.VectorSize;
+    if (bucket_) {
+      Error e = bucket_->ForEach([&](const std::string &k, const std::string &val) {
+        uint64_t id;
+        if (!conversion::NodeIdFromKey(k, 'v', &id)) return Error();
+        if (val.size() != d * 4) return Error("vector of node " + std::to_string(id) + " has the wrong length");
+        ids.push_back(id);
+        auto f = conversion::BytesToFloat32(val);
+        vectors.insert(vectors.end(), f.begin(), f.end());
+        std::string eb;
+        if (bucket_->Get(conversion::NodeKey(id, 'e'), &eb)) {
+          auto el = conversion::BytesToEdgeList(eb);
+          edges.insert(edges.end(), el.begin(), el.end());
+        }
+        offsets.push_back(edges.size());
+        return Error();
+      });
+      if (e) return e;
+    }
+    if (ids.empty()) {  // setupStartNode (vamana.go:93-120)
+      std::vector<float> sv;
+      if (start_vector) sv = *start_vector;
+      else sv = randomUnitVector(d);
+      if (int rc = sdb_index_set_start(h_, sv.data(), SDB_MEM_HOST)) return Error::wrap("could not setup start node", rc);
+      if (bucket_) {
+        bucket_->Put(conversion::NodeKey(STARTID, 'v'), conversion::Float32ToBytes(sv.data(), d));
+        bucket_->Put(conversion::NodeKey(STARTID, 'e'), "");
+      }
+      return Error();
+    }
+    if (edges.empty()) edges.push_back(0);
+    if (int rc = sdb_index_load(h_, ids.size(), ids.data(), vectors.data(), offsets.data(), edges.data(), SDB_MEM_HOST))
+      return Error::wrap("could not load index into HBM", rc);
+    return Error();
+  }
+
+  static std::vector<float> randomUnitVector(size_t d) {  // vamana.go:99-110
+    std::vector<float> v(d);
+    uint64_t s = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1;
+    float sum = 0;
+    for (size_t i = 0; i < d; i++) {
+      s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+      v[i] = (float)((s >> 40) & 0xFFFFFF) / (float)0x1000000 * 2 - 1;
+      sum += v[i] * v[i];
+    }
+    const float norm = 1 / (float)std::sqrt((double)sum);
+    for (auto &x : v) x *= norm;
+    return v;
+  }
+
+  void batcherLoop() {
+    for (;;) {
+      std::vector<Request *> batch;
+      {
+        std::unique_lock<std::mutex> lk(qmu_);
+        qcv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (stop_ && queue_.empty()) return;
+        // wait a short window for more callers (or until the batch is full)
+        const auto deadline = std::chrono::steady_clock::now() + window_;
+        while (queue_.size() < max_batch_ && !stop_)
+          if (qcv_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+        // one device call per (limit, searchSize, filtered) group, oldest group first
+        Request *head = queue_.front();
+        for (auto it = queue_.begin(); it != queue_.end() && batch.size() < max_batch_;) {
+          Request *r = *it;
+          if (r->q->Limit == head->q->Limit && r->q->SearchSize == head->q->SearchSize &&
+              (r->filter != nullptr) == (head->filter != nullptr)) {
+            batch.push_back(r);
+            it = queue_.erase(it);
+          } else {
+            ++it;
+          }
+        }
+      }
+      runBatch(batch);
+    }
+  }
+
+  void runBatch(const std::vector<Request *> &reqs) {
+    const size_t nq = reqs.size(), d = parameters_.VectorSize;
+    const uint32_t limit = (uint32_t)reqs[0]->q->Limit, L = (uint32_t)reqs[0]->q->SearchSize;
+    std::vector<float> queries(nq * d);
+    for (size_t i = 0; i < nq; i++) std::memcpy(queries.data() + i * d, reqs[i]->q->Vector.data(), d * 4);
+    std::vector<uint64_t> ids(nq * limit), f_off, f_ids;
+    std::vector<float> dists(nq * limit);
+    std::vector<uint32_t> counts(nq);
+    const bool filtered = reqs[0]->filter != nullptr;
+    if (filtered) {
+      f_off.push_back(0);
+      for (auto *r : reqs) {
+        f_ids.insert(f_ids.end(), r->filter->begin(), r->filter->end());  // ascending, like roaring
+        f_off.push_back(f_ids.size());
+      }
+      if (f_ids.empty()) f_ids.push_back(0);
+    }
+    const int rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, filtered ? f_off.data() : nullptr,
+                                          filtered ? f_ids.data() : nullptr, ids.data(), dists.data(), counts.data(),
+                                          nullptr, SDB_MEM_HOST, nullptr);
+    n_batches_++;
+    Error err = rc ? Error(std::string(sdb_last_error())) : Error();
+    for (size_t i = 0; i < nq; i++) {
+      Request *r = reqs[i];
+      {
+        std::lock_guard<std::mutex> g(r->mu);
+        if (!rc) {
+          r->ids.assign(ids.begin() + i * limit, ids.begin() + i * limit + counts[i]);
+          r->dists.assign(dists.begin() + i * limit, dists.begin() + i * limit + counts[i]);
+        }
+        r->err = err;
+        r->done = true;
+      }
+      r->cv.notify_one();
+    }
+  }
+
+  std::string name_;
+  models::IndexVectorVamanaParameters parameters_;
+  diskstore::Bucket *bucket_ = nullptr;
+  sdb_index *h_ = nullptr;
+  std::mutex write_mu_;
+  // micro-batcher
+  std::thread batcher_;
+  std::mutex qmu_;
+  std::condition_variable qcv_;
+  std::vector<Request *> queue_;
+  bool stop_ = false;
+  size_t max_batch_ = 1024;
+  std::chrono::microseconds window_{200};
+  std::atomic<uint64_t> n_batches_{0};
+};
+
+inline std::pair<std::unique_ptr<IndexVamana>, Error> NewIndexVamana(const std::string &name,
+                                                                    const models::IndexVectorVamanaParameters &params,
+                                                                    diskstore::Bucket *bucket, int device = 0,
+                                                                    const std::vector<float> *start_vector = nullptr) {
+  return IndexVamana::NewIndexVamana(name, params, bucket, device, start_vector);
+}
+}  // namespace vamana
+}  // namespace semadb

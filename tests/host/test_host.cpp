@@ -1,0 +1,183 @@
+// test_host.cpp -- the reference's own Go tests for the hot path, replayed through the C++ host mirror
+// (semadb_amd/host/semadb_host.hpp) on a real GPU.  Each block names the Go test it follows.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../semadb_amd/host/semadb_host.hpp"
+
+using namespace semadb;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                       \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);         \
+      g_fail++;                                                           \
+    }                                                                     \
+  } while (0)
+
+static models::IndexVectorVamanaParameters vamanaParams() {  // vamana_test.go:21-27
+  models::IndexVectorVamanaParameters p;
+  p.VectorSize = 2, p.DistanceMetric = "euclidean", p.SearchSize = 75, p.DegreeBound = 64, p.Alpha = 1.2f;
+  return p;
+}
+
+static void test_distance_table() {  // distance/distance_test.go:9-39, distance_amd64_test.go:12-27
+  struct Row {
+    std::vector<float> x, y;
+    float dot, l2;
+  } table[] = {{{0, 0, 0}, {0, 0, 0}, 0, 0},
+               {{1, 1}, {1, 1}, 2, 0},
+               {{1, 2, 3}, {4, 5, 6}, 32, 27},
+               {{-1, -2, -3}, {-4, -5, -6}, 32, 27},
+               {{-1, 2, 3}, {4, -5, 6}, 4, 83}};
+  distance::FloatDistFunc dot, l2, cosd, bad;
+  CHECK(!distance::GetFloatDistanceFn("dot", &dot));
+  CHECK(!distance::GetFloatDistanceFn("euclidean", &l2));
+  CHECK(!distance::GetFloatDistanceFn("cosine", &cosd));
+  CHECK((bool)distance::GetFloatDistanceFn("manhattan", &bad));  // distance.go:81
+  for (auto &r : table) {
+    CHECK(dot(r.x, r.y) == -r.dot);       // dotProductDistance distance.go:19-21
+    CHECK(l2(r.x, r.y) == r.l2);
+    CHECK(cosd(r.x, r.y) == 1 - r.dot);   // cosineDistance distance.go:23-25
+  }
+}
+
+static void test_conversion() {  // conversion/keys.go, conversion.go
+  uint64_t id = 0;
+  auto k = conversion::NodeKey(0x0102030405060708ull, 'v');
+  CHECK(k.size() == 10 && k[0] == 'n' && k[9] == 'v' && (uint8_t)k[1] == 0x08 && (uint8_t)k[8] == 0x01);
+  CHECK(conversion::NodeIdFromKey(k, 'v', &id) && id == 0x0102030405060708ull);
+  CHECK(!conversion::NodeIdFromKey(k, 'e', &id));
+  std::vector<uint64_t> e{1, 42, 1ull << 40};
+  CHECK(conversion::BytesToEdgeList(conversion::EdgeListToBytes(e)) == e);
+  std::vector<float> f{1.5f, -2.25f, 1e-30f};
+  CHECK(conversion::BytesToFloat32(conversion::Float32ToBytes(f.data(), f.size())) == f);
+  CHECK(conversion::BytesToUint64(conversion::Uint64ToBytes(4242)) == 4242);
+}
+
+static std::vector<vamana::IndexVectorChange> detPoints(int n) {  // shard/index/dispatch_test.go:66-89
+  std::vector<vamana::IndexVectorChange> pts;
+  for (int i = 0; i < n; i++) {
+    float fi = (float)(i + 2);
+    pts.push_back({(uint64_t)(i + 2), {fi, fi + 1}});
+  }
+  return pts;
+}
+
+static void test_deterministic_search() {
+  diskstore::MemBucket bucket;
+  auto [inv, err] = vamana::NewIndexVamana("test", vamanaParams(), &bucket);
+  CHECK(!err);
+  CHECK(!inv->InsertUpdateDelete(detPoints(100)));
+  models::SearchVectorVamanaOptions q;
+  q.Vector = {42, 43}, q.SearchSize = 75, q.Limit = 10;
+  auto r = inv->Search(q);  // TestSearch_Single shard/index/search_test.go:89-144
+  CHECK(!r.err && r.results.size() == 10 && r.results[0].NodeId == 42 && r.set.count(42));
+  q.Limit = 5;
+  q.Weight = 0.5f;  // TestSearch_OrVector :414-457
+  r = inv->Search(q);
+  CHECK((r.set == std::set<uint64_t>{40, 41, 42, 43, 44}));
+  for (auto &sr : r.results) CHECK(sr.HybridScore + sr.HybridScore == -sr.Distance);
+  q.Limit = 10, q.Weight.reset();
+  vamana::IndexVamana::Filter f47{47};  // TestSearch_FilterById :196-244
+  r = inv->Search(q, &f47);
+  CHECK(r.results.size() == 1 && r.results[0].NodeId == 47 && r.results[0].Distance == 50.0f);
+  vamana::IndexVamana::Filter f5{42, 43, 44, 45, 46};  // TestSearch_FilterSpecific :246-288
+  r = inv->Search(q, &f5);
+  CHECK(r.results.size() == 5 && r.set == f5 && r.results[0].NodeId == 42);
+  q.SearchSize = 25, q.Limit = 30;  // search.go:23-25
+  CHECK((bool)inv->Search(q).err);
+  // persistence: a second index over the same bucket (what a cold reader builds, manager.go:165-181)
+  std::string v;
+  CHECK(bucket.Get(conversion::NodeKey(42, 'v'), &v) && v.size() == 8);
+  CHECK(bucket.Get(conversion::NodeKey(42, 'e'), &v) && !v.empty() && v.size() % 8 == 0);
+  CHECK(bucket.Get(vamana::MAXNODEIDKEY, &v) && conversion::BytesToUint64(v) == 101);
+  auto [inv2, err2] = vamana::NewIndexVamana("test", vamanaParams(), &bucket);
+  CHECK(!err2 && inv2->maxNodeId() == 101);
+  q.SearchSize = 75, q.Limit = 10;
+  auto a = inv->Search(q), b = inv2->Search(q);
+  CHECK(a.results.size() == b.results.size());
+  for (size_t i = 0; i < a.results.size() && i < b.results.size(); i++)
+    CHECK(a.results[i].NodeId == b.results[i].NodeId && a.results[i].Distance == b.results[i].Distance);
+  CHECK(inv->SizeInMemory() > 0);
+}
+
+static void test_invalid_ids_and_empty() {
+  diskstore::MemBucket bucket;
+  auto [inv, err] = vamana::NewIndexVamana("test", vamanaParams(), &bucket);
+  CHECK(!err);
+  // Test_EmptySearch vamana_test.go:213-228
+  models::SearchVectorVamanaOptions q;
+  q.Vector = {0.5f, 0.5f};
+  auto r = inv->Search(q);
+  CHECK(!r.err && r.set.empty() && r.results.empty());
+  // Test_InvalidIdInsert vamana_test.go:77-90
+  CHECK((bool)inv->InsertUpdateDelete({{0, {0.5f, 0.5f}}}));
+  CHECK((bool)inv->InsertUpdateDelete({{1, {0.5f, 0.5f}}}));
+  auto bad = vamanaParams();
+  bad.Alpha = 3.0f;  // models/index.go:305-307
+  CHECK((bool)vamana::NewIndexVamana("bad", bad, nullptr).second);
+  bad = vamanaParams();
+  bad.DistanceMetric = "hamming";
+  CHECK((bool)vamana::NewIndexVamana("bad", bad, nullptr).second);
+}
+
+static void test_self_retrieval_and_concurrency() {
+  // Test_Search vamana_test.go:230-252 (randPoints :48-61), then the same queries from 32 threads at once
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> U(0, 1);
+  std::vector<vamana::IndexVectorChange> pts;
+  for (int i = 0; i < 200; i++) pts.push_back({(uint64_t)(i + 2), {U(rng), U(rng)}});
+  diskstore::MemBucket bucket;
+  auto [inv, err] = vamana::NewIndexVamana("test", vamanaParams(), &bucket);
+  CHECK(!err && !inv->InsertUpdateDelete(pts));
+  std::vector<std::vector<uint64_t>> seq(200);
+  for (int i = 0; i < 200; i++) {
+    models::SearchVectorVamanaOptions q;
+    q.Vector = pts[i].Vector;
+    auto r = inv->Search(q);
+    CHECK(!r.err && r.results.size() == 10 && r.results[0].NodeId == pts[i].Id && r.results[0].Distance == 0);
+    for (auto &sr : r.results) seq[i].push_back(sr.NodeId);
+  }
+  const uint64_t before = inv->deviceBatches();
+  inv->setBatching(1024, std::chrono::microseconds(2000));
+  std::vector<std::thread> th;
+  std::atomic<int> bad{0};
+  for (int t = 0; t < 32; t++)
+    th.emplace_back([&, t] {
+      for (int i = t; i < 200; i += 32) {
+        models::SearchVectorVamanaOptions q;
+        q.Vector = pts[i].Vector;
+        auto r = inv->Search(q);
+        std::vector<uint64_t> got;
+        for (auto &sr : r.results) got.push_back(sr.NodeId);
+        if (r.err || got != seq[i]) bad++;
+      }
+    });
+  for (auto &x : th) x.join();
+  CHECK(bad == 0);
+  const uint64_t used = inv->deviceBatches() - before;
+  std::printf("concurrent: 200 Search calls from 32 threads -> %llu device batches\n", (unsigned long long)used);
+  CHECK(used < 200);  // calls were coalesced
+}
+
+int main() {
+  int ndev = 0;
+  if (sdb_device_count(&ndev) != SDB_OK) {
+    std::printf("no GPU: %s\n", sdb_last_error());
+    return 2;
+  }
+  test_distance_table();
+  test_conversion();
+  test_deterministic_search();
+  test_invalid_ids_and_empty();
+  test_self_retrieval_and_concurrency();
+  if (g_fail) {
+    std::printf("%d HOST CHECKS FAILED\n", g_fail);
+    return 1;
+  }
+  std::printf("ALL HOST TESTS PASSED\n");
+  return 0;
+}

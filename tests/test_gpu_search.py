@@ -189,3 +189,29 @@ def test_hash_set_overflow_falls_back_to_bitset(oracle, monkeypatch):
     monkeypatch.setenv("SDB_HASH_LIMIT", "700")
     _check_batch(o, ix, q, 10, 50)            # a mix of both
     ix.close()
+
+
+def test_async_batches_on_two_streams(oracle):
+    """Device-memory calls return before the kernel runs; batches in flight on different streams must not
+    share a visited-set workspace."""
+    import torch
+    rng = np.random.default_rng(5)
+    base = unit_rows(rng, 4000, 64)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ix = _gpu_index(o, 64, "cosine", 32, 50)
+    qs = [torch.from_numpy(unit_rows(rng, 256, 64)).cuda() for _ in range(6)]
+    ref = []
+    for q in qs:
+        ids, d, c, _ = ix.search_batch(q, 10, 120)   # bitset path (searchSize > 96)
+        torch.cuda.synchronize()
+        ref.append(ids.clone())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None] * len(qs)
+    for rep in range(3):
+        for i, q in enumerate(qs):
+            with torch.cuda.stream(streams[i % 2]):
+                outs[i] = ix.search_batch(q, 10, 120)[0]
+        torch.cuda.synchronize()
+        for i in range(len(qs)):
+            assert torch.equal(outs[i], ref[i])
+    ix.close()
