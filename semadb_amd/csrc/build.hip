@@ -189,13 +189,19 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
       nb == kNoSlot ? kNoKey : ((uint64_t)nb << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
 }
 
-// One wavefront per sorted key; only the first key of each target B proceeds and applies all of B's
-// requests in insert order (insert.go:36-65).
+// One wavefront per sorted key; only the first key of each target B proceeds and applies B's requests
+// (insert.go:36-65).  Requests are taken in insert order, as many at a time as fit the candidate buffer
+// (kBackCap - degree): if they all fit under the degree bound they are appended (:62), otherwise B is
+// re-pruned once over its neighbours plus those new points (:47-58: candidateSet.Add(neighbours...),
+// Add(A), Sort, robustPrune).  With one request per target -- always the case for round_size = 1 -- this is
+// exactly the reference's per-edge rule; with several it is the same rule applied to the group, which
+// spares a hub node one full re-prune per incoming edge.
+constexpr uint32_t kBackCap = 512;
+
 template <int NG, bool L2>
 __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  const uint32_t cap = 128;
-  PruneLds l(lds_raw, cap);
+  PruneLds l(lds_raw, kBackCap);
   const int lane = threadIdx.x, L = lane & 31;
   const size_t pos = blockIdx.x;
   const size_t total = (size_t)a.nnew * 64;
@@ -204,76 +210,78 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
   const uint32_t b = (uint32_t)(key >> 32);
   if (pos > 0 && (uint32_t)(a.keys_sorted[pos - 1] >> 32) == b) return;  // not the head of B's segment
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
+  // segment length m: requests for B, already in insert order
+  size_t m = 1;
+  while (pos + m < total) {
+    const uint64_t kk = a.keys_sorted[pos + m];
+    if (kk == kNoKey || (uint32_t)(kk >> 32) != b) break;
+    m++;
+  }
   uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
   uint32_t deg = a.deg[b];
   bool row_dirty = false;
-  for (size_t k = pos; k < total; k++) {
-    const uint64_t kk = a.keys_sorted[k];
-    if (kk == kNoKey || (uint32_t)(kk >> 32) != b) break;
-    const uint32_t anew = a.first_slot + (uint32_t)((kk & 0xFFFFFFFFull) >> 6);
-    if (deg + 1 > a.R) {  // insert.go:47: B is full -> candidateSet = B's neighbours + A, re-prune
-      if (row_dirty) {
-        a.adj[(size_t)b * kAdjStride + lane] = row;
-        row_dirty = false;
+  auto req_slot = [&](size_t r) { return a.first_slot + (uint32_t)((a.keys_sorted[pos + r] & 0xFFFFFFFFull) >> 6); };
+  size_t done = 0;
+  while (done < m) {
+    size_t t = m - done;
+    if (t > kBackCap - deg) t = kBackCap - deg;
+    if (deg + t <= a.R) {  // insert.go:62 nodeB.AddNeighbour(vecA), t times
+      for (size_t r = 0; r < t; r++) {
+        const uint32_t anew = req_slot(done + r);
+        if (lane == (int)deg) row = anew;
+        deg++;
       }
-      // distances from B (distFn = DistanceFromPoint(nB) :49) to its neighbours and to A
-      PointRow<NG> pr;
-      const float *brow = a.slab + (size_t)b * a.ld;
-      if constexpr (NG >= 0) {
-#pragma unroll
-        for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(brow)[g * 32 + L];
-        if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pr.xt = a.tail ? brow[NG * 128 + L] : 0.0f;
-      } else {
-        __syncthreads();
-        for (uint32_t t = lane; t < a.ld; t += 64) l.qs[t] = brow[t];
-        __syncthreads();
-      }
-      // candidate c: c < deg -> row entry c (lane c), c == deg -> A   (:55-56; Add dedupes, and a new
-      // node can not already be a neighbour)
-      const int nc = (int)deg + 1;
-      for (int c0 = 0; c0 < nc; c0 += 2 * U) {
-        uint32_t slot[U];
-        float res[U];
-        int cidx[2 * U];
-#pragma unroll
-        for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int i0 = cidx[2 * u], i1 = cidx[2 * u + 1];
-          const uint32_t s0 = i0 < (int)deg ? rl(row, i0) : anew;
-          const uint32_t s1 = i1 < (int)deg ? rl(row, i1) : anew;
-          slot[u] = lane < 32 ? s0 : s1;
-        }
-        if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
-        else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const float d0 = metric_finish(rlf(res[u], 0), a.metric);
-          const float d1 = metric_finish(rlf(res[u], 32), a.metric);
-          if (lane == 0) {
-            const int i0 = cidx[2 * u], i1 = cidx[2 * u + 1];
-            l.in_dist[i0] = d0;
-            l.in_dist[i1] = d1;
-          }
-        }
-      }
-      if (lane < (int)deg) l.in_slot[lane] = row;
-      if (lane == 0) l.in_slot[deg] = anew;
-      __syncthreads();
-      robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane);  // :57-58
-      __syncthreads();
-      row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
-      deg = 0;
-      {
-        const uint64_t m = __ballot(row != kNoSlot);
-        deg = (uint32_t)__popcll(m);
-      }
-    } else {  // insert.go:62 nodeB.AddNeighbour(vecA)
-      if (lane == (int)deg) row = anew;
-      deg++;
       row_dirty = true;
+      done += t;
+      continue;
     }
+    // B overflows: distances from B (distFn = DistanceFromPoint(nB) :49) to its neighbours and the t new points
+    PointRow<NG> pr;
+    const float *brow = a.slab + (size_t)b * a.ld;
+    if constexpr (NG >= 0) {
+#pragma unroll
+      for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(brow)[g * 32 + L];
+      if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pr.xt = a.tail ? brow[NG * 128 + L] : 0.0f;
+    } else {
+      __syncthreads();
+      for (uint32_t x = lane; x < a.ld; x += 64) l.qs[x] = brow[x];
+      __syncthreads();
+    }
+    // candidate c: c < deg -> row entry c (edge order), then the new points in insert order (:55-56; Add
+    // dedupes, and a new node can not already be a neighbour)
+    const int nc = (int)deg + (int)t;
+    for (int c0 = 0; c0 < nc; c0 += 2 * U) {
+      uint32_t slot[U];
+      float res[U];
+      int cidx[2 * U];
+      uint32_t cs[2 * U];
+#pragma unroll
+      for (int k2 = 0; k2 < 2 * U; k2++) {
+        cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
+        cs[k2] = cidx[k2] < (int)deg ? rl(row, cidx[k2]) : req_slot(done + (size_t)(cidx[k2] - (int)deg));
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) slot[u] = lane < 32 ? cs[2 * u] : cs[2 * u + 1];
+      if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+      else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+        const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+        if (lane == 0) {
+          l.in_dist[cidx[2 * u]] = d0, l.in_slot[cidx[2 * u]] = cs[2 * u];
+          l.in_dist[cidx[2 * u + 1]] = d1, l.in_slot[cidx[2 * u + 1]] = cs[2 * u + 1];
+        }
+      }
+    }
+    __syncthreads();
+    robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane);  // :57-58
+    __syncthreads();
+    row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
+    deg = (uint32_t)__popcll(__ballot(row != kNoSlot));
+    row_dirty = false;
+    done += t;
   }
   if (row_dirty) {
     a.adj[(size_t)b * kAdjStride + lane] = row;
@@ -290,7 +298,7 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   size_t tmp = sort_tmp_bytes;
   SDB_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp, a.keys_in, a.keys_sorted, (int)((size_t)a.nnew * 64), 0,
                                             sort_end_bit, stream));
-  const size_t lds2 = prune_lds_bytes(128, NG, a.ld);
+  const size_t lds2 = prune_lds_bytes(kBackCap, NG, a.ld);
   hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;

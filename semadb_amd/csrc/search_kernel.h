@@ -329,27 +329,44 @@ struct BitVisited {
     const uint32_t bit = 1u << (slot & 31);
     return !(atomicOr(&bits[slot >> 5], bit) & bit);
   }
-  __device__ __forceinline__ bool overflowed() const { return false; }
 };
 
 // VisitedMap (distset.go:71-87) as an exact open-addressing hash set in LDS: a query marks a few thousand
 // ids, so the set fits next to the wave and CheckAndVisit costs an LDS atomic instead of an HBM round
 // trip.  Keys inserted by one instruction are distinct (rows are deduplicated), so the CAS loop only
-// resolves slot collisions.  When it fills past kHashLimit the query is rerun on the bitset.
+// resolves slot collisions.  When the table fills past `limit` the set SPILLS: the wave clears its HBM
+// bitset, replays every stored key into it and carries on there -- the set stays exact and the walk is
+// not repeated (the reference makes the same kind of switch by id range, distset.go:140-153).
 constexpr uint32_t kHashCap = 8192;  // 32 KB per wave -> 4 waves per CU
 constexpr uint32_t kHashLimit = 6000;
 struct HashVisited {
   uint32_t *tab;
-  uint32_t count, limit;
-  __device__ __forceinline__ void init(uint32_t *lds, int lane, uint32_t lim) {
-    tab = lds;
-    count = 0;
-    limit = lim;
+  uint32_t *bits;
+  uint32_t words, count, limit;
+  bool spilled;
+  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
+    tab = lds, bits = bitset, words = nwords;
+    count = 0, limit = lim, spilled = false;
     uint4 *t4 = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = lane; i < kHashCap / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
     __syncthreads();
   }
+  __device__ __forceinline__ void spill(int lane) {
+    for (uint32_t i = lane; i < words; i += 64) bits[i] = 0u;  // ClearAll distset.go:101
+    __threadfence();                                           // the clears land before the atomics below
+    for (uint32_t i = lane; i < kHashCap; i += 64) {
+      const uint32_t k = tab[i];
+      if (k != kNoSlot) atomicOr(&bits[k >> 5], 1u << (k & 31));
+    }
+    __threadfence();
+    spilled = true;
+  }
   __device__ __forceinline__ bool test_and_set(bool active, uint32_t slot, int lane) {
+    if (spilled) {
+      if (!active) return false;
+      const uint32_t bit = 1u << (slot & 31);
+      return !(atomicOr(&bits[slot >> 5], bit) & bit);
+    }
     bool isnew = false, done = !active;
     // double hashing: the probe stride is odd (coprime with the table size), so every slot is reached and
     // probe chains of different keys do not pile up the way linear probing clusters
@@ -364,15 +381,14 @@ struct HashVisited {
       }
     }
     count += (uint32_t)__popcll(__ballot(isnew));
+    if (count > limit) spill(lane);  // at most 64 keys past the limit: the table never fills
     return isnew;
   }
-  __device__ __forceinline__ bool overflowed() const { return count > limit; }
 };
 
-// greedySearch for one query by one wavefront.  Returns false only when the LDS hash set overflowed
-// (the caller then reruns the query on the HBM bitset).
+// greedySearch for one query by one wavefront.
 template <class Dist, int NREG, bool FILT, class Visited>
-__device__ __forceinline__ bool search_body(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist,
+__device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist,
                                             Visited &vis) {
   uint32_t cid[NREG];
   float cd[NREG];
@@ -491,7 +507,6 @@ __device__ __forceinline__ bool search_body(const SearchArgs &a, const uint32_t 
     SDB_STAMP(st_adj)
     // CheckAndVisit distset.go:174 -- marks before any distance test
     const bool isnew = vis.test_and_set(valid, nb, lane);
-    if (vis.overflowed()) return false;
     const uint64_t pend = __ballot(isnew);
     SDB_STAMP(st_atom)
     if (pend) {
@@ -551,11 +566,11 @@ __device__ __forceinline__ bool search_body(const SearchArgs &a, const uint32_t 
     if (a.tr_nedges) a.tr_nedges[q] = n_edges;
     if (a.vis_count) a.vis_count[q] = n_hop;
   }
-  return true;
 }
 
 
-// HASH: visited set in LDS with bitset fallback (plain store, unfiltered); otherwise the HBM bitset.
+// HASH: visited set in LDS, spilling to the HBM bitset when it fills (plain store, unfiltered); otherwise the
+// HBM bitset from the start.
 template <class Dist, int NREG, bool FILT, bool HASH>
 __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   const int lane = threadIdx.x;
@@ -566,14 +581,12 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
   if constexpr (HASH) {
     HashVisited hv;
-    hv.init(reinterpret_cast<uint32_t *>(lds_f), lane, a.hash_limit);
-    if (search_body<Dist, NREG, FILT>(a, q, lane, dist, hv)) return;
-    // overflow (rare): clear this query's bitset and run the identical walk on it
-    for (uint32_t i = lane; i < a.words_per_query; i += 64) bits[i] = 0u;
-    __threadfence();
+    hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
+  } else {
+    BitVisited bv{bits};
+    search_body<Dist, NREG, FILT>(a, q, lane, dist, bv);
   }
-  BitVisited bv{bits};
-  search_body<Dist, NREG, FILT>(a, q, lane, dist, bv);
 }
 
 // host-side launcher: picks the instantiation for (ng, metric, search_size)
