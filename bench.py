@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="rows per shard (per GPU)")
+    ap.add_argument("--rows", type=int, default=1_000_000, help="rows per shard (per GPU)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
@@ -107,24 +107,39 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                              % (a.gpus, a.gpus))
         a.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    # BENCH_BACKEND=gloo + more ranks than GPUs is a functional test of the N > 1 path on a 1-GPU box
+    # (ranks share the device; RCCL itself refuses two ranks on one GPU).  The driver never sets it.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
     use_dist = world > 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def barrier():
+        if not use_dist:
+            return
+        if backend == "nccl":
+            dist.barrier(device_ids=[dev_index])
+        else:
+            dist.barrier()
 
     from semadb_amd import cluster, vamana
 
-    d, n, nq, k, L = a.dim, a.n, a.batch, a.k, a.search_size
+    d, n, nq, k, L = a.dim, a.rows, a.batch, a.k, a.search_size
     # ---- data: shard `rank` = rows generated with seed 20250620 + rank (per-shard offset)
     t0 = time.time()
     base = gen_rows(n, d, 20250620 + rank, a.dist, dev)
     queries = gen_rows(a.query_batches * nq, d, 20250621, a.dist, dev).view(a.query_batches, nq, d)
     params = vamana.IndexVectorVamanaParameters(d, a.metric, a.search_size, a.degree_bound, a.alpha)
-    ix = vamana.NewIndexVamana("bench", params, device=local_rank, capacity=n + 1, strict=True)
+    ix = vamana.NewIndexVamana("bench", params, device=dev_index, capacity=n + 1, strict=True)
     ix.set_start(start_vector(d))
     torch.cuda.synchronize()
     t1 = time.time()
@@ -143,7 +158,7 @@ def main():
         ids, dists, counts, tr = ix.search_batch(q, per_shard, L, trace=True)
         if not use_dist:
             return ids, dists, None, counts, tr
-        m_ids, m_d, m_sh, m_c = cluster.allgather_merge(ids, dists, counts, k, device=local_rank)
+        m_ids, m_d, m_sh, m_c = cluster.allgather_merge(ids, dists, counts, k, device=dev_index)
         return m_ids, m_d, m_sh, m_c, tr
 
     # ---- recall@10 against exact ground truth over all shards, on every distinct query batch
@@ -175,8 +190,7 @@ def main():
     for w in range(a.warmup):
         step(w)
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
+    barrier()
     ix.profile_read()
     torch.cuda.synchronize()
     traces = []
@@ -185,8 +199,7 @@ def main():
         out = step(a.warmup + s)
         traces.append(out[4])
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if use_dist:
@@ -267,7 +280,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     ix.close()
 
