@@ -53,10 +53,72 @@ struct PointRow {
 // sort with strict '<', so equal distances keep arrival order).  Then for each surviving candidate in
 // order: add it as an edge (:118), stop at DegreeBound (:119-121), and mark every later candidate j
 // with alpha * dist(p*, c_j) < c_j.Distance as removed (:132).
+constexpr int kPairMax = 80;  // candidate sets up to this size get their pair distances precomputed in LDS
+
+// Rows kept in registers while the other candidates stream past (pair-distance tiles)
+template <int NG>
+struct TileRows {
+  static constexpr int value = NG <= 3 ? 8 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3));
+};
+
+// D[i][j] = distFn(c_i, c_j) for the SORTED candidates, i < j < nc <= kPairMax (vecStore.DistanceFromPoint,
+// plain.go:87-97; same arithmetic as everywhere).  A tile of P rows sits in registers and every other row
+// is loaded once per tile instead of once per selected neighbour: ~nc^2/(2P) row loads instead of ~nc^2/2.
+template <int NG, bool L2>
+__device__ void pair_matrix(const BuildArgs &a, int nc, const uint32_t *s_slot, float *D, int lane) {
+  static_assert(NG >= 0, "register tiles need a compile-time group count");
+  constexpr int P = TileRows<NG>::value;
+  constexpr int NGR = NG > 0 ? NG : 1;
+  constexpr int U = 4;
+  const int L = lane & 31, half = lane >> 5;
+  for (int i0 = 0; i0 + 1 < nc; i0 += P) {
+    float4 xp[P][NGR];
+    float xtp[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const int i = (i0 + p < nc) ? i0 + p : nc - 1;
+      const float *row = a.slab + (size_t)s_slot[i] * a.ld;
+#pragma unroll
+      for (int g = 0; g < NG; g++) xp[p][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
+      if (NG == 0) xp[p][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      xtp[p] = a.tail ? row[NG * 128 + L] : 0.0f;
+    }
+    for (int j0 = i0 + 1; j0 < nc; j0 += 2 * U) {
+      float4 y[U][NGR];
+      float yt[U];
+      int jm[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int j = j0 + 2 * u + half;
+        jm[u] = j;
+        const float *row = a.slab + (size_t)s_slot[j < nc ? j : nc - 1] * a.ld;
+#pragma unroll
+        for (int g = 0; g < NG; g++) y[u][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
+        yt[u] = a.tail ? row[NG * 128 + L] : 0.0f;
+      }
+#pragma unroll
+      for (int p = 0; p < P; p++) {
+        const int i = i0 + p;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xp[p][g], y[u][g]);
+          const float t = a.tail ? tail_chain<L2>(xtp[p], yt[u], a.tail, lane) : 0.0f;
+          const float r = asm_reduce(acc, t, lane);
+          if (L == 0 && i < nc && jm[u] < nc && jm[u] > i) D[i * kPairMax + jm[u]] = metric_finish(r, a.metric);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// D == nullptr: pair distances are computed when needed (large candidate sets); else looked up.
 template <int NG, bool L2>
 __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc, const uint32_t *in_slot,
                                   const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
-                                  float *qs, int lane) {
+                                  float *qs, int lane, float *D = nullptr) {
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
   for (int i = lane; i < nc; i += 64) {
@@ -71,6 +133,9 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     s_rem[rank] = 0;
   }
   __syncthreads();
+  if constexpr (NG >= 0) {
+    if (D) pair_matrix<NG, L2>(a, nc, s_slot, D, lane);
+  }
   uint32_t my_out = kNoSlot;  // lane e holds edge e of the new row
   int cnt = 0;
   int i = 0;
@@ -87,6 +152,15 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     if (lane == cnt) my_out = p;  // node.AddNeighbour :118
     cnt++;
     if (cnt >= (int)a.R) break;  // :119-121
+    if (D) {  // pair distances are in LDS: the sweep is a lookup
+      for (int base = (found + 1) & ~63; base < nc; base += 64) {
+        const int j = base + lane;
+        if (j > found && j < nc && !s_rem[j] && a.alpha * D[found * kPairMax + j] < s_dist[j]) s_rem[j] = 1;  // :132
+      }
+      __syncthreads();
+      i = found + 1;
+      continue;
+    }
     // bind p (DistanceFromPoint :124)
     PointRow<NG> pr;
     const float *prow = a.slab + (size_t)p * a.ld;
@@ -153,7 +227,13 @@ struct PruneLds {
   float *s_dist;
   uint32_t *s_rem;
   float *qs;
-  __device__ PruneLds(char *base, uint32_t cap) {
+  float *D;  // [kPairMax][kPairMax], only carved by k_backedges
+  __device__ PruneLds(char *base, uint32_t cap, bool with_pairs = false) {
+    D = with_pairs ? reinterpret_cast<float *>(base + (size_t)cap * 20) : nullptr;
+    base_init(base, cap);
+    if (with_pairs) qs = D + kPairMax * kPairMax;
+  }
+  __device__ void base_init(char *base, uint32_t cap) {
     in_slot = reinterpret_cast<uint32_t *>(base);
     in_dist = reinterpret_cast<float *>(in_slot + cap);
     s_slot = reinterpret_cast<uint32_t *>(in_dist + cap);
@@ -163,8 +243,8 @@ struct PruneLds {
   }
 };
 
-static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld) {
-  return (size_t)cap * 20 + (NG < 0 ? (size_t)ld * 4 + 16 : 0);
+static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld, bool with_pairs = false) {
+  return (size_t)cap * 20 + (with_pairs ? (size_t)kPairMax * kPairMax * 4 : 0) + (NG < 0 ? (size_t)ld * 4 + 16 : 0);
 }
 
 // robustPrune(nodeA, visitedSet) for every new node of the round (insert.go:29-31), then emit the
@@ -196,12 +276,12 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
 // Add(A), Sort, robustPrune).  With one request per target -- always the case for round_size = 1 -- this is
 // exactly the reference's per-edge rule; with several it is the same rule applied to the group, which
 // spares a hub node one full re-prune per incoming edge.
-constexpr uint32_t kBackCap = 512;
+constexpr uint32_t kBackCap = 256;
 
 template <int NG, bool L2>
 __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  PruneLds l(lds_raw, kBackCap);
+  PruneLds l(lds_raw, kBackCap, NG >= 0);
   const int lane = threadIdx.x, L = lane & 31;
   const size_t pos = blockIdx.x;
   const size_t total = (size_t)a.nnew * 64;
@@ -276,7 +356,8 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       }
     }
     __syncthreads();
-    robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane);  // :57-58
+    robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane,
+                              (NG >= 0 && nc <= kPairMax) ? l.D : nullptr);  // :57-58
     __syncthreads();
     row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
     deg = (uint32_t)__popcll(__ballot(row != kNoSlot));
@@ -298,7 +379,7 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   size_t tmp = sort_tmp_bytes;
   SDB_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp, a.keys_in, a.keys_sorted, (int)((size_t)a.nnew * 64), 0,
                                             sort_end_bit, stream));
-  const size_t lds2 = prune_lds_bytes(kBackCap, NG, a.ld);
+  const size_t lds2 = prune_lds_bytes(kBackCap, NG, a.ld, NG >= 0);
   hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
