@@ -155,10 +155,14 @@ def main():
     def step(b):
         """one batch through the hot path; returns merged (ids, dists, shards, counts, trace)"""
         q = queries[b % a.query_batches]
-        ids, dists, counts, tr = ix.search_batch(q, per_shard, L, trace=True)
         if not use_dist:
+            ids, dists, counts, tr = ix.search_batch(q, per_shard, L, trace=True)
             return ids, dists, None, counts, tr
-        m_ids, m_d, m_sh, m_c = cluster.allgather_merge(ids, dists, counts, k, device=dev_index)
+        # the kernel writes into the all-gather message; one collective per batch, then the device merge
+        blk = cluster.PackedTopK(nq, per_shard, dev)
+        _, _, _, tr = ix.search_batch(q, per_shard, L, trace=True, out=blk.out())
+        g_ids, g_d, g_c = blk.allgather()
+        m_ids, m_d, m_sh, m_c = cluster.topk_merge(g_ids, g_d, g_c, k, device=dev_index)
         return m_ids, m_d, m_sh, m_c, tr
 
     # ---- recall@10 against exact ground truth over all shards, on every distinct query batch

@@ -78,3 +78,34 @@ def allgather_merge(ids, dists, counts, limit, device=0):
     merged answer, like every SemaDB server can answer the REST call)."""
     g_ids, g_d, g_c = allgather_topk(ids, dists, counts)
     return topk_merge(g_ids, g_d, g_c, limit, device=device)
+
+
+class PackedTopK:
+    """One shard's [nq, per_shard] result block laid out as a single byte buffer (ids | dists | counts), so the
+    search kernel writes straight into the message of ONE all-gather per batch instead of three."""
+
+    def __init__(self, nq, per_shard, device):
+        import torch
+        self.nq, self.per = nq, per_shard
+        self.b_ids, self.b_d, self.b_c = nq * per_shard * 8, nq * per_shard * 4, nq * 4
+        self.buf = torch.zeros(self.b_ids + self.b_d + self.b_c, dtype=torch.uint8, device=device)
+        self.ids = self.buf[:self.b_ids].view(torch.int64).view(nq, per_shard)
+        self.dists = self.buf[self.b_ids:self.b_ids + self.b_d].view(torch.float32).view(nq, per_shard)
+        self.counts = self.buf[self.b_ids + self.b_d:].view(torch.int32)
+
+    def out(self):
+        return self.ids, self.dists, self.counts
+
+    def allgather(self):
+        """-> shard-major (ids [W,nq,per], dists, counts [W,nq]) on every rank"""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        g = torch.empty(world * self.buf.numel(), dtype=torch.uint8, device=self.buf.device)
+        dist.all_gather_into_tensor(g, self.buf)
+        g = g.view(world, -1)
+        ids = g[:, :self.b_ids].contiguous().view(torch.int64).view(world, self.nq, self.per)
+        d = g[:, self.b_ids:self.b_ids + self.b_d].contiguous().view(torch.float32).view(world, self.nq, self.per)
+        c = g[:, self.b_ids + self.b_d:].contiguous().view(torch.int32).view(world, self.nq)
+        return ids, d, c
+

@@ -174,7 +174,7 @@ class IndexVamana:
             results.append(SearchResult(int(ids[0, i]), d, np.float32(-1) * d * weight))  # vamana.go:303
         return set(r.NodeId for r in results), results
 
-    def search_batch(self, queries, limit, search_size, filters=None, trace=False, visit_cap=0):
+    def search_batch(self, queries, limit, search_size, filters=None, trace=False, visit_cap=0, out=None):
         """nq queries at once.  numpy in -> numpy out (synchronous); torch CUDA in -> torch out, enqueued
         on the current stream.  Returns (ids [nq,limit] uint64, dists, counts, BatchTrace|None)."""
         k, qp, mem, shape = _buf.as_f32(queries)
@@ -191,9 +191,13 @@ class IndexVamana:
                 off.append(len(flat))
             f_off = np.array(off, dtype=np.uint64)
             f_ids = np.array(flat if flat else [0], dtype=np.uint64)
-        ids, idp = _buf.empty_like_mem(mem, (nq, limit), "uint64", self.device)
-        dists, dp = _buf.empty_like_mem(mem, (nq, limit), "float32", self.device)
-        counts, cp = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
+        if out is not None:  # caller-provided device tensors (ids int64 [nq,limit], dists f32, counts int32)
+            ids, dists, counts = out
+            idp, dp, cp = (C.c_void_p(t.data_ptr()) for t in out)
+        else:
+            ids, idp = _buf.empty_like_mem(mem, (nq, limit), "uint64", self.device)
+            dists, dp = _buf.empty_like_mem(mem, (nq, limit), "float32", self.device)
+            counts, cp = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
         tr_struct, tr_out = None, None
         if trace:
             nd, ndp = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)

@@ -35,6 +35,11 @@ def _worker(rank, world, port, q):
     nq, per = 16, 10
     ids, d, c = _shard_results(rank, nq, per)
     g_ids, g_d, g_c = cluster.allgather_topk(torch.from_numpy(ids), torch.from_numpy(d), torch.from_numpy(c))
+    # the packed form bench.py uses: one all-gather of (ids | dists | counts) per batch
+    blk = cluster.PackedTopK(nq, per, "cpu")
+    blk.ids.copy_(torch.from_numpy(ids)); blk.dists.copy_(torch.from_numpy(d)); blk.counts.copy_(torch.from_numpy(c))
+    p_ids, p_d, p_c = blk.allgather()
+    assert torch.equal(p_ids, g_ids) and torch.equal(p_d, g_d) and torch.equal(p_c, g_c)
     q.put((rank, g_ids.numpy(), g_d.numpy(), g_c.numpy()))
     dist.barrier()
     dist.destroy_process_group()
