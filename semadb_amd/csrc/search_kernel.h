@@ -301,6 +301,65 @@ __device__ __forceinline__ void add_with_limit_lanes(uint32_t (&cid)[NREG], floa
   }
 }
 
+// The same AddWithLimit over several points at once, for a FULL and SORTED candidate array (the unfiltered
+// search after its first hops).  With no two equal distances among the array and the points that beat the
+// tail, replaying them one by one ends in exactly one state: the `cap` smallest of (array U points), in
+// order -- so that state is computed directly: every array entry moves up by the number of points below
+// it, every point lands at (#entries below it + #points below it), entries pushed past `cap` vanish.  The
+// scatter goes through a 2*NREG*64-word LDS scratch.  Any tie, NaN, or a not-yet-full array falls back to
+// the one-by-one replay, which is the specification.
+template <int NREG>
+__device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap,
+                                                     uint32_t idreg, float mydist, uint64_t pd, int lane,
+                                                     uint32_t *scratch) {
+  if (len != cap) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  const float tail0 = list_tail(cd, cap);
+  const uint64_t cm = __ballot(!(mydist > tail0)) & pd;  // the points the replay would look at first
+  if (__popcll(cm) < 2 || (__ballot(mydist != mydist) & pd))
+    return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  const bool inC = (cm >> lane) & 1ull;
+  uint32_t up[NREG];  // per array entry: points strictly below it
+#pragma unroll
+  for (int r = 0; r < NREG; r++) up[r] = 0;
+  uint32_t rl_me = 0, rc_me = 0;  // per point lane: entries below it, points below it
+  bool tie = false;
+  for (uint64_t t = cm; t; t &= t - 1) {
+    const int j = __ffsll((unsigned long long)t) - 1;
+    const float dj = rlf(mydist, j);
+    uint32_t below = 0;
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+      const bool valid = (r * 64 + lane) < len;
+      up[r] += (valid && dj < cd[r]) ? 1u : 0u;
+      tie |= valid && dj == cd[r];
+      below += (uint32_t)__popcll(__ballot(valid && cd[r] < dj));
+    }
+    if (lane == j) rl_me = below;
+    rc_me += (inC && dj < mydist) ? 1u : 0u;
+    tie |= inC && lane != j && dj == mydist;
+  }
+  if (__ballot(tie)) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  uint32_t *s_id = scratch;
+  float *s_d = reinterpret_cast<float *>(scratch + NREG * 64);
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    const int e = r * 64 + lane;
+    const uint32_t np = (uint32_t)e + up[r];
+    if (e < len && np < (uint32_t)cap) s_id[np] = cid[r], s_d[np] = cd[r];
+  }
+  if (inC) {
+    const uint32_t np = rl_me + rc_me;
+    if (np < (uint32_t)cap) s_id[np] = idreg, s_d[np] = mydist;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    const int e = r * 64 + lane;
+    if (e < cap) cid[r] = s_id[e], cd[r] = s_d[e];
+  }
+  __syncthreads();
+}
+
 // roaring Contains on this query's ascending slot list: 64-ary search, all lanes probe at once
 __device__ __forceinline__ bool filter_contains(const uint32_t *__restrict__ arr, uint32_t n, uint32_t target,
                                                 int lane) {
@@ -397,6 +456,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
   int len = 0;
   const int cap = (int)a.search_size;
   uint32_t n_dist = 0, n_hop = 0, n_edges = 0;
+  __shared__ uint32_t s_scatter[2 * NREG * 64];  // add_with_limit_merge scratch
 
   // filtered search (search.go:33-51): resultSet = DistSet(cap k) with its own visited set
   uint32_t rid[FILT ? NREG : 1];
@@ -517,7 +577,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #endif
       SDB_STAMP(st_vec)
       // AddWithLimit over the new neighbours, in edge order distset.go:184-198
-      add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);
+      if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
+      else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
       SDB_STAMP(st_ins)
     }
     if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
