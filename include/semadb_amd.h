@@ -160,6 +160,20 @@ int sdb_index_last_search_ms(sdb_index *ix, float *ms);
 /* durations of the most recent profiled K2 launches (oldest first, at most 256 kept); resets the log */
 int sdb_index_profile_read(sdb_index *ix, float *ms, uint32_t cap, uint32_t *n);
 
+/* IndexFlat.Search (shard/index/flat/flat.go:76-132): exact scan of the stored vectors with the same
+ * distance closure (vecStore.DistanceFromFloat), keeping the `limit` closest with the reference's
+ * `dist >= tail -> skip` rule (:104).  The reference walks the store in Go-map order (unspecified); here
+ * the walk is in storage order, so among equal distances the first stored stays.  The graph's start node
+ * is not a point and never appears.  Optional filter as in sdb_index_search_batch (only ids in the filter
+ * are scanned, flat.go:100).  limit <= 128.  Also the exact-kNN ground truth for recall. */
+int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
+                          const uint64_t *filter_offsets, const uint64_t *filter_ids, uint64_t *out_ids,
+                          float *out_dists, uint32_t *out_counts, int mem, void *stream);
+
+/* vecStore.Set without graph maintenance -- what IndexFlat.InsertUpdateDelete does for an insert
+ * (flat.go:46-49).  ids == NULL assigns max_id+1.. ; existing ids are rejected (updates are host-side). */
+int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem);
+
 /* cache.Cachable.SizeInMemory (vamana.go:83-85): bytes of HBM held */
 int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes);
 /* number of nodes (start node included) / edges */
