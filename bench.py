@@ -188,6 +188,13 @@ def main():
         total += nq * k
     recall = hits / total
     log("recall@%d = %.4f at searchSize %d (%d queries)" % (k, recall, L, total // k))
+    # cross-check of the ground truth itself: the device flat scan (IndexFlat.Search, flat.go:76-132, same
+    # bit-exact distances) against the torch matmul top-k, first batch, this rank's shard
+    from semadb_amd import flat
+    f_ids, _, _ = flat.flat_search_batch(ix._h, d, queries[0], k, device=dev_index)
+    t_ids = exact_topk(queries[0], base, k)[1] + 2
+    truth_agree = float((f_ids.to(torch.int64).unsqueeze(2) == t_ids.unsqueeze(1)).any(2).float().mean().item())
+    log("flat scan vs matmul ground truth agreement: %.4f" % truth_agree)
 
     # ---- timed region
     ix.set_profiling(True)
@@ -242,6 +249,7 @@ def main():
                                                                        nq, k, world, n),
             "dataset": "%s seed 20250620(+rank), queries seed 20250621 (not in base set)" % a.dist,
             "recall_at_10": round(recall, 4),
+            "ground_truth": "exact brute force (torch matmul top-k); agreement with the device flat scan %.4f" % truth_agree,
             "search_size": L,
             "parallelism": "shard-per-gpu x%d, RCCL all-gather top-k merge" % world if world > 1 else "1 gpu",
             "value_definition": "queries answered per second summed over shards; every shard answers every "
