@@ -120,6 +120,17 @@ int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *
 int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
                            int mem, uint32_t round_size, void *stream);
 
+/* IndexVamana.InsertUpdateDelete, delete branch (vamana.go:175-233): removeInboundEdges (prune.go:88-154) =
+ * EdgeScan (node.go:142-199) + pruneDeleteNeighbour (prune.go:12-84) for every node with an edge into the
+ * delete set + stragglers (valid nodes nobody points at) re-attached to the start node (prune.go:131-151),
+ * then the nodes are dropped from the store (vamana.go:228-233).  Unknown ids are skipped
+ * (vamana.go:161-163); ids 0 and 1 are errors.  The reference re-attaches stragglers in Go-map order
+ * (unspecified): here in storage order; and its start node may grow without bound, while a device row holds
+ * 64 edges: once the start row is full the remaining stragglers go through the full-node rule of
+ * insert.go:47-58 (candidateSet = neighbours + stragglers, Sort, robustPrune).
+ * An update (vamana.go:170-174,247-251) is delete_batch followed by insert_batch with the same id. */
+int sdb_index_delete_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, void *stream);
+
 /* per-query search trace; every pointer may be NULL.  Arrays follow the same `mem` as the
  * outputs of the call. */
 typedef struct {

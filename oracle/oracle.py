@@ -58,6 +58,7 @@ def lib():
     L.orc_index_set_start.argtypes = [C.c_void_p, f32p]
     L.orc_index_insert.argtypes = [C.c_void_p, C.c_uint64, f32p]
     L.orc_index_load.argtypes = [C.c_void_p, C.c_uint64, u64p, f32p, u64p, u64p]
+    L.orc_index_delete.argtypes = [C.c_void_p, u64p, C.c_uint64]
     L.orc_index_size.restype = C.c_uint64
     L.orc_index_size.argtypes = [C.c_void_p]
     L.orc_index_num_edges.restype = C.c_uint64
@@ -164,6 +165,10 @@ class Index:
         vec = _f32(vec)
         assert vec.size == self.dim
         return lib().orc_index_insert(self._h, int(node_id), _p(vec, C.c_float))
+
+    def delete(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        return lib().orc_index_delete(self._h, _p(ids, C.c_uint64), ids.size)
 
     def load(self, ids, vectors, offsets, edges):
         ids = np.ascontiguousarray(ids, dtype=np.uint64)

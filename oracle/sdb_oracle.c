@@ -232,6 +232,8 @@ struct orc_index {
   uint64_t *ids;
   uint32_t **edges;
   uint32_t *deg, *ecap;
+  uint8_t *alive; /* 0 after vecStore.Delete / nodeStore.Delete (vamana.go:228-233) */
+  uint64_t n_alive;
   /* id -> slot */
   uint64_t *mkeys;
   uint32_t *mvals;
@@ -411,7 +413,7 @@ static int64_t map_get(const orc_index *ix, uint64_t id) {
   if (!ix->mcap) return -1;
   uint64_t h = hash64(id) & (ix->mcap - 1);
   while (ix->mkeys[h]) {
-    if (ix->mkeys[h] == id) return ix->mvals[h];
+    if (ix->mkeys[h] == id) return ix->alive[ix->mvals[h]] ? (int64_t)ix->mvals[h] : -1;
     h = (h + 1) & (ix->mcap - 1);
   }
   return -1;
@@ -419,7 +421,7 @@ static int64_t map_get(const orc_index *ix, uint64_t id) {
 
 static void map_put_raw(uint64_t *keys, uint32_t *vals, uint64_t cap, uint64_t id, uint32_t v) {
   uint64_t h = hash64(id) & (cap - 1);
-  while (keys[h]) h = (h + 1) & (cap - 1);
+  while (keys[h] && keys[h] != id) h = (h + 1) & (cap - 1); /* a re-used id points at its newest slot */
   keys[h] = id;
   vals[h] = v;
 }
@@ -449,7 +451,7 @@ orc_index *orc_index_new(int dim, int metric, int impl, int degree_bound, int se
 void orc_index_free(orc_index *ix) {
   if (!ix) return;
   for (uint64_t i = 0; i < ix->n; i++) free(ix->edges[i]);
-  free(ix->edges), free(ix->deg), free(ix->ecap), free(ix->vectors), free(ix->ids);
+  free(ix->edges), free(ix->deg), free(ix->ecap), free(ix->vectors), free(ix->ids), free(ix->alive);
   free(ix->mkeys), free(ix->mvals), free(ix->codes);
   free(ix);
 }
@@ -463,6 +465,7 @@ static void index_reserve(orc_index *ix, uint64_t want) {
   ix->edges = realloc(ix->edges, sizeof(uint32_t *) * ncap);
   ix->deg = realloc(ix->deg, 4 * ncap);
   ix->ecap = realloc(ix->ecap, 4 * ncap);
+  ix->alive = realloc(ix->alive, ncap);
   ix->cap = ncap;
 }
 
@@ -473,6 +476,8 @@ static uint32_t index_add_node(orc_index *ix, uint64_t id, const float *vec) {
   memcpy(ix->vectors + (size_t)s * ix->dim, vec, sizeof(float) * ix->dim);
   ix->ids[s] = id;
   ix->edges[s] = NULL, ix->deg[s] = 0, ix->ecap[s] = 0;
+  ix->alive[s] = 1;
+  ix->n_alive++;
   map_put(ix, id, s);
   ix->n++;
   if (id > ix->max_node_id) ix->max_node_id = id; /* vamana.go:166-168 */
@@ -496,11 +501,12 @@ int orc_index_set_start(orc_index *ix, const float *vec) {
   return 0;
 }
 
-uint64_t orc_index_size(const orc_index *ix) { return ix->n; }
+uint64_t orc_index_size(const orc_index *ix) { return ix->n_alive; }
 
 uint64_t orc_index_num_edges(const orc_index *ix) {
   uint64_t t = 0;
-  for (uint64_t i = 0; i < ix->n; i++) t += ix->deg[i];
+  for (uint64_t i = 0; i < ix->n; i++)
+    if (ix->alive[i]) t += ix->deg[i];
   return t;
 }
 
@@ -524,15 +530,17 @@ int orc_index_load(orc_index *ix, uint64_t n, const uint64_t *ids, const float *
 
 int orc_index_export(const orc_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets,
                      uint64_t *edges) {
-  uint64_t o = 0;
+  uint64_t o = 0, k = 0;
   for (uint64_t i = 0; i < ix->n; i++) {
-    if (ids) ids[i] = ix->ids[i];
-    if (offsets) offsets[i] = o;
+    if (!ix->alive[i]) continue; /* deleted nodes are gone from the bucket (node.go:129-134) */
+    if (ids) ids[k] = ix->ids[i];
+    if (offsets) offsets[k] = o;
     for (uint32_t e = 0; e < ix->deg[i]; e++, o++)
       if (edges) edges[o] = ix->ids[ix->edges[i][e]];
+    if (vectors) memcpy(vectors + k * ix->dim, ix->vectors + (size_t)i * ix->dim, sizeof(float) * ix->dim);
+    k++;
   }
-  if (offsets) offsets[ix->n] = o;
-  if (vectors) memcpy(vectors, ix->vectors, sizeof(float) * ix->n * ix->dim);
+  if (offsets) offsets[k] = o;
   return 0;
 }
 
@@ -781,6 +789,94 @@ int orc_index_insert(orc_index *ix, uint64_t id, const float *vec) {
     }
   }
   ds_free(&ss), ds_free(&vs), free(lut);
+  return 0;
+}
+
+/* =====================================================================================
+ * 6b. delete path: removeInboundEdges (prune.go:88-154), EdgeScan (node.go:142-199),
+ *     pruneDeleteNeighbour (prune.go:12-84), then vecStore.Delete / nodeStore.Delete (vamana.go:228-233)
+ * The reference iterates Go maps in EdgeScan, so the order in which it saves stragglers onto the
+ * start node is unspecified; the oracle uses slot order (= insertion order).
+ * ===================================================================================== */
+static void prune_delete_neighbour(orc_index *ix, uint32_t a, const uint8_t *del) {
+  uint32_t *cand = malloc(4 * ((size_t)ix->deg[a] * (1 + 64) + 64 + 1)), nc = 0, *expand = malloc(4 * (ix->deg[a] + 1)), ne = 0;
+  size_t cap_c = (size_t)ix->deg[a] * 65 + 65;
+  for (uint32_t e = 0; e < ix->deg[a]; e++) { /* prune.go:25-34 */
+    uint32_t b = ix->edges[a][e];
+    if (del[b]) expand[ne++] = b;
+    else cand[nc++] = b;
+  }
+  for (uint32_t i = 0; i < ne; i++) { /* :46-55 neighbours of the deleted neighbours */
+    uint32_t b = expand[i];
+    if (nc + ix->deg[b] > cap_c) {
+      cap_c = (nc + ix->deg[b]) * 2;
+      cand = realloc(cand, 4 * cap_c);
+    }
+    for (uint32_t e = 0; e < ix->deg[b]; e++)
+      if (!del[ix->edges[b][e]]) cand[nc++] = ix->edges[b][e];
+  }
+  distfn df;
+  bind_from_point(ix, a, &df); /* :58 */
+  distset c;
+  ds_init(&c, (int)ix->deg[a] * 2, 0, NULL, &df);
+  ds_add(&c, cand, (int)nc); /* :63 dedupes */
+  ds_sort(&c);               /* :64 */
+  if (c.len > ix->R) {       /* :66-68 */
+    robust_prune(ix, a, &c);
+  } else { /* :69-80 */
+    ix->deg[a] = 0;
+    for (int i = 0; i < c.len; i++)
+      if (c.items[i].slot != a) node_add_neighbour(ix, a, c.items[i].slot);
+  }
+  ds_free(&c);
+  free(cand), free(expand);
+}
+
+int orc_index_delete(orc_index *ix, const uint64_t *ids, uint64_t n) {
+  if (ix->start_slot < 0) return -2;
+  uint8_t *del = calloc(ix->n ? ix->n : 1, 1);
+  uint64_t ndel = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (ids[i] == ORC_STARTID || ids[i] == 0) { /* vamana.go:150-157 */
+      free(del);
+      return -3;
+    }
+    int64_t s = map_get(ix, ids[i]);
+    if (s < 0) continue; /* !exists && Vector == nil: nothing to do (vamana.go:161-163) */
+    if (!del[s]) del[s] = 1, ndel++;
+  }
+  if (ndel == 0) {
+    free(del);
+    return 0;
+  }
+  /* EdgeScan node.go:142-199 */
+  uint8_t *has_inbound = calloc(ix->n, 1), *to_prune = calloc(ix->n, 1);
+  for (uint64_t v = 0; v < ix->n; v++) {
+    if (!ix->alive[v] || del[v]) continue;
+    for (uint32_t e = 0; e < ix->deg[v]; e++) {
+      uint32_t t = ix->edges[v][e];
+      has_inbound[t] = 1;
+      if (del[t]) to_prune[v] = 1;
+    }
+  }
+  for (uint64_t v = 0; v < ix->n; v++)
+    if (to_prune[v]) prune_delete_neighbour(ix, (uint32_t)v, del); /* prune.go:107-111 */
+  /* stragglers back onto the start node, prune.go:131-151 */
+  uint32_t st = (uint32_t)ix->start_slot;
+  for (uint64_t v = 0; v < ix->n; v++) {
+    if (!ix->alive[v] || del[v] || has_inbound[v] || v == st) continue;
+    int exists = 0;
+    for (uint32_t e = 0; e < ix->deg[st]; e++) exists |= ix->edges[st][e] == v; /* AddNeighbourIfNotExists node.go:73-80 */
+    if (!exists) node_add_neighbour(ix, st, (uint32_t)v);
+  }
+  for (uint64_t v = 0; v < ix->n; v++) /* vamana.go:228-233 */
+    if (del[v]) {
+      ix->alive[v] = 0;
+      ix->n_alive--;
+      free(ix->edges[v]);
+      ix->edges[v] = NULL, ix->deg[v] = 0, ix->ecap[v] = 0;
+    }
+  free(del), free(has_inbound), free(to_prune);
   return 0;
 }
 

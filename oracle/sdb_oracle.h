@@ -75,6 +75,12 @@ int orc_index_set_start(orc_index *ix, const float *vec);
  * the order to the call order).  ids 0 and 1 are rejected (vamana.go:150-157). returns 0 ok. */
 int orc_index_insert(orc_index *ix, uint64_t id, const float *vec);
 
+/* IndexVamana.InsertUpdateDelete, delete branch (vamana.go:175-233): removeInboundEdges (prune.go:88-154) over
+ * EdgeScan (node.go:142-199) and pruneDeleteNeighbour (prune.go:12-84), stragglers re-attached to the start
+ * node, then the nodes are dropped.  Unknown ids are skipped (vamana.go:161-163); ids 0/1 are errors.  An
+ * update (vamana.go:170-174,247-251) is this followed by orc_index_insert with the same id. */
+int orc_index_delete(orc_index *ix, const uint64_t *ids, uint64_t n);
+
 /* Bulk load of an existing graph (what ItemCache would read from the bucket, node.go:96-111,
  * plain.go:125-141).  edges hold node ids; ids missing from `ids` are silently dropped the way
  * ItemCache.GetMany skips them (itemcache.go:109-128).  The start node (id 1) must be among

@@ -557,3 +557,5 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
 }
+
+#include "delete.inc"

@@ -72,6 +72,7 @@ struct FlatFoldArgs {
   const uint32_t *slots;    // filtered: slot of value i of query q
   uint32_t first_row;       // unfiltered: slot of value i is first_row + i
   uint32_t skip_slot;       // the graph's start node never belongs to a flat result (it is not a point)
+  const uint64_t *ids;      // slot -> id, 0 = deleted
   uint32_t limit;
   uint32_t *top_slot;       // [nq][128] running state
   float *top_dist;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(64) void k_flat_fold(const FlatFoldArgs a) {
     const bool has = i < n;
     const float dist = has ? d[i] : 0.0f;
     const uint32_t slot = has ? (myslots ? myslots[i] : a.first_row + i) : kNoSlot;
-    uint64_t pd = __ballot(has && slot != a.skip_slot);
+    // deleted rows (tombstones, id 0) are not in the store any more
+    uint64_t pd = __ballot(has && slot != a.skip_slot && a.ids[slot] != 0);
     while (pd) {
       bool ok = true;
       if (len == cap) ok = dist < list_tail(cd, cap);  // :104 `dist >= tail -> skip`
@@ -231,6 +233,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     FlatFoldArgs fa{};
     fa.dists = d_dist, fa.stride = stride, fa.count = rows, fa.slot_off = d_fo, fa.slots = d_fs, fa.first_row = first;
     fa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
+    fa.ids = ix->d_ids;
     fa.limit = limit, fa.top_slot = top_slot, fa.top_dist = top_dist, fa.top_len = top_len;
     hipLaunchKernelGGL(k_flat_fold, dim3((unsigned)nq), dim3(64), 0, stream, fa);
     SDB_HIP(hipGetLastError());

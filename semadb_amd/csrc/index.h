@@ -41,6 +41,7 @@ struct sdb_index {
   sdb_index_params P{};
   sdb::RowLayout lay;
   uint32_t n = 0;    // rows in use (slot ids are 0..n-1)
+  uint32_t n_dead = 0;  // of which deleted: tombstones with id 0, empty row, unreachable
   uint32_t cap = 0;  // rows allocated
   int64_t start_slot = -1;
   uint64_t max_node_id = 0;  // vamana.go:47

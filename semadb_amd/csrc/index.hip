@@ -670,7 +670,7 @@ int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) {
 
 int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
-  if (n_nodes) *n_nodes = ix->n;
+  if (n_nodes) *n_nodes = ix->n - ix->n_dead;  // live nodes (start node included)
   if (max_node_id) *max_node_id = ix->max_node_id;
   if (n_edges) {
     DeviceGuard dg(ix->P.device);
@@ -688,28 +688,43 @@ int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_
   DeviceGuard dg(ix->P.device);
   SDB_HIP(hipDeviceSynchronize());
   const uint32_t n = ix->n;
-  if (ids)
-    for (uint32_t i = 0; i < n; i++) ids[i] = ix->h_ids[i];
+  // deleted nodes (tombstones: id 0) are gone from the bucket (node.go:129-134); live rows keep their order
+  if (ids) {
+    uint64_t k = 0;
+    for (uint32_t i = 0; i < n; i++)
+      if (ix->h_ids[i] != 0) ids[k++] = ix->h_ids[i];
+  }
   if (offsets || edges) {
     std::vector<uint32_t> adj((size_t)n * kAdjStride), deg(n);
     if (n) {
       SDB_HIP(hipMemcpy(adj.data(), ix->d_adj, adj.size() * 4, hipMemcpyDeviceToHost));
       SDB_HIP(hipMemcpy(deg.data(), ix->d_deg, deg.size() * 4, hipMemcpyDeviceToHost));
     }
-    uint64_t o = 0;
+    uint64_t o = 0, k = 0;
     for (uint32_t i = 0; i < n; i++) {
-      if (offsets) offsets[i] = o;
-      for (uint32_t k = 0; k < deg[i]; k++, o++)
-        if (edges) edges[o] = ix->h_ids[adj[(size_t)i * kAdjStride + k]];
+      if (ix->h_ids[i] == 0) continue;
+      if (offsets) offsets[k] = o;
+      for (uint32_t e = 0; e < deg[i]; e++, o++)
+        if (edges) edges[o] = ix->h_ids[adj[(size_t)i * kAdjStride + e]];
+      k++;
     }
-    if (offsets) offsets[n] = o;
+    if (offsets) offsets[k] = o;
   }
   if (vectors && n) {
     const RowLayout &l = ix->lay;
     float *tmp = nullptr;
     SDB_HIP(hipMalloc(&tmp, (size_t)n * l.dim * sizeof(float)));
     hipLaunchKernelGGL(k_unpermute_rows, dim3(n), dim3(128), 0, nullptr, ix->d_slab, tmp, n, l.dim, l.nblk, l.ng, l.ld);
-    hipError_t e = hipMemcpy(vectors, tmp, (size_t)n * l.dim * sizeof(float), hipMemcpyDeviceToHost);
+    hipError_t e = hipSuccess;
+    if (ix->n_dead == 0) {
+      e = hipMemcpy(vectors, tmp, (size_t)n * l.dim * sizeof(float), hipMemcpyDeviceToHost);
+    } else {
+      std::vector<float> all((size_t)n * l.dim);
+      e = hipMemcpy(all.data(), tmp, all.size() * sizeof(float), hipMemcpyDeviceToHost);
+      uint64_t k = 0;
+      for (uint32_t i = 0; i < n && e == hipSuccess; i++)
+        if (ix->h_ids[i] != 0) memcpy(vectors + (k++) * l.dim, all.data() + (size_t)i * l.dim, l.dim * sizeof(float));
+    }
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(e));
   }

@@ -288,23 +288,57 @@ class IndexVamana {
     return out;
   }
 
-  // IndexVamana.InsertUpdateDelete (vamana.go:127-263), insert branch on device; the bucket is then
-  // brought up to date (flush, :265-276).  Updates/deletes stay on the reference's host path.
+  // vecStore.Exists (plain.go:21-24), from the bucket-side view this mirror keeps of the live ids
+  bool Exists(uint64_t id) const { return live_.count(id) != 0; }
+
+  // IndexVamana.InsertUpdateDelete (vamana.go:127-263): same classification and order as :149-251 -- new
+  // ids are inserted first; the inbound edges of deleted AND updated ids are removed in one scan and the
+  // deleted nodes dropped; the updated points are re-inserted one by one; then the bucket is brought up
+  // to date (flush, :265-276).
   Error InsertUpdateDelete(const std::vector<IndexVectorChange> &points, uint32_t round_size = 0) {
     std::lock_guard<std::mutex> wl(write_mu_);
-    std::vector<uint64_t> ids;
-    std::vector<float> vecs;
+    std::vector<uint64_t> ins_ids, upd_ids, del_ids;
+    std::vector<float> ins_vecs, upd_vecs;
+    std::set<uint64_t> fresh;
     for (const auto &p : points) {
       if (p.Id == STARTID) return Error("could not distribute or insert points: cannot modify point with start id: 1");
       if (p.Id == 0) return Error("could not distribute or insert points: invalid point id: 0");
-      if (p.Vector.empty()) return Error("delete/update is not on the device path (prune.go)");
+      const bool exists = Exists(p.Id) || fresh.count(p.Id);
+      if (p.Vector.empty()) {  // nil vector: delete, or nothing to do (vamana.go:161-163,175-179)
+        if (exists) del_ids.push_back(p.Id);
+        continue;
+      }
       if (p.Vector.size() != parameters_.VectorSize) return Error("vector length mismatch");  // models/index.go:182-184
-      ids.push_back(p.Id);
-      vecs.insert(vecs.end(), p.Vector.begin(), p.Vector.end());  // copied: never retains caller memory
+      if (exists) {  // update :170-174
+        upd_ids.push_back(p.Id);
+        upd_vecs.insert(upd_vecs.end(), p.Vector.begin(), p.Vector.end());
+      } else {  // insert; copied: never retains caller memory
+        ins_ids.push_back(p.Id);
+        ins_vecs.insert(ins_vecs.end(), p.Vector.begin(), p.Vector.end());
+        fresh.insert(p.Id);
+      }
     }
-    if (ids.empty()) return Error();
-    if (int rc = sdb_index_insert_batch(h_, ids.size(), ids.data(), vecs.data(), SDB_MEM_HOST, round_size, nullptr))
-      return Error::wrap("could not distribute or insert points", rc);
+    if (!ins_ids.empty())
+      if (int rc = sdb_index_insert_batch(h_, ins_ids.size(), ins_ids.data(), ins_vecs.data(), SDB_MEM_HOST, round_size, nullptr))
+        return Error::wrap("could not distribute or insert points", rc);
+    for (uint64_t id : ins_ids) live_.insert(id);
+    std::vector<uint64_t> gone(del_ids);
+    gone.insert(gone.end(), upd_ids.begin(), upd_ids.end());
+    if (!gone.empty()) {
+      if (int rc = sdb_index_delete_batch(h_, gone.size(), gone.data(), nullptr))
+        return Error::wrap("could not remove inbound edges", rc);
+      for (uint64_t id : del_ids) {  // DeleteFrom (plain.go:143-148, node.go:129-134)
+        live_.erase(id);
+        if (bucket_) {
+          bucket_->Delete(conversion::NodeKey(id, 'v'));
+          bucket_->Delete(conversion::NodeKey(id, 'e'));
+        }
+      }
+    }
+    const size_t d = parameters_.VectorSize;
+    for (size_t i = 0; i < upd_ids.size(); i++)  // :247-251
+      if (int rc = sdb_index_insert_batch(h_, 1, &upd_ids[i], upd_vecs.data() + i * d, SDB_MEM_HOST, 1, nullptr))
+        return Error::wrap("could not re-insert updated point", rc);
     return flush();
   }
 
@@ -382,6 +416,8 @@ class IndexVamana {
       return Error();
     }
     if (edges.empty()) edges.push_back(0);
+    for (uint64_t id : ids)
+      if (id != STARTID) live_.insert(id);
     if (int rc = sdb_index_load(h_, ids.size(), ids.data(), vectors.data(), offsets.data(), edges.data(), SDB_MEM_HOST))
       return Error::wrap("could not load index into HBM", rc);
     return Error();
@@ -470,6 +506,7 @@ class IndexVamana {
   models::IndexVectorVamanaParameters parameters_;
   diskstore::Bucket *bucket_ = nullptr;
   sdb_index *h_ = nullptr;
+  std::set<uint64_t> live_;  // ids currently in the store (start node excluded)
   std::mutex write_mu_;
   // micro-batcher
   std::thread batcher_;

@@ -136,21 +136,46 @@ class IndexVamana:
 
     # ---- InsertUpdateDelete vamana.go:127-263 (insert branch on device) --------------------------
     def InsertUpdateDelete(self, points, round_size=0):
-        """points: iterable of IndexVectorChange.  Inserts go to the device; updates and deletes are
-        the reference's host-side path (prune.go) and are rejected here."""
-        ids, vecs = [], []
+        """points: iterable of IndexVectorChange.  Same classification and order as vamana.go:149-251: new
+        ids are inserted first; then the inbound edges of deleted AND updated ids are removed in one scan
+        and the deleted nodes dropped; then the updated points are re-inserted one by one."""
+        ins_ids, ins_vecs, upd_ids, upd_vecs, del_ids = [], [], [], [], []
+        known = set()
         for ch in points:
             if ch.Id == STARTID:
                 raise SemaDBError(1, "cannot modify point with start id: %d" % STARTID)  # vamana.go:150-153
             if ch.Id == 0:
                 raise SemaDBError(1, "invalid point id: %d" % ch.Id)  # vamana.go:154-157
+            exists = self.exists(ch.Id) or ch.Id in known
             if ch.Vector is None:
-                raise SemaDBError(3, "delete/update is not on the device path")
-            ids.append(ch.Id)
-            vecs.append(np.asarray(ch.Vector, dtype=np.float32))
-        if not ids:
-            return
-        self.insert_batch(np.array(ids, dtype=np.uint64), np.stack(vecs), round_size)
+                if exists:
+                    del_ids.append(ch.Id)  # :175-179
+                continue  # !exists && nil: nothing to do (:161-163)
+            v = np.asarray(ch.Vector, dtype=np.float32)
+            if exists:
+                upd_ids.append(ch.Id)  # :170-174
+                upd_vecs.append(v)
+            else:
+                ins_ids.append(ch.Id)
+                ins_vecs.append(v)
+                known.add(ch.Id)
+        if ins_ids:
+            self.insert_batch(np.array(ins_ids, dtype=np.uint64), np.stack(ins_vecs), round_size)
+        if del_ids or upd_ids:
+            self.delete_batch(np.array(del_ids + upd_ids, dtype=np.uint64))  # removeInboundEdges :223-233
+        for i, v in zip(upd_ids, upd_vecs):  # :247-251 re-inserted sequentially
+            self.insert_batch(np.array([i], dtype=np.uint64), v.reshape(1, -1), 1)
+
+    def exists(self, node_id):
+        """vecStore.Exists (plain.go:21-24)"""
+        q = np.zeros((1, self.parameters.VectorSize), dtype=np.float32)
+        d = self.distance_batch(q, np.array([[node_id]], dtype=np.uint64))
+        return bool(d[0, 0] != np.finfo(np.float32).max)
+
+    def delete_batch(self, ids):
+        ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
+        if ids_a.size:
+            check(lib().sdb_index_delete_batch(self._h, ids_a.size, _buf.np_ptr(ids_a), None))
 
     def insert_batch(self, ids, vectors, round_size=0):
         k, vp, mem, shape = _buf.as_f32(vectors)

@@ -163,6 +163,59 @@ static void test_self_retrieval_and_concurrency() {
   CHECK(used < 200);  // calls were coalesced
 }
 
+static void test_create_update_delete() {
+  // the CUD mix of Test_ConcurrentCUD (vamana_test.go:92-140), applied in one write like a shard transaction:
+  // 50 points, then insert 50 more + update 25 + delete 10; point count, no references to deleted ids
+  // (checkNoReferences shard_vector_test.go:187-214), bucket in sync, a cold reader sees the same graph
+  std::mt19937 rng(11);
+  std::uniform_real_distribution<float> U(0, 1);
+  auto rp = [&](int n, int off) {
+    std::vector<vamana::IndexVectorChange> v;
+    for (int i = 0; i < n; i++) v.push_back({(uint64_t)(i + off + 2), {U(rng), U(rng)}});
+    return v;
+  };
+  diskstore::MemBucket bucket;
+  auto [inv, err] = vamana::NewIndexVamana("test", vamanaParams(), &bucket);
+  CHECK(!err && !inv->InsertUpdateDelete(rp(50, 0)));
+  auto more = rp(50, 50);
+  auto upd = rp(25, 25);
+  for (int i = 0; i < 10; i++) more.push_back({(uint64_t)(i + 2), {}});  // nil vector = delete
+  more.insert(more.end(), upd.begin(), upd.end());
+  more.push_back({999999, {}});  // delete of a missing id: nothing to do
+  CHECK(!inv->InsertUpdateDelete(more));
+  size_t nv = 0, ne = 0;
+  std::set<uint64_t> ids;
+  bucket.ForEach([&](const std::string &k, const std::string &v) {
+    uint64_t id;
+    if (conversion::NodeIdFromKey(k, 'v', &id)) nv++, ids.insert(id);
+    if (conversion::NodeIdFromKey(k, 'e', &id)) ne++;
+    return Error();
+  });
+  CHECK(nv == 91 && ne == 91);  // 100 - 10 + start node
+  for (int i = 0; i < 10; i++) CHECK(!ids.count(i + 2) && !inv->Exists(i + 2));
+  bucket.ForEach([&](const std::string &k, const std::string &v) {
+    uint64_t id;
+    if (conversion::NodeIdFromKey(k, 'e', &id))
+      for (uint64_t e : conversion::BytesToEdgeList(v)) CHECK(ids.count(e));  // no edge to a deleted id
+    return Error();
+  });
+  // the updated vectors are the ones found
+  for (auto &u : upd)
+    if (u.Id >= 12) {
+      models::SearchVectorVamanaOptions q;
+      q.Vector = u.Vector;
+      auto r = inv->Search(q);
+      CHECK(!r.err && !r.results.empty() && r.results[0].NodeId == u.Id && r.results[0].Distance == 0);
+    }
+  auto [cold, err2] = vamana::NewIndexVamana("test", vamanaParams(), &bucket);
+  CHECK(!err2);
+  models::SearchVectorVamanaOptions q;
+  q.Vector = {0.5f, 0.5f};
+  auto a = inv->Search(q), b = cold->Search(q);
+  CHECK(a.results.size() == b.results.size());
+  for (size_t i = 0; i < a.results.size() && i < b.results.size(); i++) CHECK(a.results[i].NodeId == b.results[i].NodeId);
+}
+
 int main() {
   int ndev = 0;
   if (sdb_device_count(&ndev) != SDB_OK) {
@@ -174,6 +227,7 @@ int main() {
   test_deterministic_search();
   test_invalid_ids_and_empty();
   test_self_retrieval_and_concurrency();
+  test_create_update_delete();
   if (g_fail) {
     std::printf("%d HOST CHECKS FAILED\n", g_fail);
     return 1;

@@ -125,7 +125,7 @@ def test_insert_id_rules(oracle):
             ix.InsertUpdateDelete([vamana.IndexVectorChange(bad, [0.5, 0.5])])
     ix.InsertUpdateDelete([vamana.IndexVectorChange(7, [0.5, 0.5]), vamana.IndexVectorChange(9, [0.1, 0.2])])
     with pytest.raises(SemaDBError):
-        ix.InsertUpdateDelete([vamana.IndexVectorChange(7, [0.5, 0.5])])  # exists -> update path
+        ix.insert_batch(np.array([7], dtype=np.uint64), np.array([[0.5, 0.5]], np.float32))  # exists: not an insert
     rset, res = ix.Search(vamana.SearchVectorVamanaOptions([0.5, 0.5], 75, 10))
     assert [r.NodeId for r in res] == [7, 9] and res[0].Distance == 0
     n_nodes, n_edges, max_id = ix.stats()

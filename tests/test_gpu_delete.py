@@ -1,0 +1,188 @@
+"""Delete / update path on device (vamana.go:175-251, prune.go, node.go:142-199): identical graphs to the
+oracle's restatement, plus the reference's own invariants (shard/shard_vector_test.go:129-245)."""
+import numpy as np
+import pytest
+
+from tests.helpers import bits, start_vector, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(oracle, d, metric, R, L, base, seed=3):
+    """the same sequentially built graph on both sides"""
+    from semadb_amd import vamana
+    sv = start_vector(np.random.default_rng(seed), d)
+    o = oracle.Index(d, metric, R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    for i in range(base.shape[0]):
+        assert o.insert(i + 2, base[i]) == 0
+    g = vamana.NewIndexVamana("d", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.2), strict=False)
+    g.set_start(sv)
+    g.insert_batch(None, base, round_size=1)
+    return o, g
+
+
+def _same_graph(o, g):
+    o_ids, o_v, o_off, o_e = o.export()
+    g_ids, g_v, g_off, g_e = g.export()
+    assert np.array_equal(g_ids, o_ids)
+    assert np.array_equal(g_off, o_off), "degree sequence differs"
+    assert np.array_equal(g_e, o_e), "edge lists differ"
+    assert np.array_equal(bits(g_v), bits(o_v))
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("d,n,R,L,ndel", [(2, 200, 8, 25, 20), (16, 400, 4, 20, 80), (64, 500, 16, 30, 100),
+                                          (128, 400, 32, 50, 40), (384, 300, 32, 50, 30)])
+def test_delete_matches_oracle(oracle, metric, d, n, R, L, ndel):
+    rng = np.random.default_rng(d + n + ndel)
+    base = unit_rows(rng, n, d) if d > 2 else rng.random((n, d), dtype=np.float32)
+    if d == 2 and metric == "cosine":
+        # un-normalised 2-d data under "cosine" with R = 8 strands > 100 nodes per delete; the reference then
+        # grows its start node past any bound, the device row holds 64 (documented deviation, tested below)
+        pytest.skip("degenerate: start node would exceed 64 edges")
+    o, g = _pair(oracle, d, metric, R, L, base)
+    _same_graph(o, g)
+    dels = rng.choice(np.arange(2, n + 2), size=ndel, replace=False).astype(np.uint64)
+    dels_with_unknown = np.concatenate([dels, [10 ** 9]]).astype(np.uint64)  # unknown ids are skipped
+    assert o.delete(dels_with_unknown) == 0
+    g.delete_batch(dels_with_unknown)
+    _same_graph(o, g)
+    n_nodes, _, _ = g.stats()
+    assert n_nodes == n + 1 - ndel
+    # searches walk the same path and never return a deleted id
+    q = unit_rows(rng, 16, d) if d > 2 else rng.random((16, d), dtype=np.float32)
+    ids, dist, cnt, tr = g.search_batch(q, 10, L, trace=True, visit_cap=512)
+    for i in range(16):
+        o_ids, o_d, o_vis, o_tr = o.search(q[i], 10, L)
+        assert np.array_equal(ids[i, :len(o_ids)], o_ids) and np.array_equal(bits(dist[i, :len(o_ids)]), bits(o_d))
+        assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis)
+        assert not (set(int(v) for v in o_ids) & set(int(v) for v in dels))
+    # a second round of deletes on the already-holed index, then re-use of freed ids (idcounter.go:75-88)
+    left = np.setdiff1d(np.arange(2, n + 2), dels)
+    dels2 = rng.choice(left, size=max(1, ndel // 2), replace=False).astype(np.uint64)
+    assert o.delete(dels2) == 0
+    g.delete_batch(dels2)
+    _same_graph(o, g)
+    newv = unit_rows(rng, 5, d) if d > 2 else rng.random((5, d), dtype=np.float32)
+    for k in range(5):
+        assert o.insert(int(dels[k]), newv[k]) == 0
+    g.insert_batch(dels[:5], newv, round_size=1)
+    _same_graph(o, g)
+    g.close()
+
+
+def test_update_is_delete_plus_reinsert(oracle):
+    # vamana.go:170-174 (classification), :223-227 (inbound edges removed), :247-251 (re-inserted one by one)
+    from semadb_amd import vamana
+    rng = np.random.default_rng(9)
+    base = unit_rows(rng, 300, 32)
+    o, g = _pair(oracle, 32, "euclidean", 16, 30, base)
+    upd = [7, 100, 250]
+    newv = unit_rows(rng, 3, 32)
+    changes = [vamana.IndexVectorChange(i, newv[k]) for k, i in enumerate(upd)]
+    changes.append(vamana.IndexVectorChange(40, None))        # delete
+    changes.append(vamana.IndexVectorChange(999999, None))    # delete of a missing id: skipped
+    changes.append(vamana.IndexVectorChange(5000, unit_rows(rng, 1, 32)[0]))  # insert
+    g.InsertUpdateDelete(changes)
+    assert o.insert(5000, changes[-1].Vector) == 0            # inserts first (vamana.go:190-201)
+    assert o.delete(np.array([40] + upd, dtype=np.uint64)) == 0
+    for k, i in enumerate(upd):
+        assert o.insert(i, newv[k]) == 0
+    _same_graph(o, g)
+    rset, res = g.Search(vamana.SearchVectorVamanaOptions(newv[1], 30, 5))
+    assert res[0].NodeId == 100 and res[0].Distance == 0       # the updated vector is what is found
+    g.close()
+
+
+def test_reference_shard_invariants_after_delete_reinsert(oracle):
+    """shard/shard_vector_test.go:668-700 pattern at reduced size: insert, delete 500, re-insert, search;
+    checkNoReferences (:187-214), checkConnectivity (:150-185), checkPointCount (:129-148), self retrieval"""
+    from semadb_amd import vamana
+    rng = np.random.default_rng(17)
+    n, d = 4000, 32
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    base = rng.standard_normal((n, 8)).astype(np.float32) @ lat
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    g = vamana.NewIndexVamana("s", vamana.IndexVectorVamanaParameters(d, "cosine", 75, 64, 1.2))
+    g.set_start(start_vector(rng, d))
+    g.insert_batch(None, base)
+    dels = rng.choice(np.arange(2, n + 2), size=500, replace=False).astype(np.uint64)
+    g.InsertUpdateDelete([vamana.IndexVectorChange(int(i), None) for i in dels])
+
+    def check(expected):
+        ids, vecs, off, edges = g.export()
+        assert len(ids) == expected + 1                                  # checkPointCount (+ start node)
+        idset = set(int(v) for v in ids)
+        assert all(int(e) in idset for e in edges)                       # checkNoReferences
+        pos = {int(v): i for i, v in enumerate(ids)}
+        seen, stack = set(), [1]
+        while stack:
+            v = stack.pop()
+            if v in seen:
+                continue
+            seen.add(v)
+            stack.extend(int(e) for e in edges[int(off[pos[v]]):int(off[pos[v] + 1])])
+        assert len(seen) - 1 == expected                                 # checkConnectivity
+        assert int(np.diff(off.astype(np.int64)).max()) <= 64
+
+    check(n - 500)
+    assert not (set(int(v) for v in g.search_batch(base[:200], 10, 75)[0].ravel()) & set(int(v) for v in dels))
+    g.insert_batch(dels, base[dels.astype(np.int64) - 2])               # re-insert the same ids
+    check(n)
+    ids, dist, cnt, _ = g.search_batch(base[:300], 10, 75)
+    assert np.array_equal(ids[:, 0], np.arange(2, 302, dtype=np.uint64)) and np.all(dist[:, 0] <= 1e-6)
+    g.close()
+
+
+def test_flat_scan_skips_deleted(oracle):
+    from semadb_amd import flat, vamana
+    rng = np.random.default_rng(2)
+    base = unit_rows(rng, 200, 16)
+    o, g = _pair(oracle, 16, "euclidean", 8, 25, base)
+    g.delete_batch(np.array([2, 3, 50], dtype=np.uint64))
+    ids, d, c = flat.flat_search_batch(g._h, 16, base[:3], 5)
+    assert not (set(int(v) for v in ids.ravel()) & {1, 2, 3, 50})
+    assert int(ids[2, 0]) == 4 and d[2, 0] == 0
+    g.close()
+
+
+def test_delete_id_rules():
+    # vamana.go:150-157
+    from semadb_amd import vamana, SemaDBError
+    g = vamana.NewIndexVamana("r", vamana.IndexVectorVamanaParameters(2, "euclidean"))
+    g.set_start([0.6, 0.8])
+    g.InsertUpdateDelete([vamana.IndexVectorChange(5, [0.1, 0.2])])
+    for bad in (0, 1):
+        with pytest.raises(SemaDBError):
+            g.delete_batch(np.array([bad], dtype=np.uint64))
+    g.delete_batch(np.array([77], dtype=np.uint64))  # unknown: no-op
+    g.delete_batch(np.array([5], dtype=np.uint64))
+    rset, res = g.Search(vamana.SearchVectorVamanaOptions([0.1, 0.2], 75, 10))
+    assert res == []
+    g.close()
+
+
+def test_start_row_overflow_keeps_graph_valid(oracle):
+    """More stragglers than the 64-edge start row can take: the rest go through the full-node rule of
+    insert.go:47-58.  The graph stays well-formed (no dangling or duplicate edges, degree bound on the start
+    row) and every live point is still found by the exact scan."""
+    from semadb_amd import flat, vamana
+    rng = np.random.default_rng(1)
+    base = rng.random((200, 2), dtype=np.float32)
+    o, g = _pair(oracle, 2, "cosine", 8, 25, base)
+    dels = rng.choice(np.arange(2, 202), size=20, replace=False).astype(np.uint64)
+    g.delete_batch(dels)
+    ids, vecs, off, edges = g.export()
+    assert len(ids) == 181
+    idset = set(int(v) for v in ids)
+    assert all(int(e) in idset for e in edges)
+    for i in range(len(ids)):
+        row = [int(e) for e in edges[int(off[i]):int(off[i + 1])]]
+        assert len(row) == len(set(row)) and int(ids[i]) not in row and len(row) <= 64
+    f_ids, f_d, f_c = flat.flat_search_batch(g._h, 2, base[:50], 5)
+    assert np.all(f_c == 5) and not (set(int(v) for v in f_ids.ravel()) & (set(int(v) for v in dels) | {1}))
+    # the walk still works from the start node
+    s_ids, _, s_c, _ = g.search_batch(base[:50], 5, 25)
+    assert np.all(s_c == 5) and not (set(int(v) for v in s_ids.ravel()) & set(int(v) for v in dels))
+    g.close()
