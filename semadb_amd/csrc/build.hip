@@ -21,6 +21,7 @@ struct BuildArgs {
   const float *slab;
   uint32_t *adj;
   uint32_t *deg;
+  uint32_t *clean;  // [n] leading edges of each row that its last robustPrune produced (see robust_prune_wave)
   uint32_t dim, nblk, ng, tail, ld;
   int metric;
   float alpha;
@@ -114,11 +115,21 @@ __device__ void pair_matrix(const BuildArgs &a, int nc, const uint32_t *s_slot, 
   __syncthreads();
 }
 
+constexpr int kMaxDirty = 8;  // "few new candidates" mode of robust_prune_wave
+
 // D == nullptr: pair distances are computed when needed (large candidate sets); else looked up.
+//
+// n_clean: the first n_clean input candidates are this node's edges as its LAST robustPrune left them.  For two
+// such candidates i < j (sorted order) that prune evaluated alpha * dist(c_i, c_j) < c_j.Distance and found it
+// false -- c_j would not be an edge otherwise -- and it would find the same again: same vectors, same
+// arithmetic, same order (the key dist(node, .) never changes and ties keep edge order).  So only pairs with
+// a candidate that arrived since (appended edges, the new points) are evaluated: one row of distances per
+// such candidate instead of the whole triangle.  The graph that results is bit-for-bit the one the full
+// evaluation gives; the sequential-build parity tests cover it.
 template <int NG, bool L2>
 __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc, const uint32_t *in_slot,
                                   const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
-                                  float *qs, int lane, float *D = nullptr) {
+                                  float *qs, int lane, float *D = nullptr, int n_clean = 0) {
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
   for (int i = lane; i < nc; i += 64) {
@@ -130,11 +141,66 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     }
     s_slot[rank] = in_slot[i];
     s_dist[rank] = d;
-    s_rem[rank] = 0;
+    s_rem[rank] = i < n_clean ? 2u : 0u;  // bit 0: pruneRemoved (distset.go:124), bit 1: clean
   }
   __syncthreads();
+  // sparse mode: few dirty candidates and room for their distance rows in D
+  bool sparse = false;
+  uint32_t *dord = const_cast<uint32_t *>(in_slot);  // input arrays are free after the sort
   if constexpr (NG >= 0) {
-    if (D) pair_matrix<NG, L2>(a, nc, s_slot, D, lane);
+    if (D && n_clean > 0 && nc - n_clean <= kMaxDirty && nc <= kPairMax) {
+      sparse = true;
+      int nd = 0;
+      int dpos[kMaxDirty];
+#pragma unroll
+      for (int k = 0; k < kMaxDirty; k++) dpos[k] = 0;
+      for (int base = 0; base < nc; base += 64) {
+        const int j = base + lane;
+        const bool dirty = j < nc && !(s_rem[j] & 2u);
+        const uint64_t m = __ballot(dirty);
+        if (j < nc) dord[j] = dirty ? (uint32_t)(nd + __popcll(m & ((1ull << lane) - 1))) : 0xFFFFFFFFu;
+        for (uint64_t t = m; t; t &= t - 1) {
+          const int jj = base + __ffsll((unsigned long long)t) - 1;
+#pragma unroll
+          for (int k = 0; k < kMaxDirty; k++)
+            if (k == nd) dpos[k] = jj;
+          nd++;
+        }
+      }
+      __syncthreads();
+      // one row of pair distances per dirty candidate: D[k][j] = distFn(c_dirty_k, c_j)
+      for (int k = 0; k < nd; k++) {
+        int dk = 0;
+#pragma unroll
+        for (int kk = 0; kk < kMaxDirty; kk++)
+          if (kk == k) dk = dpos[kk];
+        PointRow<NG> pr;
+        const float *prow = a.slab + (size_t)s_slot[dk] * a.ld;
+#pragma unroll
+        for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(prow)[g * 32 + L];
+        if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pr.xt = a.tail ? prow[NG * 128 + L] : 0.0f;
+        for (int c0 = 0; c0 < nc; c0 += 2 * U) {
+          uint32_t slot[U];
+          float res[U];
+          int cidx[2 * U];
+#pragma unroll
+          for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
+#pragma unroll
+          for (int u = 0; u < U; u++) slot[u] = lane < 32 ? s_slot[cidx[2 * u]] : s_slot[cidx[2 * u + 1]];
+          chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+            const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+            if (lane == 0) D[k * kPairMax + cidx[2 * u]] = d0, D[k * kPairMax + cidx[2 * u + 1]] = d1;
+          }
+        }
+      }
+      __syncthreads();
+    } else if (D) {
+      pair_matrix<NG, L2>(a, nc, s_slot, D, lane);
+    }
   }
   uint32_t my_out = kNoSlot;  // lane e holds edge e of the new row
   int cnt = 0;
@@ -143,7 +209,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     int found = -1;
     for (int base = i & ~63; base < nc && found < 0; base += 64) {
       const int j = base + lane;
-      const bool ok = j >= i && j < nc && !s_rem[j] && s_slot[j] != self_slot;  // :115-117
+      const bool ok = j >= i && j < nc && !(s_rem[j] & 1u) && s_slot[j] != self_slot;  // :115-117
       const uint64_t m = __ballot(ok);
       if (m) found = base + __ffsll((unsigned long long)m) - 1;
     }
@@ -152,10 +218,27 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     if (lane == cnt) my_out = p;  // node.AddNeighbour :118
     cnt++;
     if (cnt >= (int)a.R) break;  // :119-121
+    if (sparse) {  // only pairs with a dirty candidate can prune; their distances are rows of D
+      const uint32_t fo = dord[found];
+      for (int base = (found + 1) & ~63; base < nc; base += 64) {
+        const int j = base + lane;
+        if (j > found && j < nc && !(s_rem[j] & 1u)) {
+          const uint32_t jo = dord[j];
+          if (fo != 0xFFFFFFFFu || jo != 0xFFFFFFFFu) {
+            // distFn(c_found, c_j); the arithmetic is bitwise symmetric in its two arguments
+            const float d = fo != 0xFFFFFFFFu ? D[fo * kPairMax + j] : D[jo * kPairMax + found];
+            if (a.alpha * d < s_dist[j]) s_rem[j] |= 1u;  // :132
+          }
+        }
+      }
+      __syncthreads();
+      i = found + 1;
+      continue;
+    }
     if (D) {  // pair distances are in LDS: the sweep is a lookup
       for (int base = (found + 1) & ~63; base < nc; base += 64) {
         const int j = base + lane;
-        if (j > found && j < nc && !s_rem[j] && a.alpha * D[found * kPairMax + j] < s_dist[j]) s_rem[j] = 1;  // :132
+        if (j > found && j < nc && !(s_rem[j] & 1u) && a.alpha * D[found * kPairMax + j] < s_dist[j]) s_rem[j] |= 1u;  // :132
       }
       __syncthreads();
       i = found + 1;
@@ -176,7 +259,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     }
     for (int base = (found + 1) & ~63; base < nc; base += 64) {
       const int j = base + lane;
-      const bool live = j > found && j < nc && !s_rem[j];
+      const bool live = j > found && j < nc && !(s_rem[j] & 1u);
       const uint32_t cs = live ? s_slot[j] : 0u;
       const float cdj = live ? s_dist[j] : 0.0f;
       uint64_t todo = __ballot(live);
@@ -209,14 +292,17 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
           if (lane == jj[2 * u + 1]) rm = a.alpha * d1 < cdj;
         }
       }
-      if (live && rm) s_rem[j] = 1;
+      if (live && rm) s_rem[j] |= 1u;
     }
     __syncthreads();
     i = found + 1;
   }
-  // node.edges of `self`, kNoSlot padded
+  // node.edges of `self`, kNoSlot padded; every edge of a freshly pruned row is "clean"
   a.adj[(size_t)self_slot * kAdjStride + lane] = lane < cnt ? my_out : kNoSlot;
-  if (lane == 0) a.deg[self_slot] = (uint32_t)cnt;
+  if (lane == 0) {
+    a.deg[self_slot] = (uint32_t)cnt;
+    a.clean[self_slot] = (uint32_t)cnt;
+  }
 }
 
 // dynamic LDS carve shared by both prune kernels
@@ -356,8 +442,11 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       }
     }
     __syncthreads();
+    // the first clean[b] candidates are B's edges as its last prune left them (edges appended since and the
+    // new points are not)
+    const uint32_t ncl = a.clean[b] < deg ? a.clean[b] : deg;
     robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane,
-                              (NG >= 0 && nc <= kPairMax) ? l.D : nullptr);  // :57-58
+                              (NG >= 0 && nc <= kPairMax) ? l.D : nullptr, (int)ncl);  // :57-58
     __syncthreads();
     row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
     deg = (uint32_t)__popcll(__ballot(row != kNoSlot));
@@ -542,7 +631,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_TRY(launch_greedy_search(sa, rs, stream));
     // ---- robustPrune + back-edges
     BuildArgs ba{};
-    ba.slab = ix->d_slab, ba.adj = ix->d_adj, ba.deg = ix->d_deg;
+    ba.slab = ix->d_slab, ba.adj = ix->d_adj, ba.deg = ix->d_deg, ba.clean = ix->d_clean;
     ba.dim = l.dim, ba.nblk = l.nblk, ba.ng = l.ng, ba.tail = l.tail, ba.ld = l.ld;
     ba.metric = (int)ix->P.metric, ba.alpha = ix->P.alpha, ba.R = ix->P.degree_bound;
     ba.first_slot = cur, ba.nnew = rs;

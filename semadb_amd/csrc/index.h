@@ -48,6 +48,7 @@ struct sdb_index {
   float *d_slab = nullptr;   // [cap][lay.ld] float32, permuted rows (common.h RowLayout)
   uint32_t *d_adj = nullptr; // [cap][kAdjStride] neighbour slots, kNoSlot padded, edge order kept
   uint32_t *d_deg = nullptr; // [cap]
+  uint32_t *d_clean = nullptr; // [cap] leading edges of a row produced by its last robustPrune (build.hip)
   uint64_t *d_ids = nullptr; // [cap] slot -> node id
   std::vector<uint64_t> h_ids;
   bool dense_ids = true;  // ids[i] == ids[0] + i  (then no hash map is needed)

@@ -213,25 +213,29 @@ int sdb_index::reserve(uint32_t rows) {
   uint32_t ncap = cap ? cap : 1024;
   while (ncap < rows) ncap = ncap < (1u << 30) ? ncap * 2 : rows;
   float *nslab = nullptr;
-  uint32_t *nadj = nullptr, *ndeg = nullptr;
+  uint32_t *nadj = nullptr, *ndeg = nullptr, *nclean = nullptr;
   uint64_t *nids = nullptr;
   SDB_HIP(hipMalloc(&nslab, (size_t)ncap * lay.ld * sizeof(float)));
   SDB_HIP(hipMalloc(&nadj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
   SDB_HIP(hipMalloc(&ndeg, (size_t)ncap * sizeof(uint32_t)));
+  SDB_HIP(hipMalloc(&nclean, (size_t)ncap * sizeof(uint32_t)));
   SDB_HIP(hipMalloc(&nids, (size_t)ncap * sizeof(uint64_t)));
   SDB_HIP(hipMemset(nadj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
   SDB_HIP(hipMemset(ndeg, 0, (size_t)ncap * sizeof(uint32_t)));
+  SDB_HIP(hipMemset(nclean, 0, (size_t)ncap * sizeof(uint32_t)));  // loaded / appended edges are not "clean"
   if (n) {
     SDB_HIP(hipMemcpy(nslab, d_slab, (size_t)n * lay.ld * sizeof(float), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(nadj, d_adj, (size_t)n * kAdjStride * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(ndeg, d_deg, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(nclean, d_clean, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(nids, d_ids, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
   }
   if (d_slab) (void)hipFree(d_slab);
   if (d_adj) (void)hipFree(d_adj);
   if (d_deg) (void)hipFree(d_deg);
+  if (d_clean) (void)hipFree(d_clean);
   if (d_ids) (void)hipFree(d_ids);
-  d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_ids = nids, cap = ncap;
+  d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_clean = nclean, d_ids = nids, cap = ncap;
   return SDB_OK;
 }
 
@@ -336,6 +340,7 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_slab) (void)hipFree(ix->d_slab);
   if (ix->d_adj) (void)hipFree(ix->d_adj);
   if (ix->d_deg) (void)hipFree(ix->d_deg);
+  if (ix->d_clean) (void)hipFree(ix->d_clean);
   if (ix->d_ids) (void)hipFree(ix->d_ids);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
   for (auto e : ix->ev0)
