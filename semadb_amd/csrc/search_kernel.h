@@ -179,6 +179,8 @@ struct PlainDist {
     return metric_finish(rlf(res[0], 0), a.metric);
   }
 
+  __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
+
   // distances of the new neighbours of one hop: lane j (bit j of pend) gets dist(query, row nb_j)
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
     float mydist = 0.0f;
@@ -235,8 +237,28 @@ struct PQDist {
     return dist;
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
+  // M == 8 (the documented configuration): the 8 code bytes of every neighbour are fetched as one 8-byte
+  // load BEFORE the visited-set test, so the code gather and the test-and-set round trip overlap; codes of
+  // neighbours that turn out to be already visited are simply not used (8 bytes each).
+  uint2 pre;
+  __device__ __forceinline__ void prefetch(const SearchArgs &a, uint32_t nb, bool valid) {
+    pre = make_uint2(0u, 0u);
+    if (a.pq_M == 8 && valid) pre = *reinterpret_cast<const uint2 *>(a.pq_codes + (size_t)nb * 8);
+  }
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
-    return ((pend >> lane) & 1ull) ? sum(a, nb) : 0.0f;
+    if (!((pend >> lane) & 1ull)) return 0.0f;
+    if (a.pq_M != 8) return sum(a, nb);
+    float dist = 0.0f;  // same sequential adds in index order (product.go:271-275)
+    const uint32_t K = a.pq_K;
+    dist += lut[0 * K + (pre.x & 0xFF)];
+    dist += lut[1 * K + ((pre.x >> 8) & 0xFF)];
+    dist += lut[2 * K + ((pre.x >> 16) & 0xFF)];
+    dist += lut[3 * K + (pre.x >> 24)];
+    dist += lut[4 * K + (pre.y & 0xFF)];
+    dist += lut[5 * K + ((pre.y >> 8) & 0xFF)];
+    dist += lut[6 * K + ((pre.y >> 16) & 0xFF)];
+    dist += lut[7 * K + (pre.y >> 24)];
+    return dist;
   }
 };
 
@@ -565,6 +587,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     const bool valid = nb != kNoSlot;
     n_edges += (uint32_t)__popcll(__ballot(valid));
     SDB_STAMP(st_adj)
+    dist.prefetch(a, nb, valid);
     // CheckAndVisit distset.go:174 -- marks before any distance test
     const bool isnew = vis.test_and_set(valid, nb, lane);
     const uint64_t pend = __ballot(isnew);
