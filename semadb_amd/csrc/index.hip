@@ -124,25 +124,30 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // LDS hash visited set: plain store with the query in registers, unfiltered, reference-range search size,
 // and a batch small enough that LDS (4 waves per CU) is not what limits occupancy.
 bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
-  if (a.pq_codes || a.filt_off || a.prefer_bitset) return false;
+  static const bool never = getenv("SDB_NO_HASH") != nullptr;  // measurement hook (tools/bench_pq.py)
+  if (never || a.filt_off || a.prefer_bitset) return false;
   if (a.search_size > 96 || nq > 4096) return false;
+  // quantized store: only with the small LUT of M*K <= 2048 entries next to the (prime-sized) table
+  if (a.pq_codes) return a.pq_lut_in_lds && (size_t)a.pq_M * a.pq_K <= 2048;
   switch (a.ng) {
     case 0: case 1: case 2: case 3: case 4: case 6: case 8: return true;
     default: return false;
   }
 }
 
-template <class Dist, bool HASH>
+// HCAP: 0 = bitset, else the LDS hash set's capacity (it precedes the policy's own LDS of `lds` bytes)
+template <class Dist, uint32_t HCAP>
 static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, size_t lds) {
   const bool filt = a.filt_off != nullptr;
-  if constexpr (HASH) {
-    hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, true>), dim3(nq), dim3(64), kHashCap * sizeof(uint32_t), stream, a);
+  if constexpr (HCAP != 0) {
+    const size_t total = HashVisited<HCAP>::kWords * sizeof(uint32_t) + lds;
+    hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, HCAP>), dim3(nq), dim3(64), total, stream, a);
   } else if (a.search_size <= 128) {
-    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true, false>), dim3(nq), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, false>), dim3(nq), dim3(64), lds, stream, a);
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true, 0>), dim3(nq), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, 0>), dim3(nq), dim3(64), lds, stream, a);
   } else {
-    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 8, true, false>), dim3(nq), dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL((k_greedy_search<Dist, 8, false, false>), dim3(nq), dim3(64), lds, stream, a);
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 8, true, 0>), dim3(nq), dim3(64), lds, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 8, false, 0>), dim3(nq), dim3(64), lds, stream, a);
   }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
@@ -150,8 +155,8 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 
 template <int NG, bool L2>
 static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
-  if (search_uses_hash(a, nq)) return launch_nreg<PlainDist<NG, L2, true>, true>(a, nq, stream, 0);
-  return launch_nreg<PlainDist<NG, L2, false>, false>(a, nq, stream, 0);
+  if (search_uses_hash(a, nq)) return launch_nreg<PlainDist<NG, L2, true>, kHashCap>(a, nq, stream, 0);
+  return launch_nreg<PlainDist<NG, L2, false>, 0>(a, nq, stream, 0);
 }
 
 template <bool L2>
@@ -184,7 +189,8 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
-    return launch_nreg<PQDist, false>(a, nq, stream, lds);
+    if (search_uses_hash(a, nq)) return launch_nreg<PQDist, kHashCapPQ>(a, nq, stream, lds);
+    return launch_nreg<PQDist, 0>(a, nq, stream, lds);
   }
   if (a.metric == SDB_METRIC_EUCLIDEAN) return launch_ng<true>(a, nq, stream);
   return launch_ng<false>(a, nq, stream);

@@ -44,6 +44,43 @@ __device__ __forceinline__ float dist_serial_metric(const float *x, const float 
   return metric_finish(dist_serial<false>(x, y, n), metric);
 }
 
+// The same arithmetic with one operand's NB whole 32-float blocks already in the thread's registers
+// (r) and the other operand (u) at a wave-uniform address, so its elements arrive through the scalar
+// cache and cost no vector memory instruction.  The 32 partial sums are produced in the order the
+// reduce tree consumes them, so only a handful are live at a time.  rt = the register operand's tail
+// elements in memory (sub_len % 32 of them), chained sequentially as the asm does.
+constexpr int kRegBlocksMax = 8;  // sub-vectors of up to 8 * 32 + 31 floats take the register path
+template <bool L2, int NB>
+__device__ __forceinline__ float dist_regs(const float *r, const float *__restrict__ u, const float *__restrict__ rt,
+                                           uint32_t tail) {
+  float rr[4];
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    float s[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      float part[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int L = l + 4 * h + 8 * k;
+        float acc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc = chain1<L2>(acc, r[32 * b + L], u[32 * b + L]);
+        part[k] = acc;
+      }
+      s[h] = ((part[0] + part[1]) + part[2]) + part[3];
+    }
+    rr[l] = s[0] + s[1];
+  }
+  float t = 0.0f;
+  for (uint32_t i = 0; i < tail; i++) t = chain1<L2>(t, rt[i], u[NB * 32 + i]);
+  rr[0] = rr[0] + t;
+  rr[1] = rr[1] + 0.0f;
+  rr[2] = rr[2] + 0.0f;
+  rr[3] = rr[3] + 0.0f;
+  return (rr[0] + rr[1]) + (rr[2] + rr[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k-means.  Centroid j is a VIEW: row cent_row[j] of cent_base (stride cent_stride) at cent_off --
 // either into X itself (the reference's aliasing, kmeans.go:63,82,144) or into a private copy.
@@ -263,6 +300,86 @@ __global__ void k_pq_lut(const float *__restrict__ queries, uint32_t dim, const 
                                                   cent + ((size_t)i * K + j) * sub_len, sub_len, metric);
 }
 
+// Register-tiled forms of the two kernels above for sub_len < 32 * (kRegBlocksMax + 1).
+// LUT: thread = centroid j (its row in registers), the block walks kLutQT queries whose sub-vectors
+// are wave-uniform -- the centroid table is read once per 16 queries instead of once per query.
+constexpr uint32_t kLutQT = 16;
+template <bool L2, int NB>
+__global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ queries, uint32_t nq, uint32_t dim,
+                                                  const float *__restrict__ cent, uint32_t M, uint32_t K,
+                                                  uint32_t sub_len, int metric, float *__restrict__ lut) {
+  const uint32_t i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t q0 = blockIdx.z * kLutQT, q1 = min(q0 + kLutQT, nq);
+  const float *row = cent + ((size_t)i * K + min(j, K - 1)) * sub_len;
+  float r[NB > 0 ? NB * 32 : 1];
+#pragma unroll
+  for (int e = 0; e < NB * 32; e++) r[e] = row[e];
+  const uint32_t tail = sub_len - NB * 32;
+  for (uint32_t q = q0; q < q1; q++) {
+    const float *x = queries + (size_t)q * dim + (size_t)i * sub_len;
+    float d = dist_regs<L2, NB>(r, x, row + NB * 32, tail);
+    if constexpr (!L2) d = metric_finish(d, metric);
+    if (j < K) lut[((size_t)q * M + i) * K + j] = d;
+  }
+}
+
+// encode: thread = vector (its sub-vector in registers), the K centroids are wave-uniform
+template <bool L2, int NB>
+__global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ vecs, uint64_t n, uint32_t dim,
+                                                     const float *__restrict__ cent, uint32_t M, uint32_t K,
+                                                     uint32_t sub_len, int metric, uint8_t *__restrict__ codes) {
+  const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = blockIdx.y;
+  const float *sub = vecs + (v < n ? v : n - 1) * dim + (size_t)i * sub_len;
+  float r[NB > 0 ? NB * 32 : 1];
+#pragma unroll
+  for (int e = 0; e < NB * 32; e++) r[e] = sub[e];
+  const uint32_t tail = sub_len - NB * 32;
+  float best = FLT_MAX;
+  uint32_t best_id = 0;
+  for (uint32_t j = 0; j < K; j++) {
+    float d = dist_regs<L2, NB>(r, cent + ((size_t)i * K + j) * sub_len, sub + NB * 32, tail);
+    if constexpr (!L2) d = metric_finish(d, metric);
+    if (d < best) best = d, best_id = j;
+  }
+  if (v < n) codes[v * M + i] = (uint8_t)best_id;
+}
+
+template <int NB>
+static void launch_lut_t(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
+  const dim3 grid((pq->K + 255) / 256, pq->M, (unsigned)((nq + kLutQT - 1) / kLutQT));
+  if (pq->metric == SDB_METRIC_EUCLIDEAN)
+    hipLaunchKernelGGL((k_pq_lut_t<true, NB>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
+                       pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+  else
+    hipLaunchKernelGGL((k_pq_lut_t<false, NB>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
+                       pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+}
+
+template <int NB>
+static void launch_encode_t(const sdb_pq *pq, const float *d_vecs, uint64_t n, uint8_t *d_codes, hipStream_t stream) {
+  const dim3 grid((unsigned)((n + 255) / 256), pq->M);
+  if (pq->metric == SDB_METRIC_EUCLIDEAN)
+    hipLaunchKernelGGL((k_pq_encode_t<true, NB>), grid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids,
+                       pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
+  else
+    hipLaunchKernelGGL((k_pq_encode_t<false, NB>), grid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids,
+                       pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
+}
+
+#define SDB_NB_SWITCH(fn, ...)                 \
+  switch (pq->sub_len / 32) {                  \
+    case 0: fn<0>(__VA_ARGS__); break;         \
+    case 1: fn<1>(__VA_ARGS__); break;         \
+    case 2: fn<2>(__VA_ARGS__); break;         \
+    case 3: fn<3>(__VA_ARGS__); break;         \
+    case 4: fn<4>(__VA_ARGS__); break;         \
+    case 5: fn<5>(__VA_ARGS__); break;         \
+    case 6: fn<6>(__VA_ARGS__); break;         \
+    case 7: fn<7>(__VA_ARGS__); break;         \
+    default: fn<8>(__VA_ARGS__); break;        \
+  }
+
 // out[q][c] = sum_i lut[q][i][code_c_i], sequential fp32 adds in index order (product.go:271-275)
 __global__ void k_pq_lut_dist(const float *__restrict__ lut, const uint8_t *__restrict__ codes, uint64_t nc,
                               uint32_t M, uint32_t K, float *__restrict__ out) {
@@ -293,17 +410,26 @@ __global__ void k_scatter_labels(const uint8_t *__restrict__ labels, uint8_t *__
 }
 
 int pq_build_lut(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
-  const uint32_t MK = pq->M * pq->K;
-  hipLaunchKernelGGL(k_pq_lut, dim3((MK + 127) / 128, (unsigned)nq), dim3(128), 0, stream, d_queries, pq->dim,
-                     pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+  if (nq == 0) return SDB_OK;
+  if (pq->sub_len < 32 * (kRegBlocksMax + 1)) {
+    SDB_NB_SWITCH(launch_lut_t, pq, d_queries, nq, d_lut, stream)
+  } else {
+    const uint32_t MK = pq->M * pq->K;
+    hipLaunchKernelGGL(k_pq_lut, dim3((MK + 127) / 128, (unsigned)nq), dim3(128), 0, stream, d_queries, pq->dim,
+                       pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+  }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }
 
 int pq_encode_device(const sdb_pq *pq, const float *d_vecs, uint64_t n, uint8_t *d_codes, hipStream_t stream) {
   if (n == 0) return SDB_OK;
-  hipLaunchKernelGGL(k_pq_encode, dim3((unsigned)((n + 127) / 128), pq->M), dim3(128), 0, stream, d_vecs, n, pq->dim,
-                     pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
+  if (pq->sub_len < 32 * (kRegBlocksMax + 1)) {
+    SDB_NB_SWITCH(launch_encode_t, pq, d_vecs, n, d_codes, stream)
+  } else {
+    hipLaunchKernelGGL(k_pq_encode, dim3((unsigned)((n + 127) / 128), pq->M), dim3(128), 0, stream, d_vecs, n, pq->dim,
+                       pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
+  }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }

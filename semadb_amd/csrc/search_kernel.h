@@ -418,24 +418,31 @@ struct BitVisited {
 // resolves slot collisions.  When the table fills past `limit` the set SPILLS: the wave clears its HBM
 // bitset, replays every stored key into it and carries on there -- the set stays exact and the walk is
 // not repeated (the reference makes the same kind of switch by id range, distset.go:140-153).
-constexpr uint32_t kHashCap = 8192;  // 32 KB per wave -> 4 waves per CU
-constexpr uint32_t kHashLimit = 6000;
+constexpr uint32_t kHashCap = 8192;    // plain store: 32 KB per wave -> 4 waves per CU
+constexpr uint32_t kHashLimit = 6000;  // keys a table may hold before it spills (any CAP: limit * CAP / 8192)
+constexpr uint32_t kHashCapPQ = 7417;  // quantized store: a prime, 29 KB, leaves room for the 8 KB LUT (M = 8)
+// CAP is a power of two (mask) or a prime (conditional subtract): either way every probe stride in
+// [1, CAP) reaches every slot.
+template <uint32_t CAP>
 struct HashVisited {
+  static constexpr bool kPow2 = (CAP & (CAP - 1)) == 0;
+  static constexpr uint32_t kWords = (CAP + 3) & ~3u;  // LDS words reserved (16-byte multiple)
   uint32_t *tab;
   uint32_t *bits;
   uint32_t words, count, limit;
   bool spilled;
   __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
     tab = lds, bits = bitset, words = nwords;
-    count = 0, limit = lim, spilled = false;
+    count = 0, spilled = false;
+    limit = (uint32_t)(((uint64_t)lim * CAP) >> 13);
     uint4 *t4 = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t i = lane; i < kHashCap / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
+    for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
     __syncthreads();
   }
   __device__ __forceinline__ void spill(int lane) {
     for (uint32_t i = lane; i < words; i += 64) bits[i] = 0u;  // ClearAll distset.go:101
     __threadfence();                                           // the clears land before the atomics below
-    for (uint32_t i = lane; i < kHashCap; i += 64) {
+    for (uint32_t i = lane; i < CAP; i += 64) {
       const uint32_t k = tab[i];
       if (k != kNoSlot) atomicOr(&bits[k >> 5], 1u << (k & 31));
     }
@@ -449,16 +456,21 @@ struct HashVisited {
       return !(atomicOr(&bits[slot >> 5], bit) & bit);
     }
     bool isnew = false, done = !active;
-    // double hashing: the probe stride is odd (coprime with the table size), so every slot is reached and
-    // probe chains of different keys do not pile up the way linear probing clusters
-    uint32_t h = (slot * 2654435761u) >> (32 - 13);
-    const uint32_t step = ((slot * 0x9E3779B1u) >> 19) | 1u;
+    // double hashing: probe chains of different keys do not pile up the way linear probing clusters.
+    // start = hash1 * CAP >> 32 in [0, CAP); stride in [1, CAP), odd for the power-of-two table
+    uint32_t h = (uint32_t)(((uint64_t)(slot * 2654435761u) * CAP) >> 32);
+    uint32_t step = 1u + (uint32_t)(((uint64_t)(slot * 0x9E3779B1u) * (CAP - 1)) >> 32);
+    if (kPow2) step |= 1u;
     while (__ballot(!done)) {
       if (!done) {
         const uint32_t old = atomicCAS(&tab[h], kNoSlot, slot);
         if (old == kNoSlot) isnew = true, done = true;
         else if (old == slot) done = true;
-        else h = (h + step) & (kHashCap - 1);
+        else {
+          h += step;
+          if (kPow2) h &= CAP - 1;
+          else if (h >= CAP) h -= CAP;
+        }
       }
     }
     count += (uint32_t)__popcll(__ballot(isnew));
@@ -655,19 +667,22 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 
 // HASH: visited set in LDS, spilling to the HBM bitset when it fills (plain store, unfiltered); otherwise the
 // HBM bitset from the start.
-template <class Dist, int NREG, bool FILT, bool HASH>
+// HCAP != 0: capacity of the LDS hash visited set (it sits first in dynamic LDS, the distance policy's
+// tile / LUT after it); HCAP == 0: HBM bitset from the start.
+template <class Dist, int NREG, bool FILT, uint32_t HCAP>
 __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   Dist dist;
-  dist.init(a, q, lane, lds_f);
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
-  if constexpr (HASH) {
-    HashVisited hv;
+  if constexpr (HCAP != 0) {
+    dist.init(a, q, lane, lds_f + HashVisited<HCAP>::kWords);
+    HashVisited<HCAP> hv;
     hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
     search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
   } else {
+    dist.init(a, q, lane, lds_f);
     BitVisited bv{bits};
     search_body<Dist, NREG, FILT>(a, q, lane, dist, bv);
   }
