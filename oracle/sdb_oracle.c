@@ -242,6 +242,7 @@ struct orc_index {
   uint64_t max_node_id; /* vamana.go:47 */
   const orc_pq *pq;
   uint8_t *codes;
+  size_t codes_cap; /* rows */
 };
 
 static float distfn_eval(distfn *f, uint32_t slot) {
@@ -481,6 +482,13 @@ static uint32_t index_add_node(orc_index *ix, uint64_t id, const float *vec) {
   map_put(ix, id, s);
   ix->n++;
   if (id > ix->max_node_id) ix->max_node_id = id; /* vamana.go:166-168 */
+  if (ix->pq) { /* productQuantizer.Set encodes with the fitted codebook (product.go:161-169) */
+    if (ix->n > ix->codes_cap) {
+      ix->codes_cap = ix->n * 2;
+      ix->codes = realloc(ix->codes, ix->codes_cap * ix->pq->M);
+    }
+    orc_pq_encode(ix->pq, vec, ix->codes + (size_t)s * ix->pq->M);
+  }
   return s;
 }
 
@@ -549,6 +557,7 @@ int orc_index_attach_pq(orc_index *ix, const orc_pq *pq, const uint8_t *codes) {
   ix->pq = pq;
   free(ix->codes);
   ix->codes = malloc((size_t)ix->n * pq->M);
+  ix->codes_cap = ix->n;
   memcpy(ix->codes, codes, (size_t)ix->n * pq->M);
   return 0;
 }

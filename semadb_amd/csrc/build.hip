@@ -13,6 +13,7 @@
 
 #include <algorithm>
 
+#include "pq.h"
 #include "search_kernel.h"
 
 namespace sdb {
@@ -35,7 +36,21 @@ struct BuildArgs {
   uint32_t vis_cap;
   uint64_t *keys_in;   // [nnew*64] (target slot << 32 | a_idx << 6 | edge position)
   uint64_t *keys_sorted;
+  // quantized store (NG == kQuantized): point-to-point distances are sums over the centroid-pair table
+  const uint8_t *pq_codes;  // [n][M]
+  const float *pq_cdists;   // [M][K][K]
+  uint32_t pq_M, pq_K;
 };
+
+constexpr int kQuantized = -2;  // value of the NG template parameter for a fitted product quantizer
+
+// productQuantizer.DistanceFromPoint (product.go:296-304): sequential fp32 adds over the sub-quantizers
+__device__ __forceinline__ float pq_sym_dist(const BuildArgs &a, const uint8_t *__restrict__ cx,
+                                             const uint8_t *__restrict__ cy) {
+  float dist = 0.0f;
+  for (uint32_t i = 0; i < a.pq_M; i++) dist += a.pq_cdists[((size_t)i * a.pq_K + cx[i]) * a.pq_K + cy[i]];
+  return dist;
+}
 
 constexpr uint64_t kNoKey = ~0ull;
 
@@ -244,6 +259,19 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
       i = found + 1;
       continue;
     }
+    if constexpr (NG == kQuantized) {  // one candidate per lane: M table lookups each
+      const uint8_t *cp = a.pq_codes + (size_t)p * a.pq_M;
+      for (int base = (found + 1) & ~63; base < nc; base += 64) {
+        const int j = base + lane;
+        if (j > found && j < nc && !(s_rem[j] & 1u)) {
+          const float d = pq_sym_dist(a, cp, a.pq_codes + (size_t)s_slot[j] * a.pq_M);
+          if (a.alpha * d < s_dist[j]) s_rem[j] |= 1u;  // :132
+        }
+      }
+      __syncthreads();
+      i = found + 1;
+      continue;
+    }
     // bind p (DistanceFromPoint :124)
     PointRow<NG> pr;
     const float *prow = a.slab + (size_t)p * a.ld;
@@ -329,8 +357,50 @@ struct PruneLds {
   }
 };
 
+// in_dist[c] = DistanceFromPoint(point)(in_slot[c]) for the nc candidates staged in LDS (plain.go:87-97 /
+// product.go:279-305).  Callers have synchronised after filling in_slot; synchronises before returning.
+template <int NG, bool L2>
+__device__ void dists_from_point(const BuildArgs &a, uint32_t point, uint32_t nc, const PruneLds &l, int lane) {
+  if constexpr (NG == kQuantized) {
+    const uint8_t *cp = a.pq_codes + (size_t)point * a.pq_M;
+    for (uint32_t c = lane; c < nc; c += 64) l.in_dist[c] = pq_sym_dist(a, cp, a.pq_codes + (size_t)l.in_slot[c] * a.pq_M);
+  } else {
+    constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
+    const int L = lane & 31;
+    PointRow<NG> pr;
+    const float *arow = a.slab + (size_t)point * a.ld;
+    if constexpr (NG >= 0) {
+#pragma unroll
+      for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(arow)[g * 32 + L];
+      if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pr.xt = a.tail ? arow[NG * 128 + L] : 0.0f;
+    } else {
+      for (uint32_t x = lane; x < a.ld; x += 64) l.qs[x] = arow[x];
+      __syncthreads();
+    }
+    for (uint32_t c0 = 0; c0 < nc; c0 += 2 * U) {
+      uint32_t slot[U];
+      float res[U];
+      uint32_t cidx[2 * U];
+#pragma unroll
+      for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
+#pragma unroll
+      for (int u = 0; u < U; u++) slot[u] = lane < 32 ? l.in_slot[cidx[2 * u]] : l.in_slot[cidx[2 * u + 1]];
+      if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+      else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+        const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+        if (lane == 0) l.in_dist[cidx[2 * u]] = d0, l.in_dist[cidx[2 * u + 1]] = d1;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld, bool with_pairs = false) {
-  return (size_t)cap * 20 + (with_pairs ? (size_t)kPairMax * kPairMax * 4 : 0) + (NG < 0 ? (size_t)ld * 4 + 16 : 0);
+  return (size_t)cap * 20 + (with_pairs ? (size_t)kPairMax * kPairMax * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
 }
 
 // robustPrune(nodeA, visitedSet) for every new node of the round (insert.go:29-31), then emit the
@@ -402,6 +472,16 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       continue;
     }
     // B overflows: distances from B (distFn = DistanceFromPoint(nB) :49) to its neighbours and the t new points
+    const int nc = (int)deg + (int)t;
+    if constexpr (NG == kQuantized) {
+      __syncthreads();
+      for (int c = lane; c < nc; c += 64)
+        l.in_slot[c] = c >= (int)deg ? req_slot(done + (size_t)(c - (int)deg)) : kNoSlot;
+      if (lane < (int)deg) l.in_slot[lane] = row;
+      __syncthreads();
+      const uint8_t *cb = a.pq_codes + (size_t)b * a.pq_M;
+      for (int c = lane; c < nc; c += 64) l.in_dist[c] = pq_sym_dist(a, cb, a.pq_codes + (size_t)l.in_slot[c] * a.pq_M);
+    }
     PointRow<NG> pr;
     const float *brow = a.slab + (size_t)b * a.ld;
     if constexpr (NG >= 0) {
@@ -409,15 +489,14 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(brow)[g * 32 + L];
       if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
       pr.xt = a.tail ? brow[NG * 128 + L] : 0.0f;
-    } else {
+    } else if constexpr (NG == -1) {
       __syncthreads();
       for (uint32_t x = lane; x < a.ld; x += 64) l.qs[x] = brow[x];
       __syncthreads();
     }
     // candidate c: c < deg -> row entry c (edge order), then the new points in insert order (:55-56; Add
     // dedupes, and a new node can not already be a neighbour)
-    const int nc = (int)deg + (int)t;
-    for (int c0 = 0; c0 < nc; c0 += 2 * U) {
+    for (int c0 = 0; NG != kQuantized && c0 < nc; c0 += 2 * U) {
       uint32_t slot[U];
       float res[U];
       int cidx[2 * U];
@@ -510,7 +589,6 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   if (n == 0) return SDB_OK;
   if (!vectors) return fail(SDB_ERR_INVALID, "vectors is NULL");
   if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
-  if (ix->pq) return fail(SDB_ERR_STATE, "insert into a quantized index is not on the device path yet");
   if ((uint64_t)ix->n + n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many nodes");
   // ---- ids: vamana.go:150-157 rejects 0 and the start id; an existing id would be an update
   std::vector<uint64_t> new_ids(n);
@@ -558,6 +636,10 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   } cleanup{{staging}, stream};
   // vecStore.Set for the whole batch (insert.go:17): rows are unreachable until they get in-edges
   SDB_TRY(store_rows_public(ix, n0, (uint32_t)n, dvec, stream));
+  const sdb_pq *pq = ix->pq;
+  // a fitted quantizer encodes on Set (product.go:161-169); from here on every distance of the insert is a
+  // table distance: LUT for the search (DistanceFromFloat), centroid pairs for the prunes (DistanceFromPoint)
+  if (pq) SDB_TRY(pq_encode_device(pq, dvec, n, ix->d_codes + (size_t)n0 * pq->M, stream));
   SDB_HIP(hipMemcpyAsync(ix->d_ids + n0, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
   // host-side id bookkeeping
   {
@@ -579,6 +661,8 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   const uint32_t vis_cap = std::max<uint32_t>(1024, 4 * L);
   uint32_t max_round = round_size ? round_size : 16384;
   if (max_round > n) max_round = (uint32_t)n;
+  const size_t lut_row = pq ? (size_t)pq->M * pq->K * sizeof(float) : 0;
+  if (pq && (size_t)max_round * lut_row > ((size_t)1 << 30)) max_round = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / lut_row);
   const uint32_t total_rows = n0 + (uint32_t)n;
   const uint32_t words = ((total_rows + 31) / 32 + 31) & ~31u;
   uint32_t *bitsets = nullptr, *vis_slots = nullptr, *vis_count = nullptr;
@@ -608,6 +692,11 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   cleanup.ptrs.push_back(keys_sorted);
   SDB_HIP(hipMalloc(&sort_tmp, sort_tmp_bytes ? sort_tmp_bytes : 16));
   cleanup.ptrs.push_back(sort_tmp);
+  float *lut = nullptr;
+  if (pq) {
+    SDB_HIP(hipMalloc(&lut, (size_t)max_round * lut_row));
+    cleanup.ptrs.push_back(lut);
+  }
 
   uint64_t done = 0;
   while (done < n) {
@@ -627,6 +716,11 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.start_slot = (uint32_t)ix->start_slot;
     sa.search_size = L, sa.limit = 1, sa.metric = (int)ix->P.metric;
     sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
+    if (pq) {
+      SDB_TRY(pq_build_lut(pq, sa.queries, rs, lut, stream));
+      sa.pq_lut = lut, sa.pq_codes = ix->d_codes, sa.pq_M = pq->M, sa.pq_K = pq->K;
+      sa.pq_lut_in_lds = (lut_row <= 64 * 1024) ? 1u : 0u;
+    }
     if (!search_uses_hash(sa, rs)) SDB_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
     SDB_TRY(launch_greedy_search(sa, rs, stream));
     // ---- robustPrune + back-edges
@@ -637,7 +731,9 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.first_slot = cur, ba.nnew = rs;
     ba.vis_slots = vis_slots, ba.vis_dists = vis_dists, ba.vis_count = vis_count, ba.vis_cap = vis_cap;
     ba.keys_in = keys_in, ba.keys_sorted = keys_sorted;
-    int rc = ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
+    if (pq) ba.pq_codes = ix->d_codes, ba.pq_cdists = pq->d_cdists, ba.pq_M = pq->M, ba.pq_K = pq->K;
+    int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
+         : ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
                                                   : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit);
     if (rc != SDB_OK) return rc;
     done += rs;

@@ -241,7 +241,15 @@ int sdb_index::reserve(uint32_t rows) {
   if (d_deg) (void)hipFree(d_deg);
   if (d_clean) (void)hipFree(d_clean);
   if (d_ids) (void)hipFree(d_ids);
-  d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_clean = nclean, d_ids = nids, cap = ncap;
+  d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_clean = nclean, d_ids = nids;
+  if (pq) {  // the code rows of a quantized store grow with it
+    uint8_t *ncodes = nullptr;
+    SDB_HIP(hipMalloc(&ncodes, (size_t)ncap * pq->M));
+    if (n) SDB_HIP(hipMemcpy(ncodes, d_codes, (size_t)n * pq->M, hipMemcpyDeviceToDevice));
+    if (d_codes) (void)hipFree(d_codes);
+    d_codes = ncodes;
+  }
+  cap = ncap;
   return SDB_OK;
 }
 

@@ -30,3 +30,13 @@ def build_oracle_index(orc, base, metric, R=32, L=50, alpha=1.2, seed=20250622, 
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_graph(g, o):
+    """device index g and oracle index o hold the same nodes, vectors and edge lists, in order"""
+    o_ids, o_v, o_off, o_e = o.export()
+    g_ids, g_v, g_off, g_e = g.export()
+    assert np.array_equal(g_ids, o_ids)
+    assert np.array_equal(g_off, o_off), "degree sequence differs"
+    assert np.array_equal(g_e, o_e), "edge lists differ"
+    assert np.array_equal(bits(g_v), bits(o_v))

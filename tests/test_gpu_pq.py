@@ -4,7 +4,7 @@ shard/vectorstore/product.go."""
 import numpy as np
 import pytest
 
-from tests.helpers import bits, build_oracle_index, unit_rows
+from tests.helpers import assert_same_graph, bits, build_oracle_index, unit_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -138,5 +138,46 @@ def test_pq_search_parity(oracle, metric, d, M, K):
         assert np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d))
         assert int(tr.n_hop[k]) == o_tr.n_hop and int(tr.n_dist[k]) == o_tr.n_dist
         assert np.array_equal(tr.visit_ids[k, :o_tr.n_hop], o_vis)
+    ix.close()
+    gpq.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+@pytest.mark.parametrize("d,M,K", [(32, 8, 16), (96, 8, 256)])
+def test_pq_insert_delete_parity(oracle, metric, d, M, K):
+    """a fitted quantizer encodes on Set (product.go:161-169); the insert's search then runs on LUT distances
+    and its prunes on the centroid-pair table (product.go:279-305), and so does the delete path"""
+    from semadb_amd import vamana, vectorstore as vs
+    rng = np.random.default_rng(7 * d + M + K)
+    n0, n1 = 600, 250
+    base = unit_rows(rng, n0 + n1, d)
+    o = build_oracle_index(oracle, base[:n0], metric, R=16, L=30)
+    ids, vecs, off, edges = o.export()
+    train = vecs[1:401].copy()
+    first = rng.integers(0, 400, M)
+    opq = oracle.PQ(d, metric, M, K)
+    opq.fit(train.copy(), first, alias=True)
+    assert o.attach_pq(opq, np.stack([opq.encode(v) for v in vecs])) == 0
+    ix = vamana.NewIndexVamana("pq", vamana.IndexVectorVamanaParameters(d, metric, 30, 16, 1.2), strict=False)
+    ix.load(ids, vecs, off, edges)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(train.copy(), first, alias=True)
+    vs.attach(ix, gpq)
+    new_ids = np.arange(n0 + 2, n0 + 2 + n1, dtype=np.uint64)
+    for i in range(n1):
+        assert o.insert(int(new_ids[i]), base[n0 + i]) == 0
+    ix.insert_batch(new_ids, base[n0:], round_size=1)  # one point per round = sequential insertSinglePoint
+    assert_same_graph(ix, o)
+    # searches over the grown quantized store agree too (the new rows' codes are the reference's encode())
+    q = unit_rows(rng, 16, d)
+    g_ids, g_d, g_c = ix.search_batch(q, 10, 30)[:3]
+    for k in range(16):
+        o_ids, o_d, _, _ = o.search(q[k], 10, 30)
+        assert np.array_equal(g_ids[k, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d))
+    # delete a tenth of the points: pruneDeleteNeighbour binds DistanceFromPoint (prune.go:58)
+    dead = rng.choice(np.arange(2, n0 + 2 + n1, dtype=np.uint64), 80, replace=False)
+    assert o.delete(dead) == 0
+    ix.delete_batch(dead)
+    assert_same_graph(ix, o)
     ix.close()
     gpq.close()
