@@ -60,16 +60,24 @@ __device__ __forceinline__ float tail_chain(float xt, float yt, uint32_t tail, i
 //   r[l] = r[l] + t[l]   (t = {tail, 0, 0, 0})                        VADDPS X0, X4, X0
 //   result = (r[0] + r[1]) + (r[2] + r[3])                            two VHADDPS
 // The result is valid in lane 0 of each half (wave lanes 0 and 32).
+//
+// Cross-lane moves are DPP row shifts (a modifier on the add itself, no LDS round trip) inside the 16-lane
+// rows, and one v_permlane16_swap to bring lanes 16..31 of each half next to lanes 0..15.  Lanes that do
+// not take part compute garbage that nobody reads.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {  // row_shl:n = 0x100 + n: lane i reads lane i + n of its row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float asm_reduce(float acc, float t, int lane) {
   const int L = lane & 31;
-  float a8 = __shfl_down(acc, 8, 64);
-  float a16 = __shfl_down(acc, 16, 64);
-  float a24 = __shfl_down(acc, 24, 64);
-  float s = ((acc + a8) + a16) + a24;
-  float r = s + __shfl_down(s, 4, 64);
+  // second result: even rows hold what the odd rows held -- lane l < 16 of each half gets acc[16 + l]
+  const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+  const float hi = __uint_as_float(sw[1]);
+  float s = ((acc + dpp_row<0x108>(acc)) + hi) + dpp_row<0x108>(hi);  // lanes 0..7
+  float r = s + dpp_row<0x104>(s);                                    // lanes 0..3
   r = r + (L == 0 ? t : 0.0f);
-  float u = r + __shfl_down(r, 1, 64);
-  return u + __shfl_down(u, 2, 64);
+  float u = r + dpp_row<0x101>(r);  // lane 0: r0 + r1, lane 2: r2 + r3
+  return u + dpp_row<0x102>(u);
 }
 
 // distance.go:19-25: euclidean -> as is, cosine -> 1 - dot, dot -> -dot (one more fp32 rounding)

@@ -72,15 +72,50 @@ __device__ __forceinline__ float rlf(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// min over the 64 lanes (no NaNs among the inputs), wave-uniform result: four row_shr DPP steps leave each
+// 16-lane row's minimum in its last lane, three scalar compares join the rows
+__device__ __forceinline__ float wave_min_f32(float v) {
+  constexpr int kInf = 0x7f800000;
+#define SDB_MIN_STEP(ctrl)                                                                                       \
+  {                                                                                                              \
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(kInf, __float_as_int(v), ctrl, 0xf, 0xf, false)); \
+    v = o < v ? o : v;                                                                                           \
+  }
+  SDB_MIN_STEP(0x111) SDB_MIN_STEP(0x112) SDB_MIN_STEP(0x114) SDB_MIN_STEP(0x118)
+#undef SDB_MIN_STEP
+  float a = rlf(v, 15), c = rlf(v, 47);
+  const float b = rlf(v, 31), d = rlf(v, 63);
+  a = b < a ? b : a;
+  c = d < c ? d : c;
+  return c < a ? c : a;
+}
+
+// Ordering point for LDS traffic inside ONE wavefront (the search kernels run one wave per workgroup): the
+// LDS queue is in order per wave, so a ds_write is visible to the wave's later ds_reads without a barrier;
+// only the compiler has to keep the order.  Unlike __syncthreads() this does not wait for outstanding
+// global loads, which is the point -- the next hop's adjacency row is in flight across it.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // U pairs of (query, candidate) raw distances; slot[u] is this lane's candidate row (same for the
 // 32 lanes of a half).  res[u] is valid in lanes 0 and 32.
 template <int NG, bool L2, int U>
 __device__ __forceinline__ void chunk_dist(const float *__restrict__ slab, uint32_t ld, uint32_t tail,
                                            const float4 (&xq)[NG > 0 ? NG : 1], float xt,
-                                           const uint32_t (&slot)[U], float (&res)[U], int lane) {
+                                           const uint32_t (&slot)[U], float (&res)[U], int lane
+#ifdef SDB_STAMPS
+                                           , unsigned long long *st = nullptr
+#endif
+) {
   const int L = lane & 31;
   float4 y[U][NG > 0 ? NG : 1];
   float yt[U];
+#ifdef SDB_STAMPS
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const float *row = slab + (size_t)slot[u] * ld;
@@ -89,6 +124,12 @@ __device__ __forceinline__ void chunk_dist(const float *__restrict__ slab, uint3
     for (int g = 0; g < NG; g++) y[u][g] = r4[g * 32];
     yt[u] = tail ? row[NG * 128 + L] : 0.0f;
   }
+#ifdef SDB_STAMPS
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  unsigned long long t2 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
   for (int u = 0; u < U; u++) {
     float acc = 0.0f;
@@ -97,6 +138,12 @@ __device__ __forceinline__ void chunk_dist(const float *__restrict__ slab, uint3
     float t = tail ? tail_chain<L2>(xt, yt[u], tail, lane) : 0.0f;
     res[u] = asm_reduce(acc, t, lane);
   }
+#ifdef SDB_STAMPS
+  asm volatile("" ::"v"(res[U - 1]));
+  unsigned long long t3 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (st) st[0] += t1 - t0, st[1] += t2 - t1, st[2] += t3 - t2;  // issue, wait, compute
+#endif
 }
 
 // Generic-dimension variant: the permuted query tile lives in LDS (qs, ng*32 float4 + 32 tail floats).
@@ -136,11 +183,15 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
 // ng, query tile in LDS.
 template <int NG, bool L2, bool DEEP = false>
 struct PlainDist {
+  static constexpr bool kHasStamps = true;
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4;
   float4 xq[NGR];
   float xt;
   float *qs;
+#ifdef SDB_STAMPS
+  unsigned long long st[3] = {0, 0, 0};
+#endif
 
   __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
     const int L = lane & 31;
@@ -165,8 +216,13 @@ struct PlainDist {
   }
 
   __device__ __forceinline__ void chunk(const SearchArgs &a, const uint32_t (&slot)[U], float (&res)[U], int lane) {
+#ifdef SDB_STAMPS
+    if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, xq, xt, slot, res, lane, st);
+    else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, qs, slot, res, lane);
+#else
     if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, xq, xt, slot, res, lane);
     else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, qs, slot, res, lane);
+#endif
   }
 
   // distance to one row (wave-uniform result)
@@ -219,6 +275,7 @@ struct PlainDist {
 // Fitted product quantizer: dist = sum_i lut[i*K + code_i], plain fp32 adds in index order
 // (product.go:271-275).  One lane per neighbour: all new neighbours of a hop in one pass.
 struct PQDist {
+  static constexpr bool kHasStamps = false;
   const float *lut;  // this query's [M][K] table, in LDS or in global memory
   __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
     const float *g = a.pq_lut + (size_t)q * a.pq_M * a.pq_K;
@@ -373,13 +430,13 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
     const uint32_t np = rl_me + rc_me;
     if (np < (uint32_t)cap) s_id[np] = idreg, s_d[np] = mydist;
   }
-  __syncthreads();
+  wave_lds_sync();
 #pragma unroll
   for (int r = 0; r < NREG; r++) {
     const int e = r * 64 + lane;
     if (e < cap) cid[r] = s_id[e], cd[r] = s_d[e];
   }
-  __syncthreads();
+  wave_lds_sync();
 }
 
 // roaring Contains on this query's ascending slot list: 64-ary search, all lanes probe at once
@@ -561,8 +618,109 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #else
 #define SDB_STAMP(acc)
 #endif
-  // ---- main loop search.go:65-98
-  while (true) {
+  // ---- main loop search.go:65-98, unfiltered: the same steps with the adjacency fetch of hop h+1 issued
+  // BEFORE the AddWithLimit of hop h is applied, so the fetch latency hides behind the array update.
+  // Which node hop h+1 expands is known as soon as the distances of hop h are: it is the first unvisited
+  // entry of the array AFTER the update, i.e. the smaller of (first unvisited entry now, smallest pending
+  // point that AddWithLimit will accept) -- an equal distance keeps the array entry first (:196-198 puts a
+  // new point after its equals) and equal pending points keep edge order.  The smallest pending point is
+  // accepted iff the array has room or it does not exceed the tail: points applied before it are no smaller,
+  // so the tail it meets is no smaller than it.  NaN distances take no shortcut (applied first).
+  if constexpr (!FILT) {
+    uint32_t p_id = kNoSlot;  // pending AddWithLimit arguments: lane j = edge j of the previous hop
+    float p_d = 0.0f;
+    uint64_t p_mask = 0;
+    while (true) {
+#ifdef SDB_STAMPS
+      st_t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      if (p_mask && (__ballot(p_d != p_d) & p_mask)) {
+        add_with_limit_merge(cid, cd, len, cap, p_id, p_d, p_mask, lane, s_scatter);
+        p_mask = 0;
+      }
+      int sel = -1;
+#pragma unroll
+      for (int r = 0; r < NREG; r++) {
+        uint64_t m = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
+        if (sel < 0 && m) sel = r * 64 + __ffsll((unsigned long long)m) - 1;
+      }
+      uint32_t pid = 0;
+      float pdist = 0.0f;
+#pragma unroll
+      for (int r = 0; r < NREG; r++)
+        if (sel >= 0 && (sel >> 6) == r) pid = rl(cid[r], sel & 63), pdist = rlf(cd[r], sel & 63);
+      bool have = sel >= 0;
+      if (p_mask) {
+        const bool mine = (p_mask >> lane) & 1ull;
+        const float m = wave_min_f32(mine ? p_d : __int_as_float(0x7f800000));
+        const bool fits = len < cap || !(m > list_tail(cd, cap));  // :184
+        const uint64_t at_min = __ballot(mine && p_d == m);
+        if (have && pdist < m) {
+          // the array entry: every pending point is larger, none can displace it
+        } else if (!fits) {
+          // no pending point will be accepted; the array stays as it is
+        } else if ((at_min & (at_min - 1)) == 0 && (!have || m < pdist)) {
+          const int j = __ffsll((unsigned long long)at_min) - 1;  // the one smallest pending point
+          pid = rl(p_id, j), pdist = rlf(p_d, j), have = true;
+        } else {
+          // equal distances: a later equal point may overwrite an earlier one at the tail (:184 accepts
+          // d == tail), so who comes first is decided by applying them
+          add_with_limit_merge(cid, cd, len, cap, p_id, p_d, p_mask, lane, s_scatter);
+          p_mask = 0;
+          continue;
+        }
+      }
+      if (!have) break;
+      if (lane == 0) {  // visitedSet.AddAlreadyUnique :73
+#ifndef SDB_STAMPS
+        if (a.tr_visit && n_hop < a.visit_cap) a.tr_visit[(size_t)q * a.visit_cap + n_hop] = a.ids[pid];
+#endif
+        if (a.vis_slots && n_hop < a.vis_cap) {
+          a.vis_slots[(size_t)q * a.vis_cap + n_hop] = pid;
+          a.vis_dists[(size_t)q * a.vis_cap + n_hop] = pdist;
+        }
+      }
+      n_hop++;
+      // node.neighbours in edge order :77-91 -- in flight while the pending points are applied
+      const uint32_t nb = a.adj[(size_t)pid * kAdjStride + lane];
+      if (p_mask) {
+        add_with_limit_merge(cid, cd, len, cap, p_id, p_d, p_mask, lane, s_scatter);
+        p_mask = 0;
+      }
+      SDB_STAMP(st_ins)
+      {  // :74 the node is now the first unvisited entry of the array
+        int s2 = -1;
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+          uint64_t m = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
+          if (s2 < 0 && m) s2 = r * 64 + __ffsll((unsigned long long)m) - 1;
+        }
+#pragma unroll
+        for (int r = 0; r < NREG; r++)
+          if ((s2 >> 6) == r && lane == (s2 & 63)) cid[r] |= kVisBit;
+      }
+      const bool valid = nb != kNoSlot;
+      n_edges += (uint32_t)__popcll(__ballot(valid));
+      SDB_STAMP(st_adj)
+      dist.prefetch(a, nb, valid);
+      // CheckAndVisit distset.go:174 -- marks before any distance test
+      const bool isnew = vis.test_and_set(valid, nb, lane);
+      const uint64_t pend = __ballot(isnew);
+      SDB_STAMP(st_atom)
+      if (pend) {
+        n_dist += (uint32_t)__popcll(pend);
+        p_d = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
+        p_id = nb, p_mask = pend;           // AddWithLimit distset.go:184-198 is applied in the next round
+#ifdef SDB_STAMPS
+        asm volatile("" ::"v"(p_d));
+#endif
+        SDB_STAMP(st_vec)
+      }
+    }
+  }
+  // ---- main loop search.go:65-98, filtered (the array may be unsorted: everything in program order)
+  while (FILT) {
 #ifdef SDB_STAMPS
     st_t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -611,9 +769,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       asm volatile("" ::"v"(mydist));
 #endif
       SDB_STAMP(st_vec)
-      // AddWithLimit over the new neighbours, in edge order distset.go:184-198
-      if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
-      else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
+      // AddWithLimit over the new neighbours, in edge order distset.go:184-198 (one by one: unsorted array)
+      add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);
       SDB_STAMP(st_ins)
     }
     if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
@@ -634,6 +791,12 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     a.tr_visit[(size_t)q * a.visit_cap + 1] = st_atom;
     a.tr_visit[(size_t)q * a.visit_cap + 2] = st_vec;
     a.tr_visit[(size_t)q * a.visit_cap + 3] = st_ins;
+    if constexpr (Dist::kHasStamps)
+      if (a.visit_cap >= 8) {
+        a.tr_visit[(size_t)q * a.visit_cap + 4] = dist.st[0];
+        a.tr_visit[(size_t)q * a.visit_cap + 5] = dist.st[1];
+        a.tr_visit[(size_t)q * a.visit_cap + 6] = dist.st[2];
+      }
   }
 #endif
 

@@ -17,7 +17,10 @@ queries = bench.gen_rows(10 * nq, d, 20250621, "latent:24", "cuda:0").view(10, n
 for b in range(3):
     ids, dd, c, tr = ix.search_batch(queries[b], 10, 75, trace=True, visit_cap=8)
 torch.cuda.synchronize()
-v = tr.visit_ids.cpu().numpy().astype(np.float64)[:, :4]
+full = tr.visit_ids.cpu().numpy().astype(np.float64)
+v = full[:, :4]
+sub = full[:, 4:7]
+print("inside vec, per hop (cycles): issue %.0f wait %.0f compute %.0f" % tuple(sub.mean(axis=0) / tr.n_hop.float().mean().item()))
 tot = v.sum(axis=1)
 print("mean cycles/query: adj %.0f atom %.0f vec %.0f ins %.0f  total %.0f" % (*v.mean(axis=0), tot.mean()))
 print("shares: adj %.3f atom %.3f vec %.3f ins %.3f" % tuple(v.sum(axis=0) / v.sum()))
