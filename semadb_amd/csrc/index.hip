@@ -155,8 +155,9 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 
 template <int NG, bool L2>
 static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
-  if (search_uses_hash(a, nq)) return launch_nreg<PlainDist<NG, L2, true>, kHashCap>(a, nq, stream, 0);
-  return launch_nreg<PlainDist<NG, L2, false>, 0>(a, nq, stream, 0);
+  if (search_uses_hash(a, nq))
+    return launch_nreg<PlainDist<NG, L2, true>, kHashCap>(a, nq, stream, PlainDist<NG, L2, true>::kLdsBytes);
+  return launch_nreg<PlainDist<NG, L2, false>, 0>(a, nq, stream, PlainDist<NG, L2, false>::kLdsBytes);
 }
 
 template <bool L2>

@@ -72,28 +72,10 @@ __device__ __forceinline__ float rlf(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// min over the 64 lanes (no NaNs among the inputs), wave-uniform result: four row_shr DPP steps leave each
-// 16-lane row's minimum in its last lane, three scalar compares join the rows
-__device__ __forceinline__ float wave_min_f32(float v) {
-  constexpr int kInf = 0x7f800000;
-#define SDB_MIN_STEP(ctrl)                                                                                       \
-  {                                                                                                              \
-    const float o = __int_as_float(__builtin_amdgcn_update_dpp(kInf, __float_as_int(v), ctrl, 0xf, 0xf, false)); \
-    v = o < v ? o : v;                                                                                           \
-  }
-  SDB_MIN_STEP(0x111) SDB_MIN_STEP(0x112) SDB_MIN_STEP(0x114) SDB_MIN_STEP(0x118)
-#undef SDB_MIN_STEP
-  float a = rlf(v, 15), c = rlf(v, 47);
-  const float b = rlf(v, 31), d = rlf(v, 63);
-  a = b < a ? b : a;
-  c = d < c ? d : c;
-  return c < a ? c : a;
-}
-
 // Ordering point for LDS traffic inside ONE wavefront (the search kernels run one wave per workgroup): the
 // LDS queue is in order per wave, so a ds_write is visible to the wave's later ds_reads without a barrier;
-// only the compiler has to keep the order.  Unlike __syncthreads() this does not wait for outstanding
-// global loads, which is the point -- the next hop's adjacency row is in flight across it.
+// only the compiler has to keep the order (and nothing waits for outstanding global loads, as a
+// __syncthreads() would).
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -186,17 +168,23 @@ struct PlainDist {
   static constexpr bool kHasStamps = true;
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4;
+  // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
+  // [kHopSlots], raw distances by rank [kHopSlots], a 16-word dump
+  static constexpr uint32_t kHopSlots = 80;
+  static constexpr size_t kLdsBytes = NG >= 0 ? (2 * kHopSlots + 16) * sizeof(uint32_t) : 0;
   float4 xq[NGR];
   float xt;
   float *qs;
+  uint32_t *hs;
 #ifdef SDB_STAMPS
-  unsigned long long st[3] = {0, 0, 0};
+  unsigned long long st[3] = {0, 0, 0};  // issue, wait, compute
 #endif
 
   __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
     const int L = lane & 31;
     const float *__restrict__ qv = a.queries + (size_t)q * a.dim;
     qs = lds;
+    hs = reinterpret_cast<uint32_t *>(lds);
     xt = 0.0f;
     if constexpr (NG >= 0) {
 #pragma unroll
@@ -237,8 +225,77 @@ struct PlainDist {
 
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
 
+  // The same distances for vectors without a tail (dim % 32 == 0: every configured size) with the per-row
+  // instruction count cut to the arithmetic: the pending slots are compacted into LDS by rank (mbcnt), each
+  // half-wave takes a contiguous run of them (so a lane fetches its 16 slots with plain ds_reads, no bit
+  // scans or readlanes), a row address is ONE v_mad_u64_u32 (slot * row bytes + [slab + 16 * L]), the raw
+  // distance leaves lane 0 of its half through one ds_write at the row's rank, and every pending lane reads
+  // its own rank back.  With one wave per SIMD an instruction of any kind costs an issue slot, so this is
+  // where the kernel's time was.  Rows beyond an odd count are read twice (one spare entry behind the
+  // list); their results land behind the ranks anybody reads.
+  __device__ __forceinline__ float hop_fast(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    const int L = lane & 31, half = lane >> 5;
+    const int cnt = __popcll(pend);
+    const bool mine = (pend >> lane) & 1ull;
+    const uint32_t rank =
+        __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+    uint32_t *s_slot = hs;
+    float *s_res = reinterpret_cast<float *>(hs + kHopSlots);
+    if (mine) {
+      s_slot[rank] = nb;
+      if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
+    }
+    wave_lds_sync();
+    const char *baseL = reinterpret_cast<const char *>(a.slab) + L * 16;
+    const uint32_t row_bytes = a.ld * 4u;
+    for (int c0 = 0; c0 < cnt; c0 += 2 * U) {
+      const int m = cnt - c0 < 2 * U ? cnt - c0 : 2 * U;
+      const int h0 = (m + 1) >> 1;  // rows of half 0; half 1 takes the other m - h0 (+ the spare when m is odd)
+      const int base = c0 + (half ? h0 : 0);
+#ifdef SDB_STAMPS
+      unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      uint32_t sl[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) sl[u] = s_slot[base + u];
+      float4 y[U][NGR];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (u < h0) {
+          const float4 *r4 = reinterpret_cast<const float4 *>(baseL + (uint64_t)sl[u] * row_bytes);
+#pragma unroll
+          for (int g = 0; g < NG; g++) y[u][g] = r4[g * 32];
+        }
+#ifdef SDB_STAMPS
+      unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      float *wp = (L == 0) ? s_res + base : s_res + kHopSlots;  // the other lanes write to a dump
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (u < h0) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
+          wp[u] = asm_reduce(acc, 0.0f, lane);
+        }
+#ifdef SDB_STAMPS
+      unsigned long long t3 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      st[0] += t1 - t0, st[1] += t2 - t1, st[2] += t3 - t2;  // issue, wait, compute
+#endif
+    }
+    wave_lds_sync();
+    return mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
+  }
+
   // distances of the new neighbours of one hop: lane j (bit j of pend) gets dist(query, row nb_j)
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    if constexpr (NG > 0)
+      if (a.tail == 0) return hop_fast(a, nb, pend, lane);
     float mydist = 0.0f;
     uint64_t todo = pend;
     while (todo) {
@@ -618,109 +675,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #else
 #define SDB_STAMP(acc)
 #endif
-  // ---- main loop search.go:65-98, unfiltered: the same steps with the adjacency fetch of hop h+1 issued
-  // BEFORE the AddWithLimit of hop h is applied, so the fetch latency hides behind the array update.
-  // Which node hop h+1 expands is known as soon as the distances of hop h are: it is the first unvisited
-  // entry of the array AFTER the update, i.e. the smaller of (first unvisited entry now, smallest pending
-  // point that AddWithLimit will accept) -- an equal distance keeps the array entry first (:196-198 puts a
-  // new point after its equals) and equal pending points keep edge order.  The smallest pending point is
-  // accepted iff the array has room or it does not exceed the tail: points applied before it are no smaller,
-  // so the tail it meets is no smaller than it.  NaN distances take no shortcut (applied first).
-  if constexpr (!FILT) {
-    uint32_t p_id = kNoSlot;  // pending AddWithLimit arguments: lane j = edge j of the previous hop
-    float p_d = 0.0f;
-    uint64_t p_mask = 0;
-    while (true) {
-#ifdef SDB_STAMPS
-      st_t0 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      if (p_mask && (__ballot(p_d != p_d) & p_mask)) {
-        add_with_limit_merge(cid, cd, len, cap, p_id, p_d, p_mask, lane, s_scatter);
-        p_mask = 0;
-      }
-      int sel = -1;
-#pragma unroll
-      for (int r = 0; r < NREG; r++) {
-        uint64_t m = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
-        if (sel < 0 && m) sel = r * 64 + __ffsll((unsigned long long)m) - 1;
-      }
-      uint32_t pid = 0;
-      float pdist = 0.0f;
-#pragma unroll
-      for (int r = 0; r < NREG; r++)
-        if (sel >= 0 && (sel >> 6) == r) pid = rl(cid[r], sel & 63), pdist = rlf(cd[r], sel & 63);
-      bool have = sel >= 0;
-      if (p_mask) {
-        const bool mine = (p_mask >> lane) & 1ull;
-        const float m = wave_min_f32(mine ? p_d : __int_as_float(0x7f800000));
-        const bool fits = len < cap || !(m > list_tail(cd, cap));  // :184
-        const uint64_t at_min = __ballot(mine && p_d == m);
-        if (have && pdist < m) {
-          // the array entry: every pending point is larger, none can displace it
-        } else if (!fits) {
-          // no pending point will be accepted; the array stays as it is
-        } else if ((at_min & (at_min - 1)) == 0 && (!have || m < pdist)) {
-          const int j = __ffsll((unsigned long long)at_min) - 1;  // the one smallest pending point
-          pid = rl(p_id, j), pdist = rlf(p_d, j), have = true;
-        } else {
-          // equal distances: a later equal point may overwrite an earlier one at the tail (:184 accepts
-          // d == tail), so who comes first is decided by applying them
-          add_with_limit_merge(cid, cd, len, cap, p_id, p_d, p_mask, lane, s_scatter);
-          p_mask = 0;
-          continue;
-        }
-      }
-      if (!have) break;
-      if (lane == 0) {  // visitedSet.AddAlreadyUnique :73
-#ifndef SDB_STAMPS
-        if (a.tr_visit && n_hop < a.visit_cap) a.tr_visit[(size_t)q * a.visit_cap + n_hop] = a.ids[pid];
-#endif
-        if (a.vis_slots && n_hop < a.vis_cap) {
-          a.vis_slots[(size_t)q * a.vis_cap + n_hop] = pid;
-          a.vis_dists[(size_t)q * a.vis_cap + n_hop] = pdist;
-        }
-      }
-      n_hop++;
-      // node.neighbours in edge order :77-91 -- in flight while the pending points are applied
-      const uint32_t nb = a.adj[(size_t)pid * kAdjStride + lane];
-      if (p_mask) {
-        add_with_limit_merge(cid, cd, len, cap, p_id, p_d, p_mask, lane, s_scatter);
-        p_mask = 0;
-      }
-      SDB_STAMP(st_ins)
-      {  // :74 the node is now the first unvisited entry of the array
-        int s2 = -1;
-#pragma unroll
-        for (int r = 0; r < NREG; r++) {
-          uint64_t m = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
-          if (s2 < 0 && m) s2 = r * 64 + __ffsll((unsigned long long)m) - 1;
-        }
-#pragma unroll
-        for (int r = 0; r < NREG; r++)
-          if ((s2 >> 6) == r && lane == (s2 & 63)) cid[r] |= kVisBit;
-      }
-      const bool valid = nb != kNoSlot;
-      n_edges += (uint32_t)__popcll(__ballot(valid));
-      SDB_STAMP(st_adj)
-      dist.prefetch(a, nb, valid);
-      // CheckAndVisit distset.go:174 -- marks before any distance test
-      const bool isnew = vis.test_and_set(valid, nb, lane);
-      const uint64_t pend = __ballot(isnew);
-      SDB_STAMP(st_atom)
-      if (pend) {
-        n_dist += (uint32_t)__popcll(pend);
-        p_d = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
-        p_id = nb, p_mask = pend;           // AddWithLimit distset.go:184-198 is applied in the next round
-#ifdef SDB_STAMPS
-        asm volatile("" ::"v"(p_d));
-#endif
-        SDB_STAMP(st_vec)
-      }
-    }
-  }
-  // ---- main loop search.go:65-98, filtered (the array may be unsorted: everything in program order)
-  while (FILT) {
+  // ---- main loop search.go:65-98
+  while (true) {
 #ifdef SDB_STAMPS
     st_t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -769,8 +725,9 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       asm volatile("" ::"v"(mydist));
 #endif
       SDB_STAMP(st_vec)
-      // AddWithLimit over the new neighbours, in edge order distset.go:184-198 (one by one: unsorted array)
-      add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);
+      // AddWithLimit over the new neighbours, in edge order distset.go:184-198
+      if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
+      else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
       SDB_STAMP(st_ins)
     }
     if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
