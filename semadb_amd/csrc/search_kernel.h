@@ -4,16 +4,19 @@
 // shard/index/vamana/distset.go:166-200 (DistSet.AddWithLimit) with bit-identical distances
 // (dist_core.h), so result ids, distances, visit order, n_dist and n_hop equal the reference's.
 //
-// Wave-level mapping (64 lanes, no LDS, no barriers):
+// Wave-level mapping (64 lanes, one wave per workgroup, no workgroup barriers):
 //   * candidate set S (cap = searchSize): a sorted array held in VGPRs, entry e in lane e%64 of
 //     register e/64; the `visited` flag rides in bit 31 of the slot word.
 //   * one hop: wave-uniform pick of the first unvisited entry -> one coalesced 256-byte read of
 //     its adjacency row (lane j = edge j, edge order preserved) -> per-lane test-and-set in the
-//     query's visited bitset (atomicOr; the ids of one row are distinct) -> distances for the new
-//     neighbours, two candidates per wave instruction (one per 32-lane half), 16-byte row loads,
-//     up to U pairs of rows in flight -> AddWithLimit replayed in edge order for the neighbours
-//     that beat the current tail (the tail only shrinks, so a neighbour that fails the current
-//     threshold can never pass a later one).
+//     query's visited set (an exact hash set in LDS, or the HBM bitset; the ids of one row are
+//     distinct) -> distances for the new neighbours, two candidates per wave instruction (one per
+//     32-lane half), 16-byte row loads, up to U pairs of rows in flight -> AddWithLimit for the
+//     neighbours that beat the current tail, in edge order (the tail only shrinks, so a neighbour
+//     that fails the current threshold can never pass a later one).
+//   * with one wave per SIMD every instruction of any kind costs an issue slot, so the hop is written
+//     for instruction count: the reduce tree is DPP adds (dist_core.h), row slots reach the lanes
+//     through a rank-compacted LDS list, a row address is one 64-bit mad (PlainDist::hop_fast).
 #pragma once
 #include "dist_core.h"
 #include "index.h"
