@@ -247,6 +247,12 @@ int sdb_pq_sym_distance(const sdb_pq *pq, const uint8_t *codes_x, const uint8_t 
  * prunes the symmetric table, exactly as a fitted productQuantizer store does.  The index
  * encodes every stored vector (product.go:161-169 Set -> encode). */
 int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream);
+/* Centroid ids that do not come from encode(): the k-means labels productQuantizer.Fit leaves on
+ * its training points (product.go:216-218) and the codes a bucket holds under NodeKey(id,'q')
+ * (productQuantizedPoint.ReadFrom / WriteTo, product.go:349-383).  ids [n] u64, codes [n][M] u8,
+ * host memory, on an index with an attached quantizer. */
+int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *ids, const uint8_t *codes);
+int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *codes);
 
 #ifdef __cplusplus
 }

@@ -802,3 +802,44 @@ extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream
   if (rc == SDB_OK) ix->pq = pq;
   return rc;
 }
+
+// Centroid ids that do NOT come from encode(): the k-means labels productQuantizer.Fit leaves on its
+// training points (product.go:216-218) and the codes a bucket persisted under 'q' (product.go:349-383).
+extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *ids, const uint8_t *codes) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (!ix->pq) return fail(SDB_ERR_STATE, "no quantizer attached");
+  if (n == 0) return SDB_OK;
+  if (!ids || !codes) return fail(SDB_ERR_INVALID, "NULL argument");
+  const uint32_t M = ix->pq->M;
+  DeviceGuard dg(ix->P.device);
+  // group runs of consecutive slots into one copy each (ids in storage order give one run)
+  uint64_t i = 0;
+  while (i < n) {
+    const int64_t s0 = ix->slot_of(ids[i]);
+    if (s0 < 0) return fail(SDB_ERR_NOT_FOUND, "point %llu not found", (unsigned long long)ids[i]);
+    uint64_t j = i + 1;
+    while (j < n && ix->slot_of(ids[j]) == s0 + (int64_t)(j - i)) j++;
+    SDB_HIP(hipMemcpy(ix->d_codes + (size_t)s0 * M, codes + i * M, (j - i) * M, hipMemcpyHostToDevice));
+    i = j;
+  }
+  return SDB_OK;
+}
+
+extern "C" int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *codes) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (!ix->pq) return fail(SDB_ERR_STATE, "no quantizer attached");
+  if (n == 0) return SDB_OK;
+  if (!ids || !codes) return fail(SDB_ERR_INVALID, "NULL argument");
+  const uint32_t M = ix->pq->M;
+  DeviceGuard dg(ix->P.device);
+  uint64_t i = 0;
+  while (i < n) {
+    const int64_t s0 = ix->slot_of(ids[i]);
+    if (s0 < 0) return fail(SDB_ERR_NOT_FOUND, "point %llu not found", (unsigned long long)ids[i]);
+    uint64_t j = i + 1;
+    while (j < n && ix->slot_of(ids[j]) == s0 + (int64_t)(j - i)) j++;
+    SDB_HIP(hipMemcpy(codes + i * M, ix->d_codes + (size_t)s0 * M, (j - i) * M, hipMemcpyDeviceToHost));
+    i = j;
+  }
+  return SDB_OK;
+}

@@ -149,12 +149,41 @@ namespace models {  // models/index.go:275-282, models/search.go:238-275
 constexpr const char *DistanceEuclidean = "euclidean";
 constexpr const char *DistanceCosine = "cosine";
 constexpr const char *DistanceDot = "dot";
+// models/quantizer.go:5-76 (binary quantizer: out of scope, hamming/jaccard are not on the path)
+constexpr const char *QuantizerNone = "none";
+constexpr const char *QuantizerProduct = "product";
+struct ProductQuantizerParameters {
+  int NumCentroids = 256;       // 2..256 (uint8 centroid ids)
+  int NumSubVectors = 8;        // >= 2, divides the vector size
+  int TriggerThreshold = 10000;  // 1000..10000: Fit runs once the store holds this many points
+  Error Validate() const {       // :65-76
+    if (NumCentroids < 2 || NumCentroids > 256)
+      return Error("numCentroids must be between 2 and 256, got " + std::to_string(NumCentroids));
+    if (NumSubVectors < 2) return Error("numSubVectors must be at least 2, got " + std::to_string(NumSubVectors));
+    if (TriggerThreshold < 1000 || TriggerThreshold > 10000)
+      return Error("triggerThreshold must be between 1000 and 10000, got " + std::to_string(TriggerThreshold));
+    return Error();
+  }
+};
+struct Quantizer {
+  std::string Type = QuantizerNone;
+  std::optional<ProductQuantizerParameters> Product;
+  Error Validate() const {  // :11-28
+    if (Type == QuantizerNone) return Error();
+    if (Type == QuantizerProduct) {
+      if (!Product) return Error("product quantizer parameters not provided");
+      return Product->Validate();
+    }
+    return Error("unknown quantizer type " + Type);
+  }
+};
 struct IndexVectorVamanaParameters {
   uint32_t VectorSize = 0;
   std::string DistanceMetric;
   int SearchSize = 75;
   int DegreeBound = 64;
   float Alpha = 1.2f;
+  std::optional<models::Quantizer> Quantizer;  // models/index.go:281
 };
 struct SearchVectorVamanaOptions {
   std::vector<float> Vector;
@@ -196,6 +225,9 @@ inline Error GetFloatDistanceFn(const std::string &name, FloatDistFunc *out, int
 namespace vamana {  // shard/index/vamana/vamana.go
 constexpr uint64_t STARTID = 1;                        // :28
 constexpr const char *MAXNODEIDKEY = "_vamanaMaxNodeId";  // :31
+// shard/vectorstore/product.go:17-18
+constexpr const char *productQuantizerCentroidDistsKey = "_productQuantizerCentroidDists";
+constexpr const char *productQuantizerFlatCentroidsKey = "_productQuantizerFlatCentroids";
 struct IndexVectorChange {                             // :122-125 ; empty Vector == nil == delete
   uint64_t Id = 0;
   std::vector<float> Vector;
@@ -223,6 +255,22 @@ class IndexVamana {
     p.dim = params.VectorSize, p.metric = (uint32_t)mc, p.search_size = (uint32_t)params.SearchSize;
     p.degree_bound = (uint32_t)params.DegreeBound, p.alpha = params.Alpha, p.device = device, p.strict = 1;
     if (int rc = sdb_index_create(&p, &v->h_)) return {nullptr, Error::wrap("could not create device index", rc)};
+    // vectorstore.New (vectorstore.go:47-96) -> newProductQuantizer (product.go:42-88)
+    if (params.Quantizer && params.Quantizer->Type != models::QuantizerNone) {
+      if (params.Quantizer->Type != models::QuantizerProduct)
+        return {nullptr, Error("could not create vector store: unknown vector store type " + params.Quantizer->Type)};
+      if (!params.Quantizer->Product) return {nullptr, Error("could not create vector store: product quantizer parameters are nil")};
+      const auto &pp = *params.Quantizer->Product;
+      if (pp.NumSubVectors <= 0 || params.VectorSize % (uint32_t)pp.NumSubVectors != 0)
+        return {nullptr, Error("could not create vector store: vector length " + std::to_string(params.VectorSize) +
+                               " must be divisible by num subvectors " + std::to_string(pp.NumSubVectors))};
+      if (pp.NumCentroids > 256)
+        return {nullptr, Error("could not create vector store: number of centroids " + std::to_string(pp.NumCentroids) +
+                               " cannot exceed 256")};
+      if (int rc = sdb_pq_create(params.VectorSize, (uint32_t)mc, (uint32_t)pp.NumSubVectors, (uint32_t)pp.NumCentroids,
+                                 device, &v->pq_))
+        return {nullptr, Error::wrap("could not create vector store", rc)};
+    }
     if (Error e = v->loadFromBucket(start_vector)) return {nullptr, e};
     v->batcher_ = std::thread([raw = v.get()] { raw->batcherLoop(); });
     return {std::move(v), Error()};
@@ -236,7 +284,11 @@ class IndexVamana {
     qcv_.notify_all();
     if (batcher_.joinable()) batcher_.join();
     if (h_) sdb_index_destroy(h_);
+    if (pq_) sdb_pq_destroy(pq_);
   }
+  bool quantized() const { return pq_fitted_; }
+  // seed of the k-means first-centroid draws in Fit (kmeans.go:61-63 uses the global RNG); tests pin it
+  void setFitSeed(uint64_t s) { fit_seed_ = s; }
 
   int64_t SizeInMemory() const {  // vamana.go:83-85
     int64_t b = 0;
@@ -331,6 +383,7 @@ class IndexVamana {
         live_.erase(id);
         if (bucket_) {
           bucket_->Delete(conversion::NodeKey(id, 'v'));
+          bucket_->Delete(conversion::NodeKey(id, 'q'));  // product.go:375-383
           bucket_->Delete(conversion::NodeKey(id, 'e'));
         }
       }
@@ -339,7 +392,40 @@ class IndexVamana {
     for (size_t i = 0; i < upd_ids.size(); i++)  // :247-251
       if (int rc = sdb_index_insert_batch(h_, 1, &upd_ids[i], upd_vecs.data() + i * d, SDB_MEM_HOST, 1, nullptr))
         return Error::wrap("could not re-insert updated point", rc);
+    if (Error e = fit()) return Error("could not fit vector store: " + e.msg);  // vamana.go:257-260
     return flush();
+  }
+
+  // productQuantizer.Fit (product.go:175-236): once, when the store holds TriggerThreshold points (the start
+  // node counts, it lives in the same store).  k-means runs per sub-quantizer over ALL stored vectors in
+  // storage order (the reference iterates a Go map), its labels become the points' centroid ids (:216-218),
+  // and from here on every distance of the index is a table distance.
+  Error fit() {
+    if (!pq_ || pq_fitted_) return Error();
+    const auto &pp = *parameters_.Quantizer->Product;
+    uint64_t n = 0, ne = 0, mx = 0;
+    sdb_index_stats(h_, &n, &ne, &mx);
+    if (n < (uint64_t)pp.TriggerThreshold) return Error();
+    const size_t d = parameters_.VectorSize;
+    std::vector<uint64_t> ids(n), off(n + 1), edges(ne ? ne : 1);
+    std::vector<float> vecs(n * d);
+    if (int rc = sdb_index_export(h_, ids.data(), vecs.data(), off.data(), edges.data()))
+      return Error::wrap("could not collect vectors for kmeans", rc);
+    std::vector<uint32_t> first((size_t)pp.NumSubVectors);
+    uint64_t s = fit_seed_ ? fit_seed_ : ((uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() | 1);
+    for (auto &f : first) {
+      s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+      f = (uint32_t)(s % n);
+    }
+    std::vector<uint8_t> codes(n * (size_t)pp.NumSubVectors);
+    // alias = 1: centroid slices alias the data rows and are overwritten by the means, as in the reference
+    // (kmeans.go:63,82,144); `vecs` is this function's private copy, the slab keeps the vectors
+    if (int rc = sdb_pq_fit(pq_, vecs.data(), (uint32_t)n, first.data(), 1, codes.data(), SDB_MEM_HOST, nullptr))
+      return Error::wrap("kmeans", rc);
+    if (int rc = sdb_index_attach_pq(h_, pq_, nullptr)) return Error::wrap("could not attach quantizer", rc);
+    if (int rc = sdb_index_set_codes(h_, n, ids.data(), codes.data())) return Error::wrap("could not store centroid ids", rc);
+    pq_fitted_ = true;
+    return Error();
   }
 
   // vamana.go:265-276: vectors -> 'n<id>v', edges -> 'n<id>e', max node id
@@ -358,6 +444,18 @@ class IndexVamana {
       bucket_->Put(conversion::NodeKey(ids[i], 'e'), conversion::EdgeListToBytes(e));
     }
     bucket_->Put(MAXNODEIDKEY, conversion::Uint64ToBytes(mx));
+    if (pq_fitted_) {  // productQuantizer.Flush (product.go:307-320) + productQuantizedPoint.WriteTo (:361-373)
+      const auto &pp = *parameters_.Quantizer->Product;
+      const size_t M = (size_t)pp.NumSubVectors, K = (size_t)pp.NumCentroids, sub = d / M;
+      std::vector<uint8_t> codes(n * M);
+      if (int rc = sdb_index_get_codes(h_, n, ids.data(), codes.data())) return Error::wrap("could not flush", rc);
+      for (uint64_t i = 0; i < n; i++)
+        bucket_->Put(conversion::NodeKey(ids[i], 'q'), std::string((const char *)codes.data() + i * M, M));
+      std::vector<float> fc(M * K * sub), cd(M * K * K);
+      if (int rc = sdb_pq_get_codebook(pq_, fc.data(), cd.data())) return Error::wrap("could not flush", rc);
+      bucket_->Put(productQuantizerCentroidDistsKey, conversion::Float32ToBytes(cd.data(), cd.size()));
+      bucket_->Put(productQuantizerFlatCentroidsKey, conversion::Float32ToBytes(fc.data(), fc.size()));
+    }
     return Error();
   }
 
@@ -420,6 +518,30 @@ class IndexVamana {
       if (id != STARTID) live_.insert(id);
     if (int rc = sdb_index_load(h_, ids.size(), ids.data(), vectors.data(), offsets.data(), edges.data(), SDB_MEM_HOST))
       return Error::wrap("could not load index into HBM", rc);
+    // newProductQuantizer reads the tables back (product.go:80-86); points carry their ids under 'q'
+    // (ReadFrom :334-357).  The centroid-pair table is recomputed from the centroids: same arithmetic.
+    std::string fcb;
+    if (pq_ && bucket_ && bucket_->Get(productQuantizerFlatCentroidsKey, &fcb)) {
+      const auto &pp = *parameters_.Quantizer->Product;
+      const size_t M = (size_t)pp.NumSubVectors, K = (size_t)pp.NumCentroids;
+      auto fc = conversion::BytesToFloat32(fcb);
+      if (fc.size() != M * K * (d / M)) return Error("stored centroids have the wrong size");
+      if (int rc = sdb_pq_set_codebook(pq_, fc.data(), SDB_MEM_HOST)) return Error::wrap("could not load centroids", rc);
+      if (int rc = sdb_index_attach_pq(h_, pq_, nullptr)) return Error::wrap("could not attach quantizer", rc);
+      std::vector<uint64_t> qids;
+      std::vector<uint8_t> qcodes;
+      for (uint64_t id : ids) {
+        std::string qb;
+        if (bucket_->Get(conversion::NodeKey(id, 'q'), &qb) && qb.size() == M) {
+          qids.push_back(id);
+          qcodes.insert(qcodes.end(), qb.begin(), qb.end());
+        }
+      }
+      if (!qids.empty())
+        if (int rc = sdb_index_set_codes(h_, qids.size(), qids.data(), qcodes.data()))
+          return Error::wrap("could not load centroid ids", rc);
+      pq_fitted_ = true;
+    }
     return Error();
   }
 
@@ -506,6 +628,9 @@ class IndexVamana {
   models::IndexVectorVamanaParameters parameters_;
   diskstore::Bucket *bucket_ = nullptr;
   sdb_index *h_ = nullptr;
+  sdb_pq *pq_ = nullptr;  // product quantizer of the vector store (vectorstore.New), if configured
+  bool pq_fitted_ = false;
+  uint64_t fit_seed_ = 0;
   std::set<uint64_t> live_;  // ids currently in the store (start node excluded)
   std::mutex write_mu_;
   // micro-batcher

@@ -25,6 +25,7 @@ class IndexVectorVamanaParameters:
     SearchSize: int = 75
     DegreeBound: int = 64
     Alpha: float = 1.2
+    Quantizer: object = None  # vectorstore.Quantizer (models/index.go:281)
 
 
 @dataclass
@@ -62,10 +63,17 @@ class BatchTrace:
 class IndexVamana:
     """vamana.IndexVamana (vamana.go:36-52) with its state pinned in one MI355X's HBM."""
 
-    def __init__(self, name, params: IndexVectorVamanaParameters, bucket=None, device=0, capacity=0, strict=True):
+    def __init__(self, name, params: IndexVectorVamanaParameters, bucket=None, device=0, capacity=0, strict=True,
+                 fit_seed=None):
         if params.DistanceMetric not in METRICS:
             raise SemaDBError(1, "unknown distance metric %s" % params.DistanceMetric)
         self.name, self.parameters, self.device = name, params, device
+        # vectorstore.New (vamana.go:64): None = plain store (the slab); a ProductQuantizer waits for Fit
+        from . import vectorstore
+        self._store = vectorstore.New(getattr(params, "Quantizer", None), params.DistanceMetric, params.VectorSize, device)
+        self._pq = None
+        self._fit_rng = np.random.default_rng(fit_seed)
+        self.last_fit_first_idx = None
         p = IndexParams(params.VectorSize, METRICS[params.DistanceMetric], params.SearchSize, params.DegreeBound,
                         params.Alpha, device, capacity, 1 if strict else 0)
         h = C.c_void_p()
@@ -165,6 +173,26 @@ class IndexVamana:
             self.delete_batch(np.array(del_ids + upd_ids, dtype=np.uint64))  # removeInboundEdges :223-233
         for i, v in zip(upd_ids, upd_vecs):  # :247-251 re-inserted sequentially
             self.insert_batch(np.array([i], dtype=np.uint64), v.reshape(1, -1), 1)
+        self.Fit()  # vamana.go:257-260
+
+    def Fit(self):
+        """vecStore.Fit (vamana.go:258) = productQuantizer.Fit (product.go:175-236): once, when the store holds
+        TriggerThreshold points (the start node is one of them).  k-means per sub-quantizer over all stored
+        vectors in storage order (the reference walks a Go map), first centroid drawn at random
+        (kmeans.go:61-63); the labels become the points' centroid ids (:216-218)."""
+        pq = self._store
+        if pq is None or self._pq is not None:
+            return False
+        n = self.stats()[0]
+        if n < pq.params.TriggerThreshold:
+            return False
+        from . import vectorstore
+        ids, vecs, _, _ = self.export()
+        first = self._fit_rng.integers(0, n, pq.M)
+        self.last_fit_first_idx = first
+        codes = pq.Fit(vecs, first, alias=True)  # `vecs` is a private copy: the aliasing write-through stays in it
+        vectorstore.attach(self, pq, ids, codes)
+        return True
 
     def exists(self, node_id):
         """vecStore.Exists (plain.go:21-24)"""

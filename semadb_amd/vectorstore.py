@@ -92,7 +92,54 @@ class ProductQuantizer:
         return out
 
 
-def attach(index, pq: ProductQuantizer):
-    """Switch a vamana.IndexVamana to the fitted quantizer (what a fitted productQuantizer store does)."""
+def attach(index, pq: ProductQuantizer, ids=None, codes=None):
+    """Switch a vamana.IndexVamana to the fitted quantizer (what a fitted productQuantizer store does).
+    Every stored vector is encoded; `ids`/`codes` then overwrite the centroid ids of those points -- the
+    k-means labels Fit leaves on its training points (product.go:216-218) or codes read back from a bucket."""
     check(lib().sdb_index_attach_pq(index._h, pq._h, None))
     index._pq = pq  # keep alive
+    if ids is not None:
+        set_codes(index, ids, codes)
+
+
+def set_codes(index, ids, codes):
+    ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
+    cd = np.ascontiguousarray(codes, dtype=np.uint8)
+    assert cd.shape == (ids_a.size, index._pq.M)
+    check(lib().sdb_index_set_codes(index._h, ids_a.size, _buf.np_ptr(ids_a), _buf.np_ptr(cd)))
+
+
+def get_codes(index, ids):
+    ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
+    cd = np.zeros((ids_a.size, index._pq.M), dtype=np.uint8)
+    check(lib().sdb_index_get_codes(index._h, ids_a.size, _buf.np_ptr(ids_a), _buf.np_ptr(cd)))
+    return cd
+
+
+QuantizerNone, QuantizerProduct = "none", "product"
+
+
+class Quantizer:
+    """models.Quantizer (models/quantizer.go:5-28); the binary quantizer is out of scope (hamming/jaccard)"""
+
+    def __init__(self, Type=QuantizerNone, Product: ProductQuantizerParameters = None):
+        self.Type, self.Product = Type, Product
+
+
+def New(params, distFnName, vectorLength, device=0):
+    """vectorstore.New (vectorstore.go:47-96): None for the plain store (the index slab), a ProductQuantizer
+    for `product`."""
+    if distFnName not in METRICS:
+        raise SemaDBError(1, "unknown float32 distance function: %s" % distFnName)
+    if params is None or params.Type == QuantizerNone:
+        return None
+    if params.Type != QuantizerProduct:
+        raise SemaDBError(1, "unknown vector store type %s" % params.Type)
+    if params.Product is None:
+        raise SemaDBError(1, "product quantizer parameters are nil")
+    pp = params.Product
+    if vectorLength % pp.NumSubVectors != 0:  # product.go:44-46
+        raise SemaDBError(1, "vector length %d must be divisible by num subvectors %d" % (vectorLength, pp.NumSubVectors))
+    if pp.NumCentroids > 256:  # product.go:63-65
+        raise SemaDBError(1, "number of centroids %d cannot exceed 256" % pp.NumCentroids)
+    return ProductQuantizer(distFnName, pp, vectorLength, device)

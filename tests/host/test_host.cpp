@@ -216,6 +216,86 @@ static void test_create_update_delete() {
   for (size_t i = 0; i < a.results.size() && i < b.results.size(); i++) CHECK(a.results[i].NodeId == b.results[i].NodeId);
 }
 
+
+// vectorstore.New with a product quantizer (vectorstore.go:86-91), the Fit trigger after a write
+// (vamana.go:257-260, product.go:175-236) and the bucket round trip of codes and centroids
+// (product.go:80-86,307-320,334-373); the store-level expectations of vectorestore_test.go:112-154 hold
+// at index level as "a stored point is found by its own vector".
+static void test_quantized_index() {
+  models::IndexVectorVamanaParameters p;
+  p.VectorSize = 8, p.DistanceMetric = "euclidean", p.SearchSize = 50, p.DegreeBound = 32, p.Alpha = 1.2f;
+  models::Quantizer q;
+  q.Type = models::QuantizerProduct;
+  CHECK((bool)q.Validate());  // product parameters not provided (quantizer.go:20-24)
+  q.Product = models::ProductQuantizerParameters{256, 3, 1000};
+  p.Quantizer = q;
+  diskstore::MemBucket bucket;
+  {
+    auto bad = vamana::IndexVamana::NewIndexVamana("pq", p, &bucket);  // 8 % 3 != 0 (product.go:44-46)
+    CHECK((bool)bad.second);
+  }
+  p.Quantizer->Product->NumSubVectors = 4;
+  CHECK(!p.Quantizer->Validate());
+  diskstore::MemBucket b2;
+  auto [ix, err] = vamana::IndexVamana::NewIndexVamana("pq", p, &b2);
+  CHECK(!err);
+  ix->setFitSeed(12345);
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> U(-1, 1);
+  auto mk = [&](uint64_t first, int n) {
+    std::vector<vamana::IndexVectorChange> ch;
+    for (int i = 0; i < n; i++) {
+      vamana::IndexVectorChange c;
+      c.Id = first + i;
+      for (int k = 0; k < 8; k++) c.Vector.push_back(U(rng));
+      ch.push_back(c);
+    }
+    return ch;
+  };
+  auto a = mk(2, 700);
+  CHECK(!ix->InsertUpdateDelete(a));
+  CHECK(!ix->quantized());  // 701 points < TriggerThreshold
+  std::string tmp;
+  CHECK(!b2.Get(vamana::productQuantizerFlatCentroidsKey, &tmp));
+  auto b = mk(702, 500);
+  CHECK(!ix->InsertUpdateDelete(b));
+  CHECK(ix->quantized());  // 1 201 points: fitted, encoded, persisted
+  CHECK(b2.Get(vamana::productQuantizerFlatCentroidsKey, &tmp) && tmp.size() == 4 * 256 * 2 * 4);
+  CHECK(b2.Get(vamana::productQuantizerCentroidDistsKey, &tmp) && tmp.size() == 4 * 256 * 256 * 4);
+  CHECK(b2.Get(conversion::NodeKey(2, 'q'), &tmp) && tmp.size() == 4);
+  CHECK(b2.Get(conversion::NodeKey(vamana::STARTID, 'q'), &tmp));  // the start node lives in the same store
+  // writes keep working on the quantized store: insert, update, delete
+  auto c = mk(1202, 100);
+  c.push_back({5, {}});                 // delete
+  c.push_back({6, a[4].Vector});        // update id 6 with id 6's old neighbour's vector
+  CHECK(!ix->InsertUpdateDelete(c));
+  CHECK(!ix->Exists(5) && ix->Exists(1250));
+  CHECK(!b2.Get(conversion::NodeKey(5, 'q'), &tmp));
+  // a stored point is retrieved by its own vector (table distances, no re-ranking)
+  int found = 0;
+  std::vector<std::vector<models::SearchResult>> before;
+  for (int i = 0; i < 20; i++) {
+    models::SearchVectorVamanaOptions so;
+    so.Vector = b[i * 7].Vector, so.SearchSize = 50, so.Limit = 10;
+    auto r = ix->Search(so);
+    CHECK(!r.err && r.results.size() == 10);
+    for (auto &x : r.results) found += x.NodeId == b[i * 7].Id;
+    before.push_back(r.results);
+  }
+  CHECK(found >= 15);
+  // cold reader: a second index over the same bucket comes up quantized and answers identically
+  auto [ix2, err2] = vamana::IndexVamana::NewIndexVamana("pq", p, &b2);
+  CHECK(!err2 && ix2->quantized());
+  for (int i = 0; i < 20; i++) {
+    models::SearchVectorVamanaOptions so;
+    so.Vector = b[i * 7].Vector, so.SearchSize = 50, so.Limit = 10;
+    auto r = ix2->Search(so);
+    CHECK(!r.err && r.results.size() == before[i].size());
+    for (size_t k = 0; k < r.results.size() && k < before[i].size(); k++)
+      CHECK(r.results[k].NodeId == before[i][k].NodeId && r.results[k].Distance == before[i][k].Distance);
+  }
+}
+
 int main() {
   int ndev = 0;
   if (sdb_device_count(&ndev) != SDB_OK) {
@@ -228,6 +308,7 @@ int main() {
   test_invalid_ids_and_empty();
   test_self_retrieval_and_concurrency();
   test_create_update_delete();
+  test_quantized_index();
   if (g_fail) {
     std::printf("%d HOST CHECKS FAILED\n", g_fail);
     return 1;

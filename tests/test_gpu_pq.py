@@ -181,3 +181,52 @@ def test_pq_insert_delete_parity(oracle, metric, d, M, K):
     assert_same_graph(ix, o)
     ix.close()
     gpq.close()
+
+
+def test_fit_trigger_matches_oracle(oracle):
+    """vecStore.Fit after a write (vamana.go:257-260): the index crosses TriggerThreshold, k-means runs over every
+    stored vector in storage order, the labels become the centroid ids (product.go:216-218) and later inserts and
+    searches run on table distances -- the oracle given the same first-centroid draws ends in the same graph."""
+    from semadb_amd import vamana, vectorstore as vs
+    d, M, K, thr = 16, 4, 16, 1000
+    rng = np.random.default_rng(99)
+    base = unit_rows(rng, 1400, d)
+    sv = unit_rows(np.random.default_rng(5), 1, d)[0]
+    q = vs.Quantizer(vs.QuantizerProduct, vs.ProductQuantizerParameters(K, M, thr))
+    ix = vamana.NewIndexVamana("fit", vamana.IndexVectorVamanaParameters(d, "euclidean", 30, 16, 1.2, q), strict=False,
+                               fit_seed=7)
+    ix.set_start(sv)
+    o = oracle.Index(d, "euclidean", 16, 30, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    # 600 points: below the threshold, nothing happens
+    ch = [vamana.IndexVectorChange(i + 2, base[i]) for i in range(600)]
+    ix.InsertUpdateDelete(ch, round_size=1)
+    assert ix._pq is None
+    for i in range(600):
+        assert o.insert(i + 2, base[i]) == 0
+    # 500 more: 1 101 points with the start node -> Fit
+    ch = [vamana.IndexVectorChange(i + 2, base[i]) for i in range(600, 1100)]
+    ix.InsertUpdateDelete(ch, round_size=1)
+    assert ix._pq is not None
+    for i in range(600, 1100):
+        assert o.insert(i + 2, base[i]) == 0
+    ids, vecs, _, _ = o.export()
+    opq = oracle.PQ(d, "euclidean", M, K)
+    o_codes = opq.fit(vecs.copy(), ix.last_fit_first_idx, alias=True)
+    assert o.attach_pq(opq, o_codes) == 0
+    assert np.array_equal(vs.get_codes(ix, ids), o_codes)
+    fc, cd = ix._pq.codebook()
+    assert np.array_equal(bits(fc.ravel()), bits(np.asarray(opq.flat_centroids).ravel()))
+    # the quantized index keeps taking writes
+    ch = [vamana.IndexVectorChange(i + 2, base[i]) for i in range(1100, 1400)] + [vamana.IndexVectorChange(10, None)]
+    ix.InsertUpdateDelete(ch, round_size=1)
+    for i in range(1100, 1400):
+        assert o.insert(i + 2, base[i]) == 0
+    assert o.delete(np.array([10], dtype=np.uint64)) == 0
+    assert_same_graph(ix, o)
+    qs = unit_rows(rng, 8, d)
+    g_ids, g_d, g_c = ix.search_batch(qs, 5, 30)[:3]
+    for k in range(8):
+        o_ids, o_d, _, _ = o.search(qs[k], 5, 30)
+        assert np.array_equal(g_ids[k, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d))
+    ix.close()
