@@ -74,7 +74,7 @@ constexpr int kPairMax = 80;  // candidate sets up to this size get their pair d
 // Rows kept in registers while the other candidates stream past (pair-distance tiles)
 template <int NG>
 struct TileRows {
-  static constexpr int value = NG <= 3 ? 8 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3));
+  static constexpr int value = NG <= 3 ? 8 : NG <= 4 ? 6 : NG <= 6 ? 4 : NG <= 8 ? 3 : 2;
 };
 
 // D[i][j] = distFn(c_i, c_j) for the SORTED candidates, i < j < nc <= kPairMax (vecStore.DistanceFromPoint,
@@ -85,7 +85,7 @@ __device__ void pair_matrix(const BuildArgs &a, int nc, const uint32_t *s_slot, 
   static_assert(NG >= 0, "register tiles need a compile-time group count");
   constexpr int P = TileRows<NG>::value;
   constexpr int NGR = NG > 0 ? NG : 1;
-  constexpr int U = 4;
+  constexpr int U = NG <= 8 ? 4 : NG <= 12 ? 2 : 1;
   const int L = lane & 31, half = lane >> 5;
   for (int i0 = 0; i0 + 1 < nc; i0 += P) {
     float4 xp[P][NGR];
@@ -563,6 +563,9 @@ static int launch_round_ng(const BuildArgs &a, hipStream_t s, void *t, size_t tb
     case 4: return launch_round<4, L2>(a, s, t, tb, eb);
     case 6: return launch_round<6, L2>(a, s, t, tb, eb);
     case 8: return launch_round<8, L2>(a, s, t, tb, eb);
+    case 12: return launch_round<12, L2>(a, s, t, tb, eb);  // 1536
+    case 16: return launch_round<16, L2>(a, s, t, tb, eb);  // 2048
+    case 24: return launch_round<24, L2>(a, s, t, tb, eb);  // 3072
     default: return launch_round<-1, L2>(a, s, t, tb, eb);
   }
 }

@@ -130,7 +130,7 @@ bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
   // quantized store: only with the small LUT of M*K <= 2048 entries next to the (prime-sized) table
   if (a.pq_codes) return a.pq_lut_in_lds && (size_t)a.pq_M * a.pq_K <= 2048;
   switch (a.ng) {
-    case 0: case 1: case 2: case 3: case 4: case 6: case 8: return true;
+    case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: return true;
     default: return false;
   }
 }
@@ -171,6 +171,9 @@ static int launch_ng(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
     case 4: return launch_plain<4, L2>(a, nq, stream);
     case 6: return launch_plain<6, L2>(a, nq, stream);
     case 8: return launch_plain<8, L2>(a, nq, stream);
+    case 12: return launch_plain<12, L2>(a, nq, stream);  // 1536
+    case 16: return launch_plain<16, L2>(a, nq, stream);  // 2048
+    case 24: return launch_plain<24, L2>(a, nq, stream);  // 3072
     default: return launch_nreg<PlainDist<-1, L2>, false>(a, nq, stream, lds);
   }
 }

@@ -64,8 +64,8 @@ struct SearchArgs {
 // otherwise ~96 so that three waves per SIMD still fit (large build rounds).
 template <int NG, bool DEEP>
 struct ChunkPairs {
-  static constexpr int base = NG <= 3 ? 8 : (NG <= 4 ? 6 : (NG <= 6 ? 4 : 3));
-  static constexpr int value = DEEP ? 2 * base : base;
+  static constexpr int base = NG <= 3 ? 8 : NG <= 4 ? 6 : NG <= 6 ? 4 : NG <= 8 ? 3 : NG <= 12 ? 2 : 1;
+  static constexpr int value = DEEP ? 2 * base : base;  // DEEP: 32 / 24 / 16 / 12 / 8 / 4 rows in flight
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -172,9 +172,9 @@ struct PlainDist {
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4;
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
-  // [kHopSlots], raw distances by rank [kHopSlots], a 16-word dump
-  static constexpr uint32_t kHopSlots = 80;
-  static constexpr size_t kLdsBytes = NG >= 0 ? (2 * kHopSlots + 16) * sizeof(uint32_t) : 0;
+  // [kHopSlots], raw distances by rank [kHopSlots], a U-word dump
+  static constexpr uint32_t kHopSlots = 64 + U;  // ranks 0..63 and the overrun of the last half-wave run
+  static constexpr size_t kLdsBytes = NG >= 0 ? (2 * kHopSlots + U) * sizeof(uint32_t) : 0;
   float4 xq[NGR];
   float xt;
   float *qs;

@@ -30,7 +30,8 @@ def _reachable(ids, offsets, edges):
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
 @pytest.mark.parametrize("d,n,R,L", [(2, 250, 8, 25), (33, 300, 16, 30), (96, 400, 32, 50), (128, 500, 64, 75),
-                                     (384, 300, 32, 50), (160, 200, 16, 30)])
+                                     (384, 300, 32, 50), (160, 200, 16, 30), (1536, 150, 16, 30), (3072, 100, 8, 25),
+                                     (1280, 120, 8, 25)])
 def test_sequential_build_identical_to_oracle(oracle, metric, d, n, R, L):
     rng = np.random.default_rng(d + n)
     base = unit_rows(rng, n, d) if d > 2 else rng.random((n, d), dtype=np.float32)
