@@ -9,6 +9,7 @@
 // phase 2 folds it into the per-query top list, one wavefront per query.
 #include <cfloat>
 
+#include "pq.h"
 #include "search_kernel.h"
 
 namespace sdb {
@@ -61,6 +62,30 @@ __global__ __launch_bounds__(256) void k_flat_dist(const float *__restrict__ sla
     if (L == 0 && live[u]) out[(size_t)q * out_stride + c0 + u] = metric_finish(res[u], metric);
     if (L == 0 && live2[u]) out[(size_t)q * out_stride + c0 + U + u] = metric_finish(res2[u], metric);
   }
+}
+
+// phase 1 over a quantized store: vecStore.DistanceFromFloat is the LUT distance (product.go:250-277),
+// sum over the sub-quantizers in index order.  Thread per row, the query's table read through the cache.
+__global__ __launch_bounds__(256) void k_flat_dist_pq(const float *__restrict__ lut, const uint8_t *__restrict__ codes,
+                                                      const uint32_t *__restrict__ slots,
+                                                      const uint32_t *__restrict__ slot_off, uint32_t first_row,
+                                                      uint32_t rows, float *__restrict__ out, uint32_t out_stride,
+                                                      uint32_t M, uint32_t K) {
+  const uint32_t q = blockIdx.y;
+  uint32_t nrows = rows;
+  const uint32_t *myslots = nullptr;
+  if (slots) {
+    myslots = slots + slot_off[q];
+    nrows = slot_off[q + 1] - slot_off[q];
+  }
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nrows) return;
+  const uint32_t slot = myslots ? myslots[c] : first_row + c;
+  const float *l = lut + (size_t)q * M * K;
+  const uint8_t *cd = codes + (size_t)slot * M;
+  float dist = 0.0f;
+  for (uint32_t i = 0; i < M; i++) dist += l[i * K + cd[i]];
+  out[(size_t)q * out_stride + c] = dist;
 }
 
 // ---- phase 2: fold a distance block into the running top list (flat.go:98-124), one wave per query -------
@@ -145,7 +170,6 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   if (!queries || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
   if (limit < 1 || limit > 128) return fail(SDB_ERR_INVALID, "limit must be between 1 and 128, got %u", limit);
   if (nq > 65535) return fail(SDB_ERR_INVALID, "at most 65535 queries per call");
-  if (ix->pq) return fail(SDB_ERR_STATE, "flat search over a quantized store is not on the device path");
   const bool filtered = filter_offsets != nullptr;
   if (filtered && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
   DeviceGuard dg(ix->P.device);
@@ -184,6 +208,8 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const size_t o_ts = carve(nq * 128 * 4), o_td = carve(nq * 128 * 4), o_tl = carve(nq * 4);
   const size_t o_fo = carve(filtered ? (nq + 1) * 4 : 0), o_fs = carve(filtered ? f_slots.size() * 4 : 0);
   const size_t o_d = carve((size_t)nq * stride * 4);
+  const sdb_pq *pq = ix->pq;
+  const size_t o_lut = carve(pq ? (size_t)nq * pq->M * pq->K * 4 : 0);
   char *buf = nullptr;
   SDB_HIP(hipMalloc(&buf, off));
   struct Free {
@@ -223,7 +249,11 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   for (uint32_t first = 0; first < total; first += chunk) {
     const uint32_t rows = std::min<uint32_t>(chunk, total - first);
     dim3 grid((rows + 63) / 64, (unsigned)nq);
-    if (ix->P.metric == SDB_METRIC_EUCLIDEAN)
+    if (pq) {
+      if (first == 0) SDB_TRY(pq_build_lut(pq, dq, nq, (float *)(buf + o_lut), stream));
+      hipLaunchKernelGGL(k_flat_dist_pq, dim3((rows + 255) / 256, (unsigned)nq), dim3(256), 0, stream,
+                         (const float *)(buf + o_lut), ix->d_codes, d_fs, d_fo, first, rows, d_dist, stride, pq->M, pq->K);
+    } else if (ix->P.metric == SDB_METRIC_EUCLIDEAN)
       hipLaunchKernelGGL(k_flat_dist<true>, grid, dim3(256), lds, stream, ix->d_slab, dq, d_fs, d_fo, first, rows, d_dist,
                          stride, l.dim, l.nblk, l.ng, l.tail, l.ld, (int)ix->P.metric);
     else

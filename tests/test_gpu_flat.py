@@ -79,3 +79,37 @@ def test_flat_is_the_ground_truth_of_the_graph_index(oracle):
     hits = sum(len(set(map(int, g_ids[i])) & set(map(int, t_ids[i]))) for i in range(100))
     assert hits / 1000 >= 0.95
     ix.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+def test_flat_over_quantized_store(oracle, metric):
+    """flat.go:86 binds vecStore.DistanceFromFloat: over a fitted product quantizer that is the LUT distance
+    (product.go:250-277), same scan and same `dist >= tail -> skip` rule"""
+    from semadb_amd import flat, vectorstore as vs
+    d, M, K, n = 32, 8, 16, 900
+    rng = np.random.default_rng(17)
+    base = unit_rows(rng, n, d)
+    ids = np.arange(5, n + 5, dtype=np.uint64)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, metric))
+    ix.InsertUpdateDelete([flat.IndexVectorChange(int(ids[i]), base[i]) for i in range(n)])
+    first = rng.integers(0, 400, M)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(base[:400].copy(), first, alias=True)
+    vs.attach(ix, gpq)
+    opq = oracle.PQ(d, metric, M, K)
+    opq.fit(base[:400].copy(), first, alias=True)
+    codes = np.stack([opq.encode(v) for v in base])
+    q = unit_rows(rng, 7, d)
+    allowed = [set(int(v) for v in rng.choice(ids, size=60, replace=False)) for _ in range(7)]
+    for filt in (None, allowed):
+        g_ids, g_d, g_c = ix.search_batch(q, 10, filters=filt)
+        for i in range(7):
+            lut = opq.lut(q[i])
+            dist = np.array([opq.dist_lut(lut, codes[j]) for j in range(n)], dtype=np.float32)
+            idx = np.arange(n) if filt is None else np.array([j for j in range(n) if int(ids[j]) in filt[i]])
+            order = idx[np.argsort(dist[idx], kind="stable")][:10]
+            assert int(g_c[i]) == len(order)
+            assert np.array_equal(g_ids[i, :len(order)], ids[order])
+            assert np.array_equal(bits(g_d[i, :len(order)]), bits(dist[order]))
+    ix.close()
+    gpq.close()
