@@ -23,6 +23,8 @@ struct BuildArgs {
   uint32_t *adj;
   uint32_t *deg;
   uint32_t *clean;  // [n] leading edges of each row that its last robustPrune produced (see robust_prune_wave)
+  float *adjdist;    // [n][64] distFn(row, edge) for the first dcount[row] edges (index.h)
+  uint32_t *dcount;  // [n]
   uint32_t dim, nblk, ng, tail, ld;
   int metric;
   float alpha;
@@ -144,7 +146,8 @@ constexpr int kMaxDirty = 8;  // "few new candidates" mode of robust_prune_wave
 template <int NG, bool L2>
 __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc, const uint32_t *in_slot,
                                   const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
-                                  float *qs, int lane, float *D = nullptr, int n_clean = 0) {
+                                  float *qs, int lane, float *D = nullptr, int n_clean = 0,
+                                  bool dists_are_point_to_point = true) {
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
   for (int i = lane; i < nc; i += 64) {
@@ -218,6 +221,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     }
   }
   uint32_t my_out = kNoSlot;  // lane e holds edge e of the new row
+  float my_outd = 0.0f;       // and its distance from `self`
   int cnt = 0;
   int i = 0;
   while (i < nc) {
@@ -230,7 +234,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     }
     if (found < 0) break;
     const uint32_t p = s_slot[found];
-    if (lane == cnt) my_out = p;  // node.AddNeighbour :118
+    if (lane == cnt) my_out = p, my_outd = s_dist[found];  // node.AddNeighbour :118
     cnt++;
     if (cnt >= (int)a.R) break;  // :119-121
     if (sparse) {  // only pairs with a dirty candidate can prune; their distances are rows of D
@@ -327,9 +331,13 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
   }
   // node.edges of `self`, kNoSlot padded; every edge of a freshly pruned row is "clean"
   a.adj[(size_t)self_slot * kAdjStride + lane] = lane < cnt ? my_out : kNoSlot;
+  a.adjdist[(size_t)self_slot * kAdjStride + lane] = my_outd;
   if (lane == 0) {
     a.deg[self_slot] = (uint32_t)cnt;
     a.clean[self_slot] = (uint32_t)cnt;
+    // the candidates' distances are distFn(self, .) except for a new node of a quantized store, whose
+    // candidate list carries the search's LUT distances (DistanceFromFloat), not DistanceFromPoint
+    a.dcount[self_slot] = dists_are_point_to_point ? (uint32_t)cnt : 0u;
   }
 }
 
@@ -419,7 +427,8 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
     l.in_dist[i] = a.vis_dists[(size_t)q * a.vis_cap + i];
   }
   __syncthreads();
-  robust_prune_wave<NG, L2>(a, self, (int)nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane);
+  robust_prune_wave<NG, L2>(a, self, (int)nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane, nullptr, 0,
+                            NG != kQuantized);
   const uint32_t nb = a.adj[(size_t)self * kAdjStride + lane];  // this lane wrote it
   a.keys_in[(size_t)q * 64 + lane] =
       nb == kNoSlot ? kNoKey : ((uint64_t)nb << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
@@ -454,9 +463,19 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     m++;
   }
   uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
+  float rowd = a.adjdist[(size_t)b * kAdjStride + lane];  // cached distFn(B, edge), valid for lanes < dc
   uint32_t deg = a.deg[b];
+  uint32_t dc = a.dcount[b] < deg ? a.dcount[b] : deg;
   bool row_dirty = false;
   auto req_slot = [&](size_t r) { return a.first_slot + (uint32_t)((a.keys_sorted[pos + r] & 0xFFFFFFFFull) >> 6); };
+  // distFn(B, A) for request r: A's own row holds distFn(A, B) at the edge position the key carries, and the
+  // arithmetic is bitwise symmetric in its two arguments -- valid when A's row has its distances cached
+  auto req_dist = [&](size_t r, bool *valid) {
+    const uint32_t anew = req_slot(r);
+    const uint32_t epos = (uint32_t)(a.keys_sorted[pos + r] & 63ull);
+    *valid = a.dcount[anew] > epos;
+    return a.adjdist[(size_t)anew * kAdjStride + epos];
+  };
   size_t done = 0;
   while (done < m) {
     size_t t = m - done;
@@ -464,7 +483,10 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     if (deg + t <= a.R) {  // insert.go:62 nodeB.AddNeighbour(vecA), t times
       for (size_t r = 0; r < t; r++) {
         const uint32_t anew = req_slot(done + r);
-        if (lane == (int)deg) row = anew;
+        bool have;
+        const float d = req_dist(done + r, &have);
+        if (lane == (int)deg) row = anew, rowd = d;
+        if (dc == deg && have) dc = deg + 1;  // the cached prefix grows only without a gap
         deg++;
       }
       row_dirty = true;
@@ -481,42 +503,54 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       __syncthreads();
       const uint8_t *cb = a.pq_codes + (size_t)b * a.pq_M;
       for (int c = lane; c < nc; c += 64) l.in_dist[c] = pq_sym_dist(a, cb, a.pq_codes + (size_t)l.in_slot[c] * a.pq_M);
-    }
-    PointRow<NG> pr;
-    const float *brow = a.slab + (size_t)b * a.ld;
-    if constexpr (NG >= 0) {
-#pragma unroll
-      for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(brow)[g * 32 + L];
-      if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      pr.xt = a.tail ? brow[NG * 128 + L] : 0.0f;
-    } else if constexpr (NG == -1) {
+    } else {
+      // candidate c: c < deg -> row entry c (edge order), then the new points in insert order (:55-56; Add
+      // dedupes, and a new node can not already be a neighbour).  Cached distances are taken as they are;
+      // the indices of the others are collected in s_slot (free until the prune sorts into it).
       __syncthreads();
-      for (uint32_t x = lane; x < a.ld; x += 64) l.qs[x] = brow[x];
-      __syncthreads();
-    }
-    // candidate c: c < deg -> row entry c (edge order), then the new points in insert order (:55-56; Add
-    // dedupes, and a new node can not already be a neighbour)
-    for (int c0 = 0; NG != kQuantized && c0 < nc; c0 += 2 * U) {
-      uint32_t slot[U];
-      float res[U];
-      int cidx[2 * U];
-      uint32_t cs[2 * U];
-#pragma unroll
-      for (int k2 = 0; k2 < 2 * U; k2++) {
-        cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
-        cs[k2] = cidx[k2] < (int)deg ? rl(row, cidx[k2]) : req_slot(done + (size_t)(cidx[k2] - (int)deg));
+      int nmiss = 0;
+      for (int base = 0; base < nc; base += 64) {
+        const int c = base + lane;
+        bool have = false;
+        if (c < (int)deg) {
+          l.in_slot[c] = row, l.in_dist[c] = rowd, have = c < (int)dc;
+        } else if (c < nc) {
+          l.in_slot[c] = req_slot(done + (size_t)(c - (int)deg));
+          l.in_dist[c] = req_dist(done + (size_t)(c - (int)deg), &have);
+        }
+        const uint64_t mm = __ballot(c < nc && !have);
+        if (c < nc && !have) l.s_slot[nmiss + __popcll(mm & ((1ull << lane) - 1))] = (uint32_t)c;
+        nmiss += __popcll(mm);
       }
+      __syncthreads();
+      if (nmiss) {
+        PointRow<NG> pr;
+        const float *brow = a.slab + (size_t)b * a.ld;
+        if constexpr (NG >= 0) {
 #pragma unroll
-      for (int u = 0; u < U; u++) slot[u] = lane < 32 ? cs[2 * u] : cs[2 * u + 1];
-      if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
-      else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+          for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(brow)[g * 32 + L];
+          if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+          pr.xt = a.tail ? brow[NG * 128 + L] : 0.0f;
+        } else {
+          for (uint32_t x = lane; x < a.ld; x += 64) l.qs[x] = brow[x];
+          __syncthreads();
+        }
+        for (int m0 = 0; m0 < nmiss; m0 += 2 * U) {
+          uint32_t slot[U];
+          float res[U];
+          int cidx[2 * U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const float d0 = metric_finish(rlf(res[u], 0), a.metric);
-        const float d1 = metric_finish(rlf(res[u], 32), a.metric);
-        if (lane == 0) {
-          l.in_dist[cidx[2 * u]] = d0, l.in_slot[cidx[2 * u]] = cs[2 * u];
-          l.in_dist[cidx[2 * u + 1]] = d1, l.in_slot[cidx[2 * u + 1]] = cs[2 * u + 1];
+          for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (int)l.s_slot[m0 + k2 < nmiss ? m0 + k2 : nmiss - 1];
+#pragma unroll
+          for (int u = 0; u < U; u++) slot[u] = lane < 32 ? l.in_slot[cidx[2 * u]] : l.in_slot[cidx[2 * u + 1]];
+          if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+          else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+            const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+            if (lane == 0) l.in_dist[cidx[2 * u]] = d0, l.in_dist[cidx[2 * u + 1]] = d1;
+          }
         }
       }
     }
@@ -528,13 +562,16 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
                               (NG >= 0 && nc <= kPairMax) ? l.D : nullptr, (int)ncl);  // :57-58
     __syncthreads();
     row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
+    rowd = a.adjdist[(size_t)b * kAdjStride + lane];
     deg = (uint32_t)__popcll(__ballot(row != kNoSlot));
+    dc = deg;  // every edge of a freshly pruned row carries its distance
     row_dirty = false;
     done += t;
   }
   if (row_dirty) {
     a.adj[(size_t)b * kAdjStride + lane] = row;
-    if (lane == 0) a.deg[b] = deg;
+    a.adjdist[(size_t)b * kAdjStride + lane] = rowd;
+    if (lane == 0) a.deg[b] = deg, a.dcount[b] = dc;
   }
 }
 
@@ -729,6 +766,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     // ---- robustPrune + back-edges
     BuildArgs ba{};
     ba.slab = ix->d_slab, ba.adj = ix->d_adj, ba.deg = ix->d_deg, ba.clean = ix->d_clean;
+    ba.adjdist = ix->d_adjdist, ba.dcount = ix->d_dcount;
     ba.dim = l.dim, ba.nblk = l.nblk, ba.ng = l.ng, ba.tail = l.tail, ba.ld = l.ld;
     ba.metric = (int)ix->P.metric, ba.alpha = ix->P.alpha, ba.R = ix->P.degree_bound;
     ba.first_slot = cur, ba.nnew = rs;

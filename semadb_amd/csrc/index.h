@@ -49,6 +49,12 @@ struct sdb_index {
   uint32_t *d_adj = nullptr; // [cap][kAdjStride] neighbour slots, kNoSlot padded, edge order kept
   uint32_t *d_deg = nullptr; // [cap]
   uint32_t *d_clean = nullptr; // [cap] leading edges of a row produced by its last robustPrune (build.hip)
+  // write-path cache: d_adjdist[r][e] = distFn(r, adj[r][e]) for e < d_dcount[r] (a prefix of the row).  A full
+  // node that gets one more back-edge is re-pruned over neighbours + new point (insert.go:47-58); the
+  // distances to its old neighbours are the ones computed when those edges were made -- same vectors, same
+  // arithmetic -- so they are read back (256 B) instead of recomputed from 64 rows.  Full-precision store only.
+  float *d_adjdist = nullptr;    // [cap][kAdjStride]
+  uint32_t *d_dcount = nullptr;  // [cap]
   uint64_t *d_ids = nullptr; // [cap] slot -> node id
   std::vector<uint64_t> h_ids;
   bool dense_ids = true;  // ids[i] == ids[0] + i  (then no hash map is needed)

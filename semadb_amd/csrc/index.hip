@@ -246,6 +246,20 @@ int sdb_index::reserve(uint32_t rows) {
   if (d_clean) (void)hipFree(d_clean);
   if (d_ids) (void)hipFree(d_ids);
   d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_clean = nclean, d_ids = nids;
+  {  // edge-distance cache of the write path (index.h); a row without cached distances has d_dcount 0
+    float *nad = nullptr;
+    uint32_t *ndc = nullptr;
+    SDB_HIP(hipMalloc(&nad, (size_t)ncap * kAdjStride * sizeof(float)));
+    SDB_HIP(hipMalloc(&ndc, (size_t)ncap * sizeof(uint32_t)));
+    SDB_HIP(hipMemset(ndc, 0, (size_t)ncap * sizeof(uint32_t)));
+    if (n) {
+      SDB_HIP(hipMemcpy(nad, d_adjdist, (size_t)n * kAdjStride * sizeof(float), hipMemcpyDeviceToDevice));
+      SDB_HIP(hipMemcpy(ndc, d_dcount, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    }
+    if (d_adjdist) (void)hipFree(d_adjdist);
+    if (d_dcount) (void)hipFree(d_dcount);
+    d_adjdist = nad, d_dcount = ndc;
+  }
   if (pq) {  // the code rows of a quantized store grow with it
     uint8_t *ncodes = nullptr;
     SDB_HIP(hipMalloc(&ncodes, (size_t)ncap * pq->M));
@@ -359,6 +373,8 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_adj) (void)hipFree(ix->d_adj);
   if (ix->d_deg) (void)hipFree(ix->d_deg);
   if (ix->d_clean) (void)hipFree(ix->d_clean);
+  if (ix->d_adjdist) (void)hipFree(ix->d_adjdist);
+  if (ix->d_dcount) (void)hipFree(ix->d_dcount);
   if (ix->d_ids) (void)hipFree(ix->d_ids);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
   for (auto e : ix->ev0)
@@ -687,7 +703,8 @@ int sdb_index_last_search_ms(sdb_index *ix, float *ms) {
 int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) {
   if (!ix || !bytes) return fail(SDB_ERR_INVALID, "NULL argument");
   // vecStore.SizeInMemory + nodeStore.SizeInMemory (vamana.go:83-85), as held in HBM
-  *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + kAdjStride * 4 + 4 + 8);
+  // slab row + adjacency row + its distance cache + degree / clean / cached counters + id (+ code row)
+  *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + 2 * kAdjStride * 4 + 3 * 4 + 8 + (ix->pq ? ix->pq->M : 0));
   return SDB_OK;
 }
 
