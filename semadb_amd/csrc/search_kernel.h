@@ -578,15 +578,33 @@ struct HashVisited {
     uint32_t h = (uint32_t)(((uint64_t)(slot * 2654435761u) * CAP) >> 32);
     uint32_t step = 1u + (uint32_t)(((uint64_t)(slot * 0x9E3779B1u) * (CAP - 1)) >> 32);
     if (kPow2) step |= 1u;
+    auto next = [&](uint32_t x) {
+      x += step;
+      if (kPow2) x &= CAP - 1;
+      else if (x >= CAP) x -= CAP;
+      return x;
+    };
+    // A round reads FOUR consecutive probe positions at once (one LDS round trip), takes the first that is
+    // empty or already holds the key -- nothing is ever removed, so a key that is present sits before the
+    // first empty position of its chain -- and only then spends the atomic: almost every lane finishes in one
+    // round, where a compare-and-swap per probe made the whole wave wait for its longest chain.
     while (__ballot(!done)) {
+      const uint32_t h0 = h, h1 = next(h0), h2 = next(h1), h3 = next(h2);
+      const uint32_t k0 = tab[h0], k1 = tab[h1], k2 = tab[h2], k3 = tab[h3];
+      const bool s0 = k0 == slot || k0 == kNoSlot, s1 = k1 == slot || k1 == kNoSlot;
+      const bool s2 = k2 == slot || k2 == kNoSlot, s3 = k3 == slot || k3 == kNoSlot;
+      const uint32_t hs = s0 ? h0 : s1 ? h1 : s2 ? h2 : h3;
+      const uint32_t ks = s0 ? k0 : s1 ? k1 : s2 ? k2 : k3;
       if (!done) {
-        const uint32_t old = atomicCAS(&tab[h], kNoSlot, slot);
-        if (old == kNoSlot) isnew = true, done = true;
-        else if (old == slot) done = true;
-        else {
-          h += step;
-          if (kPow2) h &= CAP - 1;
-          else if (h >= CAP) h -= CAP;
+        if (!(s0 || s1 || s2 || s3)) {
+          h = next(h3);
+        } else if (ks == slot) {
+          done = true;
+        } else {
+          const uint32_t old = atomicCAS(&tab[hs], kNoSlot, slot);
+          if (old == kNoSlot) isnew = true, done = true;
+          else if (old == slot) done = true;
+          else h = hs;  // another lane's key landed there in this round: carry on from it
         }
       }
     }
@@ -630,6 +648,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       const bool has = j < ns;
       const uint32_t slot = has ? a.seeds[s0 + j] : kNoSlot;
       // searchSet.Add (:49): CheckAndVisit, distance, plain append -- NOT sorted
+      dist.prefetch(a, slot, has);
       const bool isnew = vis.test_and_set(has, slot, lane);
       const uint64_t pend = __ballot(isnew);
       n_dist += (uint32_t)__popcll(pend);
@@ -715,6 +734,9 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     const uint32_t nb = a.adj[(size_t)pid * kAdjStride + lane];
     const bool valid = nb != kNoSlot;
     n_edges += (uint32_t)__popcll(__ballot(valid));
+#ifdef SDB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the adjacency round trip to st_adj
+#endif
     SDB_STAMP(st_adj)
     dist.prefetch(a, nb, valid);
     // CheckAndVisit distset.go:174 -- marks before any distance test

@@ -138,6 +138,19 @@ def test_pq_search_parity(oracle, metric, d, M, K):
         assert np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d))
         assert int(tr.n_hop[k]) == o_tr.n_hop and int(tr.n_dist[k]) == o_tr.n_dist
         assert np.array_equal(tr.visit_ids[k, :o_tr.n_hop], o_vis)
+    # repeated batches walk the same path (workspaces, LUT buffers and the hash table are reused)
+    for rep in range(2):
+        g2 = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
+        assert np.array_equal(g2[0], g_ids) and np.array_equal(bits(g2[1]), bits(g_d))
+        assert np.array_equal(g2[3].visit_ids, tr.visit_ids)
+    # filtered search over the quantized store: seeds and result set use the LUT distance too
+    filters = [set(int(v) for v in rng.choice(ids[1:], size=40, replace=False)) for _ in range(32)]
+    f_ids, f_d, f_c, f_tr = ix.search_batch(q, 5, 50, filters=filters, trace=True, visit_cap=512)
+    for k in range(32):
+        o_ids, o_d, o_vis, o_tr = o.search(q[k], 5, 50, filter_ids=sorted(filters[k]))
+        assert int(f_c[k]) == len(o_ids)
+        assert np.array_equal(f_ids[k, :len(o_ids)], o_ids) and np.array_equal(bits(f_d[k, :len(o_ids)]), bits(o_d))
+        assert np.array_equal(f_tr.visit_ids[k, :o_tr.n_hop], o_vis)
     ix.close()
     gpq.close()
 
