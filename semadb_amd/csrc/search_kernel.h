@@ -457,46 +457,61 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
   if (__popcll(cm) < 2 || (__ballot(mydist != mydist) & pd))
     return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
   const bool inC = (cm >> lane) & 1ull;
+  // The pass over the points is the hot part (about a dozen points per hop): per point one readlane, and per
+  // array register one compare-and-count each way.  Ties are not looked for here; they show up afterwards
+  // as two elements on one position (checked below), which costs nothing per point.
+  float cdx[NREG];    // the array's distances, +inf in the lanes past its end
   uint32_t up[NREG];  // per array entry: points strictly below it
 #pragma unroll
-  for (int r = 0; r < NREG; r++) up[r] = 0;
+  for (int r = 0; r < NREG; r++) up[r] = 0, cdx[r] = (r * 64 + lane) < cap ? cd[r] : __int_as_float(0x7f800000);
   uint32_t rl_me = 0, rc_me = 0;  // per point lane: entries below it, points below it
-  bool tie = false;
   for (uint64_t t = cm; t; t &= t - 1) {
     const int j = __ffsll((unsigned long long)t) - 1;
     const float dj = rlf(mydist, j);
     uint32_t below = 0;
 #pragma unroll
     for (int r = 0; r < NREG; r++) {
-      const bool valid = (r * 64 + lane) < len;
-      up[r] += (valid && dj < cd[r]) ? 1u : 0u;
-      tie |= valid && dj == cd[r];
-      below += (uint32_t)__popcll(__ballot(valid && cd[r] < dj));
+      up[r] += dj < cdx[r] ? 1u : 0u;
+      below += (uint32_t)__popcll(__ballot(cdx[r] < dj));
     }
     if (lane == j) rl_me = below;
-    rc_me += (inC && dj < mydist) ? 1u : 0u;
-    tie |= inC && lane != j && dj == mydist;
+    rc_me += dj < mydist ? 1u : 0u;
   }
-  if (__ballot(tie)) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  // positions; with no two equal distances they are a permutation and exactly `cap` of them lie below `cap`
+  const uint32_t np_me = rl_me + rc_me;
+  uint32_t kept = (uint32_t)__popcll(__ballot(inC && np_me < (uint32_t)cap));
   uint32_t *s_id = scratch;
   float *s_d = reinterpret_cast<float *>(scratch + NREG * 64);
 #pragma unroll
   for (int r = 0; r < NREG; r++) {
     const int e = r * 64 + lane;
-    const uint32_t np = (uint32_t)e + up[r];
-    if (e < len && np < (uint32_t)cap) s_id[np] = cid[r], s_d[np] = cd[r];
+    kept += (uint32_t)__popcll(__ballot(e < cap && (uint32_t)e + up[r] < (uint32_t)cap));
+    if (e < cap) s_id[e] = kNoSlot;  // a position nobody lands on stays marked
   }
-  if (inC) {
-    const uint32_t np = rl_me + rc_me;
-    if (np < (uint32_t)cap) s_id[np] = idreg, s_d[np] = mydist;
-  }
+  if (kept != (uint32_t)cap) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
   wave_lds_sync();
 #pragma unroll
   for (int r = 0; r < NREG; r++) {
     const int e = r * 64 + lane;
-    if (e < cap) cid[r] = s_id[e], cd[r] = s_d[e];
+    const uint32_t np = (uint32_t)e + up[r];
+    if (e < cap && np < (uint32_t)cap) s_id[np] = cid[r], s_d[np] = cd[r];
+  }
+  if (inC && np_me < (uint32_t)cap) s_id[np_me] = idreg, s_d[np_me] = mydist;
+  wave_lds_sync();
+  uint32_t nid[NREG];
+  float nd[NREG];
+  bool hole = false;
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    const int e = r * 64 + lane;
+    nid[r] = e < cap ? s_id[e] : cid[r], nd[r] = e < cap ? s_d[e] : cd[r];
+    hole |= e < cap && nid[r] == kNoSlot;
   }
   wave_lds_sync();
+  // an unfilled position = two elements shared another one = equal distances: replay one by one
+  if (__ballot(hole)) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+#pragma unroll
+  for (int r = 0; r < NREG; r++) cid[r] = nid[r], cd[r] = nd[r];
 }
 
 // roaring Contains on this query's ascending slot list: 64-ary search, all lanes probe at once
