@@ -553,12 +553,16 @@ int orc_index_export(const orc_index *ix, uint64_t *ids, float *vectors, uint64_
 }
 
 int orc_index_attach_pq(orc_index *ix, const orc_pq *pq, const uint8_t *codes) {
+  /* codes: one row per LIVE node in storage order (the order orc_index_export lists them); slots of deleted
+   * nodes hold nothing the walk can reach */
   if (!pq->fitted || pq->dim != ix->dim) return -1;
   ix->pq = pq;
   free(ix->codes);
-  ix->codes = malloc((size_t)ix->n * pq->M);
+  ix->codes = calloc((size_t)(ix->n ? ix->n : 1), pq->M);
   ix->codes_cap = ix->n;
-  memcpy(ix->codes, codes, (size_t)ix->n * pq->M);
+  size_t k = 0;
+  for (uint64_t s = 0; s < ix->n; s++)
+    if (ix->alive[s]) memcpy(ix->codes + (size_t)s * pq->M, codes + (k++) * pq->M, pq->M);
   return 0;
 }
 

@@ -186,3 +186,65 @@ def test_start_row_overflow_keeps_graph_valid(oracle):
     s_ids, _, s_c, _ = g.search_batch(base[:50], 5, 25)
     assert np.all(s_c == 5) and not (set(int(v) for v in s_ids.ravel()) & set(int(v) for v in dels))
     g.close()
+
+
+@pytest.mark.parametrize("metric,quantized", [("euclidean", False), ("cosine", False), ("euclidean", True)])
+def test_mixed_operations_differential(oracle, metric, quantized):
+    """A random sequence of write batches -- inserts, updates (delete + re-insert, vamana.go:170-174,247-251) and
+    deletes -- applied to both sides; after every batch the graphs are identical and searches walk the same path.
+    With `quantized` the store is switched to a fitted product quantizer half way (all later distances are table
+    distances)."""
+    from semadb_amd import vamana, vectorstore as vs
+    from tests.helpers import assert_same_graph
+    d, R, L = 32, 12, 30
+    rng = np.random.default_rng(2024 + quantized)
+    sv = start_vector(np.random.default_rng(9), d)
+    o = oracle.Index(d, metric, R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    g = vamana.NewIndexVamana("mix", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.2), strict=False)
+    g.set_start(sv)
+    live, next_id = [], 2
+    for step in range(14):
+        changes = []
+        n_ins = int(rng.integers(20, 60))
+        for _ in range(n_ins):
+            changes.append((next_id, unit_rows(rng, 1, d)[0]))
+            next_id += 1
+        n_del = int(rng.integers(0, min(15, len(live)) + 1)) if live else 0
+        dels = [int(v) for v in rng.choice(live, size=n_del, replace=False)] if n_del else []
+        rest = [v for v in live if v not in dels]
+        n_upd = int(rng.integers(0, min(8, len(rest)) + 1)) if rest else 0
+        upds = [int(v) for v in rng.choice(rest, size=n_upd, replace=False)] if n_upd else []
+        upd_vecs = unit_rows(rng, max(n_upd, 1), d)
+        # device side: one InsertUpdateDelete per batch
+        ch = [vamana.IndexVectorChange(i, v) for i, v in changes]
+        ch += [vamana.IndexVectorChange(i, None) for i in dels]
+        ch += [vamana.IndexVectorChange(i, upd_vecs[k]) for k, i in enumerate(upds)]
+        g.InsertUpdateDelete(ch, round_size=1)
+        # oracle side: the same order vamana.go applies -- inserts, one removeInboundEdges over deleted + updated,
+        # then the updated points re-inserted one by one
+        for i, v in changes:
+            assert o.insert(i, v) == 0
+        if dels or upds:
+            assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
+        for k, i in enumerate(upds):
+            assert o.insert(i, upd_vecs[k]) == 0
+        live = [v for v in live if v not in dels] + [i for i, _ in changes]
+        assert_same_graph(g, o)
+        if quantized and step == 6:
+            ids, vecs, _, _ = o.export()
+            first = rng.integers(0, len(ids), 4)
+            opq = oracle.PQ(d, metric, 4, 16)
+            codes = opq.fit(vecs.copy(), first, alias=True)
+            assert o.attach_pq(opq, codes) == 0
+            gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(16, 4), d)
+            gcodes = gpq.Fit(vecs.copy(), first, alias=True)
+            assert np.array_equal(gcodes, codes)
+            vs.attach(g, gpq, ids, gcodes)
+        q = unit_rows(rng, 6, d)
+        ids_g, d_g, c_g, tr = g.search_batch(q, 5, L, trace=True, visit_cap=256)
+        for i in range(6):
+            o_ids, o_d, o_vis, o_tr = o.search(q[i], 5, L)
+            assert np.array_equal(ids_g[i, :len(o_ids)], o_ids) and np.array_equal(bits(d_g[i, :len(o_ids)]), bits(o_d))
+            assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis)
+    g.close()
