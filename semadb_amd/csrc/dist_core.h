@@ -40,16 +40,17 @@ __device__ __forceinline__ float chain4(float acc, const float4 &x, const float4
   return acc;
 }
 
-// Sequential tail chain (dot.s:35-43 / euclidean.s:44-53).  Lane L of each half holds tail
-// element L of x and of y; every lane of the half replays the chain in element order.
+// Sequential tail chain (dot.s:35-43 / euclidean.s:44-53).  Lane L of each half holds tail element L of x
+// and of y; x is the bound point (the same in both halves), y the half's own row.  The chain runs in lane 0
+// of each half -- the only lanes whose result asm_reduce uses: element i of x comes from a readlane, the
+// row's elements walk down to lane 0 with one wave_shl DPP move per step (no LDS round trips).
 template <bool L2>
 __device__ __forceinline__ float tail_chain(float xt, float yt, uint32_t tail, int lane) {
   float t = 0.0f;
-  const int hb = lane & 32;
   for (uint32_t i = 0; i < tail; i++) {
-    float xi = __shfl(xt, hb + (int)i, 64);
-    float yi = __shfl(yt, hb + (int)i, 64);
-    t = chain1<L2>(t, xi, yi);
+    const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xt), (int)i));
+    t = chain1<L2>(t, xi, yt);
+    yt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(yt), 0x130, 0xf, 0xf, true));  // wave_shl:1
   }
   return t;
 }

@@ -228,14 +228,17 @@ struct PlainDist {
 
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
 
-  // The same distances for vectors without a tail (dim % 32 == 0: every configured size) with the per-row
-  // instruction count cut to the arithmetic: the pending slots are compacted into LDS by rank (mbcnt), each
+  // The hop with the per-row instruction count cut to the arithmetic: the pending slots are compacted into LDS by rank (mbcnt), each
   // half-wave takes a contiguous run of them (so a lane fetches its 16 slots with plain ds_reads, no bit
   // scans or readlanes), a row address is ONE v_mad_u64_u32 (slot * row bytes + [slab + 16 * L]), the raw
   // distance leaves lane 0 of its half through one ds_write at the row's rank, and every pending lane reads
   // its own rank back.  With one wave per SIMD an instruction of any kind costs an issue slot, so this is
   // where the kernel's time was.  Rows beyond an odd count are read twice (one spare entry behind the
   // list); their results land behind the ranks anybody reads.
+  // TAIL (dim % 32 != 0, e.g. 100, 784): the sequential scalar chain over the tail elements (dot.s:35-43)
+  // runs in lane 0 of each half -- the query element comes from a readlane (once per element, shared by all
+  // rows of the chunk), the row's elements walk down to lane 0 with one wave_shl DPP move per step.
+  template <bool TAIL>
   __device__ __forceinline__ float hop_fast(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
     const int L = lane & 31, half = lane >> 5;
     const int cnt = __popcll(pend);
@@ -270,6 +273,15 @@ struct PlainDist {
 #pragma unroll
           for (int g = 0; g < NG; g++) y[u][g] = r4[g * 32];
         }
+      float yt[TAIL ? U : 1];
+      if constexpr (TAIL) {
+        const char *baseT = reinterpret_cast<const char *>(a.slab) + (NG * 128 + L) * 4;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          yt[u] = 0.0f;
+          if (u < h0) yt[u] = *reinterpret_cast<const float *>(baseT + (uint64_t)sl[u] * row_bytes);
+        }
+      }
 #ifdef SDB_STAMPS
       unsigned long long t1 = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -277,14 +289,37 @@ struct PlainDist {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       float *wp = (L == 0) ? s_res + base : s_res + kHopSlots;  // the other lanes write to a dump
+      if constexpr (!TAIL) {
 #pragma unroll
-      for (int u = 0; u < U; u++)
-        if (u < h0) {
-          float acc = 0.0f;
+        for (int u = 0; u < U; u++)
+          if (u < h0) {
+            float acc = 0.0f;
 #pragma unroll
-          for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
-          wp[u] = asm_reduce(acc, 0.0f, lane);
+            for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
+            wp[u] = asm_reduce(acc, 0.0f, lane);
+          }
+      } else {
+        float acc[U], t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          acc[u] = 0.0f, t[u] = 0.0f;
+          if (u < h0) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) acc[u] = chain4<L2>(acc[u], xq[g], y[u][g]);
+          }
         }
+        for (uint32_t i = 0; i < a.tail; i++) {
+          const float xi = rlf(xt, (int)i);  // both halves hold the query's tail in lanes 0..31
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            t[u] = chain1<L2>(t[u], xi, yt[u]);  // lane 0 of each half: element i of its row
+            yt[u] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(yt[u]), 0x130, 0xf, 0xf, true));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (u < h0) wp[u] = asm_reduce(acc[u], t[u], lane);
+      }
 #ifdef SDB_STAMPS
       unsigned long long t3 = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -297,8 +332,7 @@ struct PlainDist {
 
   // distances of the new neighbours of one hop: lane j (bit j of pend) gets dist(query, row nb_j)
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
-    if constexpr (NG > 0)
-      if (a.tail == 0) return hop_fast(a, nb, pend, lane);
+    if constexpr (NG >= 0) return a.tail ? hop_fast<true>(a, nb, pend, lane) : hop_fast<false>(a, nb, pend, lane);
     float mydist = 0.0f;
     uint64_t todo = pend;
     while (todo) {
