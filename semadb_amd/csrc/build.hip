@@ -42,6 +42,10 @@ struct BuildArgs {
   const uint8_t *pq_codes;  // [n][M]
   const float *pq_cdists;   // [M][K][K]
   uint32_t pq_M, pq_K;
+  // distances the round's searches evaluated: per new point a direct-mapped table of (slot, distance bits),
+  // 2^(32 - dcache_shift) entries, written by K2 (SearchArgs::dcache); NULL when not collected
+  const uint2 *dcache;
+  uint32_t dcache_shift;
 };
 
 constexpr int kQuantized = -2;  // value of the NG template parameter for a fitted product quantizer
@@ -71,70 +75,11 @@ struct PointRow {
 // sort with strict '<', so equal distances keep arrival order).  Then for each surviving candidate in
 // order: add it as an edge (:118), stop at DegreeBound (:119-121), and mark every later candidate j
 // with alpha * dist(p*, c_j) < c_j.Distance as removed (:132).
-constexpr int kPairMax = 80;  // candidate sets up to this size get their pair distances precomputed in LDS
+constexpr int kPairMax = 80;  // largest candidate set of the few-new-candidates mode (rows of D)
 
-// Rows kept in registers while the other candidates stream past (pair-distance tiles)
-template <int NG>
-struct TileRows {
-  static constexpr int value = NG <= 3 ? 8 : NG <= 4 ? 6 : NG <= 6 ? 4 : NG <= 8 ? 3 : 2;
-};
+constexpr int kMaxDirty = 16;  // "few new candidates" mode of robust_prune_wave
 
-// D[i][j] = distFn(c_i, c_j) for the SORTED candidates, i < j < nc <= kPairMax (vecStore.DistanceFromPoint,
-// plain.go:87-97; same arithmetic as everywhere).  A tile of P rows sits in registers and every other row
-// is loaded once per tile instead of once per selected neighbour: ~nc^2/(2P) row loads instead of ~nc^2/2.
-template <int NG, bool L2>
-__device__ void pair_matrix(const BuildArgs &a, int nc, const uint32_t *s_slot, float *D, int lane) {
-  static_assert(NG >= 0, "register tiles need a compile-time group count");
-  constexpr int P = TileRows<NG>::value;
-  constexpr int NGR = NG > 0 ? NG : 1;
-  constexpr int U = NG <= 8 ? 4 : NG <= 12 ? 2 : 1;
-  const int L = lane & 31, half = lane >> 5;
-  for (int i0 = 0; i0 + 1 < nc; i0 += P) {
-    float4 xp[P][NGR];
-    float xtp[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-      const int i = (i0 + p < nc) ? i0 + p : nc - 1;
-      const float *row = a.slab + (size_t)s_slot[i] * a.ld;
-#pragma unroll
-      for (int g = 0; g < NG; g++) xp[p][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
-      if (NG == 0) xp[p][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      xtp[p] = a.tail ? row[NG * 128 + L] : 0.0f;
-    }
-    for (int j0 = i0 + 1; j0 < nc; j0 += 2 * U) {
-      float4 y[U][NGR];
-      float yt[U];
-      int jm[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int j = j0 + 2 * u + half;
-        jm[u] = j;
-        const float *row = a.slab + (size_t)s_slot[j < nc ? j : nc - 1] * a.ld;
-#pragma unroll
-        for (int g = 0; g < NG; g++) y[u][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
-        yt[u] = a.tail ? row[NG * 128 + L] : 0.0f;
-      }
-#pragma unroll
-      for (int p = 0; p < P; p++) {
-        const int i = i0 + p;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xp[p][g], y[u][g]);
-          const float t = a.tail ? tail_chain<L2>(xtp[p], yt[u], a.tail, lane) : 0.0f;
-          const float r = asm_reduce(acc, t, lane);
-          if (L == 0 && i < nc && jm[u] < nc && jm[u] > i) D[i * kPairMax + jm[u]] = metric_finish(r, a.metric);
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
-constexpr int kMaxDirty = 8;  // "few new candidates" mode of robust_prune_wave
-
-// D == nullptr: pair distances are computed when needed (large candidate sets); else looked up.
+// D: LDS scratch of kMaxDirty rows of kPairMax pair distances for the few-new-candidates mode, or nullptr.
 //
 // n_clean: the first n_clean input candidates are this node's edges as its LAST robustPrune left them.  For two
 // such candidates i < j (sorted order) that prune evaluated alpha * dist(c_i, c_j) < c_j.Distance and found it
@@ -165,6 +110,10 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
   // sparse mode: few dirty candidates and room for their distance rows in D
   bool sparse = false;
   uint32_t *dord = const_cast<uint32_t *>(in_slot);  // input arrays are free after the sort
+  uint32_t my_out = kNoSlot;  // lane e holds edge e of the new row
+  float my_outd = 0.0f;       // and its distance from `self`
+  int cnt = 0;
+  bool decided = false;  // the sparse mode below settles the whole prune without walking the neighbours
   if constexpr (NG >= 0) {
     if (D && n_clean > 0 && nc - n_clean <= kMaxDirty && nc <= kPairMax) {
       sparse = true;
@@ -186,45 +135,113 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
         }
       }
       __syncthreads();
-      // one row of pair distances per dirty candidate: D[k][j] = distFn(c_dirty_k, c_j)
+      // one row of pair distances per dirty candidate: D[k][j] = distFn(c_dirty_k, c_j).  When the dirty
+      // candidate is a point of this round, its own search evaluated most of these a moment ago (the node
+      // being re-pruned was expanded there, so its neighbours were looked at): BuildArgs::dcache holds what
+      // survived in that search's direct-mapped table -- exact values, same arithmetic (bitwise symmetric) --
+      // and only the misses are computed from rows.
+      uint32_t *miss = reinterpret_cast<uint32_t *>(const_cast<float *>(in_dist));  // free after the sort
       for (int k = 0; k < nd; k++) {
         int dk = 0;
 #pragma unroll
         for (int kk = 0; kk < kMaxDirty; kk++)
           if (kk == k) dk = dpos[kk];
-        PointRow<NG> pr;
-        const float *prow = a.slab + (size_t)s_slot[dk] * a.ld;
+        const uint32_t sd = s_slot[dk];
+        const uint2 *tab = nullptr;
+        if (a.dcache && sd >= a.first_slot && sd - a.first_slot < a.nnew)
+          tab = a.dcache + ((size_t)(sd - a.first_slot) << (32 - a.dcache_shift));
+        int nmiss = 0;
+        for (int base = 0; base < nc; base += 64) {
+          const int j = base + lane;
+          bool need = j < nc;
+          if (need && tab) {
+            const uint32_t cs = s_slot[j];
+            const uint2 e = tab[(cs * 2654435761u) >> a.dcache_shift];
+            if (e.x == cs) D[k * kPairMax + j] = __uint_as_float(e.y), need = false;
+          }
+          const uint64_t mm = __ballot(need);
+          if (need) miss[nmiss + __popcll(mm & ((1ull << lane) - 1))] = (uint32_t)j;
+          nmiss += __popcll(mm);
+        }
+        __syncthreads();
+        if (nmiss) {
+          PointRow<NG> pr;
+          const float *prow = a.slab + (size_t)sd * a.ld;
 #pragma unroll
-        for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(prow)[g * 32 + L];
-        if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pr.xt = a.tail ? prow[NG * 128 + L] : 0.0f;
-        for (int c0 = 0; c0 < nc; c0 += 2 * U) {
-          uint32_t slot[U];
-          float res[U];
-          int cidx[2 * U];
+          for (int g = 0; g < NG; g++) pr.xq[g] = reinterpret_cast<const float4 *>(prow)[g * 32 + L];
+          if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+          pr.xt = a.tail ? prow[NG * 128 + L] : 0.0f;
+          for (int m0 = 0; m0 < nmiss; m0 += 2 * U) {
+            uint32_t slot[U];
+            float res[U];
+            int cidx[2 * U];
 #pragma unroll
-          for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (c0 + k2 < nc) ? c0 + k2 : nc - 1;
+            for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (int)miss[m0 + k2 < nmiss ? m0 + k2 : nmiss - 1];
 #pragma unroll
-          for (int u = 0; u < U; u++) slot[u] = lane < 32 ? s_slot[cidx[2 * u]] : s_slot[cidx[2 * u + 1]];
-          chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+            for (int u = 0; u < U; u++) slot[u] = lane < 32 ? s_slot[cidx[2 * u]] : s_slot[cidx[2 * u + 1]];
+            chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
 #pragma unroll
-          for (int u = 0; u < U; u++) {
-            const float d0 = metric_finish(rlf(res[u], 0), a.metric);
-            const float d1 = metric_finish(rlf(res[u], 32), a.metric);
-            if (lane == 0) D[k * kPairMax + cidx[2 * u]] = d0, D[k * kPairMax + cidx[2 * u + 1]] = d1;
+            for (int u = 0; u < U; u++) {
+              const float d0 = metric_finish(rlf(res[u], 0), a.metric);
+              const float d1 = metric_finish(rlf(res[u], 32), a.metric);
+              if (lane == 0) D[k * kPairMax + cidx[2 * u]] = d0, D[k * kPairMax + cidx[2 * u + 1]] = d1;
+            }
           }
         }
+        __syncthreads();  // `miss` is reused by the next dirty candidate
       }
       __syncthreads();
-    } else if (D) {
-      pair_matrix<NG, L2>(a, nc, s_slot, D, lane);
+      // With the clean pairs settled, a candidate is removed only by a dirty candidate before it, or -- if it
+      // is dirty itself -- by any selected candidate before it.  So the dirty candidates are taken in order
+      // (there are at most kMaxDirty): each is tested against everything alive before it (one ballot over
+      // its row of D), and if it survives it strikes out what it beats further on (one lane-parallel step).
+      // What is alive at the end, in order, cut at the degree bound, is the row: the candidate at which the
+      // sequential loop would break (:119-121) and everything after it are not among the first R alive, and
+      // removals only ever reach forward, so nothing past the break can change what comes before it.
+      {
+        const int j0 = lane, j1 = lane + 64;  // nc <= kPairMax <= 128
+        const bool v0 = j0 < nc, v1 = j1 < nc;
+        const uint32_t sl0 = v0 ? s_slot[j0] : kNoSlot, sl1 = v1 ? s_slot[j1] : kNoSlot;
+        const float sd0 = v0 ? s_dist[j0] : 0.0f, sd1 = v1 ? s_dist[j1] : 0.0f;
+        const bool ok0 = v0 && sl0 != self_slot, ok1 = v1 && sl1 != self_slot;  // :115-117
+        bool rem0 = false, rem1 = false;
+        for (int k = 0; k < nd; k++) {
+          int pd = 0;
+#pragma unroll
+          for (int kk = 0; kk < kMaxDirty; kk++)
+            if (kk == k) pd = dpos[kk];
+          const float dpd = s_dist[pd];
+          const float e0 = v0 ? D[k * kPairMax + j0] : 0.0f, e1 = v1 ? D[k * kPairMax + j1] : 0.0f;
+          const bool kills0 = ok0 && !rem0 && j0 < pd && a.alpha * e0 < dpd;  // :132 seen from the victim
+          const bool kills1 = ok1 && !rem1 && j1 < pd && a.alpha * e1 < dpd;
+          if (__ballot(kills0 || kills1) || s_slot[pd] == self_slot) {
+            rem0 |= j0 == pd, rem1 |= j1 == pd;
+          } else {
+            rem0 |= v0 && j0 > pd && a.alpha * e0 < sd0;  // :132
+            rem1 |= v1 && j1 > pd && a.alpha * e1 < sd1;
+          }
+        }
+        const bool al0 = ok0 && !rem0, al1 = ok1 && !rem1;
+        const uint64_t m0 = __ballot(al0), m1 = __ballot(al1);
+        const uint32_t r0 = (uint32_t)__popcll(m0 & ((1ull << lane) - 1));
+        const uint32_t r1 = (uint32_t)(__popcll(m0) + __popcll(m1 & ((1ull << lane) - 1)));
+        const int alive = __popcll(m0) + __popcll(m1);
+        cnt = alive < (int)a.R ? alive : (int)a.R;
+        uint32_t *o_slot = dord;  // both input arrays are free now
+        float *o_dist = const_cast<float *>(in_dist);
+        __syncthreads();
+        if (al0 && r0 < a.R) o_slot[r0] = sl0, o_dist[r0] = sd0;
+        if (al1 && r1 < a.R) o_slot[r1] = sl1, o_dist[r1] = sd1;
+        __syncthreads();
+        if (lane < cnt) my_out = o_slot[lane], my_outd = o_dist[lane];
+        decided = true;
+      }
+    } else {
+      D = nullptr;  // the scratch holds kMaxDirty rows, not a full matrix: pairs are computed as they come
     }
   }
-  uint32_t my_out = kNoSlot;  // lane e holds edge e of the new row
-  float my_outd = 0.0f;       // and its distance from `self`
-  int cnt = 0;
   int i = 0;
-  while (i < nc) {
+  while (!decided && i < nc) {
     int found = -1;
     for (int base = i & ~63; base < nc && found < 0; base += 64) {
       const int j = base + lane;
@@ -349,11 +366,11 @@ struct PruneLds {
   float *s_dist;
   uint32_t *s_rem;
   float *qs;
-  float *D;  // [kPairMax][kPairMax], only carved by k_backedges
+  float *D;  // [kMaxDirty][kPairMax], only carved by k_backedges
   __device__ PruneLds(char *base, uint32_t cap, bool with_pairs = false) {
     D = with_pairs ? reinterpret_cast<float *>(base + (size_t)cap * 20) : nullptr;
     base_init(base, cap);
-    if (with_pairs) qs = D + kPairMax * kPairMax;
+    if (with_pairs) qs = D + kMaxDirty * kPairMax;
   }
   __device__ void base_init(char *base, uint32_t cap) {
     in_slot = reinterpret_cast<uint32_t *>(base);
@@ -408,7 +425,7 @@ __device__ void dists_from_point(const BuildArgs &a, uint32_t point, uint32_t nc
 }
 
 static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld, bool with_pairs = false) {
-  return (size_t)cap * 20 + (with_pairs ? (size_t)kPairMax * kPairMax * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
+  return (size_t)cap * 20 + (with_pairs ? (size_t)kMaxDirty * kPairMax * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
 }
 
 // robustPrune(nodeA, visitedSet) for every new node of the round (insert.go:29-31), then emit the
@@ -737,6 +754,13 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_HIP(hipMalloc(&lut, (size_t)max_round * lut_row));
     cleanup.ptrs.push_back(lut);
   }
+  // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
+  constexpr uint32_t kDcacheBits = 13;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
+  uint2 *dcache = nullptr;
+  if (!pq) {
+    SDB_HIP(hipMalloc(&dcache, ((size_t)max_round << kDcacheBits) * sizeof(uint2)));
+    cleanup.ptrs.push_back(dcache);
+  }
 
   uint64_t done = 0;
   while (done < n) {
@@ -756,6 +780,10 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.start_slot = (uint32_t)ix->start_slot;
     sa.search_size = L, sa.limit = 1, sa.metric = (int)ix->P.metric;
     sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
+    if (dcache) {
+      SDB_HIP(hipMemsetAsync(dcache, 0xFF, ((size_t)rs << kDcacheBits) * sizeof(uint2), stream));  // no slot is ~0
+      sa.dcache = dcache, sa.dcache_shift = 32 - kDcacheBits;
+    }
     if (pq) {
       SDB_TRY(pq_build_lut(pq, sa.queries, rs, lut, stream));
       sa.pq_lut = lut, sa.pq_codes = ix->d_codes, sa.pq_M = pq->M, sa.pq_K = pq->K;
@@ -773,6 +801,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.vis_slots = vis_slots, ba.vis_dists = vis_dists, ba.vis_count = vis_count, ba.vis_cap = vis_cap;
     ba.keys_in = keys_in, ba.keys_sorted = keys_sorted;
     if (pq) ba.pq_codes = ix->d_codes, ba.pq_cdists = pq->d_cdists, ba.pq_M = pq->M, ba.pq_K = pq->K;
+    ba.dcache = dcache, ba.dcache_shift = 32 - kDcacheBits;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
                                                   : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit);

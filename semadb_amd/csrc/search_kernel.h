@@ -55,6 +55,11 @@ struct SearchArgs {
   // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
   const uint32_t *seed_off, *seeds, *filt_off, *filt_slots;
   uint32_t *rbitsets;
+  // build path, full-precision store: every evaluated (slot, distance) also goes into the query's
+  // direct-mapped table of 2^(32 - dcache_shift) entries (last writer wins); the back-edge prunes of the
+  // round look their pair distances up there (build.hip BuildArgs::dcache).  NULL: not collected.
+  uint2 *dcache;
+  uint32_t dcache_shift;
   uint32_t prefer_bitset;  // != 0: never use the LDS hash visited set (large build rounds)
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
@@ -169,6 +174,7 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
 template <int NG, bool L2, bool DEEP = false>
 struct PlainDist {
   static constexpr bool kHasStamps = true;
+  static constexpr bool kPointDistances = true;  // dist(query, row) is distFn between two stored vectors
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4;
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
@@ -370,6 +376,7 @@ struct PlainDist {
 // (product.go:271-275).  One lane per neighbour: all new neighbours of a hop in one pass.
 struct PQDist {
   static constexpr bool kHasStamps = false;
+  static constexpr bool kPointDistances = false;  // LUT distance != the centroid-pair distance of the prunes
   const float *lut;  // this query's [M][K] table, in LDS or in global memory
   __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
     const float *g = a.pq_lut + (size_t)q * a.pq_M * a.pq_K;
@@ -795,6 +802,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     if (pend) {
       n_dist += (uint32_t)__popcll(pend);
       const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
+      if constexpr (Dist::kPointDistances)
+        if (a.dcache && ((pend >> lane) & 1ull))
+          a.dcache[((size_t)q << (32 - a.dcache_shift)) + ((nb * 2654435761u) >> a.dcache_shift)] =
+              make_uint2(nb, __float_as_uint(mydist));
 #ifdef SDB_STAMPS
       asm volatile("" ::"v"(mydist));
 #endif
