@@ -151,6 +151,7 @@ def main():
         (rank, t1 - t0, build_s, n / build_s, n_edges / n_nodes))
 
     per_shard = cluster.shard_limit(k, world, 75)  # actions.go:291-299
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     def step(b):
         """one batch through the hot path; returns merged (ids, dists, shards, counts, trace)"""
@@ -158,17 +159,27 @@ def main():
         if not use_dist:
             ids, dists, counts, tr = ix.search_batch(q, per_shard, L, trace=True)
             return ids, dists, None, counts, tr
-        # the kernel writes into the all-gather message; one collective per batch, then the device merge
+        # the kernel writes into the all-gather message; one collective per batch, then the device merge.
+        # The exchange step runs on its own stream: the all-gather and merge of batch i overlap the graph
+        # walk of batch i + 1 (every batch still goes through search -> all-gather -> merge; the timed region
+        # ends with a synchronise over both streams).
         blk = cluster.PackedTopK(nq, per_shard, dev)
         _, _, _, tr = ix.search_batch(q, per_shard, L, trace=True, out=blk.out())
-        g_ids, g_d, g_c = blk.allgather()
-        m_ids, m_d, m_sh, m_c = cluster.topk_merge(g_ids, g_d, g_c, k, device=dev_index)
+        searched = torch.cuda.Event()
+        searched.record()
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(searched)
+            blk.buf.record_stream(comm_stream)
+            g_ids, g_d, g_c = blk.allgather()
+            m_ids, m_d, m_sh, m_c = cluster.topk_merge(g_ids, g_d, g_c, k, device=dev_index)
         return m_ids, m_d, m_sh, m_c, tr
 
     # ---- recall@10 against exact ground truth over all shards, on every distinct query batch
     hits = total = 0
     for b in range(a.query_batches):
         m_ids, m_d, m_sh, m_c, _ = step(b)
+        if use_dist:
+            torch.cuda.current_stream().wait_stream(comm_stream)  # the merged block was produced there
         ts, ti = exact_topk(queries[b], base, k)
         if use_dist:
             all_s = [torch.empty_like(ts) for _ in range(world)]
