@@ -150,13 +150,24 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
     r4[u] = reinterpret_cast<const float4 *>(slab + (size_t)slot[u] * ld) + L;
   }
   const float4 *q4 = reinterpret_cast<const float4 *>(qs) + L;
-  for (uint32_t g = 0; g < ng; g++) {
-    float4 x = q4[g * 32];
-    float4 y[U];
+  // four 128-float groups of every row per step: 4 * U row loads in flight instead of U; the partial sums
+  // still take their groups in ascending order
+  constexpr int GC = 4;
+  for (uint32_t g0 = 0; g0 < ng; g0 += GC) {
+    float4 y[U][GC];
 #pragma unroll
-    for (int u = 0; u < U; u++) y[u] = r4[u][g * 32];
+    for (int k = 0; k < GC; k++)
+      if (g0 + k < ng) {
 #pragma unroll
-    for (int u = 0; u < U; u++) acc[u] = chain4<L2>(acc[u], x, y[u]);
+        for (int u = 0; u < U; u++) y[u][k] = r4[u][(g0 + k) * 32];
+      }
+#pragma unroll
+    for (int k = 0; k < GC; k++)
+      if (g0 + k < ng) {
+        const float4 x = q4[(g0 + k) * 32];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[u] = chain4<L2>(acc[u], x, y[u][k]);
+      }
   }
   float xt = tail ? qs[ng * 128 + L] : 0.0f;
 #pragma unroll

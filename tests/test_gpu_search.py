@@ -30,8 +30,9 @@ def _check_batch(o, ix, queries, limit, L, visit_cap=1024):
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
 @pytest.mark.parametrize("d,n", [(2, 300), (33, 400), (96, 600), (128, 800), (384, 700), (160, 300), (768, 300),
-                                 # 1024 / 1536 / 2048 / 3072: register-query kernels; 1280: the generic (LDS tile) one
-                                 (1024, 200), (1536, 200), (2048, 150), (3072, 120), (1280, 150),
+                                 # 1024 / 1536 / 2048 / 3072: register-query kernels; 1280: rows zero-padded to the
+                                 # 1536 kernel; 2112 and 4096: the generic (LDS tile) kernel
+                                 (1024, 200), (1536, 200), (2048, 150), (3072, 120), (1280, 150), (2112, 100), (4096, 80),
                                  # the reference's ann-benchmarks shapes with a tail (d % 32 != 0): glove-25/-100, mnist
                                  (25, 500), (100, 500), (784, 300)])
 def test_search_parity(oracle, metric, d, n):
