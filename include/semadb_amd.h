@@ -247,6 +247,13 @@ int sdb_pq_sym_distance(const sdb_pq *pq, const uint8_t *codes_x, const uint8_t 
  * prunes the symmetric table, exactly as a fitted productQuantizer store does.  The index
  * encodes every stored vector (product.go:161-169 Set -> encode). */
 int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream);
+/* insert.go:47-58 for a node and SEVERAL candidates at once: candidateSet.Add(neighbours...),
+ * Add(extra...), Sort, robustPrune(node).  The device build applies this rule to a target that has
+ * several back-edge requests in one round, and the delete path to an overflowing start row
+ * (prune.go:131-151).  chip_wide = 0: one wavefront; 1: the sequence of chip-wide kernels the
+ * build uses for hub nodes.  Both give the oracle's row (tests/test_gpu_build.py). */
+int sdb_index_union_prune(sdb_index *ix, uint64_t id, uint64_t m, const uint64_t *extra_ids,
+                          int chip_wide, void *stream);
 /* Centroid ids that do not come from encode(): the k-means labels productQuantizer.Fit leaves on
  * its training points (product.go:216-218) and the codes a bucket holds under NodeKey(id,'q')
  * (productQuantizedPoint.ReadFrom / WriteTo, product.go:349-383).  ids [n] u64, codes [n][M] u8,

@@ -59,6 +59,7 @@ def lib():
     L.orc_index_insert.argtypes = [C.c_void_p, C.c_uint64, f32p]
     L.orc_index_load.argtypes = [C.c_void_p, C.c_uint64, u64p, f32p, u64p, u64p]
     L.orc_index_delete.argtypes = [C.c_void_p, u64p, C.c_uint64]
+    L.orc_index_union_prune.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_uint64]
     L.orc_index_size.restype = C.c_uint64
     L.orc_index_size.argtypes = [C.c_void_p]
     L.orc_index_num_edges.restype = C.c_uint64
@@ -169,6 +170,11 @@ class Index:
     def delete(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
         return lib().orc_index_delete(self._h, _p(ids, C.c_uint64), ids.size)
+
+    def union_prune(self, node_id, extra_ids):
+        """insert.go:47-58 over the node's neighbours + several candidates at once"""
+        ex = np.ascontiguousarray(extra_ids, dtype=np.uint64)
+        return lib().orc_index_union_prune(self._h, int(node_id), _p(ex, C.c_uint64), ex.size)
 
     def load(self, ids, vectors, offsets, edges):
         ids = np.ascontiguousarray(ids, dtype=np.uint64)

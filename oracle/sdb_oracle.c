@@ -845,6 +845,35 @@ static void prune_delete_neighbour(orc_index *ix, uint32_t a, const uint8_t *del
   free(cand), free(expand);
 }
 
+/* insert.go:47-58 for a node and SEVERAL new candidates at once: candidateSet.Add(node's neighbours...),
+ * Add(extra...) (Add dedupes, distset.go:203-211), Sort, robustPrune(node).  With one extra point this is the
+ * reference's rule for a full node; with several it is the grouped form the device build applies to a target
+ * that has several requests waiting in one round (DESIGN.md, K4 rounds), and what the delete path does when
+ * the start row overflows.  Distances are DistanceFromPoint(node). */
+int orc_index_union_prune(orc_index *ix, uint64_t id, const uint64_t *extra, uint64_t m) {
+  int64_t s = map_get(ix, id);
+  if (s < 0) return -1;
+  uint32_t node = (uint32_t)s;
+  distfn df;
+  bind_from_point(ix, node, &df);
+  distset c;
+  ds_init(&c, (int)(ix->deg[node] + m + 1), 0, NULL, &df);
+  uint32_t *slots = malloc(4 * (ix->deg[node] + m + 1));
+  memcpy(slots, ix->edges[node], 4 * ix->deg[node]);
+  ds_add(&c, slots, (int)ix->deg[node]);
+  uint64_t k = 0;
+  for (uint64_t i = 0; i < m; i++) {
+    int64_t e = map_get(ix, extra[i]);
+    if (e >= 0) slots[k++] = (uint32_t)e;
+  }
+  ds_add(&c, slots, (int)k);
+  ds_sort(&c);
+  robust_prune(ix, node, &c);
+  free(slots);
+  ds_free(&c);
+  return 0;
+}
+
 int orc_index_delete(orc_index *ix, const uint64_t *ids, uint64_t n) {
   if (ix->start_slot < 0) return -2;
   uint8_t *del = calloc(ix->n ? ix->n : 1, 1);

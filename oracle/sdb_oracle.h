@@ -80,6 +80,8 @@ int orc_index_insert(orc_index *ix, uint64_t id, const float *vec);
  * node, then the nodes are dropped.  Unknown ids are skipped (vamana.go:161-163); ids 0/1 are errors.  An
  * update (vamana.go:170-174,247-251) is this followed by orc_index_insert with the same id. */
 int orc_index_delete(orc_index *ix, const uint64_t *ids, uint64_t n);
+/* insert.go:47-58 over a node's neighbours + several new candidates at once (Add, Sort, robustPrune) */
+int orc_index_union_prune(orc_index *ix, uint64_t id, const uint64_t *extra, uint64_t m);
 
 /* Bulk load of an existing graph (what ItemCache would read from the bucket, node.go:96-111,
  * plain.go:125-141).  edges hold node ids; ids missing from `ids` are silently dropped the way

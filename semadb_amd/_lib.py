@@ -77,6 +77,7 @@ SIGNATURES = {
     "sdb_pq_sym_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
                                       C.c_void_p]),
     "sdb_index_attach_pq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdb_index_union_prune": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]),
     "sdb_index_set_codes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "sdb_index_get_codes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
 }

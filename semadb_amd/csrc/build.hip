@@ -46,6 +46,11 @@ struct BuildArgs {
   // 2^(32 - dcache_shift) entries, written by K2 (SearchArgs::dcache); NULL when not collected
   const uint2 *dcache;
   uint32_t dcache_shift;
+  // targets with at least big_min requests in this round are not handled by their k_backedges wave but listed
+  // (position of the first request, count, target, its degree) for the chip-wide prune (bigprune.inc)
+  uint32_t *big_count;
+  uint4 *big_list;
+  uint32_t big_min, big_cap;
 };
 
 constexpr int kQuantized = -2;  // value of the NG template parameter for a fitted product quantizer
@@ -451,6 +456,12 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
       nb == kNoSlot ? kNoKey : ((uint64_t)nb << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
 }
 
+}  // namespace sdb
+
+#include "bigprune.inc"
+
+namespace sdb {
+
 // One wavefront per sorted key; only the first key of each target B proceeds and applies B's requests
 // (insert.go:36-65).  Requests are taken in insert order, as many at a time as fit the candidate buffer
 // (kBackCap - degree): if they all fit under the degree bound they are appended (:62), otherwise B is
@@ -478,6 +489,13 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     const uint64_t kk = a.keys_sorted[pos + m];
     if (kk == kNoKey || (uint32_t)(kk >> 32) != b) break;
     m++;
+  }
+  if (a.big_count && m >= a.big_min) {  // a hub: the whole chip prunes it afterwards (bigprune.inc)
+    if (lane == 0) {
+      const uint32_t at = atomicAdd(a.big_count, 1u);
+      if (at < a.big_cap) a.big_list[at] = make_uint4((uint32_t)pos, (uint32_t)m, b, a.deg[b]);
+    }
+    return;
   }
   uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
   float rowd = a.adjdist[(size_t)b * kAdjStride + lane];  // cached distFn(B, edge), valid for lanes < dc
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
 
 template <int NG, bool L2>
 static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, size_t sort_tmp_bytes,
-                        int sort_end_bit) {
+                        int sort_end_bit, BigScratch *big) {
   const size_t lds1 = prune_lds_bytes(a.vis_cap, NG, a.ld);
   hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a);
   SDB_HIP(hipGetLastError());
@@ -602,25 +620,44 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   SDB_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp, a.keys_in, a.keys_sorted, (int)((size_t)a.nnew * 64), 0,
                                             sort_end_bit, stream));
   const size_t lds2 = prune_lds_bytes(kBackCap, NG, a.ld, NG >= 0);
+  if (a.big_count) SDB_HIP(hipMemsetAsync(a.big_count, 0, 4, stream));
   hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
   SDB_HIP(hipGetLastError());
+  if (a.big_count && (size_t)a.nnew * 64 >= a.big_min) {  // the hubs of this round, if any (bigprune.inc)
+    uint32_t nbig = 0;
+    SDB_HIP(hipMemcpyAsync(&nbig, a.big_count, 4, hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipStreamSynchronize(stream));
+    if (nbig > a.big_cap) return fail(SDB_ERR_DEVICE, "hub list overflow (%u > %u)", nbig, a.big_cap);
+    if (nbig) {
+      std::vector<uint4> list(nbig);
+      SDB_HIP(hipMemcpy(list.data(), a.big_list, (size_t)nbig * sizeof(uint4), hipMemcpyDeviceToHost));
+      std::sort(list.begin(), list.end(), [](const uint4 &x, const uint4 &y) { return x.x < y.x; });
+      for (const uint4 &e : list) {
+        const size_t pos = e.x;
+        const uint32_t deg = e.w;
+        SDB_TRY((big_prune<NG, L2>(a, e.z, deg + e.y, *big, stream, [&](const BigArgs &g, unsigned tb) {
+          hipLaunchKernelGGL(k_big_fill_round, dim3(tb), dim3(256), 0, stream, g, pos, deg);
+        })));
+      }
+    }
+  }
   return SDB_OK;
 }
 
 template <bool L2>
-static int launch_round_ng(const BuildArgs &a, hipStream_t s, void *t, size_t tb, int eb) {
+static int launch_round_ng(const BuildArgs &a, hipStream_t s, void *t, size_t tb, int eb, BigScratch *big) {
   switch (a.ng) {
-    case 0: return launch_round<0, L2>(a, s, t, tb, eb);
-    case 1: return launch_round<1, L2>(a, s, t, tb, eb);
-    case 2: return launch_round<2, L2>(a, s, t, tb, eb);
-    case 3: return launch_round<3, L2>(a, s, t, tb, eb);
-    case 4: return launch_round<4, L2>(a, s, t, tb, eb);
-    case 6: return launch_round<6, L2>(a, s, t, tb, eb);
-    case 8: return launch_round<8, L2>(a, s, t, tb, eb);
-    case 12: return launch_round<12, L2>(a, s, t, tb, eb);  // 1536
-    case 16: return launch_round<16, L2>(a, s, t, tb, eb);  // 2048
-    case 24: return launch_round<24, L2>(a, s, t, tb, eb);  // 3072
-    default: return launch_round<-1, L2>(a, s, t, tb, eb);
+    case 0: return launch_round<0, L2>(a, s, t, tb, eb, big);
+    case 1: return launch_round<1, L2>(a, s, t, tb, eb, big);
+    case 2: return launch_round<2, L2>(a, s, t, tb, eb, big);
+    case 3: return launch_round<3, L2>(a, s, t, tb, eb, big);
+    case 4: return launch_round<4, L2>(a, s, t, tb, eb, big);
+    case 6: return launch_round<6, L2>(a, s, t, tb, eb, big);
+    case 8: return launch_round<8, L2>(a, s, t, tb, eb, big);
+    case 12: return launch_round<12, L2>(a, s, t, tb, eb, big);  // 1536
+    case 16: return launch_round<16, L2>(a, s, t, tb, eb, big);  // 2048
+    case 24: return launch_round<24, L2>(a, s, t, tb, eb, big);  // 3072
+    default: return launch_round<-1, L2>(a, s, t, tb, eb, big);
   }
 }
 
@@ -754,6 +791,20 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_HIP(hipMalloc(&lut, (size_t)max_round * lut_row));
     cleanup.ptrs.push_back(lut);
   }
+  // hubs: targets with this many requests in one round go to the chip-wide prune (bigprune.inc)
+  uint32_t big_min = 512;
+  if (const char *e = getenv("SDB_BIG_MIN")) {  // test hook: exercise the path on small graphs
+    long v = atol(e);
+    if (v >= 2) big_min = (uint32_t)v;
+  }
+  const uint32_t big_cap = (uint32_t)((size_t)max_round * 64 / big_min + 2);
+  uint32_t *big_count = nullptr;
+  uint4 *big_list = nullptr;
+  SDB_HIP(hipMalloc(&big_count, 4));
+  cleanup.ptrs.push_back(big_count);
+  SDB_HIP(hipMalloc(&big_list, (size_t)big_cap * sizeof(uint4)));
+  cleanup.ptrs.push_back(big_list);
+  BigScratch big_scratch;
   // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
   constexpr uint32_t kDcacheBits = 13;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
   uint2 *dcache = nullptr;
@@ -802,9 +853,10 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.keys_in = keys_in, ba.keys_sorted = keys_sorted;
     if (pq) ba.pq_codes = ix->d_codes, ba.pq_cdists = pq->d_cdists, ba.pq_M = pq->M, ba.pq_K = pq->K;
     ba.dcache = dcache, ba.dcache_shift = 32 - kDcacheBits;
-    int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
-         : ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit)
-                                                  : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit);
+    ba.big_count = big_count, ba.big_list = big_list, ba.big_min = big_min, ba.big_cap = big_cap;
+    int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch)
+         : ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch)
+                                                  : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch);
     if (rc != SDB_OK) return rc;
     done += rs;
     ix->n = n0 + (uint32_t)done;

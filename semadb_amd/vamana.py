@@ -194,6 +194,11 @@ class IndexVamana:
         vectorstore.attach(self, pq, ids, codes)
         return True
 
+    def union_prune(self, node_id, extra_ids, chip_wide=False):
+        """insert.go:47-58 over the node's neighbours + several candidates at once (Add, Sort, robustPrune)"""
+        ex = np.ascontiguousarray(extra_ids, dtype=np.uint64)
+        check(lib().sdb_index_union_prune(self._h, int(node_id), ex.size, _buf.np_ptr(ex), 1 if chip_wide else 0, None))
+
     def exists(self, node_id):
         """vecStore.Exists (plain.go:21-24)"""
         q = np.zeros((1, self.parameters.VectorSize), dtype=np.float32)

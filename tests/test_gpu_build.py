@@ -132,3 +132,54 @@ def test_insert_id_rules(oracle):
     n_nodes, n_edges, max_id = ix.stats()
     assert n_nodes == 3 and max_id == 9
     ix.close()
+
+
+@pytest.mark.parametrize("chip_wide", [False, True])
+@pytest.mark.parametrize("metric,d,n,m,R", [("euclidean", 32, 700, 40, 16), ("cosine", 96, 900, 300, 32),
+                                           ("dot", 100, 2600, 2400, 32), ("cosine", 384, 1500, 1300, 64),
+                                           ("euclidean", 8, 1800, 1700, 8)])
+def test_union_prune_paths_match_oracle(oracle, chip_wide, metric, d, n, m, R):
+    """insert.go:47-58 over a node's neighbours + MANY new candidates at once (the rule a build round applies to
+    a target with several requests; the entry node of a big round gets thousands): the one-wavefront kernel and
+    the chip-wide kernel sequence (bigprune.inc) both give the oracle's row -- sort order with ties, the
+    degree-bound stop, self / duplicate / unknown candidates dropped like candidateSet.Add does."""
+    from semadb_amd import vamana
+    from tests.helpers import assert_same_graph
+    rng = np.random.default_rng(n + m)
+    base = unit_rows(rng, n, d) if d > 8 else rng.integers(0, 5, size=(n, d)).astype(np.float32)  # d = 8: ties
+    o = build_oracle_index(oracle, base, metric, R=R, L=max(25, R))
+    ids, vecs, off, edges = o.export()
+    g = vamana.NewIndexVamana("u", vamana.IndexVectorVamanaParameters(d, metric, max(25, R), R, 1.2), strict=False)
+    g.load(ids, vecs, off, edges)
+    for node in (1, int(ids[len(ids) // 2])):  # the start node and an ordinary one
+        extra = rng.choice(ids[1:], size=m, replace=False).astype(np.uint64)
+        extra = np.concatenate([extra, [node, 10 ** 9], extra[:5]]).astype(np.uint64)  # self, unknown, repeats
+        assert o.union_prune(node, extra) == 0
+        g.union_prune(node, extra, chip_wide=chip_wide)
+        assert_same_graph(g, o)
+    g.close()
+
+
+def test_hub_targets_through_the_build(oracle, monkeypatch):
+    """SDB_BIG_MIN = 3 sends every target with three or more requests in a round through the chip-wide prune:
+    the graph keeps the reference's invariants and the recall of the ordinary build."""
+    from semadb_amd import vamana
+    monkeypatch.setenv("SDB_BIG_MIN", "3")
+    rng = np.random.default_rng(77)
+    d, n = 48, 6000
+    base = unit_rows(rng, n, d)
+    g = vamana.NewIndexVamana("hub", vamana.IndexVectorVamanaParameters(d, "cosine", 50, 24, 1.2), strict=False)
+    g.set_start(unit_rows(np.random.default_rng(1), 1, d)[0])
+    g.insert_batch(None, base, round_size=512)
+    ids, vecs, off, edges = g.export()
+    deg = np.diff(off.astype(np.int64))
+    assert deg.max() <= 24 and len(ids) == n + 1
+    idset = set(int(v) for v in ids)
+    assert all(int(e) in idset for e in edges)
+    for i in range(len(ids)):  # no self loops, no duplicate edges
+        row = [int(e) for e in edges[int(off[i]):int(off[i + 1])]]
+        assert int(ids[i]) not in row and len(set(row)) == len(row)
+    q = base[:200]
+    got = g.search_batch(q, 1, 50)[0]
+    assert (got[:, 0] == np.arange(2, 202, dtype=np.uint64)).mean() > 0.97  # every point finds itself
+    g.close()
