@@ -183,3 +183,31 @@ def test_hub_targets_through_the_build(oracle, monkeypatch):
     got = g.search_batch(q, 1, 50)[0]
     assert (got[:, 0] == np.arange(2, 202, dtype=np.uint64)).mean() > 0.97  # every point finds itself
     g.close()
+
+
+@pytest.mark.parametrize("chip_wide", [False, True])
+def test_union_prune_on_a_quantized_store(oracle, chip_wide):
+    """the grouped rule with DistanceFromPoint = centroid-pair sums (product.go:279-305), both device forms"""
+    from semadb_amd import vamana, vectorstore as vs
+    from tests.helpers import assert_same_graph
+    rng = np.random.default_rng(404)
+    d, n, M, K, R = 32, 1500, 8, 16, 24
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, "euclidean", R=R, L=30)
+    ids, vecs, off, edges = o.export()
+    first = rng.integers(0, 500, M)
+    opq = oracle.PQ(d, "euclidean", M, K)
+    opq.fit(vecs[1:501].copy(), first, alias=True)
+    assert o.attach_pq(opq, np.stack([opq.encode(v) for v in vecs])) == 0
+    g = vamana.NewIndexVamana("uq", vamana.IndexVectorVamanaParameters(d, "euclidean", 30, R, 1.2), strict=False)
+    g.load(ids, vecs, off, edges)
+    gpq = vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(vecs[1:501].copy(), first, alias=True)
+    vs.attach(g, gpq)
+    for node in (1, int(ids[700])):
+        extra = rng.choice(ids[1:], size=1200, replace=False).astype(np.uint64)
+        assert o.union_prune(node, extra) == 0
+        g.union_prune(node, extra, chip_wide=chip_wide)
+        assert_same_graph(g, o)
+    g.close()
+    gpq.close()
