@@ -33,12 +33,14 @@ def current_stream(mem):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def empty_like_mem(mem, shape, dtype, device_index=0):
-    """dtype: numpy dtype name ('float32', 'uint64', 'uint32', 'uint8')."""
+def empty_like_mem(mem, shape, dtype, device_index=0, zero=False):
+    """dtype: numpy dtype name ('float32', 'uint64', 'uint32', 'uint8').  Device buffers are NOT cleared unless
+    `zero`: every kernel that fills them writes every element (short result rows are zero-padded by the kernel),
+    and a fill kernel per output would cost more launch time than it is worth next to a 1 ms search."""
     if mem == MEM_DEVICE:
         import torch
         tdt = {"float32": torch.float32, "uint64": torch.int64, "uint32": torch.int32, "uint8": torch.uint8}[dtype]
-        t = torch.zeros(shape, dtype=tdt, device="cuda:%d" % device_index)
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=tdt, device="cuda:%d" % device_index)
         return t, C.c_void_p(t.data_ptr())
     a = np.zeros(shape, dtype=dtype)
     return a, C.c_void_p(a.ctypes.data)

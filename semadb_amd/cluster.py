@@ -88,7 +88,8 @@ class PackedTopK:
         import torch
         self.nq, self.per = nq, per_shard
         self.b_ids, self.b_d, self.b_c = nq * per_shard * 8, nq * per_shard * 4, nq * 4
-        self.buf = torch.zeros(self.b_ids + self.b_d + self.b_c, dtype=torch.uint8, device=device)
+        # not cleared: the search kernel writes every element (short rows are zero-padded by the kernel)
+        self.buf = torch.empty(self.b_ids + self.b_d + self.b_c, dtype=torch.uint8, device=device)
         self.ids = self.buf[:self.b_ids].view(torch.int64).view(nq, per_shard)
         self.dists = self.buf[self.b_ids:self.b_ids + self.b_d].view(torch.float32).view(nq, per_shard)
         self.counts = self.buf[self.b_ids + self.b_d:].view(torch.int32)

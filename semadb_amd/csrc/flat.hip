@@ -153,6 +153,9 @@ __global__ void k_flat_emit(const uint32_t *__restrict__ top_slot, const float *
     if (i < len) {
       out_ids[(size_t)q * limit + i] = ids[top_slot[(size_t)q * 128 + i]];
       out_dists[(size_t)q * limit + i] = top_dist[(size_t)q * 128 + i];
+    } else {  // short rows end in zeros
+      out_ids[(size_t)q * limit + i] = 0;
+      out_dists[(size_t)q * limit + i] = 0.0f;
     }
   }
   if (threadIdx.x == 0) out_counts[q] = len;

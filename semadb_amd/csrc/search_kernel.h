@@ -870,7 +870,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       }
       base += __popcll(m);
     }
-    if (lane == 0) a.out_counts[q] = (uint32_t)(base < (int)a.limit ? base : (int)a.limit);
+    const int got = base < (int)a.limit ? base : (int)a.limit;
+    if (lane == 0) a.out_counts[q] = (uint32_t)got;
+    for (int i = got + lane; i < (int)a.limit; i += 64)  // rows shorter than `limit` end in zeros, not in
+      a.out_ids[(size_t)q * a.limit + i] = 0, a.out_dists[(size_t)q * a.limit + i] = 0.0f;  // whatever was there
   }
   if (lane == 0) {
     if (a.tr_ndist) a.tr_ndist[q] = n_dist;

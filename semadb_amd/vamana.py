@@ -263,7 +263,7 @@ class IndexVamana:
             ne, nep = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
             vis, visp = (None, None)
             if visit_cap:
-                vis, visp = _buf.empty_like_mem(mem, (nq, visit_cap), "uint64", self.device)
+                vis, visp = _buf.empty_like_mem(mem, (nq, visit_cap), "uint64", self.device, zero=True)
             tr_struct = SearchTrace(ndp, nhp, nep, visp, visit_cap)
             tr_out = BatchTrace(nd, nh, ne, vis)
         check(lib().sdb_index_search_batch(self._h, nq, qp, limit, search_size, _buf.np_ptr(f_off),
