@@ -60,6 +60,7 @@ def lib():
     L.orc_index_load.argtypes = [C.c_void_p, C.c_uint64, u64p, f32p, u64p, u64p]
     L.orc_index_delete.argtypes = [C.c_void_p, u64p, C.c_uint64]
     L.orc_index_union_prune.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_uint64]
+    L.orc_index_insert_round.argtypes = [C.c_void_p, u64p, f32p, C.c_int, C.c_int, C.c_int]
     L.orc_index_size.restype = C.c_uint64
     L.orc_index_size.argtypes = [C.c_void_p]
     L.orc_index_num_edges.restype = C.c_uint64
@@ -171,6 +172,25 @@ class Index:
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
         return lib().orc_index_delete(self._h, _p(ids, C.c_uint64), ids.size)
 
+    def insert_rounds(self, ids, vecs, round_size=0, group_cap=256, big_min=512):
+        """The device's batched build schedule (build.hip): rounds of at most 2 % of the nodes already in the
+        graph (and at most round_size, 0 = 16384), each applied by orc_index_insert_round."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        vecs = _f32(vecs)
+        n = ids.size
+        max_round = min(round_size if round_size else 16384, n)
+        done = 0
+        while done < n:
+            cur = self.n_slots()
+            rs = max(1, int(float(cur) * 0.02))
+            rs = min(rs, max_round, n - done)
+            rc = lib().orc_index_insert_round(self._h, _p(ids[done:done + rs], C.c_uint64),
+                                              _p(vecs[done:done + rs], C.c_float), rs, group_cap, big_min)
+            if rc:
+                return rc
+            done += rs
+        return 0
+
     def union_prune(self, node_id, extra_ids):
         """insert.go:47-58 over the node's neighbours + several candidates at once"""
         ex = np.ascontiguousarray(extra_ids, dtype=np.uint64)
@@ -187,6 +207,10 @@ class Index:
     @property
     def size(self):
         return int(lib().orc_index_size(self._h))
+
+    def n_slots(self):
+        """rows in storage (no deletes assumed by the callers that use this: equals size())"""
+        return self.size
 
     def export(self, with_vectors=True):
         n, ne = self.size, int(lib().orc_index_num_edges(self._h))

@@ -874,6 +874,83 @@ int orc_index_union_prune(orc_index *ix, uint64_t id, const uint64_t *extra, uin
   return 0;
 }
 
+/* One build round of the device schedule (semadb_amd/csrc/build.hip; DESIGN.md "K4 rounds"), restated so that
+ * the batched build -- the one the bench uses -- can be held to the oracle edge for edge, not only the
+ * sequential one.  The reference itself runs NumCPU-1 insertSinglePoint workers concurrently (vamana.go:190-196),
+ * so any deterministic interleaving is a legitimate schedule; this is the device's:
+ *   1. all rs points are stored (unreachable) and search the SAME snapshot (insert.go:22);
+ *   2. each prunes its own visit list (insert.go:29-31);
+ *   3. the back-edge requests are applied per target in insert order: a target with >= big_min requests takes
+ *      all of them in one candidateSet.Add(neighbours, points).Sort().robustPrune; otherwise requests are taken
+ *      as many at a time as fit a buffer of group_cap candidates -- appended when they all fit under the degree
+ *      bound (insert.go:62), else one Add/Sort/robustPrune over neighbours + that group (insert.go:47-58). */
+int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs, int rs, int group_cap, int big_min) {
+  if (ix->start_slot < 0) return -2;
+  uint32_t first = (uint32_t)ix->n;
+  for (int i = 0; i < rs; i++) {
+    if (ids[i] == ORC_STARTID || ids[i] == 0) return -3;
+    if (map_get(ix, ids[i]) >= 0) return -4;
+    index_add_node(ix, ids[i], vecs + (size_t)i * ix->dim);
+  }
+  /* 1. searches on the snapshot: nothing below this loop has run yet, and the new nodes have no in-edges */
+  distset *vs = calloc((size_t)rs, sizeof(distset));
+  for (int i = 0; i < rs; i++) {
+    distfn df;
+    float *lut;
+    bind_from_float(ix, ix->vectors + (size_t)(first + i) * ix->dim, &df, &lut);
+    distset ss, rsd, *res;
+    int rc = greedy_search(ix, &df, 1, ix->L, NULL, 0, NULL, NULL, &ss, &rsd, &res, &vs[i], NULL, 0, NULL);
+    ds_free(&ss);
+    free(lut);
+    if (rc) return rc;
+    vs[i].df = NULL;
+  }
+  /* 2. robustPrune of every new node over its own visit list */
+  for (int i = 0; i < rs; i++) robust_prune(ix, first + (uint32_t)i, &vs[i]);
+  for (int i = 0; i < rs; i++) ds_free(&vs[i]);
+  free(vs);
+  /* 3. requests grouped by target, insert order inside a target */
+  size_t nreq = 0;
+  for (int i = 0; i < rs; i++) nreq += ix->deg[first + i];
+  uint64_t *req = malloc(8 * (nreq ? nreq : 1)); /* target << 32 | a_idx */
+  size_t k = 0;
+  for (int i = 0; i < rs; i++)
+    for (uint32_t e = 0; e < ix->deg[first + i]; e++) req[k++] = ((uint64_t)ix->edges[first + i][e] << 32) | (uint32_t)i;
+  for (size_t i = 1; i < nreq; i++) { /* insertion sort is fine for the sizes the tests use; stable */
+    uint64_t v = req[i];
+    size_t j = i;
+    while (j > 0 && req[j - 1] > v) req[j] = req[j - 1], j--;
+    req[j] = v;
+  }
+  size_t p = 0;
+  uint64_t *grp = malloc(8 * (nreq ? nreq : 1));
+  while (p < nreq) {
+    uint32_t b = (uint32_t)(req[p] >> 32);
+    size_t m = 1;
+    while (p + m < nreq && (uint32_t)(req[p + m] >> 32) == b) m++;
+    size_t done = 0;
+    if ((int)m >= big_min) { /* hub: everything at once */
+      for (size_t r = 0; r < m; r++) grp[r] = ix->ids[first + (uint32_t)(req[p + r] & 0xFFFFFFFFu)];
+      orc_index_union_prune(ix, ix->ids[b], grp, m);
+      done = m;
+    }
+    while (done < m) {
+      size_t t = m - done;
+      if (t > (size_t)group_cap - ix->deg[b]) t = (size_t)group_cap - ix->deg[b];
+      if ((int)(ix->deg[b] + t) <= ix->R) {
+        for (size_t r = 0; r < t; r++) node_add_neighbour(ix, b, first + (uint32_t)(req[p + done + r] & 0xFFFFFFFFu));
+      } else {
+        for (size_t r = 0; r < t; r++) grp[r] = ix->ids[first + (uint32_t)(req[p + done + r] & 0xFFFFFFFFu)];
+        orc_index_union_prune(ix, ix->ids[b], grp, t);
+      }
+      done += t;
+    }
+    p += m;
+  }
+  free(req), free(grp);
+  return 0;
+}
+
 int orc_index_delete(orc_index *ix, const uint64_t *ids, uint64_t n) {
   if (ix->start_slot < 0) return -2;
   uint8_t *del = calloc(ix->n ? ix->n : 1, 1);

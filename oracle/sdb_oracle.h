@@ -82,6 +82,8 @@ int orc_index_insert(orc_index *ix, uint64_t id, const float *vec);
 int orc_index_delete(orc_index *ix, const uint64_t *ids, uint64_t n);
 /* insert.go:47-58 over a node's neighbours + several new candidates at once (Add, Sort, robustPrune) */
 int orc_index_union_prune(orc_index *ix, uint64_t id, const uint64_t *extra, uint64_t m);
+/* one round of the device's batched build schedule (see the .c file) */
+int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs, int rs, int group_cap, int big_min);
 
 /* Bulk load of an existing graph (what ItemCache would read from the bucket, node.go:96-111,
  * plain.go:125-141).  edges hold node ids; ids missing from `ids` are silently dropped the way

@@ -211,3 +211,49 @@ def test_union_prune_on_a_quantized_store(oracle, chip_wide):
         assert_same_graph(g, o)
     g.close()
     gpq.close()
+
+
+@pytest.mark.parametrize("metric,d,n,R,L", [("cosine", 48, 6000, 24, 40), ("euclidean", 128, 3000, 64, 75),
+                                           ("dot", 33, 4000, 12, 30)])
+def test_sequential_build_identical_to_oracle_larger(oracle, metric, d, n, R, L):
+    """thousands of sequential inserts: rows fill up, so almost every back-edge goes through the re-prune with
+    its distance caches, the search-time distance table and the few-new-candidates decision -- and the graph is
+    still the oracle's, edge for edge"""
+    from tests.helpers import assert_same_graph
+    rng = np.random.default_rng(d * n)
+    lat = rng.standard_normal((10, d)).astype(np.float32)
+    base = rng.standard_normal((n, 10)).astype(np.float32) @ lat + 0.1 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    o = build_oracle_index(oracle, base, metric, R=R, L=L, seed=31)
+    ix = _new_gpu(d, metric, R, L)
+    ix.set_start(start_vector(np.random.default_rng(31), d))
+    ix.insert_batch(np.arange(2, n + 2, dtype=np.uint64), base, round_size=1)
+    assert_same_graph(ix, o)
+    ix.close()
+
+
+@pytest.mark.parametrize("metric,d,n,R,L,round_size,big_min", [("cosine", 48, 5000, 24, 40, 0, 512),
+                                                              ("euclidean", 32, 4000, 16, 30, 64, 512),
+                                                              ("cosine", 64, 6000, 32, 50, 0, 3),
+                                                              ("dot", 24, 3000, 8, 25, 200, 2)])
+def test_batched_build_identical_to_oracle_schedule(oracle, monkeypatch, metric, d, n, R, L, round_size, big_min):
+    """The batched build (rounds of up to 2 % of the graph: the form the bench and bulk loads use) against the
+    oracle's restatement of the SAME schedule -- snapshot searches, own prunes, back-edge requests per target in
+    insert order, grouped, hubs all at once (oracle/sdb_oracle.c orc_index_insert_round): the graphs are equal
+    edge for edge.  big_min 2 / 3 sends nearly every multi-request target through the chip-wide hub prune."""
+    from tests.helpers import assert_same_graph
+    monkeypatch.setenv("SDB_BIG_MIN", str(big_min))
+    rng = np.random.default_rng(d + n + big_min)
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    base = rng.standard_normal((n, 8)).astype(np.float32) @ lat + 0.15 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    sv = start_vector(np.random.default_rng(3), d)
+    o = oracle.Index(d, metric, R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    assert o.insert_rounds(ids, base, round_size=round_size, big_min=big_min) == 0
+    ix = _new_gpu(d, metric, R, L)
+    ix.set_start(sv)
+    ix.insert_batch(ids, base, round_size=round_size)
+    assert_same_graph(ix, o)
+    ix.close()
