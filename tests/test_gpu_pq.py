@@ -243,3 +243,30 @@ def test_fit_trigger_matches_oracle(oracle):
         o_ids, o_d, _, _ = o.search(qs[k], 5, 30)
         assert np.array_equal(g_ids[k, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d))
     ix.close()
+
+
+def test_batched_insert_into_quantized_store_matches_oracle_schedule(oracle, monkeypatch):
+    """rounds of inserts into a store with a fitted quantizer (LUT searches, centroid-pair prunes, hub path on)
+    against the oracle's restatement of the same round schedule: equal graphs, equal codes"""
+    from semadb_amd import vamana, vectorstore as vs
+    monkeypatch.setenv("SDB_BIG_MIN", "4")
+    rng = np.random.default_rng(808)
+    d, M, K, R, L = 32, 8, 16, 16, 30
+    base = unit_rows(rng, 4000, d)
+    o = build_oracle_index(oracle, base[:1200], "euclidean", R=R, L=L)
+    ids, vecs, off, edges = o.export()
+    first = rng.integers(0, 800, M)
+    opq = oracle.PQ(d, "euclidean", M, K)
+    opq.fit(vecs[1:801].copy(), first, alias=True)
+    assert o.attach_pq(opq, np.stack([opq.encode(v) for v in vecs])) == 0
+    g = vamana.NewIndexVamana("bq", vamana.IndexVectorVamanaParameters(d, "euclidean", L, R, 1.2), strict=False)
+    g.load(ids, vecs, off, edges)
+    gpq = vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(vecs[1:801].copy(), first, alias=True)
+    vs.attach(g, gpq)
+    new_ids = np.arange(1202, 1202 + 2800, dtype=np.uint64)
+    assert o.insert_rounds(new_ids, base[1200:], round_size=0, big_min=4) == 0
+    g.insert_batch(new_ids, base[1200:], round_size=0)
+    assert_same_graph(g, o)
+    g.close()
+    gpq.close()
