@@ -67,9 +67,30 @@ def pq():
                         X_after_bits=xa.view(np.uint32), queries=qv, lut_bits=lut.view(np.uint32))
 
 
+def batched_build():
+    """the device's round schedule (build.hip), restated by orc_index_insert_round: graphs for the default hub
+    threshold and for one that sends nearly every multi-request target through the hub rule"""
+    from tests.helpers import start_vector
+    rng = np.random.default_rng(77)
+    n, d, R, L = 3000, 32, 16, 30
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    base = rng.standard_normal((n, 8)).astype(np.float32) @ lat + 0.15 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    sv = start_vector(np.random.default_rng(3), d)
+    out = {"base": base, "start": sv, "params": np.array([d, R, L], np.int64), "metric": np.array("cosine")}
+    for big_min in (512, 3):
+        o = orc.Index(d, "cosine", R, L, 1.2)
+        o.set_start(sv)
+        assert o.insert_rounds(np.arange(2, n + 2, dtype=np.uint64), base, round_size=0, big_min=big_min) == 0
+        ids, _, off, edges = o.export(with_vectors=False)
+        out["off_%d" % big_min], out["edges_%d" % big_min] = off.astype(np.uint32), edges.astype(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "batched_build_3000x32_cosine.npz"), **out)
+
+
 if __name__ == "__main__":
     distances()
     vamana("vamana_2000x32_cosine.npz", 2000, 32, "cosine", 32, 50, 24, 10, 11)
     vamana("vamana_1500x128_euclidean.npz", 1500, 128, "euclidean", 64, 75, 16, 10, 12)
     pq()
+    batched_build()
     print("golden fixtures written to", HERE)
