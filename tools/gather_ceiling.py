@@ -17,9 +17,14 @@ lib.gather_probe.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, 
 dev = "cuda:0"
 out = {}
 sink = torch.zeros(1 << 20, device=dev)
-for d, n in ((384, 1000000), (768, 1000000), (128, 2000000)):
+shapes = ((384, 1000000), (768, 1000000), (128, 2000000))
+if len(sys.argv) > 1 and sys.argv[1] == "--big":  # the C5-rank and C4 slabs: how far the ceiling itself falls with size
+    shapes = ((384, 4000000), (384, 12500000), (768, 10000000))
+for d, n in shapes:
     ng = d // 128
-    slab = torch.randn(n, d, device=dev)
+    slab = torch.empty(n, d, device=dev)
+    for i in range(0, n, 1000000):
+        slab[i:i + 1000000].normal_()
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
     res = {}
