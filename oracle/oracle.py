@@ -38,8 +38,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_SO)
+    # SDB_ORACLE_LIB: a sanitizer build of the same source (make -C oracle asan; run pytest with libasan preloaded)
+    L = C.CDLL(os.environ.get("SDB_ORACLE_LIB") or build())
     f32p, u64p, i32p, u8p = (C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_int),
                              C.POINTER(C.c_uint8))
     L.orc_dot.restype = C.c_float
