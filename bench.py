@@ -113,7 +113,9 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = "cuda:%d" % dev_index
-    use_dist = world > 1
+    # BENCH_FORCE_EXCHANGE=1: take the N > 1 code path (RCCL all-gather on the exchange stream + merge) with a
+    # single rank, so the real RCCL calls can be exercised on a 1-GPU box.  The driver never sets it.
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_EXCHANGE") == "1"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
