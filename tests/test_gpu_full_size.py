@@ -187,6 +187,47 @@ def test_c2_oracle_walks_the_same_path(c2, oracle):
         assert np.array_equal(vis[i, :o_tr.n_hop], o_vis), "query %d visit order" % i
 
 
+def test_c5_two_shards_merge(c2, oracle):
+    """C5's shape on one GPU: two 1M-row shards, every shard answers every query (actions.go:316-351), the merged
+    top-k equals the oracle's restatement of actions.go:357-376 and recalls the exact top-k of the union"""
+    import torch
+    from semadb_amd import cluster, flat, vamana
+    bench = _bench()
+    base1 = bench.gen_rows(c2.n, c2.d, 20250620 + 1, "latent:24", "cuda:0")  # shard r = seed 20250620 + r
+    ix1 = vamana.NewIndexVamana("s1", vamana.IndexVectorVamanaParameters(c2.d, "cosine", L, R, 1.2), capacity=c2.n + 1)
+    ix1.set_start(bench.start_vector(c2.d))
+    ix1.insert_batch(None, base1)
+    q = c2.queries[:1024]
+    per = cluster.shard_limit(K, 2, 75)
+    assert per == oracle.shard_limit(K, 2, 75) == 10
+    parts = [ix.search_batch(q, per, L)[:3] for ix in (c2.ix, ix1)]
+    g_ids = torch.stack([p[0] for p in parts])
+    g_d = torch.stack([p[1] for p in parts])
+    g_c = torch.stack([p[2] for p in parts])
+    m_ids, m_d, m_s, m_c = cluster.topk_merge(g_ids, g_d, g_c, K)
+    torch.cuda.synchronize()
+    m_ids, m_d, m_s = m_ids.cpu().numpy().view(np.uint64), m_d.cpu().numpy(), m_s.cpu().numpy()
+    h_ids, h_d, h_c = g_ids.cpu().numpy().view(np.uint64), g_d.cpu().numpy(), g_c.cpu().numpy()
+    assert (m_c.cpu().numpy() == K).all() and (np.diff(m_d, axis=1) >= 0).all()
+    for i in range(1024):
+        o_ids, o_d, o_s = oracle.cluster_merge(h_ids[:, i], h_d[:, i], h_c[:, i], K)
+        assert np.array_equal(bits(o_d), bits(m_d[i]))
+        if np.unique(o_d).size == o_d.size:  # the reference's sort is unstable on ties
+            assert np.array_equal(o_ids, m_ids[i]) and np.array_equal(o_s, m_s[i])
+    # recall of the merged answer against the exact scan of both shards
+    truth = []
+    for r, ix in enumerate((c2.ix, ix1)):
+        f_ids, f_d, _ = flat.flat_search_batch(ix._h, c2.d, q, K, device=0)
+        truth.append((f_d.cpu().numpy(), f_ids.cpu().numpy().view(np.uint64) + (np.uint64(r) << np.uint64(40))))
+    td = np.concatenate([t[0] for t in truth], 1)
+    ti = np.concatenate([t[1] for t in truth], 1)
+    sel = np.argsort(td, axis=1, kind="stable")[:, :K]
+    want = np.take_along_axis(ti, sel, 1)
+    got = m_ids + (m_s.astype(np.uint64) << np.uint64(40))
+    assert (got[:, :, None] == want[:, None, :]).any(2).mean() >= 0.95
+    ix1.close()
+
+
 # ---- C4: 10M x 768 + product quantizer -----------------------------------------------------------
 
 @pytest.fixture(scope="module")
