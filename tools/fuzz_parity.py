@@ -1,0 +1,251 @@
+"""Randomised differential run: device path (through the C ABI) against the oracle over randomly drawn shapes,
+metrics, parameters and operation sequences -- a soak beyond the fixed cases of tests/.  Every trial builds the
+same index on both sides (sequentially or in the batched round schedule), applies deletes / updates, optionally
+switches the store to a product quantizer, and after every stage compares the exported graphs edge for edge and
+a batch of searches (plain and filtered) id for id, distance bit for distance bit, visit for visit.
+
+  python tools/fuzz_parity.py --trials 200 --seed 1      (prints one JSON line; exit code 1 on the first mismatch)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle import oracle as orc
+from semadb_amd import vamana, vectorstore as vs
+from tests.helpers import assert_same_graph, bits, start_vector
+
+DIMS = [1, 2, 3, 7, 16, 24, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128, 130, 160, 200, 256, 300, 384, 385, 512, 640, 768,
+        784, 1024, 1280, 1536]
+METRICS = ["euclidean", "cosine", "dot"]
+
+
+def draw_rows(rng, n, d, kind):
+    if kind == "grid":  # many equal distances
+        return rng.integers(0, 3, size=(n, d)).astype(np.float32)
+    if kind == "dups":  # repeated points
+        pool = rng.standard_normal((max(2, n // 3), d)).astype(np.float32)
+        return pool[rng.integers(0, pool.shape[0], n)].copy()
+    if kind == "latent":
+        k = max(1, min(8, d))
+        x = rng.standard_normal((n, k)).astype(np.float32) @ rng.standard_normal((k, d)).astype(np.float32)
+        x += 0.15 * rng.standard_normal((n, d)).astype(np.float32)
+    else:
+        x = rng.standard_normal((n, d)).astype(np.float32)
+    nrm = np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    return (x / np.maximum(nrm, np.float32(1e-20))).astype(np.float32)
+
+
+def compare_searches(rng, g, o, d, kind, L, live, tag):
+    nq = 12
+    q = draw_rows(rng, nq, d, kind)
+    k = int(rng.integers(1, L + 1))
+    sl = int(rng.integers(max(k, 1), 2 * L + 1))
+    ids_g, d_g, c_g, tr = g.search_batch(q, k, sl, trace=True, visit_cap=2048)
+    for i in range(nq):
+        o_ids, o_d, o_vis, o_tr = o.search(q[i], k, sl)
+        assert int(c_g[i]) == len(o_ids), (tag, "count", i)
+        assert np.array_equal(ids_g[i, :len(o_ids)], o_ids), (tag, "ids", i)
+        assert np.array_equal(bits(d_g[i, :len(o_ids)]), bits(o_d)), (tag, "dist bits", i)
+        assert int(tr.n_dist[i]) == o_tr.n_dist and int(tr.n_hop[i]) == o_tr.n_hop, (tag, "counters", i)
+        assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), (tag, "visit order", i)
+    if len(live) >= 4:
+        filters = []
+        for i in range(nq):
+            m = int(rng.integers(0, min(len(live), 3 * L) + 1))
+            f = set(int(v) for v in rng.choice(live, size=m, replace=False)) if m else set()
+            if i % 4 == 1:
+                f |= {1, 10 ** 9 + i}  # the start id and an unknown id
+            filters.append(f)
+        ids_g, d_g, c_g, tr = g.search_batch(q, k, sl, filters=filters, trace=True, visit_cap=2048)
+        for i in range(nq):
+            o_ids, o_d, o_vis, o_tr = o.search(q[i], k, sl, filter_ids=sorted(filters[i]))
+            assert int(c_g[i]) == len(o_ids), (tag, "filtered count", i)
+            assert np.array_equal(ids_g[i, :len(o_ids)], o_ids), (tag, "filtered ids", i)
+            assert np.array_equal(bits(d_g[i, :len(o_ids)]), bits(o_d)), (tag, "filtered dist bits", i)
+            assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), (tag, "filtered visit order", i)
+
+
+CURRENT = {}
+
+
+class StartOverflow(Exception):
+    pass
+
+
+def explain(g, o, tag):
+    o_ids, _, o_off, o_e = o.export(with_vectors=False)
+    g_ids, _, g_off, g_e = g.export(with_vectors=False)
+    if not np.array_equal(g_ids, o_ids):
+        print(tag, ": id lists differ", len(g_ids), len(o_ids))
+        return
+    bad = [(int(o_ids[i]), g_e[g_off[i]:g_off[i + 1]].tolist(), o_e[o_off[i]:o_off[i + 1]].tolist())
+           for i in range(len(o_ids)) if not np.array_equal(g_e[g_off[i]:g_off[i + 1]], o_e[o_off[i]:o_off[i + 1]])]
+    print(tag, ": nodes differing", len(bad), "of", len(o_ids))
+    for b in bad[:4]:
+        print("   node %d\n     device %s\n     oracle %s" % b)
+
+
+def overflow_check(o):
+    if os.environ.get("FUZZ_SKIP_START_OVERFLOW"):
+        ids, _, off, _ = o.export(with_vectors=False)
+        if int(off[1] - off[0]) > 64:
+            raise StartOverflow()
+
+
+def check_graph(g, o):
+    overflow_check(o)
+    assert_same_graph(g, o)
+
+
+def trial(rng, t):
+    d = int(rng.choice(DIMS))
+    metric = str(rng.choice(METRICS))
+    kind = str(rng.choice(["unit", "latent", "grid", "dups"], p=[0.35, 0.35, 0.15, 0.15]))
+    R = int(rng.integers(4, 65))
+    L = int(rng.integers(max(R // 2, 5), 101))
+    alpha = float(rng.choice([1.0, 1.1, 1.2, 1.5]))
+    budget = 250000  # rows * dim, keeps the oracle's sequential build in seconds
+    n = int(rng.integers(50, max(60, min(3000, budget // d))))
+    batched = bool(rng.integers(0, 2))
+    big_min = int(rng.choice([2, 3, 8, 512]))
+    round_size = int(rng.choice([0, 0, 17, 64, 300]))
+    desc = dict(trial=t, d=d, metric=metric, kind=kind, R=R, L=L, alpha=alpha, n=n, batched=batched,
+                big_min=big_min, round_size=round_size)
+    CURRENT.clear()
+    CURRENT.update(desc)
+    os.environ["SDB_BIG_MIN"] = str(big_min)
+    impl = orc.IMPL_AVX2 if orc.has_avx2() else orc.IMPL_ASM
+    sv = start_vector(np.random.default_rng(int(rng.integers(1 << 30))), d)
+    o = orc.Index(d, metric, R, L, alpha, impl=impl)
+    o.set_start(sv)
+    g = vamana.NewIndexVamana("fz", vamana.IndexVectorVamanaParameters(d, metric, L, R, alpha), strict=False)
+    g.set_start(sv)
+    try:
+        base = draw_rows(rng, n, d, kind)
+        ids = np.arange(2, n + 2, dtype=np.uint64)
+        if batched:
+            assert o.insert_rounds(ids, base, round_size=round_size, big_min=big_min) == 0
+            g.insert_batch(ids, base, round_size=round_size)
+        else:
+            for i in range(n):
+                assert o.insert(int(ids[i]), base[i]) == 0
+            g.insert_batch(ids, base, round_size=1)
+        check_graph(g, o)
+        live = [int(v) for v in ids]
+        compare_searches(rng, g, o, d, kind, L, live, "after build")
+        quantized = False
+        for step in range(int(rng.integers(1, 4))):
+            if not quantized and d >= 4 and rng.integers(0, 3) == 0:
+                M = int(rng.choice([m for m in (2, 4, 8, 16) if d % m == 0] or [0]))
+                if M:
+                    Kc = int(rng.choice([4, 16, 64, 256]))
+                    o_ids, vecs, _, _ = o.export()
+                    if len(o_ids) > Kc:
+                        first = rng.integers(0, len(o_ids), M)
+                        opq = orc.PQ(d, metric, M, Kc)
+                        codes = opq.fit(vecs.copy(), first, alias=True)
+                        assert o.attach_pq(opq, codes) == 0
+                        gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(Kc, M), d)
+                        gcodes = gpq.Fit(vecs.copy(), first, alias=True)
+                        assert np.array_equal(gcodes, codes), "fit codes"
+                        vs.attach(g, gpq, o_ids, gcodes)
+                        quantized = True
+                        desc["pq"] = CURRENT["pq"] = [M, Kc]
+                        compare_searches(rng, g, o, d, kind, L, live, "after attach")
+            n_del = int(rng.integers(0, max(1, len(live) // 4)))
+            dels = [int(v) for v in rng.choice(live, size=n_del, replace=False)] if n_del else []
+            rest = [v for v in live if v not in set(dels)]
+            n_upd = int(rng.integers(0, min(10, len(rest)) + 1)) if rest else 0
+            upds = [int(v) for v in rng.choice(rest, size=n_upd, replace=False)] if n_upd else []
+            upd_vecs = draw_rows(rng, max(n_upd, 1), d, kind)
+            n_ins = int(rng.integers(0, 40))
+            new_vecs = draw_rows(rng, max(n_ins, 1), d, kind)
+            reuse = bool(dels) and bool(rng.integers(0, 2))
+            if reuse:
+                # freed ids come back, as the shard's id counter hands them out (idcounter.go:75-84): the deletes
+                # are their own batch, the inserts that re-use the ids follow
+                g.InsertUpdateDelete([vamana.IndexVectorChange(i, None) for i in dels], round_size=1)
+                assert o.delete(np.array(dels, dtype=np.uint64)) == 0
+                CURRENT["stage"] = "step %d: deletes ahead of id re-use (%d)" % (step, len(dels))
+                check_graph(g, o)
+                live = [v for v in live if v not in set(dels)]
+                new_ids = dels[:n_ins]
+                dels = []
+            else:
+                new_ids = []
+            first_new = max(live + new_ids + dels + [1]) + 1 + int(rng.integers(0, 3))
+            new_ids = new_ids + list(range(first_new, first_new + n_ins - len(new_ids)))
+            ch = [vamana.IndexVectorChange(i, new_vecs[k]) for k, i in enumerate(new_ids)]
+            ch += [vamana.IndexVectorChange(i, None) for i in dels]
+            ch += [vamana.IndexVectorChange(i, upd_vecs[k]) for k, i in enumerate(upds)]
+            CURRENT["stage"] = "step %d: %d inserts (%s), %d deletes, %d updates" % (
+                step, len(new_ids), "re-used ids" if reuse else "fresh ids", len(dels), len(upds))
+            if os.environ.get("FUZZ_SPLIT"):  # debugging aid: the same three phases as separate calls, checked one by one
+                if new_ids:
+                    g.insert_batch(np.array(new_ids, dtype=np.uint64), new_vecs[:len(new_ids)], round_size=1)
+                for k, i in enumerate(new_ids):
+                    assert o.insert(i, new_vecs[k]) == 0
+                explain(g, o, "inserts")
+                if dels or upds:
+                    g.delete_batch(np.array(dels + upds, dtype=np.uint64))
+                    assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
+                explain(g, o, "deletes")
+                for k, i in enumerate(upds):
+                    g.insert_batch(np.array([i], dtype=np.uint64), upd_vecs[k:k + 1], round_size=1)
+                    assert o.insert(i, upd_vecs[k]) == 0
+                    explain(g, o, "re-insert of %d" % i)
+            else:
+                g.InsertUpdateDelete(ch, round_size=1)
+                for k, i in enumerate(new_ids):
+                    assert o.insert(i, new_vecs[k]) == 0
+                if dels or upds:
+                    assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
+                    overflow_check(o)
+                for k, i in enumerate(upds):
+                    assert o.insert(i, upd_vecs[k]) == 0
+            live = sorted((set(live) - set(dels)) | set(new_ids))
+            check_graph(g, o)
+            compare_searches(rng, g, o, d, kind, L, live, "after write batch %d" % step)
+    finally:
+        g.close()
+    return desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=0, help="stop after this much wall time (0 = run all trials)")
+    ap.add_argument("--only", type=int, default=-1, help="run just this trial number")
+    a = ap.parse_args()
+    t0 = time.time()
+    done = skipped = 0
+    dims = set()
+    for t in ([a.only] if a.only >= 0 else range(a.trials)):
+        rng = np.random.default_rng([a.seed, t])
+        try:
+            desc = trial(rng, t)
+        except StartOverflow:
+            skipped += 1
+            continue
+        except Exception:
+            traceback.print_exc()
+            print(json.dumps({"failed_trial": t, "seed": a.seed, "trials_passed": done, "config": CURRENT}))
+            sys.exit(1)
+        dims.add(desc["d"])
+        done += 1
+        if a.seconds and time.time() - t0 > a.seconds:
+            break
+    print(json.dumps({"trials_passed": done, "seed": a.seed, "seconds": round(time.time() - t0, 1),
+                      "distinct_dims": len(dims), "mismatches": 0,
+                      "trials_cut_short_by_start_overflow": skipped}))
+
+
+if __name__ == "__main__":
+    main()
