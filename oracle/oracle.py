@@ -209,7 +209,7 @@ class Index:
         return int(lib().orc_index_size(self._h))
 
     def n_slots(self):
-        """rows in storage (no deletes assumed by the callers that use this: equals size())"""
+        """live nodes (the start node included): what the round schedule takes its 2 % of"""
         return self.size
 
     def export(self, with_vectors=True):

@@ -880,7 +880,8 @@ int orc_index_union_prune(orc_index *ix, uint64_t id, const uint64_t *extra, uin
  * so any deterministic interleaving is a legitimate schedule; this is the device's:
  *   1. all rs points are stored (unreachable) and search the SAME snapshot (insert.go:22);
  *   2. each prunes its own visit list (insert.go:29-31);
- *   3. the back-edge requests are applied per target in insert order: a target with >= big_min requests takes
+ *   3. the back-edge requests are applied per target in insert order: a target with >= big_min requests (or a
+ *      start node holding more than 64 edges) takes
  *      all of them in one candidateSet.Add(neighbours, points).Sort().robustPrune; otherwise requests are taken
  *      as many at a time as fit a buffer of group_cap candidates -- appended when they all fit under the degree
  *      bound (insert.go:62), else one Add/Sort/robustPrune over neighbours + that group (insert.go:47-58). */
@@ -929,7 +930,8 @@ int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs
     size_t m = 1;
     while (p + m < nreq && (uint32_t)(req[p + m] >> 32) == b) m++;
     size_t done = 0;
-    if ((int)m >= big_min) { /* hub: everything at once */
+    if ((int)m >= big_min || ix->deg[b] > 64) { /* hub: everything at once; so does a start node whose list has
+                                                  * outgrown an adjacency row (stragglers, prune.go:131-151) */
       for (size_t r = 0; r < m; r++) grp[r] = ix->ids[first + (uint32_t)(req[p + r] & 0xFFFFFFFFu)];
       orc_index_union_prune(ix, ix->ids[b], grp, m);
       done = m;

@@ -51,6 +51,11 @@ struct BuildArgs {
   uint32_t *big_count;
   uint4 *big_list;
   uint32_t big_min, big_cap;
+  // the start node's overflow edges (index.h h_start_ext): while there are any, the start node takes the chip-wide
+  // prune for whatever requests it gets -- the candidate set is its row + the overflow + the requests
+  uint32_t start_slot;
+  const uint32_t *start_ext;
+  uint32_t start_ext_n;
 };
 
 constexpr int kQuantized = -2;  // value of the NG template parameter for a fitted product quantizer
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     if (kk == kNoKey || (uint32_t)(kk >> 32) != b) break;
     m++;
   }
-  if (a.big_count && m >= a.big_min) {  // a hub: the whole chip prunes it afterwards (bigprune.inc)
+  if (a.big_count && (m >= a.big_min || (a.start_ext_n && b == a.start_slot))) {  // a hub: the whole chip prunes it afterwards (bigprune.inc)
     if (lane == 0) {
       const uint32_t at = atomicAdd(a.big_count, 1u);
       if (at < a.big_cap) a.big_list[at] = make_uint4((uint32_t)pos, (uint32_t)m, b, a.deg[b]);
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
 
 template <int NG, bool L2>
 static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, size_t sort_tmp_bytes,
-                        int sort_end_bit, BigScratch *big) {
+                        int sort_end_bit, BigScratch *big, bool *start_pruned) {
   const size_t lds1 = prune_lds_bytes(a.vis_cap, NG, a.ld);
   hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a);
   SDB_HIP(hipGetLastError());
@@ -623,7 +628,7 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   if (a.big_count) SDB_HIP(hipMemsetAsync(a.big_count, 0, 4, stream));
   hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
   SDB_HIP(hipGetLastError());
-  if (a.big_count && (size_t)a.nnew * 64 >= a.big_min) {  // the hubs of this round, if any (bigprune.inc)
+  if (a.big_count && ((size_t)a.nnew * 64 >= a.big_min || a.start_ext_n)) {  // the hubs of this round, if any (bigprune.inc)
     uint32_t nbig = 0;
     SDB_HIP(hipMemcpyAsync(&nbig, a.big_count, 4, hipMemcpyDeviceToHost, stream));
     SDB_HIP(hipStreamSynchronize(stream));
@@ -635,9 +640,11 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
       for (const uint4 &e : list) {
         const size_t pos = e.x;
         const uint32_t deg = e.w;
-        SDB_TRY((big_prune<NG, L2>(a, e.z, deg + e.y, *big, stream, [&](const BigArgs &g, unsigned tb) {
-          hipLaunchKernelGGL(k_big_fill_round, dim3(tb), dim3(256), 0, stream, g, pos, deg);
+        const uint32_t ext = e.z == a.start_slot ? a.start_ext_n : 0u;
+        SDB_TRY((big_prune<NG, L2>(a, e.z, deg + ext + e.y, *big, stream, [&](const BigArgs &g, unsigned tb) {
+          hipLaunchKernelGGL(k_big_fill_round, dim3(tb), dim3(256), 0, stream, g, pos, deg, ext);
         })));
+        if (ext) *start_pruned = true;  // robustPrune leaves at most DegreeBound edges: the overflow list is gone
       }
     }
   }
@@ -645,19 +652,19 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
 }
 
 template <bool L2>
-static int launch_round_ng(const BuildArgs &a, hipStream_t s, void *t, size_t tb, int eb, BigScratch *big) {
+static int launch_round_ng(const BuildArgs &a, hipStream_t s, void *t, size_t tb, int eb, BigScratch *big, bool *sp) {
   switch (a.ng) {
-    case 0: return launch_round<0, L2>(a, s, t, tb, eb, big);
-    case 1: return launch_round<1, L2>(a, s, t, tb, eb, big);
-    case 2: return launch_round<2, L2>(a, s, t, tb, eb, big);
-    case 3: return launch_round<3, L2>(a, s, t, tb, eb, big);
-    case 4: return launch_round<4, L2>(a, s, t, tb, eb, big);
-    case 6: return launch_round<6, L2>(a, s, t, tb, eb, big);
-    case 8: return launch_round<8, L2>(a, s, t, tb, eb, big);
-    case 12: return launch_round<12, L2>(a, s, t, tb, eb, big);  // 1536
-    case 16: return launch_round<16, L2>(a, s, t, tb, eb, big);  // 2048
-    case 24: return launch_round<24, L2>(a, s, t, tb, eb, big);  // 3072
-    default: return launch_round<-1, L2>(a, s, t, tb, eb, big);
+    case 0: return launch_round<0, L2>(a, s, t, tb, eb, big, sp);
+    case 1: return launch_round<1, L2>(a, s, t, tb, eb, big, sp);
+    case 2: return launch_round<2, L2>(a, s, t, tb, eb, big, sp);
+    case 3: return launch_round<3, L2>(a, s, t, tb, eb, big, sp);
+    case 4: return launch_round<4, L2>(a, s, t, tb, eb, big, sp);
+    case 6: return launch_round<6, L2>(a, s, t, tb, eb, big, sp);
+    case 8: return launch_round<8, L2>(a, s, t, tb, eb, big, sp);
+    case 12: return launch_round<12, L2>(a, s, t, tb, eb, big, sp);  // 1536
+    case 16: return launch_round<16, L2>(a, s, t, tb, eb, big, sp);  // 2048
+    case 24: return launch_round<24, L2>(a, s, t, tb, eb, big, sp);  // 3072
+    default: return launch_round<-1, L2>(a, s, t, tb, eb, big, sp);
   }
 }
 
@@ -815,10 +822,11 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
 
   uint64_t done = 0;
   while (done < n) {
-    const uint32_t cur = n0 + (uint32_t)done;  // nodes in the graph so far
-    // a round never exceeds 2 % of the nodes already in the graph (points of one round do not see each
-    // other, so early rounds are sequential and rounds grow with the graph); round_size caps it
-    uint32_t rs = (uint32_t)((double)cur * 0.02);
+    const uint32_t cur = n0 + (uint32_t)done;  // rows in storage so far = slot of the round's first point
+    // a round never exceeds 2 % of the nodes already in the graph -- live ones, deleted rows do not count --
+    // (points of one round do not see each other, so early rounds are sequential and rounds grow with the
+    // graph); round_size caps it
+    uint32_t rs = (uint32_t)((double)(cur - ix->n_dead) * 0.02);
     if (rs < 1) rs = 1;
     if (rs > max_round) rs = max_round;
     if (rs > n - done) rs = (uint32_t)(n - done);
@@ -829,6 +837,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.queries = dvec + done * l.dim;
     sa.dim = l.dim, sa.nblk = l.nblk, sa.ng = l.ng, sa.tail = l.tail, sa.ld = l.ld;
     sa.start_slot = (uint32_t)ix->start_slot;
+    sa.start_ext = ix->d_start_ext, sa.start_ext_n = (uint32_t)ix->h_start_ext.size();
     sa.search_size = L, sa.limit = 1, sa.metric = (int)ix->P.metric;
     sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
     if (dcache) {
@@ -854,10 +863,15 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     if (pq) ba.pq_codes = ix->d_codes, ba.pq_cdists = pq->d_cdists, ba.pq_M = pq->M, ba.pq_K = pq->K;
     ba.dcache = dcache, ba.dcache_shift = 32 - kDcacheBits;
     ba.big_count = big_count, ba.big_list = big_list, ba.big_min = big_min, ba.big_cap = big_cap;
-    int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch)
-         : ix->P.metric == SDB_METRIC_EUCLIDEAN ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch)
-                                                  : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch);
+    ba.start_slot = (uint32_t)ix->start_slot;
+    ba.start_ext = ix->d_start_ext, ba.start_ext_n = (uint32_t)ix->h_start_ext.size();
+    bool start_pruned = false;
+    int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
+         : ix->P.metric == SDB_METRIC_EUCLIDEAN
+             ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
+             : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned);
     if (rc != SDB_OK) return rc;
+    if (start_pruned) ix->h_start_ext.clear();  // the device copy is simply no longer referenced (count 0)
     done += rs;
     ix->n = n0 + (uint32_t)done;
   }

@@ -56,6 +56,14 @@ struct sdb_index {
   float *d_adjdist = nullptr;    // [cap][kAdjStride]
   uint32_t *d_dcount = nullptr;  // [cap]
   uint64_t *d_ids = nullptr; // [cap] slot -> node id
+  // The start node's edges beyond the 64 of its adjacency row.  Stragglers of a delete are appended to the start
+  // node with no bound (AddNeighbourIfNotExists, node.go:73-80 / prune.go:131-151); the list stays that long until
+  // the start node is next pruned (a back-edge from an insert, insert.go:47-58, or a delete among its edges).
+  // Host copy in edge order; the device copy is padded with kNoSlot to a multiple of 64 so the search reads it in
+  // row-sized chunks.  Every other node is bounded by DegreeBound <= 64.
+  std::vector<uint32_t> h_start_ext;
+  uint32_t *d_start_ext = nullptr;
+  uint32_t start_ext_cap = 0;
   std::vector<uint64_t> h_ids;
   bool dense_ids = true;  // ids[i] == ids[0] + i  (then no hash map is needed)
   std::unordered_map<uint64_t, uint32_t> id2slot;
@@ -72,6 +80,7 @@ struct sdb_index {
 
   int64_t slot_of(uint64_t id) const;
   int reserve(uint32_t rows);
+  int sync_start_ext();  // h_start_ext -> device
   sdb::Workspace *acquire_ws(hipStream_t stream, bool async) const;
   void release_ws(sdb::Workspace *ws, hipStream_t stream, bool async) const;
 };

@@ -311,6 +311,27 @@ void sdb_index::release_ws(Workspace *ws, hipStream_t stream, bool async) const 
   ws->busy = false;
 }
 
+// uploads the start node's overflow edges, padded with kNoSlot to whole 64-entry chunks (search_kernel.h reads them
+// like adjacency rows).  Writers are exclusive (the reference holds the shard's write lock), so nothing reads the
+// old buffer once the device is idle.
+int sdb_index::sync_start_ext() {
+  const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
+  if (need > start_ext_cap) {
+    SDB_HIP(hipDeviceSynchronize());
+    if (d_start_ext) (void)hipFree(d_start_ext);
+    d_start_ext = nullptr, start_ext_cap = 0;
+    const uint32_t ncap = need * 2;
+    SDB_HIP(hipMalloc(&d_start_ext, (size_t)ncap * 4));
+    start_ext_cap = ncap;
+  }
+  if (need) {
+    std::vector<uint32_t> padded(need, kNoSlot);
+    std::copy(h_start_ext.begin(), h_start_ext.end(), padded.begin());
+    SDB_HIP(hipMemcpy(d_start_ext, padded.data(), (size_t)need * 4, hipMemcpyHostToDevice));
+  }
+  return SDB_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -378,6 +399,7 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_adjdist) (void)hipFree(ix->d_adjdist);
   if (ix->d_dcount) (void)hipFree(ix->d_dcount);
   if (ix->d_ids) (void)hipFree(ix->d_ids);
+  if (ix->d_start_ext) (void)hipFree(ix->d_start_ext);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
   for (auto e : ix->ev0)
     if (e) (void)hipEventDestroy(e);
@@ -475,6 +497,7 @@ int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *
     return fail(SDB_ERR_INVALID, "start node (id %llu) is not among the loaded ids", SDB_STARTID);
   }
   ix->n = (uint32_t)n;  // slot_of works from here on
+  ix->h_start_ext.clear();
   // adjacency rows: ids -> slots, unknown ids dropped, first occurrence kept, edge order kept
   std::vector<uint32_t> adj((size_t)n * kAdjStride, kNoSlot), deg(n, 0);
   for (uint64_t i = 0; i < n; i++) {
@@ -487,19 +510,27 @@ int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *
       for (uint32_t k = 0; k < dcnt; k++) dup |= (row[k] == (uint32_t)s);
       if (dup) continue;
       if (dcnt == kAdjStride) {
+        if ((int64_t)i == ix->start_slot) {  // the start node has no bound (node.go:73-80): the rest is its overflow list
+          if (std::find(ix->h_start_ext.begin(), ix->h_start_ext.end(), (uint32_t)s) == ix->h_start_ext.end())
+            ix->h_start_ext.push_back((uint32_t)s);
+          continue;
+        }
         ix->n = 0;
+        ix->h_start_ext.clear();
         return fail(SDB_ERR_INVALID, "node %llu has more than %u edges", (unsigned long long)ix->h_ids[i], kAdjStride);
       }
       row[dcnt++] = (uint32_t)s;
     }
     deg[i] = dcnt;
   }
+  SDB_TRY(ix->sync_start_ext());
   SDB_HIP(hipMemcpy(ix->d_adj, adj.data(), adj.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SDB_HIP(hipMemcpy(ix->d_deg, deg.data(), deg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SDB_HIP(hipMemcpy(ix->d_ids, ix->h_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
   int rc = store_rows(ix, 0, (uint32_t)n, vectors, mem, nullptr);
   if (rc != SDB_OK) {
     ix->n = 0;
+    ix->h_start_ext.clear();
     return rc;
   }
   SDB_HIP(hipDeviceSynchronize());
@@ -583,6 +614,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   }
   a.dim = l.dim, a.nblk = l.nblk, a.ng = l.ng, a.tail = l.tail, a.ld = l.ld;
   a.start_slot = (uint32_t)ix->start_slot;
+  a.start_ext = ix->d_start_ext, a.start_ext_n = (uint32_t)ix->h_start_ext.size();
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
@@ -720,7 +752,7 @@ int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, u
     if (ix->n) SDB_HIP(hipMemcpy(deg.data(), ix->d_deg, (size_t)ix->n * 4, hipMemcpyDeviceToHost));
     uint64_t t = 0;
     for (uint32_t d : deg) t += d;
-    *n_edges = t;
+    *n_edges = t + ix->h_start_ext.size();
   }
   return SDB_OK;
 }
@@ -748,6 +780,11 @@ int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_
       if (offsets) offsets[k] = o;
       for (uint32_t e = 0; e < deg[i]; e++, o++)
         if (edges) edges[o] = ix->h_ids[adj[(size_t)i * kAdjStride + e]];
+      if ((int64_t)i == ix->start_slot)
+        for (uint32_t t : ix->h_start_ext) {
+          if (edges) edges[o] = ix->h_ids[t];
+          o++;
+        }
       k++;
     }
     if (offsets) offsets[k] = o;
@@ -794,6 +831,17 @@ int unpermute_rows_public(const sdb_index *ix, uint32_t first, uint32_t n, float
 
 // productQuantizer.Set -> encode for every stored vector (product.go:161-169), then searches use the
 // LUT distance (product.go:250-277).
+// The write path keeps two things per row from its last robustPrune: how many leading edges came out of it
+// (d_clean: those do not dominate each other, build.hip) and the distances to them (d_dcount / d_adjdist).  Both
+// are statements about the store's distance function.  When that changes -- the store switches to the quantizer's
+// table distances, or centroid ids are overwritten -- they no longer hold and every row starts over.
+static int forget_prune_state(sdb_index *ix) {
+  if (ix->n == 0) return SDB_OK;
+  SDB_HIP(hipMemset(ix->d_clean, 0, (size_t)ix->n * sizeof(uint32_t)));
+  SDB_HIP(hipMemset(ix->d_dcount, 0, (size_t)ix->n * sizeof(uint32_t)));
+  return SDB_OK;
+}
+
 extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream_) {
   if (!ix || !pq) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");
@@ -821,7 +869,10 @@ extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream
   }
   (void)hipStreamSynchronize(stream);
   (void)hipFree(tmp);
-  if (rc == SDB_OK) ix->pq = pq;
+  if (rc == SDB_OK) {
+    ix->pq = pq;
+    rc = forget_prune_state(ix);
+  }
   return rc;
 }
 
@@ -844,7 +895,7 @@ extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *id
     SDB_HIP(hipMemcpy(ix->d_codes + (size_t)s0 * M, codes + i * M, (j - i) * M, hipMemcpyHostToDevice));
     i = j;
   }
-  return SDB_OK;
+  return forget_prune_state(ix);
 }
 
 extern "C" int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *codes) {

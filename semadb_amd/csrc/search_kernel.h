@@ -32,6 +32,9 @@ struct SearchArgs {
   const float *queries;  // [nq][dim] original layout
   uint32_t dim, nblk, ng, tail, ld;
   uint32_t start_slot;
+  // the start node's edges beyond its 64-entry row (index.h h_start_ext), kNoSlot-padded to whole chunks of 64
+  const uint32_t *start_ext;
+  uint32_t start_ext_n;
   uint32_t search_size;
   uint32_t limit;
   int metric;
@@ -797,34 +800,44 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     }
     n_hop++;
 
-    // node.neighbours in edge order :77-91
-    const uint32_t nb = a.adj[(size_t)pid * kAdjStride + lane];
-    const bool valid = nb != kNoSlot;
-    n_edges += (uint32_t)__popcll(__ballot(valid));
+    // node.neighbours in edge order :77-91.  One pass per 64 edges: every node has one, except a start node
+    // that carries an overflow list (index.h h_start_ext) -- its chunks follow in the same edge order, which
+    // is all AddWithLimit(neighbours...) depends on.
+    const uint32_t *__restrict__ rowp = a.adj + (size_t)pid * kAdjStride;
+    uint32_t ext_left = pid == a.start_slot ? a.start_ext_n : 0u, ext_done = 0;
+    while (true) {
+      const uint32_t nb = rowp[lane];
+      const bool valid = nb != kNoSlot;
+      n_edges += (uint32_t)__popcll(__ballot(valid));
 #ifdef SDB_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the adjacency round trip to st_adj
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the adjacency round trip to st_adj
 #endif
-    SDB_STAMP(st_adj)
-    dist.prefetch(a, nb, valid);
-    // CheckAndVisit distset.go:174 -- marks before any distance test
-    const bool isnew = vis.test_and_set(valid, nb, lane);
-    const uint64_t pend = __ballot(isnew);
-    SDB_STAMP(st_atom)
-    if (pend) {
-      n_dist += (uint32_t)__popcll(pend);
-      const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
-      if constexpr (Dist::kPointDistances)
-        if (a.dcache && ((pend >> lane) & 1ull))
-          a.dcache[((size_t)q << (32 - a.dcache_shift)) + ((nb * 2654435761u) >> a.dcache_shift)] =
-              make_uint2(nb, __float_as_uint(mydist));
+      SDB_STAMP(st_adj)
+      dist.prefetch(a, nb, valid);
+      // CheckAndVisit distset.go:174 -- marks before any distance test
+      const bool isnew = vis.test_and_set(valid, nb, lane);
+      const uint64_t pend = __ballot(isnew);
+      SDB_STAMP(st_atom)
+      if (pend) {
+        n_dist += (uint32_t)__popcll(pend);
+        const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
+        if constexpr (Dist::kPointDistances)
+          if (a.dcache && ((pend >> lane) & 1ull))
+            a.dcache[((size_t)q << (32 - a.dcache_shift)) + ((nb * 2654435761u) >> a.dcache_shift)] =
+                make_uint2(nb, __float_as_uint(mydist));
 #ifdef SDB_STAMPS
-      asm volatile("" ::"v"(mydist));
+        asm volatile("" ::"v"(mydist));
 #endif
-      SDB_STAMP(st_vec)
-      // AddWithLimit over the new neighbours, in edge order distset.go:184-198
-      if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
-      else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
-      SDB_STAMP(st_ins)
+        SDB_STAMP(st_vec)
+        // AddWithLimit over the new neighbours, in edge order distset.go:184-198
+        if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
+        else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
+        SDB_STAMP(st_ins)
+      }
+      if (__builtin_expect(ext_left == 0, 1)) break;
+      rowp = a.start_ext + ext_done;
+      ext_done += 64;
+      ext_left = ext_left > 64 ? ext_left - 64 : 0;
     }
     if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
       if (filter_contains(fsorted, nfilt, pid, lane)) {

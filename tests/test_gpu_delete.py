@@ -164,22 +164,24 @@ def test_delete_id_rules():
 
 
 def test_start_row_overflow_keeps_graph_valid(oracle):
-    """More stragglers than the 64-edge start row can take: the rest go through the full-node rule of
-    insert.go:47-58.  The graph stays well-formed (no dangling or duplicate edges, degree bound on the start
-    row) and every live point is still found by the exact scan."""
+    """More stragglers than the 64-edge start row can take (the reference's start node has no bound, node.go:73-80):
+    the graph equals the oracle's, stays well-formed, and every live point is still found."""
     from semadb_amd import flat, vamana
+    from tests.helpers import assert_same_graph
     rng = np.random.default_rng(1)
     base = rng.random((200, 2), dtype=np.float32)
     o, g = _pair(oracle, 2, "cosine", 8, 25, base)
     dels = rng.choice(np.arange(2, 202), size=20, replace=False).astype(np.uint64)
     g.delete_batch(dels)
+    assert o.delete(dels) == 0
+    assert_same_graph(g, o)
     ids, vecs, off, edges = g.export()
-    assert len(ids) == 181
+    assert len(ids) == 181 and int(off[1] - off[0]) > 64
     idset = set(int(v) for v in ids)
     assert all(int(e) in idset for e in edges)
     for i in range(len(ids)):
         row = [int(e) for e in edges[int(off[i]):int(off[i + 1])]]
-        assert len(row) == len(set(row)) and int(ids[i]) not in row and len(row) <= 64
+        assert len(row) == len(set(row)) and int(ids[i]) not in row and (i == 0 or len(row) <= 64)
     f_ids, f_d, f_c = flat.flat_search_batch(g._h, 2, base[:50], 5)
     assert np.all(f_c == 5) and not (set(int(v) for v in f_ids.ravel()) & (set(int(v) for v in dels) | {1}))
     # the walk still works from the start node
@@ -247,4 +249,130 @@ def test_mixed_operations_differential(oracle, metric, quantized):
             o_ids, o_d, o_vis, o_tr = o.search(q[i], 5, L)
             assert np.array_equal(ids_g[i, :len(o_ids)], o_ids) and np.array_equal(bits(d_g[i, :len(o_ids)]), bits(o_d))
             assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis)
+    g.close()
+
+
+@pytest.mark.parametrize("metric,d,n,R,dup,quantized", [("cosine", 48, 1500, 4, False, False),
+                                                        ("euclidean", 16, 900, 5, True, False),
+                                                        ("euclidean", 32, 1200, 4, False, True)])
+def test_start_node_overflow_list(oracle, metric, d, n, R, dup, quantized):
+    """Stragglers of a delete are appended to the start node with no bound (prune.go:131-151, node.go:73-80).  A
+    small degree bound and a large delete leave hundreds of them: the start node's list outgrows its 64-entry row
+    and stays that long until it is next pruned.  Through every stage -- the overflowing delete, searches that
+    expand the long list, export / load of it, a second delete that hits edges of the list (pruneDeleteNeighbour
+    over row + overflow), an insert whose back-edge re-prunes the start node -- graphs and walks equal the
+    oracle's."""
+    from semadb_amd import vamana, vectorstore as vs
+    from tests.helpers import assert_same_graph
+    L = 20
+    rng = np.random.default_rng(n + R)
+    sv = start_vector(np.random.default_rng(5), d)
+    base = unit_rows(rng, n, d)
+    if dup:  # repeated points: zero distances and ties on top
+        base = base[rng.integers(0, n // 3, n)].copy()
+    o = oracle.Index(d, metric, R, L, 1.5, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    g = vamana.NewIndexVamana("ovf", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.5), strict=False)
+    g.set_start(sv)
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    for i in range(n):
+        assert o.insert(int(ids[i]), base[i]) == 0
+    g.insert_batch(ids, base, round_size=1)
+    if quantized:
+        o_ids, vecs, _, _ = o.export()
+        first = rng.integers(0, len(o_ids), 4)
+        opq = oracle.PQ(d, metric, 4, 16)
+        codes = opq.fit(vecs.copy(), first, alias=True)
+        assert o.attach_pq(opq, codes) == 0
+        gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(16, 4), d)
+        assert np.array_equal(gpq.Fit(vecs.copy(), first, alias=True), codes)
+        vs.attach(g, gpq, o_ids, codes)
+
+    def start_degree():
+        e_ids, _, off, _ = o.export(with_vectors=False)
+        assert e_ids[0] == 1
+        return int(off[1] - off[0])
+
+    def same_walks():
+        q = unit_rows(rng, 16, d)
+        g_ids, g_d, g_c, tr = g.search_batch(q, 5, L, trace=True, visit_cap=512)
+        for i in range(16):
+            o_ids, o_d, o_vis, o_tr = o.search(q[i], 5, L)
+            assert np.array_equal(g_ids[i, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d))
+            assert int(tr.n_dist[i]) == o_tr.n_dist and int(tr.n_edges[i]) == o_tr.n_edges
+            assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis)
+
+    live = list(int(v) for v in ids)
+    dels = rng.choice(live, size=n // 8, replace=False).astype(np.uint64)
+    g.delete_batch(dels)
+    assert o.delete(dels) == 0
+    live = sorted(set(live) - set(int(v) for v in dels))
+    assert start_degree() > 64 + 64, "the case must overflow the row by more than one chunk (%d)" % start_degree()
+    assert_same_graph(g, o)
+    assert g.stats()[1] == o.export(with_vectors=False)[3].size
+    same_walks()
+    # the long list survives export -> load
+    e_ids, e_v, e_off, e_e = g.export()
+    g2 = vamana.NewIndexVamana("ovf2", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.5), strict=False)
+    g2.load(e_ids, e_v, e_off, e_e)
+    r_ids, _, r_off, r_e = g2.export(with_vectors=False)
+    assert np.array_equal(r_ids, e_ids) and np.array_equal(r_off, e_off) and np.array_equal(r_e, e_e)
+    g2.close()
+    # a second delete: more stragglers on top of the list, and deleted ids among its edges
+    _, _, off, edges = o.export(with_vectors=False)
+    in_list = [int(v) for v in edges[off[0] + 64:off[1]]]
+    dels2 = np.array(in_list[:7] + [int(v) for v in rng.choice([v for v in live if v not in set(in_list)], 40, replace=False)],
+                     dtype=np.uint64)
+    g.delete_batch(dels2)
+    assert o.delete(dels2) == 0
+    live = sorted(set(live) - set(int(v) for v in dels2))
+    assert_same_graph(g, o)
+    same_walks()
+    # build the list up again, then an insert: its back-edge to the start node re-prunes row + list + new point
+    dels3 = rng.choice(live, size=len(live) // 6, replace=False).astype(np.uint64)
+    g.delete_batch(dels3)
+    assert o.delete(dels3) == 0
+    live = sorted(set(live) - set(int(v) for v in dels3))
+    assert_same_graph(g, o)
+    long_before = start_degree()
+    new = unit_rows(rng, 30, d)
+    new_ids = np.arange(n + 10, n + 40, dtype=np.uint64)
+    for i in range(30):
+        assert o.insert(int(new_ids[i]), new[i]) == 0
+    g.insert_batch(new_ids, new, round_size=1)
+    assert_same_graph(g, o)
+    if long_before > 64 and not dup and not quantized:  # (in the other cases no new node picks the start node)
+        assert start_degree() <= R, "an insert was expected to re-prune the start node"
+    same_walks()
+    g.close()
+
+
+def test_start_node_overflow_batched_round(oracle, monkeypatch):
+    """the same state met by a batched insert: the round's requests to the long start node are taken all at once
+    (the hub rule), as the oracle's restatement of the round schedule does"""
+    from semadb_amd import vamana
+    from tests.helpers import assert_same_graph
+    d, n, R, L = 24, 1200, 5, 20
+    rng = np.random.default_rng(77)
+    sv = start_vector(np.random.default_rng(5), d)
+    base = unit_rows(rng, n, d)
+    o = oracle.Index(d, "euclidean", R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    g = vamana.NewIndexVamana("ovb", vamana.IndexVectorVamanaParameters(d, "euclidean", L, R, 1.2), strict=False)
+    g.set_start(sv)
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    assert o.insert_rounds(ids, base) == 0
+    g.insert_batch(ids, base)
+    assert_same_graph(g, o)
+    dels = rng.choice(ids, size=n // 6, replace=False)
+    g.delete_batch(dels)
+    assert o.delete(dels) == 0
+    _, _, off, _ = o.export(with_vectors=False)
+    assert int(off[1] - off[0]) > 64
+    assert_same_graph(g, o)
+    new = unit_rows(rng, 300, d)
+    new_ids = np.arange(n + 10, n + 310, dtype=np.uint64)
+    assert o.insert_rounds(new_ids, new) == 0
+    g.insert_batch(new_ids, new)
+    assert_same_graph(g, o)
     g.close()

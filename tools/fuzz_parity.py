@@ -187,11 +187,17 @@ def trial(rng, t):
             CURRENT["stage"] = "step %d: %d inserts (%s), %d deletes, %d updates" % (
                 step, len(new_ids), "re-used ids" if reuse else "fresh ids", len(dels), len(upds))
             if os.environ.get("FUZZ_SPLIT"):  # debugging aid: the same three phases as separate calls, checked one by one
-                if new_ids:
-                    g.insert_batch(np.array(new_ids, dtype=np.uint64), new_vecs[:len(new_ids)], round_size=1)
                 for k, i in enumerate(new_ids):
+                    # the search an insert starts with (insert.go:22), on both sides, before the point goes in
+                    gi, gd, gc, gtr = g.search_batch(new_vecs[k:k + 1], 1, L, trace=True, visit_cap=2048)
+                    oi, od, ovis, otr = o.search(new_vecs[k], 1, L)
+                    same = (np.array_equal(gtr.visit_ids[0, :otr.n_hop], ovis) and int(gtr.n_hop[0]) == otr.n_hop
+                            and int(gtr.n_dist[0]) == otr.n_dist)
+                    print("insert %d: pre-search %s (hops %d/%d, dists %d/%d)" % (
+                        i, "same" if same else "DIFFERS", int(gtr.n_hop[0]), otr.n_hop, int(gtr.n_dist[0]), otr.n_dist))
+                    g.insert_batch(np.array([i], dtype=np.uint64), new_vecs[k:k + 1], round_size=1)
                     assert o.insert(i, new_vecs[k]) == 0
-                explain(g, o, "inserts")
+                    explain(g, o, "after insert of %d" % i)
                 if dels or upds:
                     g.delete_batch(np.array(dels + upds, dtype=np.uint64))
                     assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
