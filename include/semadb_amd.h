@@ -125,9 +125,9 @@ int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const
  * delete set + stragglers (valid nodes nobody points at) re-attached to the start node (prune.go:131-151),
  * then the nodes are dropped from the store (vamana.go:228-233).  Unknown ids are skipped
  * (vamana.go:161-163); ids 0 and 1 are errors.  The reference re-attaches stragglers in Go-map order
- * (unspecified): here in storage order; and its start node may grow without bound, while a device row holds
- * 64 edges: once the start row is full the remaining stragglers go through the full-node rule of
- * insert.go:47-58 (candidateSet = neighbours + stragglers, Sort, robustPrune).
+ * (unspecified): here in storage order.  Its start node grows without bound (AddNeighbourIfNotExists,
+ * node.go:73-80) and so does this one: edges past the 64 of a device row are kept on an overflow list that
+ * searches, inserts, deletes, export and load read after the row, until the start node is next pruned.
  * An update (vamana.go:170-174,247-251) is delete_batch followed by insert_batch with the same id. */
 int sdb_index_delete_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, void *stream);
 
@@ -249,9 +249,9 @@ int sdb_pq_sym_distance(const sdb_pq *pq, const uint8_t *codes_x, const uint8_t 
 int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream);
 /* insert.go:47-58 for a node and SEVERAL candidates at once: candidateSet.Add(neighbours...),
  * Add(extra...), Sort, robustPrune(node).  The device build applies this rule to a target that has
- * several back-edge requests in one round, and the delete path to an overflowing start row
- * (prune.go:131-151).  chip_wide = 0: one wavefront; 1: the sequence of chip-wide kernels the
- * build uses for hub nodes.  Both give the oracle's row (tests/test_gpu_build.py). */
+ * several back-edge requests in one round.  chip_wide = 0: one wavefront; 1: the sequence of
+ * chip-wide kernels the build uses for hub nodes.  Both give the oracle's row
+ * (tests/test_gpu_build.py).  Not available for a start node that holds an overflow list. */
 int sdb_index_union_prune(sdb_index *ix, uint64_t id, uint64_t m, const uint64_t *extra_ids,
                           int chip_wide, void *stream);
 /* Centroid ids that do not come from encode(): the k-means labels productQuantizer.Fit leaves on
