@@ -1,11 +1,13 @@
 """Randomised differential trials (tools/fuzz_parity.py: device through the C ABI vs the oracle over random shapes,
-metrics, parameters, data with ties and duplicates, build schedules and write sequences).  The numbered trials are
-the ones that exposed defects when the soak was first run:
-  seed 1 trial 0, 23   a delete leaves more stragglers than the start node's 64-entry row holds (prune.go:131-151:
-                       the reference's start node has no bound) -- now an overflow list, exact;
-  seed 1 trial 88      a store switched to the product quantizer kept per-row prune state (clean prefix, cached
-                       distances) that only holds for the distance function it was made with.
-A short fresh soak runs next to them."""
+metrics, parameters, data with ties and duplicates, build schedules, write sequences in rounds or one by one, a
+quantizer attached mid-way; graphs edge for edge, plain / filtered / exact-scan searches and K1 bit for bit).
+
+The soak's first runs exposed two defects, each now pinned by a deterministic test of its own:
+  * a delete leaving more stragglers than the start node's 64-entry row holds (the reference's start node has no
+    bound, prune.go:131-151) -> tests/test_gpu_delete.py::test_start_node_overflow_list;
+  * a store switched to the product quantizer kept per-row cached distances made with the old distance function
+    -> tests/test_gpu_pq.py::test_quantizer_attached_to_a_device_built_graph.
+A short fresh soak runs here on every `pytest -m gpu`."""
 import os
 import sys
 
@@ -24,14 +26,9 @@ def _fuzz():
     return fuzz_parity
 
 
-@pytest.mark.parametrize("seed,t", [(1, 0), (1, 23), (1, 88)])
-def test_fuzz_regressions(oracle, monkeypatch, seed, t):
+@pytest.mark.parametrize("seed", [1, 20251002])
+def test_fuzz_short_soak(oracle, monkeypatch, seed):
     monkeypatch.setenv("SDB_BIG_MIN", "512")  # trial() sets its own; monkeypatch restores the environment afterwards
-    _fuzz().trial(np.random.default_rng([seed, t]), t)
-
-
-def test_fuzz_short_soak(oracle, monkeypatch):
-    monkeypatch.setenv("SDB_BIG_MIN", "512")
     fz = _fuzz()
-    for t in range(40):
-        fz.trial(np.random.default_rng([20251002, t]), t)
+    for t in range(30):
+        fz.trial(np.random.default_rng([seed, t]), t)

@@ -270,3 +270,48 @@ def test_batched_insert_into_quantized_store_matches_oracle_schedule(oracle, mon
     assert_same_graph(g, o)
     g.close()
     gpq.close()
+
+
+@pytest.mark.parametrize("metric,M,K", [("euclidean", 2, 8), ("cosine", 4, 4)])
+def test_quantizer_attached_to_a_device_built_graph(oracle, monkeypatch, metric, M, K):
+    """The graph is built on the device with full-precision distances, THEN the store switches to a (coarse)
+    quantizer: whatever the write path remembers per row from its earlier prunes -- which leading edges came out
+    of a robustPrune, their cached distances -- was made with the old distance function and must not be used by
+    the inserts that follow (found by tools/fuzz_parity.py, seed 1 trial 88: the chip-wide prune of a target with
+    several requests read the row's cached full-precision distances).  Sequential inserts first, then batched
+    rounds with the hub threshold at 2."""
+    monkeypatch.setenv("SDB_BIG_MIN", "2")
+    from semadb_amd import vamana, vectorstore as vs
+    from tests.helpers import start_vector
+    d, n0, n1, R, L = 16, 700, 200, 8, 24
+    rng = np.random.default_rng(M * 100 + K)
+    base = unit_rows(rng, n0 + n1, d)
+    sv = start_vector(np.random.default_rng(11), d)
+    o = oracle.Index(d, metric, R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    ix = vamana.NewIndexVamana("dq", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.2), strict=False)
+    ix.set_start(sv)
+    ids = np.arange(2, n0 + 2, dtype=np.uint64)
+    for i in range(n0):
+        assert o.insert(int(ids[i]), base[i]) == 0
+    ix.insert_batch(ids, base[:n0], round_size=1)
+    assert_same_graph(ix, o)
+    o_ids, vecs, _, _ = o.export()
+    first = rng.integers(0, len(o_ids), M)
+    opq = oracle.PQ(d, metric, M, K)
+    codes = opq.fit(vecs.copy(), first, alias=True)
+    assert o.attach_pq(opq, codes) == 0
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    assert np.array_equal(gpq.Fit(vecs.copy(), first, alias=True), codes)
+    vs.attach(ix, gpq, o_ids, codes)
+    new_ids = np.arange(n0 + 2, n0 + 2 + n1, dtype=np.uint64)
+    h = n1 // 4
+    for i in range(h):
+        assert o.insert(int(new_ids[i]), base[n0 + i]) == 0
+    ix.insert_batch(new_ids[:h], base[n0:n0 + h], round_size=1)
+    assert_same_graph(ix, o)
+    assert o.insert_rounds(new_ids[h:], base[n0 + h:], big_min=2) == 0
+    ix.insert_batch(new_ids[h:], base[n0 + h:])
+    assert_same_graph(ix, o)
+    ix.close()
+    gpq.close()

@@ -41,9 +41,32 @@ def draw_rows(rng, n, d, kind):
     return (x / np.maximum(nrm, np.float32(1e-20))).astype(np.float32)
 
 
-def compare_searches(rng, g, o, d, kind, L, live, tag):
+def compare_exact(g, o, q, metric, tag):
+    """full-precision store only: the exact scan (flat.go:76-132, first seen stays among equals, the start node is
+    not a point) and K1 (plain.go:76-85; an unknown id gives MaxFloat32) against the oracle's distances"""
+    from semadb_amd import flat
+    ids, vecs, _, _ = o.export()
+    keep = ids != 1
+    ids, vecs = ids[keep], vecs[keep]
+    dm = orc.distance_matrix(q, vecs, metric, orc.IMPL_ASM)
+    k = min(10, len(ids))
+    f_ids, f_d, f_c = flat.flat_search_batch(g._h, q.shape[1], q, k)
+    for i in range(q.shape[0]):
+        order = np.argsort(dm[i], kind="stable")[:k]
+        assert int(f_c[i]) == k, (tag, "flat count", i)
+        assert np.array_equal(f_ids[i], ids[order]) and np.array_equal(bits(f_d[i]), bits(dm[i, order])), (tag, "flat", i)
+    pick = np.arange(0, len(ids), max(1, len(ids) // 16))[:16]
+    cand = np.tile(np.concatenate([ids[pick], [np.uint64(10 ** 12)]]), (q.shape[0], 1)).astype(np.uint64)
+    k1 = g.distance_batch(q, cand)
+    assert np.array_equal(bits(k1[:, :-1]), bits(dm[:, pick])), (tag, "K1")
+    assert (k1[:, -1] == np.finfo(np.float32).max).all(), (tag, "K1 unknown id")
+
+
+def compare_searches(rng, g, o, d, kind, L, live, tag, metric=None):
     nq = 12
     q = draw_rows(rng, nq, d, kind)
+    if metric is not None and len(live) >= 1:
+        compare_exact(g, o, q, metric, tag)
     k = int(rng.integers(1, L + 1))
     sl = int(rng.integers(max(k, 1), 2 * L + 1))
     ids_g, d_g, c_g, tr = g.search_batch(q, k, sl, trace=True, visit_cap=2048)
@@ -138,7 +161,7 @@ def trial(rng, t):
             g.insert_batch(ids, base, round_size=1)
         check_graph(g, o)
         live = [int(v) for v in ids]
-        compare_searches(rng, g, o, d, kind, L, live, "after build")
+        compare_searches(rng, g, o, d, kind, L, live, "after build", metric)
         quantized = False
         for step in range(int(rng.integers(1, 4))):
             if not quantized and d >= 4 and rng.integers(0, 3) == 0:
@@ -164,7 +187,8 @@ def trial(rng, t):
             n_upd = int(rng.integers(0, min(10, len(rest)) + 1)) if rest else 0
             upds = [int(v) for v in rng.choice(rest, size=n_upd, replace=False)] if n_upd else []
             upd_vecs = draw_rows(rng, max(n_upd, 1), d, kind)
-            n_ins = int(rng.integers(0, 40))
+            n_ins = int(rng.integers(0, 40)) if rng.integers(0, 3) else int(rng.integers(40, 200))
+            wr = int(rng.choice([1, 1, 0, 7, 64]))  # how the batch's new points are inserted: one by one or in rounds
             new_vecs = draw_rows(rng, max(n_ins, 1), d, kind)
             reuse = bool(dels) and bool(rng.integers(0, 2))
             if reuse:
@@ -184,8 +208,8 @@ def trial(rng, t):
             ch = [vamana.IndexVectorChange(i, new_vecs[k]) for k, i in enumerate(new_ids)]
             ch += [vamana.IndexVectorChange(i, None) for i in dels]
             ch += [vamana.IndexVectorChange(i, upd_vecs[k]) for k, i in enumerate(upds)]
-            CURRENT["stage"] = "step %d: %d inserts (%s), %d deletes, %d updates" % (
-                step, len(new_ids), "re-used ids" if reuse else "fresh ids", len(dels), len(upds))
+            CURRENT["stage"] = "step %d: %d inserts (%s, round_size %d), %d deletes, %d updates" % (
+                step, len(new_ids), "re-used ids" if reuse else "fresh ids", wr, len(dels), len(upds))
             if os.environ.get("FUZZ_SPLIT"):  # debugging aid: the same three phases as separate calls, checked one by one
                 for k, i in enumerate(new_ids):
                     # the search an insert starts with (insert.go:22), on both sides, before the point goes in
@@ -207,9 +231,13 @@ def trial(rng, t):
                     assert o.insert(i, upd_vecs[k]) == 0
                     explain(g, o, "re-insert of %d" % i)
             else:
-                g.InsertUpdateDelete(ch, round_size=1)
-                for k, i in enumerate(new_ids):
-                    assert o.insert(i, new_vecs[k]) == 0
+                g.InsertUpdateDelete(ch, round_size=wr)
+                if wr == 1:
+                    for k, i in enumerate(new_ids):
+                        assert o.insert(i, new_vecs[k]) == 0
+                elif new_ids:
+                    assert o.insert_rounds(np.array(new_ids, dtype=np.uint64), new_vecs[:len(new_ids)], round_size=wr,
+                                           big_min=big_min) == 0
                 if dels or upds:
                     assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
                     overflow_check(o)
@@ -217,7 +245,7 @@ def trial(rng, t):
                     assert o.insert(i, upd_vecs[k]) == 0
             live = sorted((set(live) - set(dels)) | set(new_ids))
             check_graph(g, o)
-            compare_searches(rng, g, o, d, kind, L, live, "after write batch %d" % step)
+            compare_searches(rng, g, o, d, kind, L, live, "after write batch %d" % step, None if quantized else metric)
     finally:
         g.close()
     return desc
