@@ -31,4 +31,6 @@ def test_fuzz_short_soak(oracle, monkeypatch, seed):
     monkeypatch.setenv("SDB_BIG_MIN", "512")  # trial() sets its own; monkeypatch restores the environment afterwards
     fz = _fuzz()
     for t in range(30):
-        fz.trial(np.random.default_rng([seed, t]), t)
+        rng = np.random.default_rng([seed, t])
+        fz.merge_trial(rng)
+        fz.trial(rng, t)

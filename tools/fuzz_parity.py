@@ -21,7 +21,7 @@ from semadb_amd import vamana, vectorstore as vs
 from tests.helpers import assert_same_graph, bits, start_vector
 
 DIMS = [1, 2, 3, 7, 16, 24, 31, 32, 33, 48, 64, 65, 96, 100, 127, 128, 130, 160, 200, 256, 300, 384, 385, 512, 640, 768,
-        784, 1024, 1280, 1536]
+        784, 1024, 1280, 1536, 2048, 2112, 3072, 4096]
 METRICS = ["euclidean", "cosine", "dot"]
 
 
@@ -133,7 +133,7 @@ def trial(rng, t):
     R = int(rng.integers(4, 65))
     L = int(rng.integers(max(R // 2, 5), 101))
     alpha = float(rng.choice([1.0, 1.1, 1.2, 1.5]))
-    budget = 250000  # rows * dim, keeps the oracle's sequential build in seconds
+    budget = 300000  # rows * dim, keeps the oracle's sequential build in seconds
     n = int(rng.integers(50, max(60, min(3000, budget // d))))
     batched = bool(rng.integers(0, 2))
     big_min = int(rng.choice([2, 3, 8, 512]))
@@ -251,6 +251,27 @@ def trial(rng, t):
     return desc
 
 
+def merge_trial(rng):
+    """the shard fan-out's merge (cluster/actions.go:357-376) on random ragged per-shard results with ties"""
+    from semadb_amd import cluster
+    n_shards = int(rng.integers(1, 17))
+    per = int(rng.integers(1, 76))
+    limit = int(rng.integers(1, 101))
+    nq = int(rng.integers(1, 70))
+    d = np.sort(rng.integers(0, int(rng.choice([4, 50, 100000])), size=(n_shards, nq, per)).astype(np.float32) / 8, axis=2)
+    if rng.integers(0, 2):
+        d = -d[:, :, ::-1].copy()  # dot-product distances are negative
+    ids = rng.integers(2, 10 ** 6, size=(n_shards, nq, per)).astype(np.uint64)
+    counts = rng.integers(0, per + 1, size=(n_shards, nq)).astype(np.uint32)
+    o_ids, o_d, o_s, o_c = cluster.topk_merge(ids, d, counts, limit)
+    for q in range(nq):
+        w_ids, w_d, w_s = orc.cluster_merge(ids[:, q, :], d[:, q, :], counts[:, q].astype(np.int32), limit)
+        n = len(w_ids)
+        assert int(o_c[q]) == n, ("merge count", n_shards, per, limit, q)
+        assert np.array_equal(o_ids[q, :n], w_ids) and np.array_equal(bits(o_d[q, :n]), bits(w_d)), ("merge", q)
+        assert np.array_equal(o_s[q, :n].astype(np.int32), w_s), ("merge shards", q)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=100)
@@ -264,6 +285,7 @@ def main():
     for t in ([a.only] if a.only >= 0 else range(a.trials)):
         rng = np.random.default_rng([a.seed, t])
         try:
+            merge_trial(rng)
             desc = trial(rng, t)
         except StartOverflow:
             skipped += 1
