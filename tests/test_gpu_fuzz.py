@@ -1,6 +1,7 @@
 """Randomised differential trials (tools/fuzz_parity.py: device through the C ABI vs the oracle over random shapes,
 metrics, parameters, data with ties and duplicates, build schedules, write sequences in rounds or one by one, a
-quantizer attached mid-way; graphs edge for edge, plain / filtered / exact-scan searches and K1 bit for bit).
+quantizer attached mid-way; graphs edge for edge, plain / filtered / exact-scan searches and K1 bit for bit; plus
+random product-quantizer fits / codecs and shard merges).
 
 The soak's first runs exposed two defects, each now pinned by a deterministic test of its own:
   * a delete leaving more stragglers than the start node's 64-entry row holds (the reference's start node has no
@@ -33,4 +34,5 @@ def test_fuzz_short_soak(oracle, monkeypatch, seed):
     for t in range(30):
         rng = np.random.default_rng([seed, t])
         fz.merge_trial(rng)
+        fz.pq_trial(rng)
         fz.trial(rng, t)

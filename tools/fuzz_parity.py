@@ -272,6 +272,48 @@ def merge_trial(rng):
         assert np.array_equal(o_s[q, :n].astype(np.int32), w_s), ("merge shards", q)
 
 
+def pq_trial(rng):
+    """productQuantizer.Fit / encode / LUT / symmetric distance (product.go, utils/kmeans.go) on random shapes and
+    degenerate data (ties, repeated points, fewer distinct points than centroids)"""
+    M = int(rng.choice([2, 3, 4, 8, 16]))
+    sub = int(rng.choice([1, 2, 3, 4, 8, 24, 32, 33, 64, 100]))
+    d = M * sub
+    K = int(rng.choice([2, 3, 16, 64, 255, 256]))
+    metric = str(rng.choice(METRICS))
+    kind = str(rng.choice(["unit", "latent", "grid", "dups"]))
+    n = int(rng.integers(1, 4)) * K + int(rng.integers(0, 50)) if rng.integers(0, 4) else int(rng.integers(2, K + 2))
+    n = max(2, min(n, max(2, 400000 // (d * max(1, K // 8)))))
+    X = draw_rows(rng, n, d, kind)
+    first = rng.integers(0, n, M)
+    alias = bool(rng.integers(0, 2))
+    CURRENT.clear()
+    CURRENT.update(dict(pq_trial=True, d=d, M=M, K=K, metric=metric, kind=kind, n=n, alias=alias))
+    xo, xg = X.copy(), X.copy()
+    opq = orc.PQ(d, metric, M, K)
+    o_codes = opq.fit(xo, first, alias=alias)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    try:
+        g_codes = gpq.Fit(xg, first, alias=alias)
+        assert np.array_equal(g_codes, o_codes), "fit codes"
+        fc, cd = gpq.codebook()
+        assert np.array_equal(bits(fc), bits(opq.flat_centroids)), "codebook"
+        assert np.array_equal(bits(cd), bits(opq.centroid_dists)), "centroid-pair table"
+        assert np.array_equal(bits(xg), bits(xo)), "aliasing write-through"
+        V = draw_rows(rng, 20, d, kind)
+        ge = gpq.encode(V)
+        assert np.array_equal(ge, np.stack([opq.encode(v) for v in V])), "encode"
+        Q = draw_rows(rng, 4, d, kind)
+        got = gpq.lut_distance(Q, ge)
+        want = np.array([[opq.dist_lut(opq.lut(q), c) for c in ge] for q in Q], dtype=np.float32)
+        assert np.array_equal(bits(got), bits(want)), "LUT distance"
+        perm = rng.permutation(20)
+        gs = gpq.sym_distance(ge, ge[perm])
+        ws = np.array([opq.dist_sym(ge[i], ge[perm[i]]) for i in range(20)], dtype=np.float32)
+        assert np.array_equal(bits(gs), bits(ws)), "symmetric distance"
+    finally:
+        gpq.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=100)
@@ -286,6 +328,7 @@ def main():
         rng = np.random.default_rng([a.seed, t])
         try:
             merge_trial(rng)
+            pq_trial(rng)
             desc = trial(rng, t)
         except StartOverflow:
             skipped += 1
