@@ -874,6 +874,11 @@ int orc_index_union_prune(orc_index *ix, uint64_t id, const uint64_t *extra, uin
   return 0;
 }
 
+static int cmp_u64(const void *x, const void *y) {
+  uint64_t a = *(const uint64_t *)x, b = *(const uint64_t *)y;
+  return a < b ? -1 : a > b;
+}
+
 /* One build round of the device schedule (semadb_amd/csrc/build.hip; DESIGN.md "K4 rounds"), restated so that
  * the batched build -- the one the bench uses -- can be held to the oracle edge for edge, not only the
  * sequential one.  The reference itself runs NumCPU-1 insertSinglePoint workers concurrently (vamana.go:190-196),
@@ -917,12 +922,7 @@ int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs
   size_t k = 0;
   for (int i = 0; i < rs; i++)
     for (uint32_t e = 0; e < ix->deg[first + i]; e++) req[k++] = ((uint64_t)ix->edges[first + i][e] << 32) | (uint32_t)i;
-  for (size_t i = 1; i < nreq; i++) { /* insertion sort is fine for the sizes the tests use; stable */
-    uint64_t v = req[i];
-    size_t j = i;
-    while (j > 0 && req[j - 1] > v) req[j] = req[j - 1], j--;
-    req[j] = v;
-  }
+  qsort(req, nreq, sizeof(uint64_t), cmp_u64); /* keys are distinct (target, insert index): any sort is stable */
   size_t p = 0;
   uint64_t *grp = malloc(8 * (nreq ? nreq : 1));
   while (p < nreq) {

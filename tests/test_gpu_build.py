@@ -257,3 +257,33 @@ def test_batched_build_identical_to_oracle_schedule(oracle, monkeypatch, metric,
     ix.insert_batch(ids, base, round_size=round_size)
     assert_same_graph(ix, o)
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,n,R,L", [("cosine", 16, 60000, 32, 50), ("euclidean", 128, 40000, 64, 75)])
+def test_batched_build_at_natural_scale(oracle, monkeypatch, metric, d, n, R, L):
+    """The batched build at a size where the schedule's own machinery is in play with its default settings: rounds
+    of 800-1200 points, the start node collecting more than 512 back-edge requests per round (the chip-wide hub
+    prune, bigprune.inc), groups of requests on ordinary targets -- equal to the oracle's restatement of the
+    schedule edge for edge, and the searches that follow walk the same path."""
+    from tests.helpers import assert_same_graph
+    monkeypatch.delenv("SDB_BIG_MIN", raising=False)
+    rng = np.random.default_rng(d + n)
+    lat = rng.standard_normal((6, d)).astype(np.float32)
+    base = rng.standard_normal((n, 6)).astype(np.float32) @ lat + 0.2 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    sv = start_vector(np.random.default_rng(3), d)
+    o = oracle.Index(d, metric, R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(sv)
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    assert o.insert_rounds(ids, base) == 0
+    ix = _new_gpu(d, metric, R, L)
+    ix.set_start(sv)
+    ix.insert_batch(ids, base)
+    assert_same_graph(ix, o)
+    q = base[rng.integers(0, n, 32)] + 0.05 * rng.standard_normal((32, d)).astype(np.float32)
+    g_ids, g_d, g_c, tr = ix.search_batch(q.astype(np.float32), 10, L, trace=True, visit_cap=512)
+    for i in range(32):
+        o_ids, o_d, o_vis, o_tr = o.search(q[i].astype(np.float32), 10, L)
+        assert np.array_equal(g_ids[i, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d))
+        assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis)
+    ix.close()
