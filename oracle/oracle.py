@@ -49,6 +49,8 @@ def lib():
     L.orc_distance.restype = C.c_float
     L.orc_distance.argtypes = [f32p, f32p, C.c_size_t, C.c_int, C.c_int]
     L.orc_distance_matrix.restype = None
+    L.orc_set_threads.restype = None
+    L.orc_set_threads.argtypes = [C.c_int]
     L.orc_distance_matrix.argtypes = [f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, f32p]
     L.orc_distset_script.restype = C.c_int
     L.orc_distset_script.argtypes = [C.c_int, C.c_int, f32p, C.c_int, i32p, C.c_int, u64p, i32p, u64p, C.c_int]
@@ -179,6 +181,7 @@ class Index:
         vecs = _f32(vecs)
         n = ids.size
         max_round = min(round_size if round_size else 16384, n)
+        lib().orc_set_threads(effective_cpus())  # a round's searches and prunes run over the host cores
         done = 0
         while done < n:
             cur = self.n_slots()

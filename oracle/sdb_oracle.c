@@ -145,6 +145,15 @@ int orc_max_threads(void) {
 #endif
 }
 
+/* threads for the parallel loops (batch search, build rounds); the caller passes what the cgroup really grants */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 float orc_dot(const float *x, const float *y, size_t n, int impl) {
   switch (impl) {
     case ORC_IMPL_AVX2: return dot_avx2(x, y, n);
@@ -899,7 +908,11 @@ int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs
     index_add_node(ix, ids[i], vecs + (size_t)i * ix->dim);
   }
   /* 1. searches on the snapshot: nothing below this loop has run yet, and the new nodes have no in-edges */
+  /* (the loops of a round run over the host cores: within a step every iteration reads the snapshot and writes
+   * one node of its own, so the order of iterations cannot matter -- that independence is the schedule) */
   distset *vs = calloc((size_t)rs, sizeof(distset));
+  int rc_all = 0;
+#pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < rs; i++) {
     distfn df;
     float *lut;
@@ -908,10 +921,15 @@ int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs
     int rc = greedy_search(ix, &df, 1, ix->L, NULL, 0, NULL, NULL, &ss, &rsd, &res, &vs[i], NULL, 0, NULL);
     ds_free(&ss);
     free(lut);
-    if (rc) return rc;
-    vs[i].df = NULL;
+    vs[i].df = NULL; /* df lives on this iteration's stack; the visit list keeps its distances */
+    if (rc) {
+#pragma omp atomic write
+      rc_all = rc;
+    }
   }
+  if (rc_all) return rc_all;
   /* 2. robustPrune of every new node over its own visit list */
+#pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < rs; i++) robust_prune(ix, first + (uint32_t)i, &vs[i]);
   for (int i = 0; i < rs; i++) ds_free(&vs[i]);
   free(vs);
@@ -923,12 +941,18 @@ int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs
   for (int i = 0; i < rs; i++)
     for (uint32_t e = 0; e < ix->deg[first + i]; e++) req[k++] = ((uint64_t)ix->edges[first + i][e] << 32) | (uint32_t)i;
   qsort(req, nreq, sizeof(uint64_t), cmp_u64); /* keys are distinct (target, insert index): any sort is stable */
-  size_t p = 0;
-  uint64_t *grp = malloc(8 * (nreq ? nreq : 1));
-  while (p < nreq) {
+  /* segment heads: one per target; targets are existing nodes (a new node has no in-edges yet), each segment
+   * writes its own target's list only */
+  size_t nseg = 0, *seg = malloc(sizeof(size_t) * (nreq + 1));
+  for (size_t q = 0; q < nreq; q++)
+    if (q == 0 || (uint32_t)(req[q] >> 32) != (uint32_t)(req[q - 1] >> 32)) seg[nseg++] = q;
+  seg[nseg] = nreq;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (size_t sg = 0; sg < nseg; sg++) {
+    size_t p = seg[sg];
     uint32_t b = (uint32_t)(req[p] >> 32);
-    size_t m = 1;
-    while (p + m < nreq && (uint32_t)(req[p + m] >> 32) == b) m++;
+    size_t m = seg[sg + 1] - p;
+    uint64_t *grp = malloc(8 * m);
     size_t done = 0;
     if ((int)m >= big_min || ix->deg[b] > 64) { /* hub: everything at once; so does a start node whose list has
                                                   * outgrown an adjacency row (stragglers, prune.go:131-151) */
@@ -947,9 +971,9 @@ int orc_index_insert_round(orc_index *ix, const uint64_t *ids, const float *vecs
       }
       done += t;
     }
-    p += m;
+    free(grp);
   }
-  free(req), free(grp);
+  free(req), free(seg);
   return 0;
 }
 

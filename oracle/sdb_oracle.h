@@ -170,6 +170,7 @@ int orc_cluster_merge(int n_shards, const int *counts, const uint64_t *ids, cons
 
 int orc_has_avx2(void);
 int orc_max_threads(void);
+void orc_set_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,34 @@ def test_c3_build_is_deterministic(c2):
     assert np.array_equal(off, off2) and np.array_equal(edges, edges2)
 
 
+def test_c3_build_equals_oracle_schedule(c2, oracle):
+    """The batched build of the BASELINE data against the oracle's restatement of the round schedule, edge for
+    edge.  The oracle runs a round's searches and prunes over the host cores; the first 250 000 rows by default,
+    SDB_TEST_C3_ORACLE_ROWS=1000000 for all of C3 (2.5 minutes on the GPU box's 16 host cores; passed at the end
+    of round 1)."""
+    from semadb_amd import vamana
+    rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 250_000)), c2.n)
+    bench = _bench()
+    base = c2.base[:rows].cpu().numpy()
+    sv = bench.start_vector(c2.d)
+    o = oracle.Index(c2.d, "cosine", R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+    o.set_start(np.asarray(sv, dtype=np.float32))
+    assert o.insert_rounds(np.arange(2, rows + 2, dtype=np.uint64), base) == 0
+    o_ids, _, o_off, o_e = o.export(with_vectors=False)
+    if rows == c2.n:
+        ix = c2.ix
+    else:
+        ix = vamana.NewIndexVamana("c3o", vamana.IndexVectorVamanaParameters(c2.d, "cosine", L, R, 1.2), capacity=rows + 1)
+        ix.set_start(sv)
+        ix.insert_batch(None, c2.base[:rows])
+    g_ids, _, g_off, g_e = ix.export(with_vectors=False)
+    if ix is not c2.ix:
+        ix.close()
+    assert np.array_equal(g_ids, o_ids)
+    assert np.array_equal(g_off, o_off), "degree sequence differs"
+    assert np.array_equal(g_e, o_e), "edge lists differ"
+
+
 def _search(ix, q, k=K, search_size=L):
     import torch
     ids, d, c, tr = ix.search_batch(q, k, search_size, trace=True)
