@@ -256,6 +256,45 @@ def test_c5_two_shards_merge(c2, oracle):
     ix1.close()
 
 
+def test_c4_quantized_walk_matches_oracle_at_1M(oracle):
+    """C4's store at a size the oracle can hold in host memory (1M x 768 = 3 GB): graph built on device, quantizer
+    fitted on the first 10 000 rows and attached, everything exported to the oracle -- the quantized walk gives
+    the same ids, LUT-distance bits, visit order and counters on a sample of queries."""
+    import torch
+    from semadb_amd import vectorstore as vs
+    bench = _bench()
+    n, d, M, Kc = int(os.environ.get("SDB_TEST_C4_ORACLE_ROWS", 1_000_000)), 768, 8, 256
+    ix, base = _build(n, d)
+    train = base[:10000].cpu().numpy().copy()
+    first = np.arange(M) * 7 % 10000
+    pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(Kc, M, 10000), d)
+    pq.Fit(train, first, alias=True)
+    vs.attach(ix, pq)
+    ids, vecs, off, edges = ix.export()
+    del base
+    torch.cuda.empty_cache()
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=impl)
+    assert o.load(ids, vecs, off, edges) == 0
+    del vecs, edges
+    opq = oracle.PQ(d, "cosine", M, Kc, impl=impl)
+    opq.set_codebook(pq.codebook()[0])
+    assert o.attach_pq(opq, vs.get_codes(ix, ids)) == 0
+    q = bench.gen_rows(64, d, 20250621, "latent:24", "cuda:0")
+    g_ids, g_d, g_c, tr = ix.search_batch(q, K, L, trace=True, visit_cap=512)
+    torch.cuda.synchronize()
+    g_ids, g_d = g_ids.cpu().numpy().view(np.uint64), g_d.cpu().numpy()
+    vis = tr.visit_ids.cpu().numpy().view(np.uint64)
+    qh = q.cpu().numpy()
+    for i in range(64):
+        o_ids, o_d, o_vis, o_tr = o.search(qh[i], K, L)
+        assert np.array_equal(g_ids[i], o_ids) and np.array_equal(bits(g_d[i]), bits(o_d)), "query %d" % i
+        assert int(tr.n_dist[i]) == o_tr.n_dist and int(tr.n_hop[i]) == o_tr.n_hop
+        assert np.array_equal(vis[i, :o_tr.n_hop], o_vis), "query %d visit order" % i
+    ix.close()
+    pq.close()
+
+
 # ---- C4: 10M x 768 + product quantizer -----------------------------------------------------------
 
 @pytest.fixture(scope="module")
