@@ -327,9 +327,16 @@ def main():
     for t in ([a.only] if a.only >= 0 else range(a.trials)):
         rng = np.random.default_rng([a.seed, t])
         try:
+            t1 = time.time()
             merge_trial(rng)
+            t2 = time.time()
             pq_trial(rng)
+            pq_desc = dict(CURRENT)
+            t3 = time.time()
             desc = trial(rng, t)
+            if time.time() - t1 > 20:
+                print("slow trial %d: merge %.1fs, pq %.1fs %s, index %.1fs %s" % (
+                    t, t2 - t1, t3 - t2, pq_desc, time.time() - t3, CURRENT), file=sys.stderr)
         except StartOverflow:
             skipped += 1
             continue
