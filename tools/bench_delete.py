@@ -15,7 +15,7 @@ from semadb_amd import vamana
 n, d = int(os.environ.get("ROWS", 1000000)), 384
 base = bench.gen_rows(n, d, 20250620, "latent:24", "cuda:0")
 q = bench.gen_rows(1024, d, 20250621, "latent:24", "cuda:0")
-ix = vamana.NewIndexVamana("del", vamana.IndexVectorVamanaParameters(d, "cosine", 75, 64, 1.2), capacity=n + 1)
+ix = vamana.NewIndexVamana("del", vamana.IndexVectorVamanaParameters(d, "cosine", 75, 64, 1.2), capacity=n + 5001)
 ix.set_start(bench.start_vector(d))
 ix.insert_batch(None, base)
 torch.cuda.synchronize()
@@ -30,6 +30,20 @@ for m in (500, 10000, 100000):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["delete_%d" % m] = {"seconds": round(dt, 3), "deletes_per_s": round(m / dt)}
+# small write transactions (the REST path's shape): new points into the 1M graph, a few at a time
+newv = bench.gen_rows(2000, d, 777, "latent:24", "cuda:0")
+nid, used = n + 10, 0
+for m in (1, 10, 100, 1000):
+    reps = 20 if m <= 10 else 3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        ix.insert_batch(np.arange(nid, nid + m, dtype=np.uint64), newv[used % 1000:used % 1000 + m].contiguous())
+        nid += m
+        used += m
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out["insert_call_%d" % m] = {"ms_per_call": round(dt * 1e3, 2), "inserts_per_s": round(m / dt)}
 ids, dd, c, _ = ix.search_batch(q, 10, 75)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
