@@ -8,7 +8,9 @@ namespace sdb {
 
 constexpr int kMergeMaxItems = 2048;  // n_shards * per_shard
 
-// one 64-thread block per query; rank-by-counting under the total order (dist, shard, id)
+// one 64-thread block per query; rank-by-counting under the total order (dist, shard, id, position) -- the
+// position only matters for a caller that hands in the same (dist, shard, id) twice: every item still gets a
+// rank of its own
 __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard,
                                                    const uint64_t *__restrict__ ids,
                                                    const float *__restrict__ dists,
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
       const float dj = s_d[j];
       // a single shard is not re-sorted at all (actions.go:357: `if len(col.ShardIds) > 1`)
       const bool before = n_shards == 1 ? (j < i)
-                                        : (dj < d || (dj == d && (s_sh[j] < sh || (s_sh[j] == sh && s_id[j] < id))));
+                                        : (dj < d || (dj == d && (s_sh[j] < sh || (s_sh[j] == sh && (s_id[j] < id || (s_id[j] == id && j < i))))));
       rank += before ? 1u : 0u;
     }
     if (rank < limit) {  // truncate to the original limit (actions.go:372-374)

@@ -134,3 +134,23 @@ def test_sharded_search_equals_single_index_union(oracle):
         truth = set((int(t // n), int(t % n) + 2) for t in top)
         hits += len(truth & set((int(m_s[i, j]), int(m_ids[i, j])) for j in range(10)))
     assert hits / 640 >= 0.95
+
+
+@pytest.mark.gpu
+def test_topk_merge_with_repeated_items(oracle):
+    """a caller may hand in the same (distance, shard, id) twice (a shard's own search never does): every item
+    still lands on a position of its own (found by tools/fuzz_parity.py, seed 301 trial 83)"""
+    from semadb_amd import cluster
+    n_shards, nq, per, limit = 3, 5, 8, 20
+    d = np.zeros((n_shards, nq, per), dtype=np.float32)
+    d[:, :, 4:] = -0.375
+    d = np.sort(d, axis=2)
+    ids = np.full((n_shards, nq, per), 7, dtype=np.uint64)
+    ids[:, :, ::3] = 9
+    counts = np.full((n_shards, nq), per, dtype=np.uint32)
+    o_ids, o_d, o_s, o_c = cluster.topk_merge(ids, d, counts, limit)
+    for q in range(nq):
+        w_ids, w_d, w_s = oracle.cluster_merge(ids[:, q, :], d[:, q, :], counts[:, q].astype(np.int32), limit)
+        assert int(o_c[q]) == len(w_ids) == limit
+        assert np.array_equal(o_ids[q], w_ids) and np.array_equal(o_d[q], w_d)
+        assert np.array_equal(o_s[q].astype(np.int32), w_s)

@@ -95,6 +95,7 @@ def compare_searches(rng, g, o, d, kind, L, live, tag, metric=None):
 
 
 CURRENT = {}
+BUDGET = 300000
 
 
 class StartOverflow(Exception):
@@ -133,8 +134,8 @@ def trial(rng, t):
     R = int(rng.integers(4, 65))
     L = int(rng.integers(max(R // 2, 5), 101))
     alpha = float(rng.choice([1.0, 1.1, 1.2, 1.5]))
-    budget = 300000  # rows * dim, keeps the oracle's sequential build in seconds
-    n = int(rng.integers(50, max(60, min(3000, budget // d))))
+    budget = BUDGET  # rows * dim, keeps the oracle's sequential build in seconds
+    n = int(rng.integers(50, max(60, min(3000 * max(1, BUDGET // 300000), budget // d))))
     batched = bool(rng.integers(0, 2))
     big_min = int(rng.choice([2, 3, 8, 512]))
     round_size = int(rng.choice([0, 0, 17, 64, 300]))
@@ -320,7 +321,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0, help="stop after this much wall time (0 = run all trials)")
     ap.add_argument("--only", type=int, default=-1, help="run just this trial number")
+    ap.add_argument("--budget", type=int, default=300000, help="rows * dim of a trial's index at most (and 3000 rows per 300000)")
     a = ap.parse_args()
+    global BUDGET
+    BUDGET = a.budget
     t0 = time.time()
     done = skipped = 0
     dims = set()
