@@ -98,10 +98,6 @@ CURRENT = {}
 BUDGET = 300000
 
 
-class StartOverflow(Exception):
-    pass
-
-
 def explain(g, o, tag):
     o_ids, _, o_off, o_e = o.export(with_vectors=False)
     g_ids, _, g_off, g_e = g.export(with_vectors=False)
@@ -115,15 +111,7 @@ def explain(g, o, tag):
         print("   node %d\n     device %s\n     oracle %s" % b)
 
 
-def overflow_check(o):
-    if os.environ.get("FUZZ_SKIP_START_OVERFLOW"):
-        ids, _, off, _ = o.export(with_vectors=False)
-        if int(off[1] - off[0]) > 64:
-            raise StartOverflow()
-
-
 def check_graph(g, o):
-    overflow_check(o)
     assert_same_graph(g, o)
 
 
@@ -241,7 +229,6 @@ def trial(rng, t):
                                            big_min=big_min) == 0
                 if dels or upds:
                     assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
-                    overflow_check(o)
                 for k, i in enumerate(upds):
                     assert o.insert(i, upd_vecs[k]) == 0
             live = sorted((set(live) - set(dels)) | set(new_ids))
@@ -326,7 +313,7 @@ def main():
     global BUDGET
     BUDGET = a.budget
     t0 = time.time()
-    done = skipped = 0
+    done = 0
     dims = set()
     for t in ([a.only] if a.only >= 0 else range(a.trials)):
         rng = np.random.default_rng([a.seed, t])
@@ -341,9 +328,6 @@ def main():
             if time.time() - t1 > 20:
                 print("slow trial %d: merge %.1fs, pq %.1fs %s, index %.1fs %s" % (
                     t, t2 - t1, t3 - t2, pq_desc, time.time() - t3, CURRENT), file=sys.stderr)
-        except StartOverflow:
-            skipped += 1
-            continue
         except Exception:
             traceback.print_exc()
             print(json.dumps({"failed_trial": t, "seed": a.seed, "trials_passed": done, "config": CURRENT}))
@@ -353,8 +337,7 @@ def main():
         if a.seconds and time.time() - t0 > a.seconds:
             break
     print(json.dumps({"trials_passed": done, "seed": a.seed, "seconds": round(time.time() - t0, 1),
-                      "distinct_dims": len(dims), "mismatches": 0,
-                      "trials_cut_short_by_start_overflow": skipped}))
+                      "distinct_dims": len(dims), "mismatches": 0}))
 
 
 if __name__ == "__main__":
