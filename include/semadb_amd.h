@@ -162,6 +162,35 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
 int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, uint64_t nc,
                              const uint64_t *cand_ids, float *out, int mem, void *stream);
 
+/* Test / measurement knobs of ONE index (never read from the environment: a serving process must not change
+ * algorithmic thresholds through getenv).  None of them changes any result -- the parity suites run with
+ * several settings of each to prove that.
+ *   SDB_TUNE_HUB_MIN     back-edge requests in one build round that send a target to the chip-wide prune
+ *                        (bigprune.inc); default 512, minimum 2
+ *   SDB_TUNE_HASH_LIMIT  ids a query's LDS visited hash set may hold before it spills to the HBM bitset;
+ *                        default 6000 (also the maximum)
+ *   SDB_TUNE_NO_HASH     != 0: the visited set is the HBM bitset from the start */
+#define SDB_TUNE_HUB_MIN 1
+#define SDB_TUNE_HASH_LIMIT 2
+#define SDB_TUNE_NO_HASH 3
+int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
+
+/* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts
+ * of search bytes + prune pair-distance rows * d * 4).  out[0..n) with n = min(cap, SDB_BUILD_STATS):
+ *   [0] distFn evaluations of the insert searches     [1] edge ids read by them
+ *   [2] pair distances evaluated by the new nodes' robustPrune (search.go:132)
+ *   [3] pair / node distances evaluated from rows by the back-edge re-prunes (insert.go:47-58)
+ *   [4] distances those re-prunes took from a cache instead (per-edge cache, the searches' tables)
+ *   [5] back-edge requests (insert.go:36)              [6] re-prunes (:47-58)      [7] plain appends (:62)
+ *   [8] candidate rows staged from HBM by the new nodes' robustPrune (each read once)
+ *   [9] rounds                                         [10] hub prunes (bigprune.inc) */
+#define SDB_BUILD_STATS 11
+int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap);
+
+/* vecStore.Exists (shard/vectorstore/plain.go:21-24) for n ids at once: out[i] = 1 if the id is stored
+ * (the start node counts), else 0.  Host-side table lookup, no device work. */
+int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *out);
+
 /* Measurement hook (the reference logs the greedy-search duration at debug level, vamana.go:284):
  * when enabled, HIP events are recorded on the launch stream immediately around the K2 kernel of
  * every search_batch (not thread-safe: a single measuring caller); sdb_index_last_search_ms waits for
@@ -209,6 +238,65 @@ int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uin
                    void *stream);
 /* per-shard limit rule, cluster/actions.go:291-299 */
 int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit, uint32_t *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * cluster fan-out exchange  (C1's device half: RCCL over xGMI, one shard per GPU)
+ * ------------------------------------------------------------------------------------------- */
+/* ClusterNode.SearchPoints (cluster/actions.go:275-379) scatters a request to every shard over
+ * msgpack net/rpc (:316-351), gathers the per-shard results and sorts / truncates them (:357-376).
+ * With the shards of one node living one per MI355X the gather step is ONE RCCL all-gather of the
+ * fixed-size per-shard result blocks, issued by this library on a stream of its own, followed by
+ * the device merge above.  A cluster handle = one rank (one shard, one GPU) of that exchange.
+ *
+ * Bootstrap is the NCCL one: some rank calls sdb_cluster_unique_id and hands the 128 bytes to the
+ * others over whatever channel the host already has (SemaDB: its cluster RPC; the tests:
+ * torch.distributed / a pipe); every rank then calls sdb_cluster_create, which blocks until all
+ * `world` ranks have arrived.  One process per GPU or one thread per GPU in one process (the shape
+ * of a Go server that owns the whole node) -- sdb_cluster_create_local sets the latter up in one call. */
+#define SDB_CLUSTER_ID_BYTES 128
+typedef struct sdb_cluster sdb_cluster;
+int sdb_cluster_unique_id(uint8_t *id /* [SDB_CLUSTER_ID_BYTES] */);
+int sdb_cluster_create(int rank, int world, const uint8_t *id, int device, sdb_cluster **out);
+/* all `n` ranks of a single-process node at once: rank r lives on devices[r] (NULL: device r) */
+int sdb_cluster_create_local(int n, const int *devices, sdb_cluster **out /* [n] */);
+int sdb_cluster_destroy(sdb_cluster *c);
+int sdb_cluster_info(const sdb_cluster *c, int *rank, int *world, int *device);
+
+/* Layout of one shard's result block for nq queries x per_shard results, the all-gather message:
+ *   [0, off_dists)            uint64 ids   [nq][per_shard]
+ *   [off_dists, off_counts)   float  dists [nq][per_shard]
+ *   [off_counts, ...)         uint32 counts[nq]            padded to `bytes` (a multiple of 16)
+ * sdb_index_search_batch can write straight into it (out_ids = block, out_dists = block + off_dists,
+ * out_counts = block + off_counts). */
+int sdb_cluster_block_layout(uint64_t nq, uint32_t per_shard, size_t *off_dists, size_t *off_counts,
+                             size_t *bytes);
+
+/* The exchange step of SearchPoints (actions.go:316-376) for a block this rank's shard produced:
+ * all-gather of `block` (device memory, layout above, written by work already enqueued on `stream`)
+ * over all ranks, then the merge (sdb_topk_merge rule) to the original `limit` on this rank's GPU.
+ * Collective: every rank calls it with the same nq / per_shard, in the same order.
+ * The exchange runs on the cluster's own stream, ordered after `stream`'s work at the time of the
+ * call, so the caller's next search overlaps it.  `block` must stay untouched and the outputs are
+ * not valid until sdb_cluster_wait(c, stream) (a stream-side wait, no host block) or
+ * sdb_cluster_synchronize(c).  out_* follow `mem`; SDB_MEM_HOST outputs are copied back and the
+ * call synchronises.  out_shards (optional) = rank of the shard each result came from. */
+int sdb_cluster_allgather_merge(sdb_cluster *c, uint64_t nq, uint32_t per_shard, const void *block,
+                                uint32_t limit, uint64_t *out_ids, float *out_dists,
+                                uint32_t *out_shards, uint32_t *out_counts, int mem, void *stream);
+
+/* ClusterNode.SearchPoints for this rank's shard, whole: per-shard limit (actions.go:291-299;
+ * the query's own Limit / SearchSize are not rewritten per shard, :301-314) -> IndexVamana.Search
+ * of all nq queries on `ix` into a block of the cluster's ring -> all-gather -> merge to `limit`.
+ * Collective like sdb_cluster_allgather_merge.  `queries` and out_* follow `mem`; with
+ * SDB_MEM_DEVICE the search is enqueued on `stream`, the exchange on the cluster's stream, and up
+ * to 4 batches may be in flight before the caller waits (sdb_cluster_wait / _synchronize). */
+int sdb_cluster_search_batch(sdb_cluster *c, sdb_index *ix, uint64_t nq, const float *queries,
+                             uint32_t limit, uint32_t search_size, uint64_t *out_ids,
+                             float *out_dists, uint32_t *out_shards, uint32_t *out_counts, int mem,
+                             void *stream);
+/* make `stream` wait (on the device) for every exchange enqueued so far / block the host for them */
+int sdb_cluster_wait(sdb_cluster *c, void *stream);
+int sdb_cluster_synchronize(sdb_cluster *c);
 
 /* ---------------------------------------------------------------------------------------------
  * utils/kmeans.go + shard/vectorstore/product.go  (K5..K8)

@@ -51,6 +51,9 @@ SIGNATURES = {
                                          C.c_int, C.c_void_p]),
     "sdb_index_distance_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p]),
+    "sdb_index_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
+    "sdb_index_build_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "sdb_index_exists_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "sdb_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "sdb_index_last_search_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sdb_index_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, u32p]),
@@ -63,6 +66,19 @@ SIGNATURES = {
     "sdb_topk_merge": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sdb_shard_limit": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
+    "sdb_cluster_unique_id": (C.c_int, [C.c_void_p]),
+    "sdb_cluster_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdb_cluster_create_local": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "sdb_cluster_destroy": (C.c_int, [C.c_void_p]),
+    "sdb_cluster_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sdb_cluster_block_layout": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                           C.POINTER(C.c_size_t)]),
+    "sdb_cluster_allgather_merge": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sdb_cluster_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sdb_cluster_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sdb_cluster_synchronize": (C.c_int, [C.c_void_p]),
     "sdb_kmeans_fit": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u32p, C.c_int, C.c_int, C.c_void_p]),
     "sdb_pq_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),

@@ -1,9 +1,17 @@
 """Mirror of the shard fan-out in ClusterNode.SearchPoints (cluster/actions.go:275-379).
 
 The reference scatters a query to every shard over msgpack net/rpc, gathers the per-shard results
-and sorts/truncates them (actions.go:316-376).  On one 8 x MI355X node the shards live one per GPU in
-one process per GPU; the gather step is a single RCCL all-gather over xGMI (torch.distributed backend
-"nccl") of the fixed-size per-shard top-k blocks, and the merge runs on device (merge.hip).
+and sorts/truncates them (actions.go:316-376).  On one 8 x MI355X node the shards live one per GPU;
+the gather step is a single RCCL all-gather over xGMI of the fixed-size per-shard top-k blocks and the
+merge runs on device (merge.hip).
+
+Two transports for the gather step:
+  Cluster        the product path: a binding of sdb_cluster_* (csrc/cluster.hip), where the library itself
+                 owns the RCCL communicator and the exchange stream -- what a Go host calls.
+  allgather_topk / PackedTopK.allgather
+                 the same exchange over any torch.distributed backend; exists so that the N > 1 logic
+                 (block layout, shard-major gather, merge rule) runs under gloo on machines without
+                 N GPUs (tests/test_cluster.py, BENCH_BACKEND=gloo).
 """
 import ctypes as C
 
@@ -88,11 +96,14 @@ class PackedTopK:
         import torch
         self.nq, self.per = nq, per_shard
         self.b_ids, self.b_d, self.b_c = nq * per_shard * 8, nq * per_shard * 4, nq * 4
-        # not cleared: the search kernel writes every element (short rows are zero-padded by the kernel)
-        self.buf = torch.empty(self.b_ids + self.b_d + self.b_c, dtype=torch.uint8, device=device)
+        off_d, off_c, total = block_layout(nq, per_shard)  # the layout the C ABI defines (semadb_amd.h)
+        assert off_d == self.b_ids and off_c == self.b_ids + self.b_d
+        # the search kernel writes every element (short rows are zero-padded by the kernel); the 16-byte
+        # padding behind the counts travels too, so the buffer starts out cleared
+        self.buf = torch.zeros(total, dtype=torch.uint8, device=device)
         self.ids = self.buf[:self.b_ids].view(torch.int64).view(nq, per_shard)
         self.dists = self.buf[self.b_ids:self.b_ids + self.b_d].view(torch.float32).view(nq, per_shard)
-        self.counts = self.buf[self.b_ids + self.b_d:].view(torch.int32)
+        self.counts = self.buf[self.b_ids + self.b_d:self.b_ids + self.b_d + self.b_c].view(torch.int32)
 
     def out(self):
         return self.ids, self.dists, self.counts
@@ -107,6 +118,96 @@ class PackedTopK:
         g = g.view(world, -1)
         ids = g[:, :self.b_ids].contiguous().view(torch.int64).view(world, self.nq, self.per)
         d = g[:, self.b_ids:self.b_ids + self.b_d].contiguous().view(torch.float32).view(world, self.nq, self.per)
-        c = g[:, self.b_ids + self.b_d:].contiguous().view(torch.int32).view(world, self.nq)
+        c = g[:, self.b_ids + self.b_d:self.b_ids + self.b_d + self.b_c].contiguous().view(torch.int32).view(world, self.nq)
         return ids, d, c
+
+
+def block_layout(nq, per_shard):
+    """(off_dists, off_counts, bytes) of one shard's result block, sdb_cluster_block_layout"""
+    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    check(lib().sdb_cluster_block_layout(nq, per_shard, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+class Cluster:
+    """One rank (one shard, one GPU) of the RCCL exchange, sdb_cluster_* of the C ABI.  The library owns
+    the communicator and the exchange stream; torch only supplies device buffers here."""
+
+    def __init__(self, handle, rank, world, device):
+        self._h, self.rank, self.world, self.device = handle, rank, world, device
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().sdb_cluster_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, rank, world, uid, device):
+        h = C.c_void_p()
+        raw = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(lib().sdb_cluster_create(rank, world, raw, device, C.byref(h)))
+        return cls(h, rank, world, device)
+
+    @classmethod
+    def create_local(cls, devices):
+        """all ranks of a single-process node (the shape of a Go server owning every GPU)"""
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        devs = (C.c_int * n)(*devices)
+        check(lib().sdb_cluster_create_local(n, devs, hs))
+        return [cls(C.c_void_p(hs[i]), i, n, devices[i]) for i in range(n)]
+
+    @classmethod
+    def from_torch_distributed(cls, device):
+        """bootstrap over an existing torch.distributed group: rank 0 draws the unique id, everybody gets it"""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.create(rank, world, box[0], device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sdb_cluster_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _outs(self, nq, limit, mem):
+        o_ids, p_ids = _buf.empty_like_mem(mem, (nq, limit), "uint64", self.device)
+        o_d, p_d = _buf.empty_like_mem(mem, (nq, limit), "float32", self.device)
+        o_s, p_s = _buf.empty_like_mem(mem, (nq, limit), "uint32", self.device)
+        o_c, p_c = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
+        return (o_ids, o_d, o_s, o_c), (p_ids, p_d, p_s, p_c)
+
+    def allgather_merge(self, block, limit, host_out=False):
+        """block: PackedTopK on this rank's GPU, written by work on the current stream.  Returns merged
+        (ids, dists, shards, counts): device tensors valid after wait()/synchronize(), or numpy if host_out."""
+        mem = 0 if host_out else MEM_DEVICE
+        outs, ptrs = self._outs(block.nq, limit, mem)
+        check(lib().sdb_cluster_allgather_merge(self._h, block.nq, block.per, C.c_void_p(block.buf.data_ptr()), limit,
+                                                ptrs[0], ptrs[1], ptrs[2], ptrs[3], mem,
+                                                _buf.current_stream(MEM_DEVICE)))
+        return outs
+
+    def search_batch(self, ix, queries, limit, search_size):
+        """ClusterNode.SearchPoints for this rank's shard: search -> all-gather -> merge.  numpy queries ->
+        numpy results (synchronous); torch CUDA queries -> device results, valid after wait()/synchronize()."""
+        k, qp, mem, shape = _buf.as_f32(queries)
+        outs, ptrs = self._outs(shape[0], limit, mem)
+        check(lib().sdb_cluster_search_batch(self._h, ix._h, shape[0], qp, limit, search_size, ptrs[0], ptrs[1],
+                                             ptrs[2], ptrs[3], mem, _buf.current_stream(mem)))
+        return outs
+
+    def wait(self):
+        """the current torch stream waits (on the device) for every exchange enqueued so far"""
+        check(lib().sdb_cluster_wait(self._h, _buf.current_stream(MEM_DEVICE)))
+
+    def synchronize(self):
+        check(lib().sdb_cluster_synchronize(self._h))
 

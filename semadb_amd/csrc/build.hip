@@ -56,7 +56,17 @@ struct BuildArgs {
   uint32_t start_slot;
   const uint32_t *start_ext;
   uint32_t start_ext_n;
+  unsigned long long *stats;  // sdb_index_build_stats counters (index.h d_bstats), or NULL
+  uint32_t *flags;            // [0] bit 0: a search's visit log did not fit vis_cap
 };
+
+// sdb_index_build_stats slots
+enum { kStSearchDist = 0, kStSearchEdges, kStPrunePairs, kStBackPairs, kStBackCached, kStRequests, kStReprunes,
+       kStAppends, kStStagedRows, kStRounds, kStHubs };
+
+__device__ __forceinline__ void stat_add(const BuildArgs &a, int slot, unsigned long long v, int lane) {
+  if (a.stats && lane == 0 && v) atomicAdd(a.stats + slot, v);
+}
 
 constexpr int kQuantized = -2;  // value of the NG template parameter for a fitted product quantizer
 
@@ -102,7 +112,9 @@ template <int NG, bool L2>
 __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc, const uint32_t *in_slot,
                                   const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
                                   float *qs, int lane, float *D = nullptr, int n_clean = 0,
-                                  bool dists_are_point_to_point = true) {
+                                  bool dists_are_point_to_point = true, uint32_t *n_eval = nullptr,
+                                  uint32_t *n_cached = nullptr) {
+  uint32_t ev = 0, ca = 0;  // pair distances evaluated / taken from the searches' tables (sdb_index_build_stats)
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
   for (int i = lane; i < nc; i += 64) {
@@ -174,6 +186,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
           nmiss += __popcll(mm);
         }
         __syncthreads();
+        ev += (uint32_t)nmiss, ca += (uint32_t)(nc - nmiss);
         if (nmiss) {
           PointRow<NG> pr;
           const float *prow = a.slab + (size_t)sd * a.ld;
@@ -294,7 +307,9 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
       const uint8_t *cp = a.pq_codes + (size_t)p * a.pq_M;
       for (int base = (found + 1) & ~63; base < nc; base += 64) {
         const int j = base + lane;
-        if (j > found && j < nc && !(s_rem[j] & 1u)) {
+        const bool lv = j > found && j < nc && !(s_rem[j] & 1u);
+        ev += (uint32_t)__popcll(__ballot(lv));
+        if (lv) {
           const float d = pq_sym_dist(a, cp, a.pq_codes + (size_t)s_slot[j] * a.pq_M);
           if (a.alpha * d < s_dist[j]) s_rem[j] |= 1u;  // :132
         }
@@ -322,6 +337,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
       const uint32_t cs = live ? s_slot[j] : 0u;
       const float cdj = live ? s_dist[j] : 0.0f;
       uint64_t todo = __ballot(live);
+      ev += (uint32_t)__popcll(todo);
       bool rm = false;
       while (todo) {
         int jj[2 * U];
@@ -366,6 +382,8 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     // candidate list carries the search's LUT distances (DistanceFromFloat), not DistanceFromPoint
     a.dcount[self_slot] = dists_are_point_to_point ? (uint32_t)cnt : 0u;
   }
+  if (n_eval) *n_eval += ev;
+  if (n_cached) *n_cached += ca;
 }
 
 // dynamic LDS carve shared by both prune kernels
@@ -448,14 +466,19 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
   const uint32_t q = blockIdx.x;
   const uint32_t self = a.first_slot + q;
   uint32_t nc = a.vis_count[q];
-  if (nc > a.vis_cap) nc = a.vis_cap;
+  if (nc > a.vis_cap) {  // the reference's visited list is unbounded (AddAlreadyUnique): never prune a cut one silently
+    if (lane == 0) atomicOr(a.flags, 1u);
+    nc = a.vis_cap;
+  }
   for (uint32_t i = lane; i < nc; i += 64) {
     l.in_slot[i] = a.vis_slots[(size_t)q * a.vis_cap + i];
     l.in_dist[i] = a.vis_dists[(size_t)q * a.vis_cap + i];
   }
   __syncthreads();
+  uint32_t n_eval = 0;
   robust_prune_wave<NG, L2>(a, self, (int)nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane, nullptr, 0,
-                            NG != kQuantized);
+                            NG != kQuantized, &n_eval);
+  stat_add(a, kStPrunePairs, n_eval, lane);
   const uint32_t nb = a.adj[(size_t)self * kAdjStride + lane];  // this lane wrote it
   a.keys_in[(size_t)q * 64 + lane] =
       nb == kNoSlot ? kNoKey : ((uint64_t)nb << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
@@ -500,6 +523,8 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       const uint32_t at = atomicAdd(a.big_count, 1u);
       if (at < a.big_cap) a.big_list[at] = make_uint4((uint32_t)pos, (uint32_t)m, b, a.deg[b]);
     }
+    stat_add(a, kStRequests, m, lane);
+    stat_add(a, kStHubs, 1, lane);
     return;
   }
   uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
@@ -517,6 +542,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     return a.adjdist[(size_t)anew * kAdjStride + epos];
   };
   size_t done = 0;
+  uint32_t st_eval = 0, st_cached = 0, st_reprune = 0, st_append = 0;
   while (done < m) {
     size_t t = m - done;
     if (t > kBackCap - deg) t = kBackCap - deg;
@@ -531,6 +557,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
       }
       row_dirty = true;
       done += t;
+      st_append += (uint32_t)t;
       continue;
     }
     // B overflows: distances from B (distFn = DistanceFromPoint(nB) :49) to its neighbours and the t new points
@@ -563,6 +590,7 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
         nmiss += __popcll(mm);
       }
       __syncthreads();
+      st_eval += (uint32_t)nmiss, st_cached += (uint32_t)(nc - nmiss);
       if (nmiss) {
         PointRow<NG> pr;
         const float *brow = a.slab + (size_t)b * a.ld;
@@ -599,7 +627,9 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     // new points are not)
     const uint32_t ncl = a.clean[b] < deg ? a.clean[b] : deg;
     robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane,
-                              (NG >= 0 && nc <= kPairMax) ? l.D : nullptr, (int)ncl);  // :57-58
+                              (NG >= 0 && nc <= kPairMax) ? l.D : nullptr, (int)ncl, true, &st_eval,
+                              &st_cached);  // :57-58
+    st_reprune++;
     __syncthreads();
     row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
     rowd = a.adjdist[(size_t)b * kAdjStride + lane];
@@ -613,6 +643,11 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
     a.adjdist[(size_t)b * kAdjStride + lane] = rowd;
     if (lane == 0) a.deg[b] = deg, a.dcount[b] = dc;
   }
+  stat_add(a, kStBackPairs, st_eval, lane);
+  stat_add(a, kStBackCached, st_cached, lane);
+  stat_add(a, kStRequests, m, lane);
+  stat_add(a, kStReprunes, st_reprune, lane);
+  stat_add(a, kStAppends, st_append, lane);
 }
 
 template <int NG, bool L2>
@@ -625,7 +660,7 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   SDB_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp, a.keys_in, a.keys_sorted, (int)((size_t)a.nnew * 64), 0,
                                             sort_end_bit, stream));
   const size_t lds2 = prune_lds_bytes(kBackCap, NG, a.ld, NG >= 0);
-  if (a.big_count) SDB_HIP(hipMemsetAsync(a.big_count, 0, 4, stream));
+  if (a.big_count) SDB_HIP(hipMemsetAsync(a.big_count, 0, 4, stream));  // word 1 = BuildArgs::flags, kept
   hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
   SDB_HIP(hipGetLastError());
   if (a.big_count && ((size_t)a.nnew * 64 >= a.big_min || a.start_ext_n)) {  // the hubs of this round, if any (bigprune.inc)
@@ -689,6 +724,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
   if (!vectors) return fail(SDB_ERR_INVALID, "vectors is NULL");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
   if ((uint64_t)ix->n + n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many nodes");
   // ---- ids: vamana.go:150-157 rejects 0 and the start id; an existing id would be an update
@@ -713,19 +749,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   hipStream_t stream = as_stream(stream_);
   const RowLayout &l = ix->lay;
   const uint32_t n0 = ix->n;
-  SDB_TRY(ix->reserve(n0 + (uint32_t)n));
-  // ---- stage the vectors (original layout) on device; they double as the search queries
-  const float *dvec = vectors;
-  float *staging = nullptr;
-  if (mem == SDB_MEM_HOST) {
-    SDB_HIP(hipMalloc(&staging, n * l.dim * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(staging, vectors, n * l.dim * sizeof(float), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) {
-      (void)hipFree(staging);
-      return fail(SDB_ERR_DEVICE, "H2D copy failed: %s", hipGetErrorString(e));
-    }
-    dvec = staging;
-  }
+  const sdb_pq *pq = ix->pq;
   struct Cleanup {
     std::vector<void *> ptrs;
     hipStream_t s;
@@ -734,30 +758,16 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
       for (void *p : ptrs)
         if (p) (void)hipFree(p);
     }
-  } cleanup{{staging}, stream};
-  // vecStore.Set for the whole batch (insert.go:17): rows are unreachable until they get in-edges
-  SDB_TRY(store_rows_public(ix, n0, (uint32_t)n, dvec, stream));
-  const sdb_pq *pq = ix->pq;
-  // a fitted quantizer encodes on Set (product.go:161-169); from here on every distance of the insert is a
-  // table distance: LUT for the search (DistanceFromFloat), centroid pairs for the prunes (DistanceFromPoint)
-  if (pq) SDB_TRY(pq_encode_device(pq, dvec, n, ix->d_codes + (size_t)n0 * pq->M, stream));
-  SDB_HIP(hipMemcpyAsync(ix->d_ids + n0, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-  // host-side id bookkeeping
-  {
-    bool dense = ix->dense_ids;
-    for (uint64_t i = 0; i < n; i++) {
-      if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
-        dense = false;  // switch to the hash map
-        ix->id2slot.reserve((ix->h_ids.size() + n) * 2);
-        for (size_t s = 0; s < ix->h_ids.size(); s++) ix->id2slot.emplace(ix->h_ids[s], (uint32_t)s);
-      }
-      if (!dense) ix->id2slot.emplace(new_ids[i], (uint32_t)ix->h_ids.size());
-      ix->h_ids.push_back(new_ids[i]);
-      if (new_ids[i] > ix->max_node_id) ix->max_node_id = new_ids[i];  // vamana.go:166-168
-    }
-    ix->dense_ids = dense;
+  } cleanup{{}, stream};
+  // ---- every allocation of the call comes first: an out-of-memory failure must leave the index as it was
+  SDB_TRY(ix->reserve(n0 + (uint32_t)n));
+  if (!ix->d_bstats) SDB_HIP(hipMalloc(&ix->d_bstats, SDB_BUILD_STATS * sizeof(uint64_t)));
+  float *staging = nullptr;
+  if (mem == SDB_MEM_HOST) {
+    SDB_HIP(hipMalloc(&staging, n * l.dim * sizeof(float)));
+    cleanup.ptrs.push_back(staging);
   }
-  // ---- per-round buffers, sized for the largest round
+  // per-round buffers, sized for the largest round
   const uint32_t L = ix->P.search_size;
   const uint32_t vis_cap = std::max<uint32_t>(1024, 4 * L);
   uint32_t max_round = round_size ? round_size : 16384;
@@ -799,15 +809,11 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     cleanup.ptrs.push_back(lut);
   }
   // hubs: targets with this many requests in one round go to the chip-wide prune (bigprune.inc)
-  uint32_t big_min = 512;
-  if (const char *e = getenv("SDB_BIG_MIN")) {  // test hook: exercise the path on small graphs
-    long v = atol(e);
-    if (v >= 2) big_min = (uint32_t)v;
-  }
+  const uint32_t big_min = ix->tune_hub_min;  // 512 unless a test set it (sdb_index_set_tuning)
   const uint32_t big_cap = (uint32_t)((size_t)max_round * 64 / big_min + 2);
-  uint32_t *big_count = nullptr;
+  uint32_t *big_count = nullptr;  // [0] hubs listed this round, [1] flags (BuildArgs::flags)
   uint4 *big_list = nullptr;
-  SDB_HIP(hipMalloc(&big_count, 4));
+  SDB_HIP(hipMalloc(&big_count, 8));
   cleanup.ptrs.push_back(big_count);
   SDB_HIP(hipMalloc(&big_list, (size_t)big_cap * sizeof(uint4)));
   cleanup.ptrs.push_back(big_list);
@@ -820,7 +826,55 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     cleanup.ptrs.push_back(dcache);
   }
 
+  // ---- from here on the call writes: rows beyond ix->n first (invisible until a round commits them)
+  SDB_HIP(hipMemsetAsync(ix->d_bstats, 0, SDB_BUILD_STATS * sizeof(uint64_t), stream));
+  SDB_HIP(hipMemsetAsync(big_count, 0, 8, stream));
+  const float *dvec = vectors;  // the vectors (original layout) on device; they double as the search queries
+  if (staging) {
+    SDB_HIP(hipMemcpyAsync(staging, vectors, n * l.dim * sizeof(float), hipMemcpyHostToDevice, stream));
+    dvec = staging;
+  }
+  // vecStore.Set for the whole batch (insert.go:17): rows are unreachable until they get in-edges
+  SDB_TRY(store_rows_public(ix, n0, (uint32_t)n, dvec, stream));
+  // a fitted quantizer encodes on Set (product.go:161-169); from here on every distance of the insert is a
+  // table distance: LUT for the search (DistanceFromFloat), centroid pairs for the prunes (DistanceFromPoint)
+  if (pq) SDB_TRY(pq_encode_device(pq, dvec, n, ix->d_codes + (size_t)n0 * pq->M, stream));
+  SDB_HIP(hipMemcpyAsync(ix->d_ids + n0, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+  // host-side id bookkeeping of the points of one completed round: h_ids / id2slot / max_node_id move together
+  // with ix->n, so that an error return never leaves ids that resolve to slots past the rows in use
+  auto commit = [&](uint64_t from, uint64_t to) {
+    bool dense = ix->dense_ids;
+    for (uint64_t i = from; i < to; i++) {
+      if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
+        dense = false;  // switch to the hash map
+        ix->id2slot.reserve((ix->h_ids.size() + (n - i)) * 2);
+        for (size_t s = 0; s < ix->h_ids.size(); s++) ix->id2slot.emplace(ix->h_ids[s], (uint32_t)s);
+      }
+      if (!dense) ix->id2slot.emplace(new_ids[i], (uint32_t)ix->h_ids.size());
+      ix->h_ids.push_back(new_ids[i]);
+      if (new_ids[i] > ix->max_node_id) ix->max_node_id = new_ids[i];  // vamana.go:166-168
+    }
+    ix->dense_ids = dense;
+    ix->n = n0 + (uint32_t)to;
+  };
+  // a round that fails after its kernels have started may have written back-edges that point at rows the
+  // host never committed: the graph is unusable from then on (index.h `broken`)
+  auto round_failed = [&](int rc) {
+    ix->broken = true;
+    return rc;
+  };
+  auto check_flags = [&]() -> int {
+    uint32_t fl = 0;
+    SDB_HIP(hipMemcpyAsync(&fl, big_count + 1, 4, hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipStreamSynchronize(stream));
+    if (fl & 1u)
+      return fail(SDB_ERR_INVALID, "an insert's greedy search expanded more than %u nodes: the visit list does not fit "
+                                   "the device log (searchSize %u)", vis_cap, L);
+    return SDB_OK;
+  };
+
   uint64_t done = 0;
+  uint64_t n_rounds = 0;
   while (done < n) {
     const uint32_t cur = n0 + (uint32_t)done;  // rows in storage so far = slot of the round's first point
     // a round never exceeds 2 % of the nodes already in the graph -- live ones, deleted rows do not count --
@@ -840,6 +894,8 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.start_ext = ix->d_start_ext, sa.start_ext_n = (uint32_t)ix->h_start_ext.size();
     sa.search_size = L, sa.limit = 1, sa.metric = (int)ix->P.metric;
     sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
+    sa.hash_limit = ix->tune_hash_limit, sa.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
+    sa.totals = reinterpret_cast<unsigned long long *>(ix->d_bstats);  // [0] n_dist, [1] n_edges
     if (dcache) {
       SDB_HIP(hipMemsetAsync(dcache, 0xFF, ((size_t)rs << kDcacheBits) * sizeof(uint2), stream));  // no slot is ~0
       sa.dcache = dcache, sa.dcache_shift = 32 - kDcacheBits;
@@ -850,7 +906,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
       sa.pq_lut_in_lds = (lut_row <= 64 * 1024) ? 1u : 0u;
     }
     if (!search_uses_hash(sa, rs)) SDB_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
-    SDB_TRY(launch_greedy_search(sa, rs, stream));
+    SDB_TRY(launch_greedy_search(sa, rs, stream));  // read-only on the graph: a failure here changes nothing
     // ---- robustPrune + back-edges
     BuildArgs ba{};
     ba.slab = ix->d_slab, ba.adj = ix->d_adj, ba.deg = ix->d_deg, ba.clean = ix->d_clean;
@@ -865,17 +921,23 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.big_count = big_count, ba.big_list = big_list, ba.big_min = big_min, ba.big_cap = big_cap;
     ba.start_slot = (uint32_t)ix->start_slot;
     ba.start_ext = ix->d_start_ext, ba.start_ext_n = (uint32_t)ix->h_start_ext.size();
+    ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
     bool start_pruned = false;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN
              ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
              : launch_round_ng<false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned);
-    if (rc != SDB_OK) return rc;
+    if (rc != SDB_OK) return round_failed(rc);
     if (start_pruned) ix->h_start_ext.clear();  // the device copy is simply no longer referenced (count 0)
+    commit(done, done + rs);
     done += rs;
-    ix->n = n0 + (uint32_t)done;
+    n_rounds++;
   }
-  SDB_HIP(hipStreamSynchronize(stream));
+  {
+    const unsigned long long nr = n_rounds;
+    SDB_HIP(hipMemcpyAsync(ix->d_bstats + kStRounds, &nr, 8, hipMemcpyHostToDevice, stream));
+  }
+  if (int rc = check_flags()) return round_failed(rc);
   return SDB_OK;
 }
 

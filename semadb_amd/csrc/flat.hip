@@ -173,6 +173,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   if (!queries || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
   if (limit < 1 || limit > 128) return fail(SDB_ERR_INVALID, "limit must be between 1 and 128, got %u", limit);
   if (nq > 65535) return fail(SDB_ERR_INVALID, "at most 65535 queries per call");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   const bool filtered = filter_offsets != nullptr;
   if (filtered && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
   DeviceGuard dg(ix->P.device);

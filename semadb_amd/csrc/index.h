@@ -70,6 +70,15 @@ struct sdb_index {
   // product quantizer attachment (product.go): codes per slot + tables
   const sdb_pq *pq = nullptr;
   uint8_t *d_codes = nullptr;
+  // sdb_index_set_tuning
+  uint32_t tune_hub_min = 512, tune_hash_limit = 0;
+  bool tune_no_hash = false;
+  // a write that failed after it had started to change the graph leaves it unusable: every later call fails
+  // until the host rebuilds the index from the bucket -- the reference scraps its cache on any error inside a
+  // write transaction the same way (shard/cache/manager.go:231-240)
+  bool broken = false;
+  // counters of the last insert_batch (sdb_index_build_stats); device-side, added to by the kernels
+  uint64_t *d_bstats = nullptr;
   // measurement hook: events around the last K2 launch
   bool profiling = false;
   static constexpr uint32_t kProfRing = 256;

@@ -126,8 +126,7 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // batch keeps them resident back to back (batch 16 384: 1.18 M QPS, 7.3 TB/s, against 0.88 M QPS on the
 // bitset variant at 16 waves per CU).
 bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
-  static const bool never = getenv("SDB_NO_HASH") != nullptr;  // measurement hook (tools/bench_pq.py)
-  if (never || a.filt_off || a.prefer_bitset) return false;
+  if (a.filt_off || a.prefer_bitset) return false;
   if (a.search_size > 96) return false;
   // quantized store: only with the small LUT of M*K <= 2048 entries next to the (prime-sized) table
   if (a.pq_codes) return a.pq_lut_in_lds && (size_t)a.pq_M * a.pq_K <= 2048;
@@ -183,14 +182,7 @@ static int launch_ng(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
 int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream) {
   if (nq == 0) return SDB_OK;
   SearchArgs a = a_in;
-  if (a.hash_limit == 0 || a.hash_limit > kHashLimit) {
-    a.hash_limit = kHashLimit;
-    // test hook: a tiny limit forces the bitset fallback for every query (tests/test_gpu_search.py)
-    if (const char *e = getenv("SDB_HASH_LIMIT")) {
-      long v = atol(e);
-      if (v > 0 && v < (long)kHashLimit) a.hash_limit = (uint32_t)v;
-    }
-  }
+  if (a.hash_limit == 0 || a.hash_limit > kHashLimit) a.hash_limit = kHashLimit;
   if (a.search_size == 0 || a.search_size > 512)
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
@@ -401,6 +393,7 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_ids) (void)hipFree(ix->d_ids);
   if (ix->d_start_ext) (void)hipFree(ix->d_start_ext);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
+  if (ix->d_bstats) (void)hipFree(ix->d_bstats);
   for (auto e : ix->ev0)
     if (e) (void)hipEventDestroy(e);
   for (auto e : ix->ev1)
@@ -550,6 +543,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   if (ix->P.strict && (search_size < 25 || search_size > 75 || limit > 75))  // models/search.go:287-297
     return fail(SDB_ERR_INVALID, "invalid searchSize %u / limit %u for vector query, expected 25-75 / 1-75",
                 search_size, limit);
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
   const bool filtered = filter_offsets != nullptr;
   if (filtered && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
@@ -616,6 +610,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   a.start_slot = (uint32_t)ix->start_slot;
   a.start_ext = ix->d_start_ext, a.start_ext_n = (uint32_t)ix->h_start_ext.size();
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
+  a.hash_limit = ix->tune_hash_limit, a.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
@@ -691,6 +686,44 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   return SDB_OK;
 }
 
+int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  switch (key) {
+    case SDB_TUNE_HUB_MIN:
+      if (value < 2 || value > 0xFFFFFFFFull) return fail(SDB_ERR_INVALID, "hub threshold must be at least 2");
+      ix->tune_hub_min = (uint32_t)value;
+      return SDB_OK;
+    case SDB_TUNE_HASH_LIMIT:
+      if (value > kHashLimit) return fail(SDB_ERR_INVALID, "hash limit is at most %u", kHashLimit);
+      ix->tune_hash_limit = (uint32_t)value;  // 0 = default
+      return SDB_OK;
+    case SDB_TUNE_NO_HASH:
+      ix->tune_no_hash = value != 0;
+      return SDB_OK;
+    default:
+      return fail(SDB_ERR_INVALID, "unknown tuning key %d", key);
+  }
+}
+
+int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) {
+  if (!ix || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+  const uint32_t n = cap < SDB_BUILD_STATS ? cap : SDB_BUILD_STATS;
+  for (uint32_t i = 0; i < n; i++) out[i] = 0;
+  if (!ix->d_bstats || n == 0) return SDB_OK;
+  DeviceGuard dg(ix->P.device);
+  SDB_HIP(hipDeviceSynchronize());
+  SDB_HIP(hipMemcpy(out, ix->d_bstats, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return SDB_OK;
+}
+
+int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *out) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (n == 0) return SDB_OK;
+  if (!ids || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+  for (uint64_t i = 0; i < n; i++) out[i] = ix->slot_of(ids[i]) >= 0 ? 1 : 0;
+  return SDB_OK;
+}
+
 int sdb_index_set_profiling(sdb_index *ix, int enabled) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   DeviceGuard dg(ix->P.device);
@@ -759,6 +792,7 @@ int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, u
 
 int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets, uint64_t *edges) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   DeviceGuard dg(ix->P.device);
   SDB_HIP(hipDeviceSynchronize());
   const uint32_t n = ix->n;

@@ -11,12 +11,16 @@ constexpr int kMergeMaxItems = 2048;  // n_shards * per_shard
 // one 64-thread block per query; rank-by-counting under the total order (dist, shard, id, position) -- the
 // position only matters for a caller that hands in the same (dist, shard, id) twice: every item still gets a
 // rank of its own
+//
+// The three per-shard arrays are addressed as base + shard * stride (bytes): separate shard-major arrays
+// (stride = the array's own per-shard size) or the packed blocks an all-gather delivers back to back
+// (stride = the block size for all three, cluster.hip).
 __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard,
-                                                   const uint64_t *__restrict__ ids,
-                                                   const float *__restrict__ dists,
-                                                   const uint32_t *__restrict__ counts, uint32_t limit,
-                                                   uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
-                                                   uint32_t *__restrict__ out_shards,
+                                                   const char *__restrict__ ids_b, size_t ids_stride,
+                                                   const char *__restrict__ dists_b, size_t dists_stride,
+                                                   const char *__restrict__ counts_b, size_t counts_stride,
+                                                   uint32_t limit, uint64_t *__restrict__ out_ids,
+                                                   float *__restrict__ out_dists, uint32_t *__restrict__ out_shards,
                                                    uint32_t *__restrict__ out_counts) {
   __shared__ float s_d[kMergeMaxItems];
   __shared__ uint64_t s_id[kMergeMaxItems];
@@ -28,7 +32,7 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
     uint32_t o = 0;
     for (uint32_t s = 0; s < n_shards; s++) {
       s_off[s] = o;
-      uint32_t c = counts[(size_t)s * nq + q];
+      uint32_t c = reinterpret_cast<const uint32_t *>(counts_b + (size_t)s * counts_stride)[q];
       o += c < per_shard ? c : per_shard;
     }
     s_off[n_shards] = o;
@@ -38,9 +42,9 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
   for (uint32_t s = 0; s < n_shards; s++) {
     const uint32_t c = s_off[s + 1] - s_off[s];
     for (uint32_t i = t; i < c; i += 64) {
-      const size_t src = ((size_t)s * nq + q) * per_shard + i;
-      s_d[s_off[s] + i] = dists[src];
-      s_id[s_off[s] + i] = ids[src];
+      const size_t src = (size_t)q * per_shard + i;
+      s_d[s_off[s] + i] = reinterpret_cast<const float *>(dists_b + (size_t)s * dists_stride)[src];
+      s_id[s_off[s] + i] = reinterpret_cast<const uint64_t *>(ids_b + (size_t)s * ids_stride)[src];
       s_sh[s_off[s] + i] = (uint16_t)s;
     }
   }
@@ -67,6 +71,27 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
   if (t == 0) out_counts[q] = total < limit ? total : limit;
 }
 
+int launch_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const void *ids, size_t ids_stride,
+                      const void *dists, size_t dists_stride, const void *counts, size_t counts_stride, uint32_t limit,
+                      uint64_t *out_ids, float *out_dists, uint32_t *out_shards, uint32_t *out_counts,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(64), 0, stream, n_shards, nq, per_shard,
+                     static_cast<const char *>(ids), ids_stride, static_cast<const char *>(dists), dists_stride,
+                     static_cast<const char *>(counts), counts_stride, limit, out_ids, out_dists, out_shards,
+                     out_counts);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
+int check_merge_shape(uint32_t n_shards, uint32_t per_shard, uint32_t limit) {
+  if (n_shards == 0 || n_shards > 64) return fail(SDB_ERR_INVALID, "n_shards must be 1..64, got %u", n_shards);
+  if (limit == 0 || per_shard == 0) return fail(SDB_ERR_INVALID, "limit and per_shard must be positive");
+  if ((uint64_t)n_shards * per_shard > kMergeMaxItems)
+    return fail(SDB_ERR_INVALID, "n_shards * per_shard = %llu exceeds %d", (unsigned long long)n_shards * per_shard,
+                kMergeMaxItems);
+  return SDB_OK;
+}
+
 }  // namespace sdb
 
 using namespace sdb;
@@ -88,23 +113,17 @@ int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uin
                    uint32_t *out_shards, uint32_t *out_counts, int mem, int device, void *stream_) {
   if (nq == 0) return SDB_OK;
   if (!ids || !dists || !counts || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
-  if (n_shards == 0 || n_shards > 64) return fail(SDB_ERR_INVALID, "n_shards must be 1..64, got %u", n_shards);
-  if (limit == 0 || per_shard == 0) return fail(SDB_ERR_INVALID, "limit and per_shard must be positive");
-  if ((uint64_t)n_shards * per_shard > kMergeMaxItems)
-    return fail(SDB_ERR_INVALID, "n_shards * per_shard = %llu exceeds %d", (unsigned long long)n_shards * per_shard,
-                kMergeMaxItems);
+  SDB_TRY(check_merge_shape(n_shards, per_shard, limit));
   int ndev = 0;
   SDB_TRY(sdb_device_count(&ndev));
   if (device < 0 || device >= ndev) return fail(SDB_ERR_INVALID, "device %d out of range", device);
   DeviceGuard dg(device);
   hipStream_t stream = as_stream(stream_);
   const size_t items = (size_t)n_shards * nq * per_shard;
-  if (mem == SDB_MEM_DEVICE) {
-    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(64), 0, stream, n_shards, nq, per_shard, ids, dists,
-                       counts, limit, out_ids, out_dists, out_shards, out_counts);
-    SDB_HIP(hipGetLastError());
-    return SDB_OK;
-  }
+  const size_t st_i = (size_t)nq * per_shard * 8, st_d = (size_t)nq * per_shard * 4, st_c = (size_t)nq * 4;
+  if (mem == SDB_MEM_DEVICE)
+    return launch_topk_merge(n_shards, nq, per_shard, ids, st_i, dists, st_d, counts, st_c, limit, out_ids, out_dists,
+                             out_shards, out_counts, stream);
   char *buf = nullptr;
   const size_t b_ids = items * 8, b_d = items * 4, b_c = (size_t)n_shards * nq * 4;
   const size_t b_oi = nq * limit * 8, b_od = nq * limit * 4, b_os = nq * limit * 4, b_oc = nq * 4;
@@ -121,11 +140,10 @@ int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uin
   if (e == hipSuccess) e = hipMemcpyAsync(d_c, counts, b_c, hipMemcpyHostToDevice, stream);
   if (e == hipSuccess) e = hipMemsetAsync(d_oi, 0, b_oi, stream);
   if (e == hipSuccess) e = hipMemsetAsync(d_od, 0, b_od + b_os + b_oc, stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(64), 0, stream, n_shards, nq, per_shard, d_ids, d_d,
-                       d_c, limit, d_oi, d_od, d_os, d_oc);
-    e = hipGetLastError();
-  }
+  if (e == hipSuccess &&
+      launch_topk_merge(n_shards, nq, per_shard, d_ids, st_i, d_d, st_d, d_c, st_c, limit, d_oi, d_od, d_os, d_oc,
+                        stream) != SDB_OK)
+    e = hipErrorLaunchFailure;
   if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oi, b_oi, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out_dists, d_od, b_od, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess && out_shards) e = hipMemcpyAsync(out_shards, d_os, b_os, hipMemcpyDeviceToHost, stream);

@@ -63,6 +63,7 @@ struct SearchArgs {
   // round look their pair distances up there (build.hip BuildArgs::dcache).  NULL: not collected.
   uint2 *dcache;
   uint32_t dcache_shift;
+  unsigned long long *totals;  // build path: [0] += n_dist, [1] += n_edges of every query (sdb_index_build_stats)
   uint32_t prefer_bitset;  // != 0: never use the LDS hash visited set (large build rounds)
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
@@ -893,6 +894,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     if (a.tr_nhop) a.tr_nhop[q] = n_hop;
     if (a.tr_nedges) a.tr_nedges[q] = n_edges;
     if (a.vis_count) a.vis_count[q] = n_hop;
+    if (a.totals) atomicAdd(a.totals, (unsigned long long)n_dist), atomicAdd(a.totals + 1, (unsigned long long)n_edges);
   }
 }
 

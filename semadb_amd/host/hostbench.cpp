@@ -1,0 +1,86 @@
+// hostbench.cpp -- serving-shaped measurement of the host side: many submitting threads, each with several
+// Search requests outstanding (the shape of a Go server: thousands of request goroutines on a few OS threads),
+// through the micro-batcher of semadb_host.hpp into sdb_index_search_batch with SDB_MEM_HOST buffers.  This is
+// the SURVEY 8d "wall time including H2D of queries and D2H of results" rate of the drop-in as a Go host would
+// drive it.  Built into libsemadb_hostbench.so; bench.py calls it on the index it has just built.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+#include "semadb_host.hpp"
+
+extern "C" {
+
+// queries [n_queries][dim] host memory; every query index is answered at least once when `seconds` allows;
+// first_ids [n_queries][limit] (optional) receives the ids of the FIRST answer to each query, for a parity check.
+int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint64_t n_queries, uint32_t limit,
+                          uint32_t search_size, uint32_t threads, uint32_t depth, uint32_t max_batch,
+                          uint32_t window_us, uint32_t workers, double seconds, uint64_t *first_ids,
+                          uint32_t *first_counts, double *qps, uint64_t *device_batches, uint64_t *served) {
+  using namespace semadb;
+  if (!h || !queries || !n_queries || !threads || !depth || !qps) return 1;
+  SearchBatcher batcher(h, dim, max_batch, std::chrono::microseconds(window_us), workers);
+  std::atomic<uint64_t> next{0}, completed{0}, errors{0};
+  std::atomic<bool> stop{false};
+  auto worker = [&](unsigned) {
+    SearchBatcher::Client client;
+    std::vector<SearchBatcher::Request> reqs(depth);
+    std::vector<uint64_t> qidx(depth);
+    std::vector<uint64_t> ids((size_t)depth * limit);
+    std::vector<float> dists((size_t)depth * limit);
+    uint64_t submitted = 0;
+    auto issue = [&](uint32_t s) {
+      const uint64_t t = next.fetch_add(1);
+      qidx[s] = t;
+      SearchBatcher::Request &r = reqs[s];
+      r.vector = queries + (t % n_queries) * dim;
+      r.limit = limit, r.search_size = search_size, r.filter = nullptr;
+      r.ids = ids.data() + (size_t)s * limit, r.dists = dists.data() + (size_t)s * limit;
+      r.count = 0, r.client = &client;
+      r.done.store(false, std::memory_order_relaxed);
+      batcher.submit(&r);
+      submitted++;
+    };
+    for (uint32_t s = 0; s < depth; s++) issue(s);
+    uint64_t harvested = 0;
+    while (harvested < submitted) {
+      SearchBatcher::waitFor(&client, harvested + 1);
+      for (uint32_t s = 0; s < depth; s++) {
+        SearchBatcher::Request &r = reqs[s];
+        if (r.client && r.done.load(std::memory_order_acquire)) {
+          if (r.err) errors++;
+          if (qidx[s] < n_queries && first_ids) {  // first pass over the query set: keep the answer
+            for (uint32_t i = 0; i < limit; i++) first_ids[qidx[s] * limit + i] = i < r.count ? r.ids[i] : 0;
+            if (first_counts) first_counts[qidx[s]] = r.count;
+          }
+          harvested++;
+          completed++;
+          r.client = nullptr;
+          if (!stop.load(std::memory_order_relaxed)) issue(s);
+        }
+      }
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < threads; t++) pool.emplace_back(worker, t);
+  // run for `seconds`, but at least until every query has been handed out once
+  for (;;) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (el >= seconds && next.load() >= n_queries) break;
+    if (el >= 20 * seconds + 30) break;  // never hang a bench run
+  }
+  const uint64_t done_at_stop = completed.load();
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  stop = true;
+  for (auto &t : pool) t.join();
+  *qps = (double)done_at_stop / el;
+  if (device_batches) *device_batches = batcher.deviceBatches();
+  if (served) *served = batcher.queriesServed();
+  return errors.load() ? 2 : 0;
+}
+
+}  // extern "C"

@@ -222,6 +222,174 @@ inline Error GetFloatDistanceFn(const std::string &name, FloatDistFunc *out, int
 }  // namespace distance
 
 // ---------------------------------------------------------------------------------------------------
+// Micro-batcher: the reference has no batch entry point -- every REST request is its own goroutine calling
+// IndexVamana.Search under the shard's RLock (shard/cache/manager.go:163, shard/index/search.go:53-87).  One
+// query alone leaves the GPU idle (a walk is ~80 dependent hops), so concurrent Search calls are coalesced
+// into sdb_index_search_batch calls: `workers` threads each take up to max_batch waiting requests of one
+// (limit, searchSize, filtered) group and run them as one device batch, so up to `workers` batches are in
+// flight (a second batch fills the SIMDs the first one's finished walks have left).
+// Completion is signalled per submitting client, not per request: a client (one OS thread, possibly with
+// many requests outstanding -- the shape of a Go server's goroutines on a few Ms) is woken once per device
+// batch that finished something of its.
+class SearchBatcher {
+ public:
+  using Filter = std::set<uint64_t>;  // roaring64.Bitmap: ascending iteration, Contains
+  struct Client {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t completed = 0;  // requests of this client finished so far
+  };
+  struct Request {
+    const float *vector = nullptr;  // `dim` floats, caller-owned until done
+    uint32_t limit = 10, search_size = 75;
+    const Filter *filter = nullptr;
+    uint64_t *ids = nullptr;  // [limit] caller-owned outputs
+    float *dists = nullptr;
+    uint32_t count = 0;
+    Error err;
+    std::atomic<bool> done{false};
+    std::atomic<bool> cancelled{false};  // context cancellation: still answered, result ignored by the caller
+    Client *client = nullptr;
+  };
+
+  SearchBatcher(sdb_index *h, uint32_t dim, size_t max_batch = 1024,
+                std::chrono::microseconds window = std::chrono::microseconds(200), unsigned workers = 2)
+      : h_(h), dim_(dim), max_batch_(max_batch), window_(window) {
+    for (unsigned i = 0; i < (workers ? workers : 1); i++) threads_.emplace_back([this] { loop(); });
+  }
+  ~SearchBatcher() {
+    {
+      std::lock_guard<std::mutex> g(qmu_);
+      stop_ = true;
+    }
+    qcv_.notify_all();
+    for (auto &t : threads_)
+      if (t.joinable()) t.join();
+  }
+  SearchBatcher(const SearchBatcher &) = delete;
+  SearchBatcher &operator=(const SearchBatcher &) = delete;
+
+  void configure(size_t max_batch, std::chrono::microseconds window) {
+    std::lock_guard<std::mutex> g(qmu_);
+    max_batch_ = max_batch, window_ = window;
+  }
+  uint64_t deviceBatches() const { return n_batches_.load(); }
+  uint64_t queriesServed() const { return n_queries_.load(); }
+
+  // enqueue; the request (and what it points to) must stay alive until r->done
+  void submit(Request *r) {
+    bool wake;
+    {
+      std::lock_guard<std::mutex> g(qmu_);
+      queue_.push_back(r);
+      wake = queue_.size() == 1 || queue_.size() >= max_batch_;
+    }
+    if (wake) qcv_.notify_one();
+  }
+  // block the client until at least `target` of its requests have completed
+  static void waitFor(Client *c, uint64_t target) {
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return c->completed >= target; });
+  }
+  // the synchronous form IndexVamana.Search uses
+  void run(Request *r) {
+    Client c;
+    r->client = &c;
+    submit(r);
+    waitFor(&c, 1);
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::vector<Request *> batch;
+      {
+        std::unique_lock<std::mutex> lk(qmu_);
+        qcv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (stop_ && queue_.empty()) return;
+        // wait a short window for more callers (or until the batch is full)
+        const auto deadline = std::chrono::steady_clock::now() + window_;
+        while (queue_.size() < max_batch_ && !stop_)
+          if (qcv_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+        if (queue_.empty()) continue;  // another worker took them
+        // one device call per (limit, searchSize, filtered) group, oldest group first
+        Request *head = queue_.front();
+        size_t keep = 0;
+        for (size_t i = 0; i < queue_.size(); i++) {
+          Request *r = queue_[i];
+          if (batch.size() < max_batch_ && r->limit == head->limit && r->search_size == head->search_size &&
+              (r->filter != nullptr) == (head->filter != nullptr))
+            batch.push_back(r);
+          else
+            queue_[keep++] = r;
+        }
+        queue_.resize(keep);
+        if (!queue_.empty()) qcv_.notify_one();  // leftovers for another worker
+      }
+      runBatch(batch);
+    }
+  }
+
+  void runBatch(const std::vector<Request *> &reqs) {
+    const size_t nq = reqs.size(), d = dim_;
+    const uint32_t limit = reqs[0]->limit, L = reqs[0]->search_size;
+    std::vector<float> queries(nq * d);
+    for (size_t i = 0; i < nq; i++) std::memcpy(queries.data() + i * d, reqs[i]->vector, d * 4);
+    std::vector<uint64_t> ids(nq * limit), f_off, f_ids;
+    std::vector<float> dists(nq * limit);
+    std::vector<uint32_t> counts(nq);
+    const bool filtered = reqs[0]->filter != nullptr;
+    if (filtered) {
+      f_off.push_back(0);
+      for (auto *r : reqs) {
+        f_ids.insert(f_ids.end(), r->filter->begin(), r->filter->end());  // ascending, like roaring
+        f_off.push_back(f_ids.size());
+      }
+      if (f_ids.empty()) f_ids.push_back(0);
+    }
+    const int rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, filtered ? f_off.data() : nullptr,
+                                          filtered ? f_ids.data() : nullptr, ids.data(), dists.data(), counts.data(),
+                                          nullptr, SDB_MEM_HOST, nullptr);
+    n_batches_++;
+    n_queries_ += nq;
+    const Error err = rc ? Error(std::string(sdb_last_error())) : Error();
+    // results out, then one wake-up per distinct client
+    std::vector<std::pair<Client *, uint64_t>> woke;
+    for (size_t i = 0; i < nq; i++) {
+      Request *r = reqs[i];
+      if (!rc) {
+        r->count = counts[i];
+        std::memcpy(r->ids, ids.data() + i * limit, (size_t)counts[i] * 8);
+        std::memcpy(r->dists, dists.data() + i * limit, (size_t)counts[i] * 4);
+      }
+      r->err = err;
+      Client *c = r->client;
+      r->done.store(true, std::memory_order_release);  // `r` may be gone once its client has been told
+      bool found = false;
+      for (auto &w : woke)
+        if (w.first == c) w.second++, found = true;
+      if (!found) woke.emplace_back(c, 1);
+    }
+    for (auto &w : woke) {  // notified under the lock: the client (often a stack object) cannot go away in between
+      std::lock_guard<std::mutex> g(w.first->mu);
+      w.first->completed += w.second;
+      w.first->cv.notify_all();
+    }
+  }
+
+  sdb_index *h_;
+  uint32_t dim_;
+  std::vector<std::thread> threads_;
+  std::mutex qmu_;
+  std::condition_variable qcv_;
+  std::vector<Request *> queue_;
+  bool stop_ = false;
+  size_t max_batch_;
+  std::chrono::microseconds window_;
+  std::atomic<uint64_t> n_batches_{0}, n_queries_{0};
+};
+
+// ---------------------------------------------------------------------------------------------------
 namespace vamana {  // shard/index/vamana/vamana.go
 constexpr uint64_t STARTID = 1;                        // :28
 constexpr const char *MAXNODEIDKEY = "_vamanaMaxNodeId";  // :31
@@ -272,17 +440,12 @@ class IndexVamana {
         return {nullptr, Error::wrap("could not create vector store", rc)};
     }
     if (Error e = v->loadFromBucket(start_vector)) return {nullptr, e};
-    v->batcher_ = std::thread([raw = v.get()] { raw->batcherLoop(); });
+    v->batcher_.reset(new SearchBatcher(v->h_, params.VectorSize));
     return {std::move(v), Error()};
   }
 
   ~IndexVamana() {
-    {
-      std::lock_guard<std::mutex> g(qmu_);
-      stop_ = true;
-    }
-    qcv_.notify_all();
-    if (batcher_.joinable()) batcher_.join();
+    batcher_.reset();  // joins its workers; no device call is in flight afterwards
     if (h_) sdb_index_destroy(h_);
     if (pq_) sdb_pq_destroy(pq_);
   }
@@ -314,28 +477,27 @@ class IndexVamana {
                       ") must be greater than k (" + std::to_string(q.Limit) + ")");
       return out;
     }
-    Request r;
-    r.q = &q, r.filter = filter;
-    {
-      std::lock_guard<std::mutex> g(qmu_);
-      queue_.push_back(&r);
+    if (q.Limit < 1) {
+      out.err = Error("could not perform graph search: invalid limit " + std::to_string(q.Limit));
+      return out;
     }
-    qcv_.notify_all();
-    {
-      std::unique_lock<std::mutex> lk(r.mu);
-      r.cv.wait(lk, [&] { return r.done; });
-    }
+    std::vector<uint64_t> ids((size_t)q.Limit);
+    std::vector<float> dists((size_t)q.Limit);
+    SearchBatcher::Request r;
+    r.vector = q.Vector.data(), r.limit = (uint32_t)q.Limit, r.search_size = (uint32_t)q.SearchSize;
+    r.filter = filter, r.ids = ids.data(), r.dists = dists.data();
+    batcher_->run(&r);
     if (r.err) {
       out.err = Error("could not perform graph search: " + r.err.msg);
       return out;
     }
     const float weight = q.Weight ? *q.Weight : 1.0f;  // vamana.go:289-292
-    for (size_t i = 0; i < r.ids.size(); i++) {
+    for (uint32_t i = 0; i < r.count; i++) {
       models::SearchResult sr;
-      sr.NodeId = r.ids[i], sr.Distance = r.dists[i];
-      sr.HybridScore = (-1 * r.dists[i] * weight);  // :303
+      sr.NodeId = ids[i], sr.Distance = dists[i];
+      sr.HybridScore = (-1 * dists[i] * weight);  // :303
       out.results.push_back(sr);
-      out.set.insert(r.ids[i]);
+      out.set.insert(ids[i]);
     }
     return out;
   }
@@ -460,25 +622,12 @@ class IndexVamana {
   }
 
   // tuning knobs of the micro-batcher (not part of the reference surface)
-  void setBatching(size_t max_batch, std::chrono::microseconds window) {
-    std::lock_guard<std::mutex> g(qmu_);
-    max_batch_ = max_batch, window_ = window;
-  }
-  uint64_t deviceBatches() const { return n_batches_.load(); }
+  void setBatching(size_t max_batch, std::chrono::microseconds window) { batcher_->configure(max_batch, window); }
+  uint64_t deviceBatches() const { return batcher_->deviceBatches(); }
+  sdb_index *handle() const { return h_; }
 
  private:
   IndexVamana() = default;
-  struct Request {
-    const models::SearchVectorVamanaOptions *q = nullptr;
-    const Filter *filter = nullptr;
-    std::vector<uint64_t> ids;
-    std::vector<float> dists;
-    Error err;
-    bool done = false;
-    std::mutex mu;
-    std::condition_variable cv;
-  };
-
   // what plainPoint.ReadFrom / graphNode.ReadFrom read lazily (plain.go:125-141, node.go:96-111)
   Error loadFromBucket(const std::vector<float> *start_vector) {
     std::vector<uint64_t> ids, offsets{0}, edges;
@@ -559,71 +708,6 @@ class IndexVamana {
     return v;
   }
 
-  void batcherLoop() {
-    for (;;) {
-      std::vector<Request *> batch;
-      {
-        std::unique_lock<std::mutex> lk(qmu_);
-        qcv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
-        if (stop_ && queue_.empty()) return;
-        // wait a short window for more callers (or until the batch is full)
-        const auto deadline = std::chrono::steady_clock::now() + window_;
-        while (queue_.size() < max_batch_ && !stop_)
-          if (qcv_.wait_until(lk, deadline) == std::cv_status::timeout) break;
-        // one device call per (limit, searchSize, filtered) group, oldest group first
-        Request *head = queue_.front();
-        for (auto it = queue_.begin(); it != queue_.end() && batch.size() < max_batch_;) {
-          Request *r = *it;
-          if (r->q->Limit == head->q->Limit && r->q->SearchSize == head->q->SearchSize &&
-              (r->filter != nullptr) == (head->filter != nullptr)) {
-            batch.push_back(r);
-            it = queue_.erase(it);
-          } else {
-            ++it;
-          }
-        }
-      }
-      runBatch(batch);
-    }
-  }
-
-  void runBatch(const std::vector<Request *> &reqs) {
-    const size_t nq = reqs.size(), d = parameters_.VectorSize;
-    const uint32_t limit = (uint32_t)reqs[0]->q->Limit, L = (uint32_t)reqs[0]->q->SearchSize;
-    std::vector<float> queries(nq * d);
-    for (size_t i = 0; i < nq; i++) std::memcpy(queries.data() + i * d, reqs[i]->q->Vector.data(), d * 4);
-    std::vector<uint64_t> ids(nq * limit), f_off, f_ids;
-    std::vector<float> dists(nq * limit);
-    std::vector<uint32_t> counts(nq);
-    const bool filtered = reqs[0]->filter != nullptr;
-    if (filtered) {
-      f_off.push_back(0);
-      for (auto *r : reqs) {
-        f_ids.insert(f_ids.end(), r->filter->begin(), r->filter->end());  // ascending, like roaring
-        f_off.push_back(f_ids.size());
-      }
-      if (f_ids.empty()) f_ids.push_back(0);
-    }
-    const int rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, filtered ? f_off.data() : nullptr,
-                                          filtered ? f_ids.data() : nullptr, ids.data(), dists.data(), counts.data(),
-                                          nullptr, SDB_MEM_HOST, nullptr);
-    n_batches_++;
-    Error err = rc ? Error(std::string(sdb_last_error())) : Error();
-    for (size_t i = 0; i < nq; i++) {
-      Request *r = reqs[i];
-      {
-        std::lock_guard<std::mutex> g(r->mu);
-        if (!rc) {
-          r->ids.assign(ids.begin() + i * limit, ids.begin() + i * limit + counts[i]);
-          r->dists.assign(dists.begin() + i * limit, dists.begin() + i * limit + counts[i]);
-        }
-        r->err = err;
-        r->done = true;
-      }
-      r->cv.notify_one();
-    }
-  }
-
   std::string name_;
   models::IndexVectorVamanaParameters parameters_;
   diskstore::Bucket *bucket_ = nullptr;
@@ -633,15 +717,7 @@ class IndexVamana {
   uint64_t fit_seed_ = 0;
   std::set<uint64_t> live_;  // ids currently in the store (start node excluded)
   std::mutex write_mu_;
-  // micro-batcher
-  std::thread batcher_;
-  std::mutex qmu_;
-  std::condition_variable qcv_;
-  std::vector<Request *> queue_;
-  bool stop_ = false;
-  size_t max_batch_ = 1024;
-  std::chrono::microseconds window_{200};
-  std::atomic<uint64_t> n_batches_{0};
+  std::unique_ptr<SearchBatcher> batcher_;  // coalesces concurrent Search calls
 };
 
 inline std::pair<std::unique_ptr<IndexVamana>, Error> NewIndexVamana(const std::string &name,

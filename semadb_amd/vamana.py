@@ -122,6 +122,29 @@ class IndexVamana:
         check(lib().sdb_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    TUNING = {"hub_min": 1, "hash_limit": 2, "no_hash": 3}  # SDB_TUNE_* (semadb_amd.h)
+
+    def set_tuning(self, key, value):
+        """test / measurement knobs of this index (sdb_index_set_tuning); none changes a result"""
+        check(lib().sdb_index_set_tuning(self._h, self.TUNING[key], int(value)))
+
+    BUILD_STATS = ("search_n_dist", "search_n_edges", "prune_pairs", "backedge_pairs", "backedge_cached",
+                   "requests", "reprunes", "appends", "staged_rows", "rounds", "hubs")
+
+    def build_stats(self):
+        """counters of the most recent insert_batch (sdb_index_build_stats)"""
+        out = np.zeros(len(self.BUILD_STATS), dtype=np.uint64)
+        check(lib().sdb_index_build_stats(self._h, _buf.np_ptr(out), out.size))
+        return dict(zip(self.BUILD_STATS, (int(v) for v in out)))
+
+    def exists_batch(self, ids):
+        """vecStore.Exists (plain.go:21-24) for many ids: host-side table lookup, no device work"""
+        ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = np.zeros(ids_a.size, dtype=np.uint8)
+        if ids_a.size:
+            check(lib().sdb_index_exists_batch(self._h, ids_a.size, _buf.np_ptr(ids_a), _buf.np_ptr(out)))
+        return out.astype(bool)
+
     def set_profiling(self, enabled=True):
         check(lib().sdb_index_set_profiling(self._h, 1 if enabled else 0))
 
@@ -149,12 +172,14 @@ class IndexVamana:
         and the deleted nodes dropped; then the updated points are re-inserted one by one."""
         ins_ids, ins_vecs, upd_ids, upd_vecs, del_ids = [], [], [], [], []
         known = set()
-        for ch in points:
+        points = list(points)
+        stored = self.exists_batch([ch.Id for ch in points])  # one table lookup for the whole change list
+        for ch, in_store in zip(points, stored):
             if ch.Id == STARTID:
                 raise SemaDBError(1, "cannot modify point with start id: %d" % STARTID)  # vamana.go:150-153
             if ch.Id == 0:
                 raise SemaDBError(1, "invalid point id: %d" % ch.Id)  # vamana.go:154-157
-            exists = self.exists(ch.Id) or ch.Id in known
+            exists = bool(in_store) or ch.Id in known
             if ch.Vector is None:
                 if exists:
                     del_ids.append(ch.Id)  # :175-179
@@ -201,9 +226,7 @@ class IndexVamana:
 
     def exists(self, node_id):
         """vecStore.Exists (plain.go:21-24)"""
-        q = np.zeros((1, self.parameters.VectorSize), dtype=np.float32)
-        d = self.distance_batch(q, np.array([[node_id]], dtype=np.uint64))
-        return bool(d[0, 0] != np.finfo(np.float32).max)
+        return bool(self.exists_batch([node_id])[0])
 
     def delete_batch(self, ids):
         ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
@@ -249,9 +272,12 @@ class IndexVamana:
                 off.append(len(flat))
             f_off = np.array(off, dtype=np.uint64)
             f_ids = np.array(flat if flat else [0], dtype=np.uint64)
-        if out is not None:  # caller-provided device tensors (ids int64 [nq,limit], dists f32, counts int32)
-            ids, dists, counts = out
-            idp, dp, cp = (C.c_void_p(t.data_ptr()) for t in out)
+        if out is not None:  # caller-provided buffers: device tensors (ids int64 [nq,limit], dists f32, counts
+            ids, dists, counts = out  # int32) for device queries, numpy arrays (e.g. pinned) for host queries
+            if mem == MEM_DEVICE:
+                idp, dp, cp = (C.c_void_p(t.data_ptr()) for t in out)
+            else:
+                idp, dp, cp = (_buf.np_ptr(t) for t in out)
         else:
             ids, idp = _buf.empty_like_mem(mem, (nq, limit), "uint64", self.device)
             dists, dp = _buf.empty_like_mem(mem, (nq, limit), "float32", self.device)

@@ -31,6 +31,15 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "not exported: %s" % missing
 
 
+def test_header_compiles_as_c99(tmp_path):
+    """cgo hands the header to a C compiler, not a C++ one"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "semadb_amd.h"\nint main(void) { sdb_index_params p; (void)p; return SDB_ABI_VERSION - 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-fsyntax-only", str(src)])
+
+
 def test_python_signature_table_matches_header():
     from semadb_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()

@@ -4,6 +4,7 @@ arithmetic paths the reference has (distance_amd64.go:19-27 picks the assembly w
 puredist.go otherwise) and both reach the same neighbours; their distances differ in the last bits, which
 is why the GPU path follows the assembly's summation order."""
 import numpy as np
+import pytest
 
 from tests.helpers import start_vector
 
@@ -40,3 +41,39 @@ def test_c1_cpu_reference_plumbing(oracle):
     assert same >= 0.9  # same neighbours almost always...
     assert np.any(a_d.view(np.uint32) != p_d.view(np.uint32))  # ...but not the same bits
     assert np.allclose(a_d, p_d, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_c1_shape_on_the_device(oracle):
+    """C1's shape with the reference's default parameters (R = 64, L = 75, alpha 1.2, assembly arithmetic) through
+    the HIP path: the device-built graph (sequential inserts) equals the oracle's edge for edge and 200 queries walk
+    it to the same ids, distance bits, visit order and counters."""
+    from semadb_amd import vamana
+    from tests.helpers import assert_same_graph
+    rng = np.random.default_rng(20250620)
+    n, d, nq, k, R, L = 10000, 128, 200, 10, 64, 75
+    allrows = _latent_rows(rng, n + nq, d)
+    base, queries = allrows[:n], allrows[n:]
+    sv = start_vector(np.random.default_rng(20250622), d)
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=impl)
+    o.set_start(sv)
+    for i in range(n):
+        assert o.insert(i + 2, base[i]) == 0
+    ix = vamana.NewIndexVamana("c1", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), strict=True)
+    ix.set_start(sv)
+    ix.insert_batch(np.arange(2, n + 2, dtype=np.uint64), base, round_size=1)  # == the reference's insert loop
+    assert_same_graph(ix, o)
+    g_ids, g_d, g_c, tr = ix.search_batch(queries, k, L, trace=True, visit_cap=512)
+    o_ids, o_d, o_c, o_nd, o_nh, o_ne = o.search_batch(queries, k, L)
+    assert np.array_equal(g_ids, o_ids) and np.array_equal(g_d.view(np.uint32), o_d.view(np.uint32))
+    assert np.array_equal(g_c, o_c.astype(np.uint32))
+    assert np.array_equal(tr.n_dist.astype(np.uint64), o_nd) and np.array_equal(tr.n_hop.astype(np.uint64), o_nh)
+    assert np.array_equal(tr.n_edges.astype(np.uint64), o_ne)
+    for q in range(0, nq, 20):
+        _, _, vis, otr = o.search(queries[q], k, L)
+        assert np.array_equal(tr.visit_ids[q, :otr.n_hop], vis)
+    truth = np.argsort(-(queries @ base.T), axis=1)[:, :k] + 2
+    rec = np.mean([len(set(g_ids[i]) & set(truth[i])) for i in range(nq)]) / k
+    assert rec >= 0.95
+    ix.close()

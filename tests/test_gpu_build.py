@@ -161,14 +161,14 @@ def test_union_prune_paths_match_oracle(oracle, chip_wide, metric, d, n, m, R):
 
 
 def test_hub_targets_through_the_build(oracle, monkeypatch):
-    """SDB_BIG_MIN = 3 sends every target with three or more requests in a round through the chip-wide prune:
+    """hub_min = 3 sends every target with three or more requests in a round through the chip-wide prune:
     the graph keeps the reference's invariants and the recall of the ordinary build."""
     from semadb_amd import vamana
-    monkeypatch.setenv("SDB_BIG_MIN", "3")
     rng = np.random.default_rng(77)
     d, n = 48, 6000
     base = unit_rows(rng, n, d)
     g = vamana.NewIndexVamana("hub", vamana.IndexVectorVamanaParameters(d, "cosine", 50, 24, 1.2), strict=False)
+    g.set_tuning("hub_min", 3)
     g.set_start(unit_rows(np.random.default_rng(1), 1, d)[0])
     g.insert_batch(None, base, round_size=512)
     ids, vecs, off, edges = g.export()
@@ -242,7 +242,6 @@ def test_batched_build_identical_to_oracle_schedule(oracle, monkeypatch, metric,
     insert order, grouped, hubs all at once (oracle/sdb_oracle.c orc_index_insert_round): the graphs are equal
     edge for edge.  big_min 2 / 3 sends nearly every multi-request target through the chip-wide hub prune."""
     from tests.helpers import assert_same_graph
-    monkeypatch.setenv("SDB_BIG_MIN", str(big_min))
     rng = np.random.default_rng(d + n + big_min)
     lat = rng.standard_normal((8, d)).astype(np.float32)
     base = rng.standard_normal((n, 8)).astype(np.float32) @ lat + 0.15 * rng.standard_normal((n, d)).astype(np.float32)
@@ -253,6 +252,7 @@ def test_batched_build_identical_to_oracle_schedule(oracle, monkeypatch, metric,
     ids = np.arange(2, n + 2, dtype=np.uint64)
     assert o.insert_rounds(ids, base, round_size=round_size, big_min=big_min) == 0
     ix = _new_gpu(d, metric, R, L)
+    ix.set_tuning("hub_min", big_min)
     ix.set_start(sv)
     ix.insert_batch(ids, base, round_size=round_size)
     assert_same_graph(ix, o)
@@ -266,7 +266,6 @@ def test_batched_build_at_natural_scale(oracle, monkeypatch, metric, d, n, R, L)
     prune, bigprune.inc), groups of requests on ordinary targets -- equal to the oracle's restatement of the
     schedule edge for edge, and the searches that follow walk the same path."""
     from tests.helpers import assert_same_graph
-    monkeypatch.delenv("SDB_BIG_MIN", raising=False)
     rng = np.random.default_rng(d + n)
     lat = rng.standard_normal((6, d)).astype(np.float32)
     base = rng.standard_normal((n, 6)).astype(np.float32) @ lat + 0.2 * rng.standard_normal((n, d)).astype(np.float32)

@@ -29,7 +29,6 @@ def _fuzz():
 
 @pytest.mark.parametrize("seed", [1, 20251002])
 def test_fuzz_short_soak(oracle, monkeypatch, seed):
-    monkeypatch.setenv("SDB_BIG_MIN", "512")  # trial() sets its own; monkeypatch restores the environment afterwards
     fz = _fuzz()
     for t in range(30):
         rng = np.random.default_rng([seed, t])

@@ -249,7 +249,6 @@ def test_batched_insert_into_quantized_store_matches_oracle_schedule(oracle, mon
     """rounds of inserts into a store with a fitted quantizer (LUT searches, centroid-pair prunes, hub path on)
     against the oracle's restatement of the same round schedule: equal graphs, equal codes"""
     from semadb_amd import vamana, vectorstore as vs
-    monkeypatch.setenv("SDB_BIG_MIN", "4")
     rng = np.random.default_rng(808)
     d, M, K, R, L = 32, 8, 16, 16, 30
     base = unit_rows(rng, 4000, d)
@@ -260,6 +259,7 @@ def test_batched_insert_into_quantized_store_matches_oracle_schedule(oracle, mon
     opq.fit(vecs[1:801].copy(), first, alias=True)
     assert o.attach_pq(opq, np.stack([opq.encode(v) for v in vecs])) == 0
     g = vamana.NewIndexVamana("bq", vamana.IndexVectorVamanaParameters(d, "euclidean", L, R, 1.2), strict=False)
+    g.set_tuning("hub_min", 4)
     g.load(ids, vecs, off, edges)
     gpq = vs.ProductQuantizer("euclidean", vs.ProductQuantizerParameters(K, M), d)
     gpq.Fit(vecs[1:801].copy(), first, alias=True)
@@ -280,7 +280,6 @@ def test_quantizer_attached_to_a_device_built_graph(oracle, monkeypatch, metric,
     the inserts that follow (found by tools/fuzz_parity.py, seed 1 trial 88: the chip-wide prune of a target with
     several requests read the row's cached full-precision distances).  Sequential inserts first, then batched
     rounds with the hub threshold at 2."""
-    monkeypatch.setenv("SDB_BIG_MIN", "2")
     from semadb_amd import vamana, vectorstore as vs
     from tests.helpers import start_vector
     d, n0, n1, R, L = 16, 700, 200, 8, 24
@@ -290,6 +289,7 @@ def test_quantizer_attached_to_a_device_built_graph(oracle, monkeypatch, metric,
     o = oracle.Index(d, metric, R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
     o.set_start(sv)
     ix = vamana.NewIndexVamana("dq", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.2), strict=False)
+    ix.set_tuning("hub_min", 2)
     ix.set_start(sv)
     ids = np.arange(2, n0 + 2, dtype=np.uint64)
     for i in range(n0):

@@ -189,9 +189,9 @@ def test_hash_set_overflow_falls_back_to_bitset(oracle, monkeypatch):
     ix = _gpu_index(o, 96, "cosine", 32, 50)
     q = unit_rows(rng, 32, 96)
     _check_batch(o, ix, q, 10, 50)            # hash path
-    monkeypatch.setenv("SDB_HASH_LIMIT", "40")
+    ix.set_tuning("hash_limit", 40)
     _check_batch(o, ix, q, 10, 50)            # every query overflows -> bitset rerun
-    monkeypatch.setenv("SDB_HASH_LIMIT", "700")
+    ix.set_tuning("hash_limit", 700)
     _check_batch(o, ix, q, 10, 50)            # a mix of both
     ix.close()
 

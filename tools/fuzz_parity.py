@@ -131,12 +131,12 @@ def trial(rng, t):
                 big_min=big_min, round_size=round_size)
     CURRENT.clear()
     CURRENT.update(desc)
-    os.environ["SDB_BIG_MIN"] = str(big_min)
     impl = orc.IMPL_AVX2 if orc.has_avx2() else orc.IMPL_ASM
     sv = start_vector(np.random.default_rng(int(rng.integers(1 << 30))), d)
     o = orc.Index(d, metric, R, L, alpha, impl=impl)
     o.set_start(sv)
     g = vamana.NewIndexVamana("fz", vamana.IndexVectorVamanaParameters(d, metric, L, R, alpha), strict=False)
+    g.set_tuning("hub_min", big_min)
     g.set_start(sv)
     try:
         base = draw_rows(rng, n, d, kind)
