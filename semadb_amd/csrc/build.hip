@@ -56,6 +56,7 @@ struct BuildArgs {
   uint32_t start_slot;
   const uint32_t *start_ext;
   uint32_t start_ext_n;
+  uint32_t no_tile;           // != 0: new nodes are pruned by k_prune_new (rows from global memory), a test knob
   unsigned long long *stats;  // sdb_index_build_stats counters (index.h d_bstats), or NULL
   uint32_t *flags;            // [0] bit 0: a search's visit log did not fit vis_cap
 };
@@ -65,7 +66,7 @@ enum { kStSearchDist = 0, kStSearchEdges, kStPrunePairs, kStBackPairs, kStBackCa
        kStAppends, kStStagedRows, kStRounds, kStHubs };
 
 __device__ __forceinline__ void stat_add(const BuildArgs &a, int slot, unsigned long long v, int lane) {
-  if (a.stats && lane == 0 && v) atomicAdd(a.stats + slot, v);
+  if (a.stats && lane == 0 && v) atomicAdd(a.stats + (blockIdx.x & 63u) * 16u + slot, v);  // index.h kStatCopies
 }
 
 constexpr int kQuantized = -2;  // value of the NG template parameter for a fitted product quantizer
@@ -484,6 +485,232 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
       nb == kNoSlot ? kNoKey : ((uint64_t)nb << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
 }
 
+
+// ---- robustPrune of the new nodes with the candidate rows staged in LDS ---------------------------------------
+// The robustPrune of a new node walks its sorted visit list (~79 entries at searchSize 75), selects ~52 edges and
+// on the way evaluates ~1 850 pair distances among those 79 rows: every row is an operand ~23 times.  k_prune_new
+// fetches the row from global memory each time (2.8 TB per 1M inserts, served mostly by L2); here one 256-thread
+// workgroup per new node gathers the list's rows ONCE into an LDS tile (79 x 1 536 B = 121 KB of the CU's 160 KB
+// at d = 384) and every pair distance reads its row from there -- same 32-chain arithmetic, same order, same
+// graph.  The tile holds the first `tile_rows` candidates of the SORTED list (the closest ones: every selection
+// comes from the front); a longer list or a wider row leaves the rest in global memory, read as before.
+//
+// Selection is sequential (search.go:113-137) but each sweep is parallel: the live candidates after the selected
+// one are dealt to the workgroup's 8 half-waves, a half-wave per (selected, candidate) pair, U pairs in flight.
+constexpr int kTileThreads = 256;
+constexpr uint32_t kTileLdsBytes = 160 * 1024;
+
+struct TileLds {
+  uint32_t *s_slot;   // [cap] sorted candidates
+  float *s_dist;      // [cap]
+  uint32_t *s_rem;    // [cap] pruneRemoved
+  uint32_t *o_slot;   // [64] the new row
+  float *o_dist;      // [64]
+  uint32_t *lists;    // [4][64] per-wave compacted live list of the current 64-candidate chunk
+  float *tile;        // [tile_rows][ld]; in_slot / in_dist [cap] each live here until the sort is done
+  __device__ TileLds(char *base, uint32_t cap) {
+    s_slot = reinterpret_cast<uint32_t *>(base);
+    s_dist = reinterpret_cast<float *>(s_slot + cap);
+    s_rem = reinterpret_cast<uint32_t *>(s_dist + cap);
+    o_slot = s_rem + cap;
+    o_dist = reinterpret_cast<float *>(o_slot + 64);
+    lists = reinterpret_cast<uint32_t *>(o_dist + 64);
+    tile = reinterpret_cast<float *>(lists + 4 * 64);
+  }
+  static size_t fixed_bytes(uint32_t cap) { return (size_t)cap * 12 + 64 * 8 + 4 * 64 * 4; }
+};
+
+static uint32_t tile_rows_for(uint32_t vis_cap, uint32_t ld) {
+  const size_t fixed = TileLds::fixed_bytes(vis_cap);
+  if (fixed + (size_t)vis_cap * 8 > kTileLdsBytes) return 0;  // not even the unsorted list fits
+  return (uint32_t)((kTileLdsBytes - fixed) / ((size_t)ld * 4));
+}
+
+template <int NG, bool L2>
+__global__ __launch_bounds__(kTileThreads) void k_prune_new_tiled(const BuildArgs a, const uint32_t tile_rows) {
+  static_assert(NG >= 1, "register-row kernels only");
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  TileLds l(lds_raw, a.vis_cap);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = lane & 31, half = lane >> 5;
+  const uint32_t q = blockIdx.x;
+  const uint32_t self = a.first_slot + q;
+  uint32_t nc = a.vis_count[q];
+  if (nc > a.vis_cap) {  // see k_prune_new
+    if (tid == 0) atomicOr(a.flags, 1u);
+    nc = a.vis_cap;
+  }
+  // ---- DistSet.Sort (distset.go:223-238): stable by distance, rank by counting
+  uint32_t *in_slot = reinterpret_cast<uint32_t *>(l.tile);
+  float *in_dist = reinterpret_cast<float *>(in_slot + a.vis_cap);
+  for (uint32_t i = tid; i < nc; i += kTileThreads) {
+    in_slot[i] = a.vis_slots[(size_t)q * a.vis_cap + i];
+    in_dist[i] = a.vis_dists[(size_t)q * a.vis_cap + i];
+  }
+  __syncthreads();
+  uint32_t my_slot[4], my_rank[4];  // nc <= vis_cap = 1024 = 4 per thread
+  float my_dist[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = tid + k * kTileThreads;
+    my_rank[k] = kNoSlot;
+    if (i < nc) {
+      const float d = in_dist[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nc; j++) {
+        const float dj = in_dist[j];
+        rank += (dj < d || (dj == d && j < i)) ? 1u : 0u;
+      }
+      my_rank[k] = rank, my_slot[k] = in_slot[i], my_dist[k] = d;
+    }
+  }
+  __syncthreads();  // in_slot / in_dist are dead: the tile may be written
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (my_rank[k] != kNoSlot) l.s_slot[my_rank[k]] = my_slot[k], l.s_dist[my_rank[k]] = my_dist[k], l.s_rem[my_rank[k]] = 0u;
+  __syncthreads();
+  // ---- gather the first nt rows of the sorted list into the tile: a half-wave per row, all loads of a wave in
+  // flight before the first LDS write
+  const uint32_t nt = nc < tile_rows ? nc : tile_rows;
+  {
+    constexpr int B = NG <= 3 ? 8 : NG <= 6 ? 4 : 2;  // rows per half-wave per batch
+    const uint32_t hw = (uint32_t)(wave * 2 + half);   // 0..7
+    for (uint32_t r0 = 0; r0 < nt; r0 += 8 * B) {
+      float4 y[B][NG];
+      float yt[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint32_t r = r0 + hw + 8 * b;
+        if (r < nt) {
+          const float *row = a.slab + (size_t)l.s_slot[r] * a.ld;
+          const float4 *r4 = reinterpret_cast<const float4 *>(row) + L;
+#pragma unroll
+          for (int g = 0; g < NG; g++) y[b][g] = r4[g * 32];
+          yt[b] = a.tail ? row[NG * 128 + L] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint32_t r = r0 + hw + 8 * b;
+        if (r < nt) {
+          float *dst = l.tile + (size_t)r * a.ld;
+          float4 *d4 = reinterpret_cast<float4 *>(dst) + L;
+#pragma unroll
+          for (int g = 0; g < NG; g++) d4[g * 32] = y[b][g];
+          if (a.tail) dst[NG * 128 + L] = yt[b];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the selection loop (search.go:113-137)
+  constexpr int U = NG <= 3 ? 4 : NG <= 6 ? 2 : 1;  // pairs in flight per half-wave
+  uint32_t *mylist = l.lists + wave * 64;
+  int cnt = 0;
+  uint32_t n_eval = 0;
+  int i = 0;
+  while (i < (int)nc) {
+    int found = -1;
+    for (int base = i & ~63; base < (int)nc && found < 0; base += 64) {
+      const int j = base + lane;
+      const bool ok = j >= i && j < (int)nc && l.s_rem[j] == 0u && l.s_slot[j] != self;  // :115-117
+      const uint64_t m = __ballot(ok);
+      if (m) found = base + __ffsll((unsigned long long)m) - 1;
+    }
+    if (found < 0) break;
+    const uint32_t p = l.s_slot[found];
+    if (tid == 0) l.o_slot[cnt] = p, l.o_dist[cnt] = l.s_dist[found];  // node.AddNeighbour :118
+    cnt++;
+    if (cnt >= (int)a.R) break;  // :119-121
+    // bind p (DistanceFromPoint :124): its row into registers, from the tile when it is there
+    float4 xq[NG];
+    float xt = 0.0f;
+    {
+      const float *prow = (uint32_t)found < nt ? l.tile + (size_t)found * a.ld : a.slab + (size_t)p * a.ld;
+      if ((uint32_t)found < nt) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) xq[g] = reinterpret_cast<const float4 *>(l.tile + (size_t)found * a.ld)[g * 32 + L];
+        if (a.tail) xt = l.tile[(size_t)found * a.ld + NG * 128 + L];
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG; g++) xq[g] = reinterpret_cast<const float4 *>(prow)[g * 32 + L];
+        if (a.tail) xt = prow[NG * 128 + L];
+      }
+    }
+    // s_rem[j] = number of the sweep that removed j (0: not removed).  The waves run through the chunks at their
+    // own pace, so a candidate this very sweep has already struck out (by a faster wave) still counts as live when
+    // a slower wave builds its list: all four lists are the same and every pair has exactly one owner.
+    const uint32_t sweep = (uint32_t)cnt;  // >= 1
+    for (int base = (found + 1) & ~63; base < (int)nc; base += 64) {
+      const int j = base + lane;
+      const uint32_t rj = j < (int)nc ? l.s_rem[j] : 1u;
+      const bool live = j > found && j < (int)nc && (rj == 0u || rj == sweep);
+      const uint64_t m = __ballot(live);
+      if (!m) continue;
+      const int c = __popcll(m);
+      if (wave == 0) n_eval += (uint32_t)c;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (live) mylist[rank] = (uint32_t)j;  // every wave builds the same list, privately: no barrier
+      wave_lds_sync();
+      // live candidate number k of the chunk belongs to half-wave k % 8 of the workgroup
+      const int hw = wave * 2 + half;
+      for (int t0 = 0; t0 < c; t0 += 8 * U) {  // wave-uniform trip count
+        int jj[U];
+        float4 y[U][NG];
+        float yt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int k = t0 + hw + 8 * u;
+          jj[u] = k < c ? (int)mylist[k] : -1;
+          yt[u] = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) y[u][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (jj[u] >= 0) {
+            if ((uint32_t)jj[u] < nt) {
+              const float *row = l.tile + (size_t)jj[u] * a.ld;
+#pragma unroll
+              for (int g = 0; g < NG; g++) y[u][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
+              if (a.tail) yt[u] = row[NG * 128 + L];
+            } else {
+              const float *row = a.slab + (size_t)l.s_slot[jj[u]] * a.ld;
+#pragma unroll
+              for (int g = 0; g < NG; g++) y[u][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
+              if (a.tail) yt[u] = row[NG * 128 + L];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          // both halves run the arithmetic together; a half without a pair computes on zeros and drops the result
+          float acc = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
+          const float t = a.tail ? tail_chain<L2>(xt, yt[u], a.tail, lane) : 0.0f;
+          const float raw = asm_reduce(acc, t, lane);
+          if (L == 0 && jj[u] >= 0) {
+            const float d = metric_finish(raw, a.metric);
+            if (a.alpha * d < l.s_dist[jj[u]]) l.s_rem[jj[u]] = sweep;  // :132 -- one owner per j: no race
+          }
+        }
+      }
+      wave_lds_sync();  // mylist is rewritten for the next chunk
+    }
+    __syncthreads();  // every wave sees the sweep's removals before the next selection
+    i = found + 1;
+  }
+  __syncthreads();
+  // ---- node.edges of the new node, kNoSlot padded; a freshly pruned row is clean and carries its distances
+  if (wave == 0) {
+    const uint32_t out = lane < cnt ? l.o_slot[lane] : kNoSlot;
+    a.adj[(size_t)self * kAdjStride + lane] = out;
+    a.adjdist[(size_t)self * kAdjStride + lane] = lane < cnt ? l.o_dist[lane] : 0.0f;
+    if (lane == 0) a.deg[self] = (uint32_t)cnt, a.clean[self] = (uint32_t)cnt, a.dcount[self] = (uint32_t)cnt;
+    a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
+        out == kNoSlot ? kNoKey : ((uint64_t)out << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
+    stat_add(a, kStPrunePairs, n_eval, lane);
+    stat_add(a, kStStagedRows, nt, lane);
+  }
+}
+
 }  // namespace sdb
 
 #include "bigprune.inc"
@@ -653,8 +880,25 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
 template <int NG, bool L2>
 static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, size_t sort_tmp_bytes,
                         int sort_end_bit, BigScratch *big, bool *start_pruned) {
-  const size_t lds1 = prune_lds_bytes(a.vis_cap, NG, a.ld);
-  hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a);
+  bool tiled = false;
+  if constexpr (NG >= 1) {
+    // candidate rows staged in LDS when a useful share of a visit list fits (always for d <= 1024 at searchSize 75)
+    const uint32_t tr = a.no_tile ? 0u : tile_rows_for(a.vis_cap, a.ld);
+    if (tr >= 24) {
+      static bool attr_set = false;  // per instantiation
+      if (!attr_set) {
+        SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBytes));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((k_prune_new_tiled<NG, L2>), dim3(a.nnew), dim3(kTileThreads), kTileLdsBytes, stream, a, tr);
+      tiled = true;
+    }
+  }
+  if (!tiled) {
+    const size_t lds1 = prune_lds_bytes(a.vis_cap, NG, a.ld);
+    hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a);
+  }
   SDB_HIP(hipGetLastError());
   size_t tmp = sort_tmp_bytes;
   SDB_HIP(hipcub::DeviceRadixSort::SortKeys(sort_tmp, tmp, a.keys_in, a.keys_sorted, (int)((size_t)a.nnew * 64), 0,
@@ -761,7 +1005,9 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   } cleanup{{}, stream};
   // ---- every allocation of the call comes first: an out-of-memory failure must leave the index as it was
   SDB_TRY(ix->reserve(n0 + (uint32_t)n));
-  if (!ix->d_bstats) SDB_HIP(hipMalloc(&ix->d_bstats, SDB_BUILD_STATS * sizeof(uint64_t)));
+  static_assert(SDB_BUILD_STATS <= sdb_index::kStatStride, "stat slots per copy");
+  const size_t bstats_bytes = (size_t)sdb_index::kStatCopies * sdb_index::kStatStride * sizeof(uint64_t);
+  if (!ix->d_bstats) SDB_HIP(hipMalloc(&ix->d_bstats, bstats_bytes));
   float *staging = nullptr;
   if (mem == SDB_MEM_HOST) {
     SDB_HIP(hipMalloc(&staging, n * l.dim * sizeof(float)));
@@ -827,7 +1073,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   }
 
   // ---- from here on the call writes: rows beyond ix->n first (invisible until a round commits them)
-  SDB_HIP(hipMemsetAsync(ix->d_bstats, 0, SDB_BUILD_STATS * sizeof(uint64_t), stream));
+  SDB_HIP(hipMemsetAsync(ix->d_bstats, 0, bstats_bytes, stream));
   SDB_HIP(hipMemsetAsync(big_count, 0, 8, stream));
   const float *dvec = vectors;  // the vectors (original layout) on device; they double as the search queries
   if (staging) {
@@ -922,6 +1168,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.start_slot = (uint32_t)ix->start_slot;
     ba.start_ext = ix->d_start_ext, ba.start_ext_n = (uint32_t)ix->h_start_ext.size();
     ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
+    ba.no_tile = ix->tune_no_tile ? 1u : 0u;
     bool start_pruned = false;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN

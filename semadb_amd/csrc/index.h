@@ -72,12 +72,15 @@ struct sdb_index {
   uint8_t *d_codes = nullptr;
   // sdb_index_set_tuning
   uint32_t tune_hub_min = 512, tune_hash_limit = 0;
-  bool tune_no_hash = false;
+  bool tune_no_hash = false, tune_no_tile = false;
   // a write that failed after it had started to change the graph leaves it unusable: every later call fails
   // until the host rebuilds the index from the bucket -- the reference scraps its cache on any error inside a
   // write transaction the same way (shard/cache/manager.go:231-240)
   bool broken = false;
-  // counters of the last insert_batch (sdb_index_build_stats); device-side, added to by the kernels
+  // counters of the last insert_batch (sdb_index_build_stats); device-side, added to by the kernels.  kStatCopies
+  // copies of kStatStride slots, one 128-byte line each: a wave adds to the copy its block index picks, so tens of
+  // millions of waves do not queue up on one address (a single set cost the build 1 s of its 3); summed on read
+  static constexpr uint32_t kStatCopies = 64, kStatStride = 16;
   uint64_t *d_bstats = nullptr;
   // measurement hook: events around the last K2 launch
   bool profiling = false;

@@ -700,6 +700,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
     case SDB_TUNE_NO_HASH:
       ix->tune_no_hash = value != 0;
       return SDB_OK;
+    case SDB_TUNE_NO_TILE:
+      ix->tune_no_tile = value != 0;
+      return SDB_OK;
     default:
       return fail(SDB_ERR_INVALID, "unknown tuning key %d", key);
   }
@@ -712,7 +715,10 @@ int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) {
   if (!ix->d_bstats || n == 0) return SDB_OK;
   DeviceGuard dg(ix->P.device);
   SDB_HIP(hipDeviceSynchronize());
-  SDB_HIP(hipMemcpy(out, ix->d_bstats, (size_t)n * 8, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> all((size_t)sdb_index::kStatCopies * sdb_index::kStatStride);
+  SDB_HIP(hipMemcpy(all.data(), ix->d_bstats, all.size() * 8, hipMemcpyDeviceToHost));
+  for (uint32_t c = 0; c < sdb_index::kStatCopies; c++)
+    for (uint32_t i = 0; i < n; i++) out[i] += all[(size_t)c * sdb_index::kStatStride + i];
   return SDB_OK;
 }
 

@@ -894,7 +894,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     if (a.tr_nhop) a.tr_nhop[q] = n_hop;
     if (a.tr_nedges) a.tr_nedges[q] = n_edges;
     if (a.vis_count) a.vis_count[q] = n_hop;
-    if (a.totals) atomicAdd(a.totals, (unsigned long long)n_dist), atomicAdd(a.totals + 1, (unsigned long long)n_edges);
+    if (a.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
+      unsigned long long *t = a.totals + (q & 63u) * 16u;
+      atomicAdd(t, (unsigned long long)n_dist), atomicAdd(t + 1, (unsigned long long)n_edges);
+    }
   }
 }
 

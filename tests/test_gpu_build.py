@@ -286,3 +286,37 @@ def test_batched_build_at_natural_scale(oracle, monkeypatch, metric, d, n, R, L)
         assert np.array_equal(g_ids[i, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d))
         assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis)
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,n,R,L,searchL", [("cosine", 96, 2500, 32, 50, 50), ("euclidean", 100, 1500, 16, 30, 30),
+                                                    ("dot", 768, 600, 16, 120, 120), ("cosine", 1536, 300, 8, 40, 40)])
+def test_new_node_prune_tiled_and_untiled_agree(oracle, metric, d, n, R, L, searchL):
+    """robustPrune of the new nodes has two device forms: candidate rows staged in an LDS tile by a 256-thread
+    workgroup (k_prune_new_tiled, the default) and rows read from global memory by one wavefront (k_prune_new,
+    forced with the no_tile knob).  Both give the oracle's graph edge for edge -- sequential inserts and batched
+    rounds; d = 100 has a tail chain, d = 768 / 1536 and searchSize 120 make visit lists longer than the tile."""
+    from tests.helpers import assert_same_graph
+    rng = np.random.default_rng(d * 7 + n)
+    lat = rng.standard_normal((6, d)).astype(np.float32)
+    base = rng.standard_normal((n, 6)).astype(np.float32) @ lat + 0.2 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    sv = start_vector(np.random.default_rng(3), d)
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    for round_size in (1, 0):
+        o = oracle.Index(d, metric, R, L, 1.2, impl=impl)
+        o.set_start(sv)
+        if round_size == 1:
+            for i in range(n):
+                assert o.insert(int(ids[i]), base[i]) == 0
+        else:
+            assert o.insert_rounds(ids, base, round_size=0) == 0
+        for no_tile in (0, 1):
+            ix = _new_gpu(d, metric, R, L)
+            ix.set_tuning("no_tile", no_tile)
+            ix.set_start(sv)
+            ix.insert_batch(ids, base, round_size=round_size)
+            assert_same_graph(ix, o)
+            st = ix.build_stats()
+            assert (st["staged_rows"] > 0) == (no_tile == 0)
+            ix.close()
