@@ -131,6 +131,15 @@ int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const
  * An update (vamana.go:170-174,247-251) is delete_batch followed by insert_batch with the same id. */
 int sdb_index_delete_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, void *stream);
 
+/* IndexVamana.EdgeScan (node.go:142-199), read-only: the ids of the valid nodes that have an edge to a member of
+ * the delete set (to_prune) and of the valid nodes that no valid node points at (to_save; the start node never
+ * is).  The reference returns both in Go-map order; here storage order.  Counts are always returned; ids are
+ * written when the arrays are given and large enough (the node count always is).  sdb_index_delete_batch runs
+ * the same scan internally -- this entry point exists because EdgeScan is part of the package's exported surface. */
+int sdb_index_edge_scan(const sdb_index *ix, uint64_t n, const uint64_t *delete_ids, uint64_t *to_prune,
+                        uint64_t cap_prune, uint64_t *n_prune, uint64_t *to_save, uint64_t cap_save,
+                        uint64_t *n_save, void *stream);
+
 /* per-query search trace; every pointer may be NULL.  Arrays follow the same `mem` as the
  * outputs of the call. */
 typedef struct {

@@ -410,3 +410,26 @@ def effective_cpus():
         except Exception:
             continue
     return max(1, n)
+
+
+def edge_scan(ids, offsets, edges, delete_set):
+    """IndexVamana.EdgeScan (shard/index/vamana/node.go:142-199) restated over an exported graph (ids [n],
+    CSR offsets / edges as node ids): returns (toPrune, toSave) as sorted lists -- the reference builds both by
+    iterating Go maps, so only the sets are defined.  toPrune: valid nodes (not in the delete set) with an edge
+    into it (:163-175); toSave: valid nodes no valid node points at, the start node excepted (:189-195)."""
+    delete_set = set(int(v) for v in delete_set)
+    valid, has_inbound, to_prune = set(), set(), []
+    for i, nid in enumerate(ids):
+        nid = int(nid)
+        if nid in delete_set:  # :158-160
+            continue
+        valid.add(nid)
+        added = False
+        for e in edges[int(offsets[i]):int(offsets[i + 1])]:
+            e = int(e)
+            has_inbound.add(e)  # :168
+            if not added and e in delete_set:  # :169-174
+                to_prune.append(nid)
+                added = True
+    to_save = [v for v in valid if v not in has_inbound and v != 1]  # :191-195, STARTID = 1
+    return sorted(to_prune), sorted(to_save)

@@ -12,9 +12,14 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "pq.h"
 #include "search_kernel.h"
+
+#ifndef SDB_DCACHE_BITS
+#define SDB_DCACHE_BITS 13
+#endif
 
 namespace sdb {
 
@@ -57,6 +62,7 @@ struct BuildArgs {
   const uint32_t *start_ext;
   uint32_t start_ext_n;
   uint32_t no_tile;           // != 0: new nodes are pruned by k_prune_new (rows from global memory), a test knob
+  uint32_t *prune_done;       // [nnew] set by k_prune_new_tiled for the nodes it pruned; NULL: k_prune_new takes all
   unsigned long long *stats;  // sdb_index_build_stats counters (index.h d_bstats), or NULL
   uint32_t *flags;            // [0] bit 0: a search's visit log did not fit vis_cap
 };
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
   PruneLds l(lds_raw, a.vis_cap);
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
+  if (a.prune_done && a.prune_done[q]) return;  // k_prune_new_tiled has pruned this node
   const uint32_t self = a.first_slot + q;
   uint32_t nc = a.vis_count[q];
   if (nc > a.vis_cap) {  // the reference's visited list is unbounded (AddAlreadyUnique): never prune a cut one silently
@@ -489,226 +496,202 @@ __global__ __launch_bounds__(64) void k_prune_new(const BuildArgs a) {
 // ---- robustPrune of the new nodes with the candidate rows staged in LDS ---------------------------------------
 // The robustPrune of a new node walks its sorted visit list (~79 entries at searchSize 75), selects ~52 edges and
 // on the way evaluates ~1 850 pair distances among those 79 rows: every row is an operand ~23 times.  k_prune_new
-// fetches the row from global memory each time (2.8 TB per 1M inserts, served mostly by L2); here one 256-thread
+// fetches the row from global memory each time (2.8 TB per 1M inserts, served mostly by L2).  Here one 256-thread
 // workgroup per new node gathers the list's rows ONCE into an LDS tile (79 x 1 536 B = 121 KB of the CU's 160 KB
-// at d = 384) and every pair distance reads its row from there -- same 32-chain arithmetic, same order, same
-// graph.  The tile holds the first `tile_rows` candidates of the SORTED list (the closest ones: every selection
-// comes from the front); a longer list or a wider row leaves the rest in global memory, read as before.
-//
-// Selection is sequential (search.go:113-137) but each sweep is parallel: the live candidates after the selected
-// one are dealt to the workgroup's 8 half-waves, a half-wave per (selected, candidate) pair, U pairs in flight.
-constexpr int kTileThreads = 256;
+// at d = 384) and works in two phases:
+//   A. every pair distance of the list, d(c_i, c_j) for i < j, by all four waves -- a half-wave per pair, row i in
+//      registers, row j from the tile, U pairs in flight.  The selection below needs about 60 % of them (which
+//      ones is only known as it goes); computing all of them removes every dependency from the arithmetic, and
+//      with one workgroup per CU (the tile fills its LDS) a dependent LDS round trip per selected edge is what the
+//      chip cannot hide.  Same 32-chain arithmetic (dist_core.h), so the same bits the one-by-one walk computes.
+//   B. the selection loop (search.go:113-137) by one wave with the list in registers: the sweep of a selected
+//      candidate is one LDS read of its row of the pair table per lane.
+// The graph is the one k_prune_new builds, edge for edge (tests/test_gpu_build.py).  The tile holds the first rows
+// of the SORTED list; what does not fit (wide rows) stays in global memory and is read from there in phase A.
+// Lists longer than kTileMaxCand are left to k_prune_new (BuildArgs::prune_done tells it which).
 constexpr uint32_t kTileLdsBytes = 160 * 1024;
+constexpr int kTileMaxCand = 128;
+constexpr uint32_t kTileFixedBytes = kTileMaxCand * 16;  // s_slot, s_dist, in_slot, in_dist
 
-struct TileLds {
-  uint32_t *s_slot;   // [cap] sorted candidates
-  float *s_dist;      // [cap]
-  uint32_t *s_rem;    // [cap] pruneRemoved
-  uint32_t *o_slot;   // [64] the new row
-  float *o_dist;      // [64]
-  uint32_t *lists;    // [4][64] per-wave compacted live list of the current 64-candidate chunk
-  float *tile;        // [tile_rows][ld]; in_slot / in_dist [cap] each live here until the sort is done
-  __device__ TileLds(char *base, uint32_t cap) {
-    s_slot = reinterpret_cast<uint32_t *>(base);
-    s_dist = reinterpret_cast<float *>(s_slot + cap);
-    s_rem = reinterpret_cast<uint32_t *>(s_dist + cap);
-    o_slot = s_rem + cap;
-    o_dist = reinterpret_cast<float *>(o_slot + 64);
-    lists = reinterpret_cast<uint32_t *>(o_dist + 64);
-    tile = reinterpret_cast<float *>(lists + 4 * 64);
-  }
-  static size_t fixed_bytes(uint32_t cap) { return (size_t)cap * 12 + 64 * 8 + 4 * 64 * 4; }
-};
-
-static uint32_t tile_rows_for(uint32_t vis_cap, uint32_t ld) {
-  const size_t fixed = TileLds::fixed_bytes(vis_cap);
-  if (fixed + (size_t)vis_cap * 8 > kTileLdsBytes) return 0;  // not even the unsorted list fits
-  return (uint32_t)((kTileLdsBytes - fixed) / ((size_t)ld * 4));
-}
-
-template <int NG, bool L2>
-__global__ __launch_bounds__(kTileThreads) void k_prune_new_tiled(const BuildArgs a, const uint32_t tile_rows) {
+template <int NG, bool L2, bool TAIL, int NW>
+__global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) {
   static_assert(NG >= 1, "register-row kernels only");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  TileLds l(lds_raw, a.vis_cap);
+  uint32_t *s_slot = reinterpret_cast<uint32_t *>(lds_raw);
+  float *s_dist = reinterpret_cast<float *>(s_slot + kTileMaxCand);
+  uint32_t *in_slot = reinterpret_cast<uint32_t *>(s_dist + kTileMaxCand);
+  float *in_dist = reinterpret_cast<float *>(in_slot + kTileMaxCand);
+  float *D = reinterpret_cast<float *>(lds_raw + kTileFixedBytes);  // [nc][nc], upper triangle used
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = lane & 31, half = lane >> 5;
   const uint32_t q = blockIdx.x;
   const uint32_t self = a.first_slot + q;
-  uint32_t nc = a.vis_count[q];
-  if (nc > a.vis_cap) {  // see k_prune_new
-    if (tid == 0) atomicOr(a.flags, 1u);
-    nc = a.vis_cap;
+  const uint32_t nc_raw = a.vis_count[q];
+  if (nc_raw > (uint32_t)kTileMaxCand) {  // a long list: the one-wave kernel prunes it
+    if (tid == 0) a.prune_done[q] = 0u;
+    return;
   }
+  const int nc = (int)nc_raw;
   // ---- DistSet.Sort (distset.go:223-238): stable by distance, rank by counting
-  uint32_t *in_slot = reinterpret_cast<uint32_t *>(l.tile);
-  float *in_dist = reinterpret_cast<float *>(in_slot + a.vis_cap);
-  for (uint32_t i = tid; i < nc; i += kTileThreads) {
-    in_slot[i] = a.vis_slots[(size_t)q * a.vis_cap + i];
-    in_dist[i] = a.vis_dists[(size_t)q * a.vis_cap + i];
+  if (tid < nc) {
+    in_slot[tid] = a.vis_slots[(size_t)q * a.vis_cap + tid];
+    in_dist[tid] = a.vis_dists[(size_t)q * a.vis_cap + tid];
   }
   __syncthreads();
-  uint32_t my_slot[4], my_rank[4];  // nc <= vis_cap = 1024 = 4 per thread
-  float my_dist[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t i = tid + k * kTileThreads;
-    my_rank[k] = kNoSlot;
-    if (i < nc) {
-      const float d = in_dist[i];
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < nc; j++) {
-        const float dj = in_dist[j];
-        rank += (dj < d || (dj == d && j < i)) ? 1u : 0u;
-      }
-      my_rank[k] = rank, my_slot[k] = in_slot[i], my_dist[k] = d;
+  if (tid < nc) {
+    const float d = in_dist[tid];
+    uint32_t rank = 0;
+    for (int j = 0; j < nc; j++) {
+      const float dj = in_dist[j];
+      rank += (dj < d || (dj == d && j < tid)) ? 1u : 0u;
     }
+    s_slot[rank] = in_slot[tid], s_dist[rank] = d;
   }
-  __syncthreads();  // in_slot / in_dist are dead: the tile may be written
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (my_rank[k] != kNoSlot) l.s_slot[my_rank[k]] = my_slot[k], l.s_dist[my_rank[k]] = my_dist[k], l.s_rem[my_rank[k]] = 0u;
   __syncthreads();
-  // ---- gather the first nt rows of the sorted list into the tile: a half-wave per row, all loads of a wave in
+  // ---- gather the first nt rows of the sorted list into the tile: a half-wave per row, a batch of loads in
   // flight before the first LDS write
-  const uint32_t nt = nc < tile_rows ? nc : tile_rows;
+  const uint32_t d_bytes = ((uint32_t)(nc * nc) * 4u + 15u) & ~15u;
+  float *tile = reinterpret_cast<float *>(lds_raw + kTileFixedBytes + d_bytes);
+  const int fit = (int)((kTileLdsBytes - kTileFixedBytes - d_bytes - 1024u) / (a.ld * 4u));  // 1 KB: DMA overhang
+  const int nt = nc < fit ? nc : fit;
   {
-    constexpr int B = NG <= 3 ? 8 : NG <= 6 ? 4 : 2;  // rows per half-wave per batch
-    const uint32_t hw = (uint32_t)(wave * 2 + half);   // 0..7
-    for (uint32_t r0 = 0; r0 < nt; r0 += 8 * B) {
-      float4 y[B][NG];
-      float yt[B];
-#pragma unroll
-      for (int b = 0; b < B; b++) {
-        const uint32_t r = r0 + hw + 8 * b;
-        if (r < nt) {
-          const float *row = a.slab + (size_t)l.s_slot[r] * a.ld;
-          const float4 *r4 = reinterpret_cast<const float4 *>(row) + L;
-#pragma unroll
-          for (int g = 0; g < NG; g++) y[b][g] = r4[g * 32];
-          yt[b] = a.tail ? row[NG * 128 + L] : 0.0f;
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < B; b++) {
-        const uint32_t r = r0 + hw + 8 * b;
-        if (r < nt) {
-          float *dst = l.tile + (size_t)r * a.ld;
-          float4 *d4 = reinterpret_cast<float4 *>(dst) + L;
-#pragma unroll
-          for (int g = 0; g < NG; g++) d4[g * 32] = y[b][g];
-          if (a.tail) dst[NG * 128 + L] = yt[b];
-        }
-      }
+    // LDS-DMA (global_load_lds_dwordx4): a wave instruction moves 64 x 16 B straight into 1 KB of the tile, no
+    // registers in between, so a wave keeps all its ~30 pieces in flight at once.  The destination is lane-linear;
+    // the source is per lane -- a piece may straddle two rows, each lane finds its own (row, column).  Row slots
+    // come from LDS: an ordinary global load in this loop would make the compiler drain the DMAs at every use.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const uint32_t rowb = a.ld * 4u, total = (uint32_t)nt * rowb;
+    char *tile_b = reinterpret_cast<char *>(tile);
+    for (uint32_t piece = (uint32_t)wave; piece * 1024u < total; piece += NW) {
+      uint32_t o = piece * 1024u + (uint32_t)lane * 16u;
+      if (o >= total) o = total - 16u;  // the last piece's overhang lands in unused LDS behind the tile
+      const uint32_t r = o / rowb, c = o - r * rowb;
+      const char *src = reinterpret_cast<const char *>(a.slab) + (size_t)s_slot[r] * rowb + c;
+      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(tile_b + piece * 1024u), 16, 0, 0);
     }
   }
-  __syncthreads();
-  // ---- the selection loop (search.go:113-137)
+  __syncthreads();  // waits for this wave's DMAs (vmcnt) and for everybody else's
+  // ---- phase A: D[i][j] = distFn(c_i, c_j), i < j.  Rows i are dealt to the four waves in a zigzag (row i has
+  // nc - 1 - i pairs: 0,7,8,15,.. / 1,6,9,14,.. come to the same total within a row's length); the two halves of
+  // a wave share the row (the bound point of DistanceFromPoint, plain.go:87-97) and take its pairs alternately.
   constexpr int U = NG <= 3 ? 4 : NG <= 6 ? 2 : 1;  // pairs in flight per half-wave
-  uint32_t *mylist = l.lists + wave * 64;
-  int cnt = 0;
-  uint32_t n_eval = 0;
-  int i = 0;
-  while (i < (int)nc) {
-    int found = -1;
-    for (int base = i & ~63; base < (int)nc && found < 0; base += 64) {
-      const int j = base + lane;
-      const bool ok = j >= i && j < (int)nc && l.s_rem[j] == 0u && l.s_slot[j] != self;  // :115-117
-      const uint64_t m = __ballot(ok);
-      if (m) found = base + __ffsll((unsigned long long)m) - 1;
+  const uint32_t rowb = a.ld * 4u;
+  const char *tileL = reinterpret_cast<const char *>(tile) + L * 16;
+  const char *slabL = reinterpret_cast<const char *>(a.slab) + L * 16;
+  auto row_pairs = [&](auto all_in_tile, int i, const float4(&xq)[NG], float xt) {
+    constexpr bool ALLT = decltype(all_in_tile)::value;
+    const int n = nc - 1 - i;
+    for (int t0 = 0; 2 * t0 < n; t0 += U) {
+      int jj[U];
+      bool ok[U];
+      float4 y[U][NG];
+      float yt[TAIL ? U : 1];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int k = 2 * (t0 + u) + half;
+        ok[u] = k < n;
+        jj[u] = i + 1 + (ok[u] ? k : 0);  // past the end: the row's first pair again, computed and dropped
+        if (ALLT || jj[u] < nt) {
+          const char *row = tileL + (uint32_t)jj[u] * rowb;
+#pragma unroll
+          for (int g = 0; g < NG; g++) y[u][g] = *reinterpret_cast<const float4 *>(row + g * 512);
+          if constexpr (TAIL) yt[u] = *reinterpret_cast<const float *>(row + NG * 512 - L * 12);
+        } else {
+          const char *row = slabL + (size_t)s_slot[jj[u]] * rowb;
+#pragma unroll
+          for (int g = 0; g < NG; g++) y[u][g] = *reinterpret_cast<const float4 *>(row + g * 512);
+          if constexpr (TAIL) yt[u] = *reinterpret_cast<const float *>(row + NG * 512 - L * 12);
+        }
+      }
+      // all U reduce trees first, stores afterwards: with nothing conditional in between, the compiler interleaves
+      // the trees (a DPP add has to wait two slots for its operand; another tree's add fills them)
+      float raw[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
+        float t = 0.0f;
+        if constexpr (TAIL) t = tail_chain<L2>(xt, yt[u], a.tail, lane);
+        raw[u] = asm_reduce(acc, t, lane);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (L == 0 && ok[u]) D[i * nc + jj[u]] = raw[u];  // the raw sum; phase B applies the metric (distance.go:19-25)
     }
-    if (found < 0) break;
-    const uint32_t p = l.s_slot[found];
-    if (tid == 0) l.o_slot[cnt] = p, l.o_dist[cnt] = l.s_dist[found];  // node.AddNeighbour :118
-    cnt++;
-    if (cnt >= (int)a.R) break;  // :119-121
-    // bind p (DistanceFromPoint :124): its row into registers, from the tile when it is there
+  };
+  for (int b = 0; NW * b < nc - 1; b++) {
+    const int i = NW * b + ((b & 1) ? NW - 1 - wave : wave);
+    if (i >= nc - 1) continue;  // wave-uniform
     float4 xq[NG];
     float xt = 0.0f;
     {
-      const float *prow = (uint32_t)found < nt ? l.tile + (size_t)found * a.ld : a.slab + (size_t)p * a.ld;
-      if ((uint32_t)found < nt) {
+      const char *prow = i < nt ? tileL + (uint32_t)i * rowb : slabL + (size_t)s_slot[i] * rowb;
+      if (i < nt) {
 #pragma unroll
-        for (int g = 0; g < NG; g++) xq[g] = reinterpret_cast<const float4 *>(l.tile + (size_t)found * a.ld)[g * 32 + L];
-        if (a.tail) xt = l.tile[(size_t)found * a.ld + NG * 128 + L];
+        for (int g = 0; g < NG; g++) xq[g] = *reinterpret_cast<const float4 *>(tileL + (uint32_t)i * rowb + g * 512);
+        if constexpr (TAIL) xt = *reinterpret_cast<const float *>(tileL + (uint32_t)i * rowb + NG * 512 - L * 12);
       } else {
 #pragma unroll
-        for (int g = 0; g < NG; g++) xq[g] = reinterpret_cast<const float4 *>(prow)[g * 32 + L];
-        if (a.tail) xt = prow[NG * 128 + L];
+        for (int g = 0; g < NG; g++) xq[g] = *reinterpret_cast<const float4 *>(prow + g * 512);
+        if constexpr (TAIL) xt = *reinterpret_cast<const float *>(prow + NG * 512 - L * 12);
       }
     }
-    // s_rem[j] = number of the sweep that removed j (0: not removed).  The waves run through the chunks at their
-    // own pace, so a candidate this very sweep has already struck out (by a faster wave) still counts as live when
-    // a slower wave builds its list: all four lists are the same and every pair has exactly one owner.
-    const uint32_t sweep = (uint32_t)cnt;  // >= 1
-    for (int base = (found + 1) & ~63; base < (int)nc; base += 64) {
-      const int j = base + lane;
-      const uint32_t rj = j < (int)nc ? l.s_rem[j] : 1u;
-      const bool live = j > found && j < (int)nc && (rj == 0u || rj == sweep);
-      const uint64_t m = __ballot(live);
-      if (!m) continue;
-      const int c = __popcll(m);
-      if (wave == 0) n_eval += (uint32_t)c;
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (live) mylist[rank] = (uint32_t)j;  // every wave builds the same list, privately: no barrier
-      wave_lds_sync();
-      // live candidate number k of the chunk belongs to half-wave k % 8 of the workgroup
-      const int hw = wave * 2 + half;
-      for (int t0 = 0; t0 < c; t0 += 8 * U) {  // wave-uniform trip count
-        int jj[U];
-        float4 y[U][NG];
-        float yt[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int k = t0 + hw + 8 * u;
-          jj[u] = k < c ? (int)mylist[k] : -1;
-          yt[u] = 0.0f;
-#pragma unroll
-          for (int g = 0; g < NG; g++) y[u][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (jj[u] >= 0) {
-            if ((uint32_t)jj[u] < nt) {
-              const float *row = l.tile + (size_t)jj[u] * a.ld;
-#pragma unroll
-              for (int g = 0; g < NG; g++) y[u][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
-              if (a.tail) yt[u] = row[NG * 128 + L];
-            } else {
-              const float *row = a.slab + (size_t)l.s_slot[jj[u]] * a.ld;
-#pragma unroll
-              for (int g = 0; g < NG; g++) y[u][g] = reinterpret_cast<const float4 *>(row)[g * 32 + L];
-              if (a.tail) yt[u] = row[NG * 128 + L];
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          // both halves run the arithmetic together; a half without a pair computes on zeros and drops the result
-          float acc = 0.0f;
-#pragma unroll
-          for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
-          const float t = a.tail ? tail_chain<L2>(xt, yt[u], a.tail, lane) : 0.0f;
-          const float raw = asm_reduce(acc, t, lane);
-          if (L == 0 && jj[u] >= 0) {
-            const float d = metric_finish(raw, a.metric);
-            if (a.alpha * d < l.s_dist[jj[u]]) l.s_rem[jj[u]] = sweep;  // :132 -- one owner per j: no race
-          }
-        }
-      }
-      wave_lds_sync();  // mylist is rewritten for the next chunk
-    }
-    __syncthreads();  // every wave sees the sweep's removals before the next selection
-    i = found + 1;
+    if (nt == nc) row_pairs(std::true_type{}, i, xq, xt);
+    else row_pairs(std::false_type{}, i, xq, xt);
   }
   __syncthreads();
-  // ---- node.edges of the new node, kNoSlot padded; a freshly pruned row is clean and carries its distances
-  if (wave == 0) {
-    const uint32_t out = lane < cnt ? l.o_slot[lane] : kNoSlot;
-    a.adj[(size_t)self * kAdjStride + lane] = out;
-    a.adjdist[(size_t)self * kAdjStride + lane] = lane < cnt ? l.o_dist[lane] : 0.0f;
-    if (lane == 0) a.deg[self] = (uint32_t)cnt, a.clean[self] = (uint32_t)cnt, a.dcount[self] = (uint32_t)cnt;
-    a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
-        out == kNoSlot ? kNoKey : ((uint64_t)out << 32) | ((uint64_t)q << 6) | (uint64_t)lane;
-    stat_add(a, kStPrunePairs, n_eval, lane);
-    stat_add(a, kStStagedRows, nt, lane);
+  if (wave != 0) return;
+  // ---- phase B: the selection loop, candidate j = 64 c + lane in registers
+  constexpr int NCH = kTileMaxCand / 64;
+  float sd[NCH];
+  uint32_t ss[NCH];
+  bool rem[NCH];  // pruneRemoved (distset.go:124); lanes past the list count as removed
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int j = c * 64 + lane;
+    sd[c] = j < nc ? s_dist[j] : 0.0f, ss[c] = j < nc ? s_slot[j] : kNoSlot, rem[c] = j >= nc;
   }
+  uint32_t my_out = kNoSlot;
+  float my_outd = 0.0f;
+  int cnt = 0, i = 0;
+  uint32_t n_eval = 0;
+  while (true) {
+    int found = -1;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const uint64_t m = __ballot(c * 64 + lane >= i && !rem[c] && ss[c] != self);  // :115-117
+      if (found < 0 && m) found = c * 64 + __ffsll((unsigned long long)m) - 1;
+    }
+    if (found < 0) break;
+    uint32_t p = 0;
+    float pd = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if ((found >> 6) == c) p = rl(ss[c], found & 63), pd = rlf(sd[c], found & 63);
+    if (lane == cnt) my_out = p, my_outd = pd;  // node.AddNeighbour :118
+    cnt++;
+    if (cnt >= (int)a.R) break;  // :119-121
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const int j = c * 64 + lane;
+      const bool live = j > found && !rem[c];
+      n_eval += (uint32_t)__popcll(__ballot(live));  // the pairs the reference's walk evaluates
+      if (live && a.alpha * metric_finish(D[found * nc + j], a.metric) < sd[c]) rem[c] = true;  // :132
+    }
+    i = found + 1;
+  }
+  // ---- node.edges of the new node, kNoSlot padded; a freshly pruned row is clean and carries its distances
+  a.adj[(size_t)self * kAdjStride + lane] = lane < cnt ? my_out : kNoSlot;
+  a.adjdist[(size_t)self * kAdjStride + lane] = my_outd;
+  if (lane == 0) {
+    a.deg[self] = (uint32_t)cnt, a.clean[self] = (uint32_t)cnt, a.dcount[self] = (uint32_t)cnt;
+    a.prune_done[q] = 1u;
+  }
+  a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
+      (lane < cnt) ? ((uint64_t)my_out << 32) | ((uint64_t)q << 6) | (uint64_t)lane : kNoKey;
+  stat_add(a, kStPrunePairs, n_eval, lane);
+  stat_add(a, kStStagedRows, (unsigned long long)nt, lane);
 }
 
 }  // namespace sdb
@@ -880,24 +863,35 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
 template <int NG, bool L2>
 static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, size_t sort_tmp_bytes,
                         int sort_end_bit, BigScratch *big, bool *start_pruned) {
-  bool tiled = false;
+  BuildArgs a1 = a;
+  a1.prune_done = nullptr;
   if constexpr (NG >= 1) {
-    // candidate rows staged in LDS when a useful share of a visit list fits (always for d <= 1024 at searchSize 75)
-    const uint32_t tr = a.no_tile ? 0u : tile_rows_for(a.vis_cap, a.ld);
-    if (tr >= 24) {
+    // candidate rows staged in LDS when a useful share of a visit list fits beside its pair table
+    // (always at d <= 1024 and searchSize 75); what the tiled kernel leaves is pruned by k_prune_new
+    const uint32_t worst = kTileFixedBytes + 80 * 80 * 4 + 1024;
+    if (a.no_tile != 1 && a.prune_done && worst + 24 * a.ld * 4 <= kTileLdsBytes) {
       static bool attr_set = false;  // per instantiation
+      auto setattr = [](const void *f) {
+        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBytes);
+      };
       if (!attr_set) {
-        SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBytes));
+        SDB_HIP(setattr(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2, false, 4>)));
+        SDB_HIP(setattr(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2, true, 4>)));
+        SDB_HIP(setattr(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2, false, 8>)));
         attr_set = true;
       }
-      hipLaunchKernelGGL((k_prune_new_tiled<NG, L2>), dim3(a.nnew), dim3(kTileThreads), kTileLdsBytes, stream, a, tr);
-      tiled = true;
+      // 8 waves (two per SIMD) for the common no-tail rows: one wave's LDS waits run under the other's arithmetic
+      // (1M x 384 build: 2.25 s with the one-wave kernel, 2.10 s tiled with 4 waves, 1.98 s with 8)
+      if (a.tail) hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, true, 4>), dim3(a.nnew), dim3(256), kTileLdsBytes, stream, a);
+      else if (a.no_tile == 2) hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, false, 4>), dim3(a.nnew), dim3(256), kTileLdsBytes, stream, a);
+      else hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, false, 8>), dim3(a.nnew), dim3(512), kTileLdsBytes, stream, a);
+      SDB_HIP(hipGetLastError());
+      a1.prune_done = a.prune_done;
     }
   }
-  if (!tiled) {
+  {
     const size_t lds1 = prune_lds_bytes(a.vis_cap, NG, a.ld);
-    hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a);
+    hipLaunchKernelGGL((k_prune_new<NG, L2>), dim3(a.nnew), dim3(64), lds1, stream, a1);
   }
   SDB_HIP(hipGetLastError());
   size_t tmp = sort_tmp_bytes;
@@ -1063,9 +1057,12 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   cleanup.ptrs.push_back(big_count);
   SDB_HIP(hipMalloc(&big_list, (size_t)big_cap * sizeof(uint4)));
   cleanup.ptrs.push_back(big_list);
+  uint32_t *prune_done = nullptr;
+  SDB_HIP(hipMalloc(&prune_done, (size_t)max_round * 4));
+  cleanup.ptrs.push_back(prune_done);
   BigScratch big_scratch;
   // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
-  constexpr uint32_t kDcacheBits = 13;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
+  constexpr uint32_t kDcacheBits = SDB_DCACHE_BITS;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
   uint2 *dcache = nullptr;
   if (!pq) {
     SDB_HIP(hipMalloc(&dcache, ((size_t)max_round << kDcacheBits) * sizeof(uint2)));
@@ -1168,7 +1165,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.start_slot = (uint32_t)ix->start_slot;
     ba.start_ext = ix->d_start_ext, ba.start_ext_n = (uint32_t)ix->h_start_ext.size();
     ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
-    ba.no_tile = ix->tune_no_tile ? 1u : 0u;
+    ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done;
     bool start_pruned = false;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN

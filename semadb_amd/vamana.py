@@ -228,6 +228,16 @@ class IndexVamana:
         """vecStore.Exists (plain.go:21-24)"""
         return bool(self.exists_batch([node_id])[0])
 
+    def EdgeScan(self, deleteSet):
+        """IndexVamana.EdgeScan (node.go:142-199): (toPrune, toSave) for a set of ids about to be deleted"""
+        ids_a = np.ascontiguousarray(sorted(int(v) for v in deleteSet), dtype=np.uint64)
+        n = self.stats()[0] + 1
+        tp, ts = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().sdb_index_edge_scan(self._h, ids_a.size, _buf.np_ptr(ids_a) if ids_a.size else None, _buf.np_ptr(tp),
+                                        n, C.byref(a), _buf.np_ptr(ts), n, C.byref(b), None))
+        return tp[:a.value].copy(), ts[:b.value].copy()
+
     def delete_batch(self, ids):
         ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
         if ids_a.size:

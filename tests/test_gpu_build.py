@@ -318,5 +318,6 @@ def test_new_node_prune_tiled_and_untiled_agree(oracle, metric, d, n, R, L, sear
             ix.insert_batch(ids, base, round_size=round_size)
             assert_same_graph(ix, o)
             st = ix.build_stats()
-            assert (st["staged_rows"] > 0) == (no_tile == 0)
+            # rows wider than 4 KB leave no room for a useful tile: those dimensions keep the one-wave kernel
+            assert (st["staged_rows"] > 0) == (no_tile == 0 and d <= 1024)
             ix.close()

@@ -374,3 +374,32 @@ def test_start_node_overflow_batched_round(oracle, monkeypatch):
     g.insert_batch(new_ids, new)
     assert_same_graph(g, o)
     g.close()
+
+
+def test_edge_scan_matches_the_reference_rule(oracle):
+    """sdb_index_edge_scan (IndexVamana.EdgeScan, node.go:142-199) against the oracle's restatement on the exported
+    graph: nodes with an edge into the delete set, and valid nodes nobody points at."""
+    from semadb_amd import vamana
+    rng = np.random.default_rng(404)
+    d, n = 24, 1200
+    base = unit_rows(rng, n, d)
+    ix = vamana.NewIndexVamana("es", vamana.IndexVectorVamanaParameters(d, "euclidean", 30, 8, 1.2), strict=False)
+    ix.set_start(start_vector(rng, d))
+    ix.insert_batch(None, base)
+    ids, _, off, edges = ix.export(with_vectors=False)
+    for trial in range(4):
+        dele = set(int(v) for v in rng.choice(np.arange(2, n + 2), size=[1, 17, 200, 900][trial], replace=False))
+        dele.add(10 ** 9)  # an id that is not stored changes nothing
+        tp, ts = ix.EdgeScan(dele)
+        w_tp, w_ts = oracle.edge_scan(ids, off, edges, dele)
+        assert sorted(int(v) for v in tp) == w_tp
+        assert sorted(int(v) for v in ts) == w_ts
+    assert ix.EdgeScan(set()) == ([], []) or (len(ix.EdgeScan(set())[0]) == 0)
+    # after a real delete the graph has tombstones: the scan skips them
+    ix.delete_batch(np.array(sorted(dele - {10 ** 9})[:50], dtype=np.uint64))
+    ids, _, off, edges = ix.export(with_vectors=False)
+    dele2 = set(int(v) for v in rng.choice(ids[1:], size=30, replace=False))
+    tp, ts = ix.EdgeScan(dele2)
+    w_tp, w_ts = oracle.edge_scan(ids, off, edges, dele2)
+    assert sorted(int(v) for v in tp) == w_tp and sorted(int(v) for v in ts) == w_ts
+    ix.close()
