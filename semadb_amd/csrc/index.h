@@ -20,8 +20,6 @@ struct Workspace {
   size_t scratch_bytes = 0;
   float *lut = nullptr;  // [nq][M*K] product-quantizer distance tables of the batch
   size_t lut_bytes = 0;
-  uint32_t *gtab = nullptr;  // [nq][kHashCap] visited hash sets of a long quantized batch (search_kernel.h)
-  size_t gtab_bytes = 0;
   void *filter = nullptr;  // seeds / filter slot lists of a filtered batch
   size_t filter_bytes = 0;
   bool busy = false;               // held by a call that has not returned yet
@@ -30,7 +28,6 @@ struct Workspace {
   hipEvent_t done = nullptr;
   int ensure_filter(size_t bytes);
   int ensure_lut(size_t bytes);
-  int ensure_gtab(size_t bytes);
   int ensure_bitsets(size_t bytes);
   int ensure_scratch(size_t bytes);
   void release();
@@ -75,7 +72,6 @@ struct sdb_index {
   uint8_t *d_codes = nullptr;
   // sdb_index_set_tuning
   uint32_t tune_hub_min = 512, tune_hash_limit = 0;
-  uint32_t tune_ghash_min = 4096;  // quantized searches of at least this many queries keep their visited sets in global memory
   bool tune_no_hash = false;
   uint32_t tune_no_tile = 0;  // 0: LDS-tiled prune of new nodes, 1: one-wave kernel only, 2: tiled with 4 waves instead of 8 (measurement)
   // a write that failed after it had started to change the graph leaves it unusable: every later call fails

@@ -56,15 +56,6 @@ int Workspace::ensure_filter(size_t bytes) {
   return SDB_OK;
 }
 
-int Workspace::ensure_gtab(size_t bytes) {
-  if (bytes <= gtab_bytes) return SDB_OK;
-  if (gtab) SDB_HIP(hipFree(gtab));
-  gtab = nullptr, gtab_bytes = 0;
-  SDB_HIP(hipMalloc(&gtab, bytes));
-  gtab_bytes = bytes;
-  return SDB_OK;
-}
-
 int Workspace::ensure_lut(size_t bytes) {
   if (bytes <= lut_bytes) return SDB_OK;
   if (lut) SDB_HIP(hipFree(lut));
@@ -79,8 +70,6 @@ void Workspace::release() {
   filter = nullptr;
   if (lut) (void)hipFree(lut);
   lut = nullptr;
-  if (gtab) (void)hipFree(gtab);
-  gtab = nullptr;
   if (bitsets) (void)hipFree(bitsets);
   if (scratch) (void)hipFree(scratch);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -198,11 +187,6 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
-    if (a.gtab && search_uses_hash(a, nq)) {  // long batch: visited sets in global memory, 16 walks per CU
-      hipLaunchKernelGGL((k_greedy_search<PQDist, 2, false, kHashCap, true>), dim3(nq), dim3(64), lds, stream, a);
-      SDB_HIP(hipGetLastError());
-      return SDB_OK;
-    }
     if (search_uses_hash(a, nq)) return launch_nreg<PQDist, kHashCapPQ>(a, nq, stream, lds);
     return launch_nreg<PQDist, 0>(a, nq, stream, lds);
   }
@@ -636,13 +620,6 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
       SDB_TRY(pq_build_lut(pq, a.queries, nq, ws->lut, stream));
       a.pq_lut = ws->lut, a.pq_codes = ix->d_codes, a.pq_M = pq->M, a.pq_K = pq->K;
       a.pq_lut_in_lds = ((size_t)pq->M * pq->K * sizeof(float) <= 64 * 1024) ? 1u : 0u;
-      // a batch long enough to put several walks on every SIMD: visited hash sets in global memory (32 KB per
-      // query, cleared per batch), which leaves the LDS to the LUTs
-      if (nq >= ix->tune_ghash_min && search_uses_hash(a, (uint32_t)nq)) {
-        SDB_TRY(ws->ensure_gtab((size_t)nq * kHashCap * sizeof(uint32_t)));
-        SDB_HIP(hipMemsetAsync(ws->gtab, 0xFF, (size_t)nq * kHashCap * sizeof(uint32_t), stream));
-        a.gtab = ws->gtab;
-      }
     }
     // ClearAll (distset.go:101); the LDS hash variant clears a bitset only for a query that overflows it
     if (!search_uses_hash(a, (uint32_t)nq))
@@ -722,9 +699,6 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       return SDB_OK;
     case SDB_TUNE_NO_HASH:
       ix->tune_no_hash = value != 0;
-      return SDB_OK;
-    case SDB_TUNE_PQ_GHASH_MIN:
-      ix->tune_ghash_min = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value;
       return SDB_OK;
     case SDB_TUNE_NO_TILE:
       ix->tune_no_tile = (uint32_t)(value > 2 ? 1 : value);

@@ -65,9 +65,6 @@ struct SearchArgs {
   uint32_t dcache_shift;
   unsigned long long *totals;  // build path: [0] += n_dist, [1] += n_edges of every query (sdb_index_build_stats)
   uint32_t prefer_bitset;  // != 0: never use the LDS hash visited set (large build rounds)
-  // quantized store, long batches: the visited hash sets live in global memory instead of LDS, [nq][kHashCap]
-  // words preset to kNoSlot (HashVisited<CAP, true>); NULL: in LDS
-  uint32_t *gtab;
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
 
@@ -614,15 +611,10 @@ constexpr uint32_t kHashLimit = 6000;  // keys a table may hold before it spills
 constexpr uint32_t kHashCapPQ = 7417;  // quantized store: a prime, 29 KB, leaves room for the 8 KB LUT (M = 8)
 // CAP is a power of two (mask) or a prime (conditional subtract): either way every probe stride in
 // [1, CAP) reaches every slot.
-//
-// GLOBAL: the same table in global memory (one per query, preset to kNoSlot by the host).  A probe round is then
-// a global round trip instead of an LDS one, but the wave needs no LDS for it: the quantized search keeps only
-// its 8 KB LUT there and a CU holds 16 walks instead of 4 -- with a long batch the chip hides the longer probe
-// under other walks (index.hip picks the variant by batch size).
-template <uint32_t CAP, bool GLOBAL = false>
+template <uint32_t CAP>
 struct HashVisited {
   static constexpr bool kPow2 = (CAP & (CAP - 1)) == 0;
-  static constexpr uint32_t kWords = GLOBAL ? 0u : ((CAP + 3) & ~3u);  // LDS words reserved (16-byte multiple)
+  static constexpr uint32_t kWords = (CAP + 3) & ~3u;  // LDS words reserved (16-byte multiple)
   uint32_t *tab;
   uint32_t *bits;
   uint32_t words, count, limit;
@@ -631,11 +623,9 @@ struct HashVisited {
     tab = lds, bits = bitset, words = nwords;
     count = 0, spilled = false;
     limit = (uint32_t)(((uint64_t)lim * CAP) >> 13);
-    if constexpr (!GLOBAL) {
-      uint4 *t4 = reinterpret_cast<uint4 *>(lds);
-      for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
-      __syncthreads();
-    }
+    uint4 *t4 = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
+    __syncthreads();
   }
   __device__ __forceinline__ void spill(int lane) {
     for (uint32_t i = lane; i < words; i += 64) bits[i] = 0u;  // ClearAll distset.go:101
@@ -916,19 +906,14 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 // HBM bitset from the start.
 // HCAP != 0: capacity of the LDS hash visited set (it sits first in dynamic LDS, the distance policy's
 // tile / LUT after it); HCAP == 0: HBM bitset from the start.
-template <class Dist, int NREG, bool FILT, uint32_t HCAP, bool GHASH = false>
+template <class Dist, int NREG, bool FILT, uint32_t HCAP>
 __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   Dist dist;
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
-  if constexpr (GHASH) {
-    dist.init(a, q, lane, lds_f);
-    HashVisited<HCAP, true> hv;
-    hv.init(a.gtab + (size_t)q * HCAP, bits, a.words_per_query, lane, a.hash_limit);
-    search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
-  } else if constexpr (HCAP != 0) {
+  if constexpr (HCAP != 0) {
     dist.init(a, q, lane, lds_f + HashVisited<HCAP>::kWords);
     HashVisited<HCAP> hv;
     hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);

@@ -143,17 +143,6 @@ def test_pq_search_parity(oracle, metric, d, M, K):
         g2 = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
         assert np.array_equal(g2[0], g_ids) and np.array_equal(bits(g2[1]), bits(g_d))
         assert np.array_equal(g2[3].visit_ids, tr.visit_ids)
-    # long batches keep their visited hash sets in global memory (HashVisited<CAP, true>): forced on here, with
-    # the table limit low enough that some walks spill to the bitset on the way -- same walk either way
-    if M * K <= 2048:
-        for lim in (0, 150):
-            ix.set_tuning("pq_ghash_min", 1)
-            ix.set_tuning("hash_limit", lim)
-            g3 = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
-            assert np.array_equal(g3[0], g_ids) and np.array_equal(bits(g3[1]), bits(g_d)) and np.array_equal(g3[2], g_c)
-            assert np.array_equal(g3[3].visit_ids, tr.visit_ids) and np.array_equal(g3[3].n_dist, tr.n_dist)
-        ix.set_tuning("pq_ghash_min", 1 << 30)
-        ix.set_tuning("hash_limit", 0)
     # filtered search over the quantized store: seeds and result set use the LUT distance too
     filters = [set(int(v) for v in rng.choice(ids[1:], size=40, replace=False)) for _ in range(32)]
     f_ids, f_d, f_c, f_tr = ix.search_batch(q, 5, 50, filters=filters, trace=True, visit_cap=512)
