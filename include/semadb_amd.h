@@ -20,8 +20,10 @@
  *     (vamana.go:28) and ids 0/1 are rejected on write (vamana.go:150-157).
  *   - vectors are row-major float32, `dim` floats per row (conversion.BytesToFloat32 layout).
  *   - search calls may be issued concurrently from many threads on one index (the reference
- *     serves searches from concurrent goroutines under an RLock, shard/cache/manager.go:163);
- *     load/insert calls are exclusive, like its write lock.
+ *     serves searches from concurrent goroutines under an RLock, shard/cache/manager.go:163), also
+ *     while ONE thread writes (insert / delete): they see the last committed graph (see
+ *     sdb_index_begin_write).  Writers are exclusive among themselves, like the shard's write lock;
+ *     load / attach_pq / set_codes / set_start are maintenance calls with no search in flight.
  */
 #ifndef SEMADB_AMD_H
 #define SEMADB_AMD_H
@@ -130,6 +132,22 @@ int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const
  * searches, inserts, deletes, export and load read after the row, until the start node is next pruned.
  * An update (vamana.go:170-174,247-251) is delete_batch followed by insert_batch with the same id. */
 int sdb_index_delete_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, void *stream);
+
+/* Write transactions.  IndexVamana.InsertUpdateDelete (vamana.go:127-263) is ONE transaction of the shard made of
+ * several calls here (inserts, one delete scan, re-inserts of updated points); the reference runs it under the
+ * shard's write lock while searches are served from the cache or, if that is locked, from a cold index built on
+ * the last committed bucket (shard/cache/manager.go:159-181).  Here searches (sdb_index_search_batch,
+ * sdb_index_flat_search, sdb_cluster_search_batch) always walk the last COMMITTED graph: whatever a walk reads and
+ * a write changes in place exists twice in HBM, a write changes the writer's copy only, and commit publishes it
+ * (the searches launched before drain on the old copy; nobody blocks).  Between sdb_index_begin_write and
+ * sdb_index_commit all insert / delete calls belong to one transaction; without begin_write every such call is a
+ * transaction of its own.  One writer at a time (the shard's write lock).  There is no rollback: a write that fails
+ * half-way leaves the handle unusable (SDB_ERR_STATE), the host reloads from the bucket -- the reference scraps its
+ * cache after any error inside a transaction the same way (manager.go:231-240). */
+int sdb_index_begin_write(sdb_index *ix);
+int sdb_index_commit(sdb_index *ix, void *stream);
+/* test support: rows on which the committed and the writer's copy of the graph differ (0 outside a transaction) */
+int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows);
 
 /* IndexVamana.EdgeScan (node.go:142-199), read-only: the ids of the valid nodes that have an edge to a member of
  * the delete set (to_prune) and of the valid nodes that no valid node points at (to_save; the start node never

@@ -46,9 +46,9 @@ type IndexVamana struct {
 	pq         *C.sdb_pq // product quantizer of the vector store (vectorstore.New), nil for the plain store
 	pqFitted   bool
 	batcher    *searchBatcher // coalesces concurrent Search calls
-	// load / insert / delete are exclusive, like the shard's write transaction (shard/cache/manager.go:183-240);
-	// searches only take the read side
-	mu sync.RWMutex
+	// writers exclude each other, like the shard's write transaction (shard/cache/manager.go:183-240).  Searches do
+	// NOT take this lock: the library serves them from the last committed graph while a write is open.
+	mu sync.Mutex
 }
 
 func lastErr(what string, rc C.int) error {
@@ -171,9 +171,7 @@ func (v *IndexVamana) Search(ctx context.Context, q models.SearchVectorVamanaOpt
 	if len(q.Vector) != int(v.parameters.VectorSize) { // rejected upstream, models/search.go:198-200
 		return nil, nil, fmt.Errorf("could not perform graph search: query vector length %d, index %d", len(q.Vector), v.parameters.VectorSize)
 	}
-	v.mu.RLock()
 	ids, dists, err := v.batcher.submit(ctx, q.Vector, q.Limit, q.SearchSize, filter)
-	v.mu.RUnlock()
 	if err != nil {
 		return nil, nil, fmt.Errorf("could not perform graph search: %w", err)
 	}
@@ -243,6 +241,13 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 			delIds = append(delIds, p.Id)
 		}
 	}
+	if len(insIds)+len(delIds)+len(updIds) == 0 {
+		return nil
+	}
+	// one write transaction, like the shard's: concurrent searches see all of it or none of it
+	if rc := C.sdb_index_begin_write(v.h); rc != C.SDB_OK {
+		return lastErr("could not start the write", rc)
+	}
 	if len(insIds) > 0 {
 		if rc := C.sdb_index_insert_batch(v.h, C.uint64_t(len(insIds)), (*C.uint64_t)(unsafe.Pointer(&insIds[0])),
 			(*C.float)(unsafe.Pointer(&insVecs[0])), C.SDB_MEM_HOST, 0, nil); rc != C.SDB_OK {
@@ -261,6 +266,9 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 			return lastErr("could not re-insert updated point", rc)
 		}
 	}
+	if rc := C.sdb_index_commit(v.h, nil); rc != C.SDB_OK {
+		return lastErr("could not commit the write", rc)
+	}
 	if err := v.fit(); err != nil { // vecStore.Fit (:257-260)
 		return fmt.Errorf("could not fit vector store: %w", err)
 	}
@@ -270,8 +278,8 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 // EdgeScan (node.go:142-199), same signature: nodes with an edge into deleteSet, and valid nodes nobody
 // points at.  The reference returns both in map order; so may this.
 func (v *IndexVamana) EdgeScan(deleteSet map[uint64]struct{}) (toPrune, toSave []uint64, err error) {
-	v.mu.RLock()
-	defer v.mu.RUnlock()
+	v.mu.Lock()
+	defer v.mu.Unlock()
 	del := make([]uint64, 0, len(deleteSet))
 	for id := range deleteSet {
 		del = append(del, id)

@@ -46,6 +46,9 @@ SIGNATURES = {
     "sdb_index_insert_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32,
                                          C.c_void_p]),
     "sdb_index_delete_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "sdb_index_begin_write": (C.c_int, [C.c_void_p]),
+    "sdb_index_commit": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sdb_index_version_diff": (C.c_int, [C.c_void_p, u64p]),
     "sdb_index_edge_scan": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p,
                                       C.c_uint64, u64p, C.c_void_p]),
     "sdb_index_search_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,

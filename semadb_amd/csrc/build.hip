@@ -63,6 +63,7 @@ struct BuildArgs {
   uint32_t start_ext_n;
   uint32_t no_tile;           // != 0: new nodes are pruned by k_prune_new (rows from global memory), a test knob
   uint32_t *prune_done;       // [nnew] set by k_prune_new_tiled for the nodes it pruned; NULL: k_prune_new takes all
+  uint8_t *dirty;             // [n] set for every row whose adjacency this call writes (index.h graph versions)
   unsigned long long *stats;  // sdb_index_build_stats counters (index.h d_bstats), or NULL
   uint32_t *flags;            // [0] bit 0: a search's visit log did not fit vis_cap
 };
@@ -383,6 +384,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
   a.adj[(size_t)self_slot * kAdjStride + lane] = lane < cnt ? my_out : kNoSlot;
   a.adjdist[(size_t)self_slot * kAdjStride + lane] = my_outd;
   if (lane == 0) {
+    if (a.dirty) a.dirty[self_slot] = 1;
     a.deg[self_slot] = (uint32_t)cnt;
     a.clean[self_slot] = (uint32_t)cnt;
     // the candidates' distances are distFn(self, .) except for a new node of a quantized store, whose
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
   if (lane == 0) {
     a.deg[self] = (uint32_t)cnt, a.clean[self] = (uint32_t)cnt, a.dcount[self] = (uint32_t)cnt;
     a.prune_done[q] = 1u;
+    if (a.dirty) a.dirty[self] = 1;
   }
   a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
       (lane < cnt) ? ((uint64_t)my_out << 32) | ((uint64_t)q << 6) | (uint64_t)lane : kNoKey;
@@ -851,7 +854,10 @@ __global__ __launch_bounds__(64) void k_backedges(const BuildArgs a) {
   if (row_dirty) {
     a.adj[(size_t)b * kAdjStride + lane] = row;
     a.adjdist[(size_t)b * kAdjStride + lane] = rowd;
-    if (lane == 0) a.deg[b] = deg, a.dcount[b] = dc;
+    if (lane == 0) {
+      a.deg[b] = deg, a.dcount[b] = dc;
+      if (a.dirty) a.dirty[b] = 1;
+    }
   }
   stat_add(a, kStBackPairs, st_eval, lane);
   stat_add(a, kStBackCached, st_cached, lane);
@@ -1069,7 +1075,9 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     cleanup.ptrs.push_back(dcache);
   }
 
-  // ---- from here on the call writes: rows beyond ix->n first (invisible until a round commits them)
+  // ---- from here on the call writes, into the writer's copy of the graph (index.h graph versions): searches
+  // issued meanwhile keep walking the last committed version.  Rows beyond ix->n first.
+  SDB_TRY(ix->begin_write());
   SDB_HIP(hipMemsetAsync(ix->d_bstats, 0, bstats_bytes, stream));
   SDB_HIP(hipMemsetAsync(big_count, 0, 8, stream));
   const float *dvec = vectors;  // the vectors (original layout) on device; they double as the search queries
@@ -1086,6 +1094,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   // host-side id bookkeeping of the points of one completed round: h_ids / id2slot / max_node_id move together
   // with ix->n, so that an error return never leaves ids that resolve to slots past the rows in use
   auto commit = [&](uint64_t from, uint64_t to) {
+    std::unique_lock<std::shared_mutex> wl(ix->view_mu);  // searches translate filter ids with these tables
     bool dense = ix->dense_ids;
     for (uint64_t i = from; i < to; i++) {
       if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
@@ -1165,7 +1174,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.start_slot = (uint32_t)ix->start_slot;
     ba.start_ext = ix->d_start_ext, ba.start_ext_n = (uint32_t)ix->h_start_ext.size();
     ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
-    ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done;
+    ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done, ba.dirty = ix->d_dirty;
     bool start_pruned = false;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN
@@ -1182,6 +1191,10 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_HIP(hipMemcpyAsync(ix->d_bstats + kStRounds, &nr, 8, hipMemcpyHostToDevice, stream));
   }
   if (int rc = check_flags()) return round_failed(rc);
+  if (!ix->tx_explicit) {  // the call is its own transaction: publish
+    if (int rc = ix->commit(stream)) return round_failed(rc);
+    SDB_HIP(hipStreamSynchronize(stream));
+  }
   return SDB_OK;
 }
 

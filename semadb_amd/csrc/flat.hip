@@ -179,7 +179,11 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   DeviceGuard dg(ix->P.device);
   hipStream_t stream = as_stream(stream_);
   const RowLayout &l = ix->lay;
-  const uint32_t n = ix->n;
+  // the scan sees the last committed version like a graph search does (index.h graph versions); the shared lock
+  // is kept until everything is enqueued
+  std::shared_lock<std::shared_mutex> rl(ix->view_mu);
+  const sdb_index::View vw = ix->view;
+  const uint32_t n = vw.n;
   // ---- filtered: per-query candidate slots, ascending (filter.Contains(point.Id()), flat.go:100)
   std::vector<uint32_t> f_off, f_slots;
   uint32_t max_f = 0;
@@ -188,7 +192,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     for (uint64_t q = 0; q < nq; q++) {
       const size_t f0 = f_slots.size();
       for (uint64_t i = filter_offsets[q]; i < filter_offsets[q + 1]; i++) {
-        const int64_t s = ix->slot_of(filter_ids[i]);
+        const int64_t s = ix->slot_of_committed(filter_ids[i], vw.n);
         if (s >= 0 && s != ix->start_slot) f_slots.push_back((uint32_t)s);
       }
       std::sort(f_slots.begin() + f0, f_slots.end());
@@ -267,14 +271,22 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     FlatFoldArgs fa{};
     fa.dists = d_dist, fa.stride = stride, fa.count = rows, fa.slot_off = d_fo, fa.slots = d_fs, fa.first_row = first;
     fa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
-    fa.ids = ix->d_ids;
+    fa.ids = vw.ids;
     fa.limit = limit, fa.top_slot = top_slot, fa.top_dist = top_dist, fa.top_len = top_len;
     hipLaunchKernelGGL(k_flat_fold, dim3((unsigned)nq), dim3(64), 0, stream, fa);
     SDB_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_flat_emit, dim3((unsigned)nq), dim3(64), 0, stream, top_slot, top_dist, top_len, ix->d_ids, limit,
+  hipLaunchKernelGGL(k_flat_emit, dim3((unsigned)nq), dim3(64), 0, stream, top_slot, top_dist, top_len, vw.ids, limit,
                      d_oi, d_od, d_oc);
   SDB_HIP(hipGetLastError());
+  {  // a commit must wait for this scan before it hands the copy it reads to the writer
+    Workspace *ws = ix->acquire_ws(stream, false);
+    if (!ws->launched) (void)hipEventCreateWithFlags(&ws->launched, hipEventDisableTiming);
+    if (ws->launched && hipEventRecord(ws->launched, stream) == hipSuccess) ws->launched_valid = true;
+    else (void)hipStreamSynchronize(stream);
+    ix->release_ws(ws, stream, false);
+  }
+  rl.unlock();
   if (mem == SDB_MEM_HOST) {
     SDB_HIP(hipMemcpyAsync(out_ids, d_oi, nq * limit * 8, hipMemcpyDeviceToHost, stream));
     SDB_HIP(hipMemcpyAsync(out_dists, d_od, nq * limit * 4, hipMemcpyDeviceToHost, stream));
@@ -318,6 +330,8 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   if (staging) (void)hipFree(staging);
   if (rc != SDB_OK) return rc;
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "id copy failed: %s", hipGetErrorString(e));
+  SDB_TRY(ix->begin_write());  // appended rows become visible to searches at commit
+  std::unique_lock<std::shared_mutex> wl(ix->view_mu);
   bool dense = ix->dense_ids;
   for (uint64_t i = 0; i < n; i++) {
     if (dense && !ix->h_ids.empty() && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
@@ -331,5 +345,10 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   }
   ix->dense_ids = dense;
   ix->n = n0 + (uint32_t)n;
+  wl.unlock();
+  if (!ix->tx_explicit) {
+    SDB_TRY(ix->commit(nullptr));
+    SDB_HIP(hipDeviceSynchronize());
+  }
   return SDB_OK;
 }

@@ -2,6 +2,7 @@
 // include/semadb_amd.h).
 #pragma once
 #include <map>
+#include <shared_mutex>
 #include <unordered_map>
 
 #include "common.h"
@@ -22,6 +23,8 @@ struct Workspace {
   size_t lut_bytes = 0;
   void *filter = nullptr;  // seeds / filter slot lists of a filtered batch
   size_t filter_bytes = 0;
+  hipEvent_t launched = nullptr;   // recorded behind the last search kernels that were given a graph version
+  bool launched_valid = false;
   bool busy = false;               // held by a call that has not returned yet
   bool pending = false;            // device work of an asynchronous call may still be running
   hipStream_t bound_stream = nullptr;
@@ -70,6 +73,36 @@ struct sdb_index {
   // product quantizer attachment (product.go): codes per slot + tables
   const sdb_pq *pq = nullptr;
   uint8_t *d_codes = nullptr;
+  // ---- graph versions (SURVEY 8b Threading; shard/cache/manager.go:159-181) --------------------------------
+  // A search walks the last COMMITTED graph while a write transaction changes the graph: everything a walk reads
+  // and a write changes in place exists twice -- adjacency rows, the slot -> id table, the start node's overflow
+  // list.  d_adj / d_ids / d_start_ext above are the writer's copies (all write paths use them unchanged);
+  // r_adj / r_ids / r_start_ext are what `view` hands to searches.  Commit swaps the two sets and then brings the
+  // writer's (now stale) set up to date from the dirty-row flags the write kernels left, once the searches that
+  // were launched on it have drained (stream-side waits on their events).  Outside a transaction both sets are
+  // identical.  The slab is append-only (rows past view.n are invisible), so it exists once.
+  uint32_t *r_adj = nullptr;
+  uint64_t *r_ids = nullptr;
+  uint32_t *r_start_ext = nullptr;
+  uint32_t r_start_ext_cap = 0;
+  uint8_t *d_dirty = nullptr;  // [cap] != 0: the open transaction wrote this row's adjacency or id
+  struct View {
+    uint32_t n = 0;  // committed rows
+    const uint32_t *adj = nullptr;
+    const uint64_t *ids = nullptr;
+    const uint32_t *start_ext = nullptr;
+    uint32_t start_ext_n = 0;
+  } view;
+  // readers: shared from taking `view` until their kernels are enqueued and their event recorded; writers:
+  // exclusive while they change the host-side id tables or publish a view
+  mutable std::shared_mutex view_mu;
+  bool in_tx = false, tx_explicit = false;
+  uint32_t tx_n0 = 0;  // rows at the start of the open transaction
+  std::unordered_map<uint64_t, uint32_t> tx_deleted;  // ids the open transaction has removed -> their slots
+  int begin_write();
+  int commit(hipStream_t stream);   // publish the writer's state; `stream` carries the write
+  int publish_full();               // exclusive maintenance calls (load, attach_pq ...): drain, copy everything
+  int64_t slot_of_committed(uint64_t id, uint32_t view_n) const;  // what a search may resolve; view_mu held
   // sdb_index_set_tuning
   uint32_t tune_hub_min = 512, tune_hash_limit = 0;
   bool tune_no_hash = false;

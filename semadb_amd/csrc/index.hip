@@ -75,6 +75,8 @@ void Workspace::release() {
   if (own_stream) (void)hipStreamDestroy(own_stream);
   if (done) (void)hipEventDestroy(done);
   done = nullptr;
+  if (launched) (void)hipEventDestroy(launched);
+  launched = nullptr, launched_valid = false;
   bitsets = nullptr, scratch = nullptr, own_stream = nullptr;
 }
 
@@ -217,51 +219,167 @@ int sdb_index::reserve(uint32_t rows) {
   uint32_t ncap = cap ? cap : 1024;
   while (ncap < rows) ncap = ncap < (1u << 30) ? ncap * 2 : rows;
   float *nslab = nullptr;
-  uint32_t *nadj = nullptr, *ndeg = nullptr, *nclean = nullptr;
-  uint64_t *nids = nullptr;
+  uint32_t *nadj = nullptr, *nradj = nullptr, *ndeg = nullptr, *nclean = nullptr;
+  uint64_t *nids = nullptr, *nrids = nullptr;
+  uint8_t *ndirty = nullptr;
   SDB_HIP(hipMalloc(&nslab, (size_t)ncap * lay.ld * sizeof(float)));
   SDB_HIP(hipMalloc(&nadj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
+  SDB_HIP(hipMalloc(&nradj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
   SDB_HIP(hipMalloc(&ndeg, (size_t)ncap * sizeof(uint32_t)));
   SDB_HIP(hipMalloc(&nclean, (size_t)ncap * sizeof(uint32_t)));
   SDB_HIP(hipMalloc(&nids, (size_t)ncap * sizeof(uint64_t)));
+  SDB_HIP(hipMalloc(&nrids, (size_t)ncap * sizeof(uint64_t)));
+  SDB_HIP(hipMalloc(&ndirty, (size_t)ncap));
+  // the old buffers are freed below: nothing may still be walking them (searches run on streams of their own)
+  if (cap) SDB_HIP(hipDeviceSynchronize());
   SDB_HIP(hipMemset(nadj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
+  SDB_HIP(hipMemset(nradj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
   SDB_HIP(hipMemset(ndeg, 0, (size_t)ncap * sizeof(uint32_t)));
   SDB_HIP(hipMemset(nclean, 0, (size_t)ncap * sizeof(uint32_t)));  // loaded / appended edges are not "clean"
+  SDB_HIP(hipMemset(ndirty, 0, (size_t)ncap));
   if (n) {
     SDB_HIP(hipMemcpy(nslab, d_slab, (size_t)n * lay.ld * sizeof(float), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(nadj, d_adj, (size_t)n * kAdjStride * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(nradj, r_adj, (size_t)n * kAdjStride * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(ndeg, d_deg, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(nclean, d_clean, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(nids, d_ids, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(nrids, r_ids, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(ndirty, d_dirty, (size_t)n, hipMemcpyDeviceToDevice));
   }
-  if (d_slab) (void)hipFree(d_slab);
-  if (d_adj) (void)hipFree(d_adj);
-  if (d_deg) (void)hipFree(d_deg);
-  if (d_clean) (void)hipFree(d_clean);
-  if (d_ids) (void)hipFree(d_ids);
-  d_slab = nslab, d_adj = nadj, d_deg = ndeg, d_clean = nclean, d_ids = nids;
-  {  // edge-distance cache of the write path (index.h); a row without cached distances has d_dcount 0
-    float *nad = nullptr;
-    uint32_t *ndc = nullptr;
-    SDB_HIP(hipMalloc(&nad, (size_t)ncap * kAdjStride * sizeof(float)));
-    SDB_HIP(hipMalloc(&ndc, (size_t)ncap * sizeof(uint32_t)));
-    SDB_HIP(hipMemset(ndc, 0, (size_t)ncap * sizeof(uint32_t)));
-    if (n) {
-      SDB_HIP(hipMemcpy(nad, d_adjdist, (size_t)n * kAdjStride * sizeof(float), hipMemcpyDeviceToDevice));
-      SDB_HIP(hipMemcpy(ndc, d_dcount, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-    }
-    if (d_adjdist) (void)hipFree(d_adjdist);
-    if (d_dcount) (void)hipFree(d_dcount);
-    d_adjdist = nad, d_dcount = ndc;
+  float *nad = nullptr;  // edge-distance cache of the write path (index.h); a row without cached distances has d_dcount 0
+  uint32_t *ndc = nullptr;
+  SDB_HIP(hipMalloc(&nad, (size_t)ncap * kAdjStride * sizeof(float)));
+  SDB_HIP(hipMalloc(&ndc, (size_t)ncap * sizeof(uint32_t)));
+  SDB_HIP(hipMemset(ndc, 0, (size_t)ncap * sizeof(uint32_t)));
+  if (n) {
+    SDB_HIP(hipMemcpy(nad, d_adjdist, (size_t)n * kAdjStride * sizeof(float), hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(ndc, d_dcount, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
   }
+  uint8_t *ncodes = nullptr;
   if (pq) {  // the code rows of a quantized store grow with it
-    uint8_t *ncodes = nullptr;
     SDB_HIP(hipMalloc(&ncodes, (size_t)ncap * pq->M));
     if (n) SDB_HIP(hipMemcpy(ncodes, d_codes, (size_t)n * pq->M, hipMemcpyDeviceToDevice));
-    if (d_codes) (void)hipFree(d_codes);
-    d_codes = ncodes;
   }
-  cap = ncap;
+  SDB_HIP(hipDeviceSynchronize());
+  {
+    std::unique_lock<std::shared_mutex> wl(view_mu);  // searches pick their pointers up under this lock
+    for (void *p : {(void *)d_slab, (void *)d_adj, (void *)r_adj, (void *)d_deg, (void *)d_clean, (void *)d_ids,
+                    (void *)r_ids, (void *)d_dirty, (void *)d_adjdist, (void *)d_dcount})
+      if (p) (void)hipFree(p);
+    if (pq && d_codes) (void)hipFree(d_codes);
+    d_slab = nslab, d_adj = nadj, r_adj = nradj, d_deg = ndeg, d_clean = nclean, d_ids = nids, r_ids = nrids;
+    d_dirty = ndirty, d_adjdist = nad, d_dcount = ndc;
+    if (pq) d_codes = ncodes;
+    cap = ncap;
+    view.adj = r_adj, view.ids = r_ids;
+  }
+  return SDB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// graph versions
+// ------------------------------------------------------------------------------------------
+namespace sdb {
+// rows the transaction wrote (dirty flags) and rows it appended: committed copy -> the writer's stale copy
+__global__ void k_sync_rows(const uint32_t *__restrict__ src_adj, uint32_t *__restrict__ dst_adj,
+                            const uint64_t *__restrict__ src_ids, uint64_t *__restrict__ dst_ids,
+                            uint8_t *__restrict__ dirty, uint32_t n, uint32_t first_new) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  if (row < first_new && !dirty[row]) return;
+  dst_adj[(size_t)row * kAdjStride + lane] = src_adj[(size_t)row * kAdjStride + lane];
+  if (lane == 0) dst_ids[row] = src_ids[row], dirty[row] = 0;
+}
+// test support: rows on which the two copies differ
+__global__ void k_count_version_diff(const uint32_t *a_adj, const uint32_t *b_adj, const uint64_t *a_ids,
+                                     const uint64_t *b_ids, uint32_t n, unsigned long long *out) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const bool diff = a_adj[(size_t)row * kAdjStride + lane] != b_adj[(size_t)row * kAdjStride + lane] ||
+                    (lane == 0 && a_ids[row] != b_ids[row]);
+  if (__ballot(diff) && lane == 0) atomicAdd(out, 1ull);
+}
+}  // namespace sdb
+
+int sdb_index::begin_write() {
+  if (!in_tx) in_tx = true, tx_n0 = n;
+  return SDB_OK;
+}
+
+int64_t sdb_index::slot_of_committed(uint64_t id, uint32_t view_n) const {
+  int64_t s = slot_of(id);
+  if (s < 0 && in_tx) {  // removed by the open transaction: still there for a search on the committed graph
+    auto it = tx_deleted.find(id);
+    if (it != tx_deleted.end()) s = (int64_t)it->second;
+  }
+  return (s >= 0 && (uint32_t)s < view_n) ? s : -1;  // rows past the committed count belong to the transaction
+}
+
+int sdb_index::commit(hipStream_t stream) {
+  if (!in_tx) return SDB_OK;
+  const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
+  {
+    std::unique_lock<std::shared_mutex> wl(view_mu);
+    // every search that took the old view has enqueued its kernels and recorded its event by now (it held the
+    // shared lock until then): the writer's stream waits for them before it touches the copy they walk
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (auto *w : pool)
+        if (w->launched_valid) SDB_HIP(hipStreamWaitEvent(stream, w->launched, 0));
+    }
+    std::swap(d_adj, r_adj);
+    std::swap(d_ids, r_ids);
+    std::swap(d_start_ext, r_start_ext);
+    std::swap(start_ext_cap, r_start_ext_cap);
+    view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
+    view.start_ext_n = (uint32_t)h_start_ext.size();
+    tx_deleted.clear();
+    in_tx = false, tx_explicit = false;
+  }
+  // the writer's copy is now the one the last version's searches walked: bring it up to date
+  if (n) {
+    hipLaunchKernelGGL(sdb::k_sync_rows, dim3((n + 3) / 4), dim3(256), 0, stream, r_adj, d_adj, r_ids, d_ids, d_dirty, n,
+                       tx_n0 < n ? tx_n0 : n);
+    SDB_HIP(hipGetLastError());
+  }
+  if (need) {
+    if (need > start_ext_cap) {
+      SDB_HIP(hipStreamSynchronize(stream));
+      if (d_start_ext) (void)hipFree(d_start_ext);
+      d_start_ext = nullptr, start_ext_cap = 0;
+      SDB_HIP(hipMalloc(&d_start_ext, (size_t)need * 2 * 4));
+      start_ext_cap = need * 2;
+    }
+    SDB_HIP(hipMemcpyAsync(d_start_ext, r_start_ext, (size_t)need * 4, hipMemcpyDeviceToDevice, stream));
+  }
+  return SDB_OK;
+}
+
+int sdb_index::publish_full() {
+  SDB_HIP(hipDeviceSynchronize());
+  std::unique_lock<std::shared_mutex> wl(view_mu);
+  if (n) {
+    SDB_HIP(hipMemcpy(r_adj, d_adj, (size_t)n * kAdjStride * 4, hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemcpy(r_ids, d_ids, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    SDB_HIP(hipMemset(d_dirty, 0, n));
+  }
+  const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
+  if (need) {
+    if (need > r_start_ext_cap) {
+      if (r_start_ext) (void)hipFree(r_start_ext);
+      r_start_ext = nullptr, r_start_ext_cap = 0;
+      SDB_HIP(hipMalloc(&r_start_ext, (size_t)need * 2 * 4));
+      r_start_ext_cap = need * 2;
+    }
+    SDB_HIP(hipMemcpy(r_start_ext, d_start_ext, (size_t)need * 4, hipMemcpyDeviceToDevice));
+  }
+  view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
+  view.start_ext_n = (uint32_t)h_start_ext.size();
+  tx_deleted.clear();
+  in_tx = false, tx_explicit = false;
   return SDB_OK;
 }
 
@@ -391,6 +509,10 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_adjdist) (void)hipFree(ix->d_adjdist);
   if (ix->d_dcount) (void)hipFree(ix->d_dcount);
   if (ix->d_ids) (void)hipFree(ix->d_ids);
+  if (ix->r_adj) (void)hipFree(ix->r_adj);
+  if (ix->r_ids) (void)hipFree(ix->r_ids);
+  if (ix->r_start_ext) (void)hipFree(ix->r_start_ext);
+  if (ix->d_dirty) (void)hipFree(ix->d_dirty);
   if (ix->d_start_ext) (void)hipFree(ix->d_start_ext);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
   if (ix->d_bstats) (void)hipFree(ix->d_bstats);
@@ -448,7 +570,7 @@ int sdb_index_set_start(sdb_index *ix, const float *vec, int mem) {
   ix->dense_ids = true;
   ix->n = 1;
   ix->start_slot = 0;
-  return SDB_OK;
+  return ix->publish_full();
 }
 
 int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
@@ -526,7 +648,58 @@ int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *
     ix->h_start_ext.clear();
     return rc;
   }
+  return ix->publish_full();
+}
+
+// IndexVamana.InsertUpdateDelete is ONE write transaction made of several calls here (inserts, one delete scan,
+// re-inserts of the updated points); the shard runs it under its write lock while searches keep being served --
+// by a cold index built from the bucket when the cached one is locked (shard/cache/manager.go:159-181).  Here the
+// searches simply keep walking the last committed graph: between begin_write and commit every insert_batch /
+// delete_batch changes the writer's copy only.  Without begin_write each such call is a transaction by itself.
+int sdb_index_begin_write(sdb_index *ix) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
+  if (ix->in_tx && ix->tx_explicit) return fail(SDB_ERR_STATE, "a write transaction is already open");
+  SDB_TRY(ix->begin_write());
+  ix->tx_explicit = true;
+  return SDB_OK;
+}
+
+int sdb_index_commit(sdb_index *ix, void *stream_) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (!ix->in_tx) return fail(SDB_ERR_STATE, "no write transaction is open");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
+  DeviceGuard dg(ix->P.device);
+  hipStream_t stream = as_stream(stream_);
+  SDB_TRY(ix->commit(stream));
+  SDB_HIP(hipStreamSynchronize(stream));
+  return SDB_OK;
+}
+
+// test support: the number of rows on which the two graph copies differ (0 whenever no transaction is open)
+int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows) {
+  if (!ix || !rows) return fail(SDB_ERR_INVALID, "NULL argument");
+  *rows = 0;
+  if (ix->n == 0) return SDB_OK;
+  DeviceGuard dg(ix->P.device);
+  unsigned long long *d = nullptr;
+  SDB_HIP(hipMalloc(&d, 8));
+  SDB_HIP(hipMemset(d, 0, 8));
   SDB_HIP(hipDeviceSynchronize());
+  hipLaunchKernelGGL(k_count_version_diff, dim3((ix->n + 3) / 4), dim3(256), 0, nullptr, ix->d_adj, ix->r_adj, ix->d_ids,
+                     ix->r_ids, ix->n, d);
+  unsigned long long h = 0;
+  hipError_t e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "version check failed: %s", hipGetErrorString(e));
+  *rows = h;
+  if (ix->h_start_ext.size()) {
+    const size_t m = ix->h_start_ext.size();
+    std::vector<uint32_t> a(m), b(m);
+    SDB_HIP(hipMemcpy(a.data(), ix->d_start_ext, m * 4, hipMemcpyDeviceToHost));
+    SDB_HIP(hipMemcpy(b.data(), ix->r_start_ext, m * 4, hipMemcpyDeviceToHost));
+    if (a != b) *rows += 1;
+  }
   return SDB_OK;
 }
 
@@ -564,12 +737,16 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     stream = ws->own_stream;
   }
   const RowLayout &l = ix->lay;
-  const uint32_t words = ((ix->n + 31) / 32 + 31) & ~31u;  // per-query bitset, 128-byte multiple
+  // the graph version this batch walks: the last committed one, whatever a writer is doing meanwhile.  The shared
+  // lock is held until the kernels are enqueued and their event recorded (sdb_index::commit counts on that).
+  std::shared_lock<std::shared_mutex> rl(ix->view_mu);
+  const sdb_index::View vw = ix->view;
+  const uint32_t words = ((vw.n + 31) / 32 + 31) & ~31u;  // per-query bitset, 128-byte multiple
   const size_t bs_bytes = (size_t)nq * words * sizeof(uint32_t);
   SDB_TRY(ws->ensure_bitsets(filtered ? 2 * bs_bytes : bs_bytes));
 
   SearchArgs a{};
-  a.slab = ix->d_slab, a.adj = ix->d_adj, a.ids = ix->d_ids;
+  a.slab = ix->d_slab, a.adj = vw.adj, a.ids = vw.ids;
   a.bitsets = ws->bitsets, a.words_per_query = words;
   if (filtered) {
     // search.go:41-48: seeds = the first <= searchSize filter ids (ascending) that exist; Contains (:93) is
@@ -582,7 +759,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
       for (uint64_t i = b; i < e; i++) {
         if (i > b && filter_ids[i] <= filter_ids[i - 1])
           return fail(SDB_ERR_INVALID, "filter ids of query %llu are not strictly ascending", (unsigned long long)q);
-        const int64_t s = ix->slot_of(filter_ids[i]);
+        const int64_t s = ix->slot_of_committed(filter_ids[i], vw.n);
         if (s < 0) continue;  // GetMany skips unknown ids (itemcache.go:109-128)
         if (i - b < search_size) seeds.push_back((uint32_t)s);
         fslots.push_back((uint32_t)s);
@@ -608,7 +785,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   }
   a.dim = l.dim, a.nblk = l.nblk, a.ng = l.ng, a.tail = l.tail, a.ld = l.ld;
   a.start_slot = (uint32_t)ix->start_slot;
-  a.start_ext = ix->d_start_ext, a.start_ext_n = (uint32_t)ix->h_start_ext.size();
+  a.start_ext = vw.start_ext, a.start_ext_n = vw.start_ext_n;
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
   a.hash_limit = ix->tune_hash_limit, a.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
 
@@ -632,6 +809,11 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
       (void)hipEventRecord(ix->ev1[slot], stream);
       ix->prof_count++;
     }
+    // from here on a commit may hand the copy this batch walks to the writer: it waits for this event first
+    if (!ws->launched) (void)hipEventCreateWithFlags(&ws->launched, hipEventDisableTiming);
+    if (ws->launched && hipEventRecord(ws->launched, stream) == hipSuccess) ws->launched_valid = true;
+    else if (rc == SDB_OK) (void)hipStreamSynchronize(stream);  // no event: finish before letting go of the version
+    rl.unlock();
     return rc;
   };
   if (mem == SDB_MEM_DEVICE) {

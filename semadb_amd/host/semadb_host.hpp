@@ -532,6 +532,10 @@ class IndexVamana {
         fresh.insert(p.Id);
       }
     }
+    // one write transaction, like the shard's: searches see all of it or none of it (sdb_index_begin_write)
+    const bool any = !ins_ids.empty() || !del_ids.empty() || !upd_ids.empty();
+    if (any)
+      if (int rc = sdb_index_begin_write(h_)) return Error::wrap("could not start the write", rc);
     if (!ins_ids.empty())
       if (int rc = sdb_index_insert_batch(h_, ins_ids.size(), ins_ids.data(), ins_vecs.data(), SDB_MEM_HOST, round_size, nullptr))
         return Error::wrap("could not distribute or insert points", rc);
@@ -554,6 +558,8 @@ class IndexVamana {
     for (size_t i = 0; i < upd_ids.size(); i++)  // :247-251
       if (int rc = sdb_index_insert_batch(h_, 1, &upd_ids[i], upd_vecs.data() + i * d, SDB_MEM_HOST, 1, nullptr))
         return Error::wrap("could not re-insert updated point", rc);
+    if (any)
+      if (int rc = sdb_index_commit(h_, nullptr)) return Error::wrap("could not commit the write", rc);
     if (Error e = fit()) return Error("could not fit vector store: " + e.msg);  // vamana.go:257-260
     return flush();
   }

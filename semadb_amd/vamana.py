@@ -192,12 +192,16 @@ class IndexVamana:
                 ins_ids.append(ch.Id)
                 ins_vecs.append(v)
                 known.add(ch.Id)
+        if not (ins_ids or del_ids or upd_ids):
+            return
+        self.begin_write()  # one transaction, like the shard's (searches see it whole or not at all)
         if ins_ids:
             self.insert_batch(np.array(ins_ids, dtype=np.uint64), np.stack(ins_vecs), round_size)
         if del_ids or upd_ids:
             self.delete_batch(np.array(del_ids + upd_ids, dtype=np.uint64))  # removeInboundEdges :223-233
         for i, v in zip(upd_ids, upd_vecs):  # :247-251 re-inserted sequentially
             self.insert_batch(np.array([i], dtype=np.uint64), v.reshape(1, -1), 1)
+        self.commit()
         self.Fit()  # vamana.go:257-260
 
     def Fit(self):
@@ -227,6 +231,19 @@ class IndexVamana:
     def exists(self, node_id):
         """vecStore.Exists (plain.go:21-24)"""
         return bool(self.exists_batch([node_id])[0])
+
+    def begin_write(self):
+        """open a write transaction: until commit() searches keep walking the graph as it is now"""
+        check(lib().sdb_index_begin_write(self._h))
+
+    def commit(self):
+        check(lib().sdb_index_commit(self._h, None))
+
+    def version_diff(self):
+        """test support: rows on which the committed and the writer's copy differ"""
+        v = C.c_uint64(0)
+        check(lib().sdb_index_version_diff(self._h, C.byref(v)))
+        return v.value
 
     def EdgeScan(self, deleteSet):
         """IndexVamana.EdgeScan (node.go:142-199): (toPrune, toSave) for a set of ids about to be deleted"""

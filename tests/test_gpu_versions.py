@@ -1,0 +1,145 @@
+"""Searches during a write transaction walk the last committed graph (SURVEY 8b Threading; the reference serves a
+reader that cannot get the cache's read lock from a cold index on the committed bucket, shard/cache/manager.go:159-181).
+The device keeps two copies of what a walk reads and a write changes; these tests hold the visible behaviour to the
+oracle: exactly the pre-transaction answers until commit, exactly the post-transaction answers after."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from tests.helpers import bits, start_vector
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(rng, n, d, lat):
+    x = rng.standard_normal((n, lat.shape[0])).astype(np.float32) @ lat + 0.15 * rng.standard_normal((n, d)).astype(np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def _oracle_answers(o, q, k, L, filters=None):
+    out = []
+    for i in range(q.shape[0]):
+        ids, d, _, _ = o.search(q[i], k, L) if filters is None else o.search(q[i], k, L, filter_ids=sorted(filters[i]))
+        out.append((ids, d))
+    return out
+
+
+def _same(got, want):
+    g_ids, g_d, g_c = got[:3]
+    for i, (ids, d) in enumerate(want):
+        if int(g_c[i]) != len(ids) or not np.array_equal(g_ids[i, :len(ids)], ids):
+            return False
+        if not np.array_equal(bits(g_d[i, :len(ids)]), bits(d)):
+            return False
+    return True
+
+
+def test_transaction_is_invisible_until_commit(oracle):
+    from semadb_amd import vamana
+    rng = np.random.default_rng(2026)
+    d, n0, m, R, L, k = 32, 12000, 12000, 32, 50, 10
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    base0, base1, q = _rows(rng, n0, d, lat), _rows(rng, m, d, lat), _rows(rng, 64, d, lat)
+    sv = start_vector(np.random.default_rng(4), d)
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    ids0 = np.arange(2, n0 + 2, dtype=np.uint64)
+    ids1 = np.arange(n0 + 2, n0 + m + 2, dtype=np.uint64)
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=impl)
+    o.set_start(sv)
+    assert o.insert_rounds(ids0, base0, round_size=0) == 0
+    ix = vamana.NewIndexVamana("ver", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), strict=False)
+    ix.set_start(sv)
+    ix.insert_batch(ids0, base0)
+    assert ix.version_diff() == 0
+    pre = _oracle_answers(o, q, k, L)
+    assert _same(ix.search_batch(q, k, L), pre)
+    filt = [set(int(v) for v in rng.choice(ids0, 30, replace=False)) | {int(ids1[i])} for i in range(64)]
+    pre_f = _oracle_answers(o, q, 5, L, filt)
+
+    # ---- an open transaction: 12 000 inserts have run on the device, nothing is visible
+    ix.begin_write()
+    ix.insert_batch(ids1, base1)
+    assert ix.version_diff() > 0
+    assert _same(ix.search_batch(q, k, L), pre), "a search saw an uncommitted insert"
+    assert _same(ix.search_batch(q, 5, L, filters=filt), pre_f), "a filter resolved an uncommitted id"
+    from semadb_amd import flat
+    f_ids, _, f_c = flat.flat_search_batch(ix._h, d, q, 3)
+    assert int(f_ids.max()) <= int(ids0.max()), "the exact scan saw uncommitted rows"
+    ix.commit()
+    assert ix.version_diff() == 0
+    assert o.insert_rounds(ids1, base1, round_size=0) == 0
+    post = _oracle_answers(o, q, k, L)
+    assert _same(ix.search_batch(q, k, L), post)
+    assert not _same(ix.search_batch(q, k, L), pre)  # the insert did change the answers
+    assert _same(ix.search_batch(q, 5, L, filters=filt), _oracle_answers(o, q, 5, L, filt))
+
+    # ---- a delete inside a transaction: the deleted points keep answering until commit
+    gone = np.array(sorted(set(int(v) for row in post for v in row[0][:3])), dtype=np.uint64)  # the best answers
+    ix.begin_write()
+    ix.delete_batch(gone)
+    assert ix.version_diff() > 0
+    assert _same(ix.search_batch(q, k, L), post), "a search saw an uncommitted delete"
+    filt2 = [set(int(v) for v in gone[:20]) for _ in range(64)]
+    assert _same(ix.search_batch(q, 5, L, filters=filt2), _oracle_answers(o, q, 5, L, filt2))
+    ix.commit()
+    assert ix.version_diff() == 0
+    assert o.delete(gone) == 0
+    after = _oracle_answers(o, q, k, L)
+    got = ix.search_batch(q, k, L)
+    assert _same(got, after)
+    assert not set(int(v) for v in got[0].ravel()) & set(int(v) for v in gone)
+    ix.close()
+
+
+def test_searches_run_while_a_writer_inserts(oracle):
+    """a writer thread inserts (one call = one transaction) while this thread keeps searching: every answer is the
+    pre-insert oracle answer or the post-insert one, never a mix; at least one search ran during the write"""
+    from semadb_amd import vamana
+    rng = np.random.default_rng(77)
+    d, n0, m, R, L, k = 48, 8000, 40000, 32, 50, 10
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    base0, base1, q = _rows(rng, n0, d, lat), _rows(rng, m, d, lat), _rows(rng, 128, d, lat)
+    sv = start_vector(np.random.default_rng(5), d)
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    ids0 = np.arange(2, n0 + 2, dtype=np.uint64)
+    ids1 = np.arange(n0 + 2, n0 + m + 2, dtype=np.uint64)
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=impl)
+    o.set_start(sv)
+    assert o.insert_rounds(ids0, base0, round_size=0) == 0
+    pre = _oracle_answers(o, q, k, L)
+    assert o.insert_rounds(ids1, base1, round_size=0) == 0
+    post = _oracle_answers(o, q, k, L)
+    ix = vamana.NewIndexVamana("conc", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), strict=False)
+    ix.set_start(sv)
+    ix.insert_batch(ids0, base0)
+    state = {"done": False, "err": None}
+
+    def writer():
+        try:
+            ix.insert_batch(ids1, base1)
+        except Exception as e:  # pragma: no cover
+            state["err"] = e
+        state["done"] = True
+
+    t = threading.Thread(target=writer)
+    seen_pre = seen_post = during = 0
+    t.start()
+    while True:
+        finished_before = state["done"]
+        got = ix.search_batch(q, k, L)
+        if not state["done"]:
+            during += 1
+        is_pre, is_post = _same(got, pre), _same(got, post)
+        assert is_pre or is_post, "a search returned neither the committed nor the new version's answers"
+        seen_pre += is_pre
+        seen_post += is_post
+        assert not (finished_before and is_pre and not is_post), "stale answers after the commit"
+        if finished_before:
+            break
+    t.join()
+    assert state["err"] is None
+    assert during >= 1 and seen_pre >= 1 and seen_post >= 1
+    assert ix.version_diff() == 0
+    ix.close()
