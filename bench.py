@@ -103,6 +103,8 @@ def build_index(a, base, dev_index, name="bench"):
     params = vamana.IndexVectorVamanaParameters(d, a.metric, a.search_size, a.degree_bound, a.alpha)
     ix = vamana.NewIndexVamana(name, params, device=dev_index, capacity=base.shape[0] + 1, strict=True)
     ix.set_start(start_vector(d))
+    if os.environ.get("BENCH_NO_TILE"):  # measurement only (tools/pmc_build.sh): the one-wave prune of new nodes
+        ix.set_tuning("no_tile", int(os.environ["BENCH_NO_TILE"]))
     torch.cuda.synchronize()
     t1 = time.time()
     ix.insert_batch(None, base)  # ids 2..n+1 ; K4 on device

@@ -24,8 +24,8 @@ for line in open(benchlog):
         bench = json.loads(line)
 rows = list(csv.DictReader(open(one(tag + "_trace/**/*kernel_stats.csv"))))
 with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (MI355X)\n")
-    f.write("# whole process: data generation + K4 build of 1M x 384 + 10 recall batches + 3 warmup + 20 timed steps\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-rates (MI355X)\n")
+    f.write("# whole process: data generation + K4 build of 1M x 384 + 10 recall batches + 5 warmup + 20 timed steps + 20 counter-pass batches\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in rows[:14]:
         f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
@@ -53,22 +53,25 @@ factor = exp["calibration"]["bytes"] / (cal_fetch * 1024)
 alg = st.mean(r["alg_bytes"] for r in exp["search"])
 read_b = st.mean(s_fetch) * 1024 * factor
 write_b = st.mean(s_write) * 1024
-t20 = st.mean(d[-20:])
+# launch order in bench.py: recall batches, warmup, the timed steps, then the counter pass (trace on)
+n_recall, n_warm, n_steps = 10, bench["warmup"], bench["steps"]
+timed = d[n_recall + n_warm:n_recall + n_warm + n_steps]
+t20 = st.mean(timed)
 md = f"""# {tag} -- search kernel (K2) profile
 
 Commands (GPU box, `cd /tmp; export TMPDIR=/tmp`):
 
-    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/{tag}_trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/{tag}_trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-rates
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/{tag}_pmc_fetch -- python3 tools/pmc_run.py
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/{tag}_pmc_write -- python3 tools/pmc_run.py
 
 ## `{kname}`
 grid 1024 x 64 (one wavefront per query), 1M x 384 cosine, searchSize 75, batch 1024
 
-kernel-trace durations of the {len(d)} batch launches (10 recall + 3 warmup + 20 timed), ms:
+kernel-trace durations of the {len(d)} batch launches (10 recall + {n_warm} warmup + {n_steps} timed + the counter pass), ms:
 {[round(x, 3) for x in d]}
 
-* rocprofv3 average over the 20 timed launches: **{t20:.4f} ms**
+* rocprofv3 average over the {len(timed)} timed launches (trace counters off, batches never walked before): **{t20:.4f} ms**
 * bench.py HIP-event average, un-profiled run of the same command: {bench['roofline']['kernel_ms_avg']} ms
   (value {bench['value']} queries/s, roofline.achieved {bench['roofline']['achieved']} GB/s)
 * VGPR_Count {gs[0].get('VGPR_Count')}, LDS_Block_Size {gs[0].get('LDS_Block_Size')}, Scratch_Size {gs[0].get('Scratch_Size')}
