@@ -161,6 +161,226 @@ __global__ void k_flat_emit(const uint32_t *__restrict__ top_slot, const float *
   if (threadIdx.x == 0) out_counts[q] = len;
 }
 
+
+// ---- the streaming scan: every slab row read ONCE, against all queries ---------------------------------------
+// k_flat_dist above recomputes nothing but re-reads everything: a block is one query x 64 rows, so the slab
+// streams through the cache hierarchy once per query (1.5 TB for 1 024 queries over 1M x 384) and the
+// [nq][chunk] distance block makes a round trip through HBM before the fold.  k_flat_scan turns the loop around:
+// a workgroup stages 64 rows in LDS (padded so that lane r reads row r without bank conflicts), lane r of every
+// wave OWNS row r, and the waves walk the queries -- whose elements are wave-uniform, i.e. scalar operands -- four
+// at a time: 32 partial sums per (row, query) in registers, FMA chains over the blocks in order, the reduce tree
+// as plain adds in the lane (dot.s:45-53).  Same arithmetic, same bits as dist_core.h; no cross-lane traffic at
+// all.  A (row, query) pair whose distance is not above the query's current threshold (an upper bound of its
+// k-th best distance, taken from the rows scanned so far) is appended to the query's candidate list; k_flat_merge
+// folds the few candidates into the running top list under (distance, slot) order -- the order the reference's
+// walk in storage order with `dist >= tail -> skip` produces (flat.go:104,121-123).
+constexpr int kScanQ = 4;          // queries per pass of a wave
+constexpr uint32_t kScanRows = 64;  // rows per workgroup tile = lanes of a wave
+
+struct FlatScanArgs {
+  const float *slab;     // [n][ld] permuted rows
+  const float *qperm;    // [nq][ld] the queries in the same permuted layout
+  const uint64_t *ids;   // slot -> id, 0 = deleted
+  const float *thr;      // [nq] upper bound of the query's limit-th best distance so far (+inf: list not full)
+  uint32_t *cnt;         // [nq] candidates appended in this launch
+  uint2 *cand;           // [nq][cap] (slot, distance bits)
+  uint32_t cap;
+  uint32_t first, rows;  // slab rows [first, first + rows)
+  uint32_t nq, ld, skip_slot;
+  int metric;
+};
+
+// LDS: the row tile [64][NG*128 + 4] and two blocks of 16 queries [2][16][NG*128] (four per wave; the next block is
+// fetched into registers while the current one is used, and written to the other buffer before the barrier).  A
+// lane reads its row with ds_read_b128 (padded stride: no bank conflicts) and the query elements with broadcast
+// ds_read_b128 (all lanes one address).
+// Both are laid out for v_pk_fma_f32: inside a 128-float group, float 8j + 2k + h holds element 32(4g + k) + 2j + h,
+// i.e. the partial sums L = 2j and 2j + 1 of block k side by side, so one packed instruction advances two of the
+// reference's 32 partial sums with both operands being natural register pairs -- each half is the reference's own
+// fused multiply-add (VFMADD231PS, dot.s:24-27), in the reference's block order.  The slab's own layout (float
+// 4L + k) is turned into this one while staging.
+constexpr int kScanQB = 16;  // queries per block = 4 waves x kScanQ
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <bool L2>
+__device__ __forceinline__ f2v chain1_pk(f2v acc, f2v x, f2v y) {
+  if constexpr (L2) {
+    const f2v d = x - y;  // separately rounded, like VSUBPS (euclidean.s:27)
+    return __builtin_elementwise_fma(d, d, acc);
+  } else {
+    return __builtin_elementwise_fma(x, y, acc);
+  }
+}
+// slab float4 c of a row (c = 32 g + L: blocks 4g..4g+3 of partial sum L) -> its four floats' places in the pair layout
+__device__ __forceinline__ void scatter_pairs(float *dst_row, uint32_t c, const float4 &v) {
+  const uint32_t g = c >> 5, Lx = c & 31;
+  float *d = dst_row + g * 128 + (Lx >> 1) * 8 + (Lx & 1);
+  d[0] = v.x, d[2] = v.y, d[4] = v.z, d[6] = v.w;
+}
+template <bool L2, int NG>
+__global__ __launch_bounds__(256) void k_flat_scan(const float *__restrict__ slab, const float *__restrict__ qperm,
+                                                   const FlatScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  constexpr uint32_t kStride = NG * 128 + 4;    // floats; +16 B: lane r -> banks 4r.. (no conflict)
+  constexpr uint32_t kRowF4 = NG * 32;          // float4 per row
+  constexpr uint32_t kQF4 = kScanQB * kRowF4;   // float4 per query block
+  constexpr int kPre = (kQF4 + 255) / 256;      // float4 a thread moves per block
+  float *tile = lds_f;
+  float *qbuf = lds_f + (size_t)kScanRows * kStride;  // [2][kScanQB][NG * 128]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t row0 = a.first + blockIdx.x * kScanRows;
+  const uint32_t nrows = min(kScanRows, a.first + a.rows - row0);
+  const uint32_t nblocks = (a.nq + kScanQB - 1) / kScanQB;
+  const float4 *q4 = reinterpret_cast<const float4 *>(qperm);
+  const uint32_t q_f4 = a.nq * kRowF4;
+  auto fetch = [&](uint32_t blk, float4(&pre)[kPre]) {
+#pragma unroll
+    for (int j = 0; j < kPre; j++) {
+      uint32_t i = blk * kQF4 + (uint32_t)tid + 256u * j;
+      i = i < q_f4 ? i : q_f4 - 1;  // the last block's overhang: any valid address, never used
+      pre[j] = q4[i];
+    }
+  };
+  auto stash = [&](uint32_t buf, const float4(&pre)[kPre]) {
+#pragma unroll
+    for (int j = 0; j < kPre; j++) {
+      const uint32_t i = (uint32_t)tid + 256u * j;
+      if (i < kQF4) scatter_pairs(qbuf + ((size_t)buf * kScanQB + i / kRowF4) * NG * 128, i % kRowF4, pre[j]);
+    }
+  };
+  float4 pre[kPre];
+  fetch(0, pre);
+  // ---- stage the row tile: consecutive threads read consecutive 16 B of a row
+  for (uint32_t i = tid; i < kScanRows * kRowF4; i += 256) {
+    const uint32_t r = i / kRowF4, c = i % kRowF4;
+    const uint32_t rr = r < nrows ? r : nrows - 1;
+    scatter_pairs(tile + (size_t)r * kStride, c, reinterpret_cast<const float4 *>(slab + (size_t)(row0 + rr) * a.ld)[c]);
+  }
+  stash(0, pre);
+  __syncthreads();
+  const uint32_t slot = row0 + (uint32_t)lane;
+  const bool live = (uint32_t)lane < nrows && slot != a.skip_slot && a.ids[(uint32_t)lane < nrows ? slot : row0] != 0;
+  const float4 *myrow = reinterpret_cast<const float4 *>(tile) + (size_t)lane * (kStride / 4);
+  for (uint32_t blk = 0; blk < nblocks; blk++) {
+    if (blk + 1 < nblocks) fetch(blk + 1, pre);  // in flight under the arithmetic below
+    const float4 *myq = reinterpret_cast<const float4 *>(qbuf) + ((size_t)(blk & 1) * kScanQB + (size_t)wave * kScanQ) * kRowF4;
+    f2v acc[kScanQ][16];  // [query][j]: partial sums 2j, 2j + 1
+#pragma unroll
+    for (int k = 0; k < kScanQ; k++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[k][j] = f2v{0.0f, 0.0f};
+#pragma unroll 1
+    for (int g = 0; g < NG; g++) {
+#pragma unroll
+      for (int i = 0; i < 32; i++) {  // float4 i of the group: pair j = i / 2, blocks 2 (i % 2) and 2 (i % 2) + 1
+        const float4 y = myrow[g * 32 + i];
+#pragma unroll
+        for (int k = 0; k < kScanQ; k++) {
+          const float4 x = myq[k * kRowF4 + g * 32 + i];
+          f2v t = acc[k][i >> 1];
+          t = chain1_pk<L2>(t, f2v{x.x, x.y}, f2v{y.x, y.y});
+          t = chain1_pk<L2>(t, f2v{x.z, x.w}, f2v{y.z, y.w});
+          acc[k][i >> 1] = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kScanQ; k++) {
+      // the reduce tree of dot.s:45-53 / euclidean.s:55-63 over acc[L] = acc[k][L / 2][L % 2] (the tail vector
+      // {t,0,0,0} is all zero here)
+      auto A = [&](int L) { return acc[k][L >> 1][L & 1]; };
+      float r4[4];
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const float s0 = ((A(l) + A(8 + l)) + A(16 + l)) + A(24 + l);
+        const float s1 = ((A(l + 4) + A(12 + l)) + A(20 + l)) + A(28 + l);
+        r4[l] = (s0 + s1) + 0.0f;
+      }
+      const float dist = metric_finish((r4[0] + r4[1]) + (r4[2] + r4[3]), a.metric);
+      const uint32_t q = blk * kScanQB + (uint32_t)wave * kScanQ + k;
+      if (q < a.nq && live && !(dist > a.thr[q])) {  // rare: a handful per query and million rows
+        const uint32_t at = atomicAdd(a.cnt + q, 1u);
+        if (at < a.cap) a.cand[(size_t)q * a.cap + at] = make_uint2(slot, __float_as_uint(dist));
+      }
+    }
+    if (blk + 1 < nblocks) stash((blk + 1) & 1, pre);
+    __syncthreads();  // everybody is done with this block's buffer and the next one is complete
+  }
+}
+
+// fold a launch's candidates into the running top list of one query (64 threads): the `limit` smallest of
+// (list U candidates) under (distance, slot) order; then the new threshold.  cnt > cap: the list was cut -- flag it.
+__global__ __launch_bounds__(64) void k_flat_merge(const uint32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
+                                                   uint32_t cap, uint32_t limit, uint32_t *__restrict__ top_slot,
+                                                   float *__restrict__ top_dist, uint32_t *__restrict__ top_len,
+                                                   float *__restrict__ thr, uint32_t *__restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(8))) uint2 items[];  // [128 + cap]
+  const uint32_t q = blockIdx.x;
+  const int t = threadIdx.x;
+  const uint32_t len = top_len[q];
+  uint32_t c = cnt[q];
+  if (c > cap) {
+    if (t == 0) atomicOr(overflow, 1u);
+    c = cap;
+  }
+  if (c == 0) {
+    if (t == 0) thr[q] = len >= limit ? top_dist[(size_t)q * 128 + limit - 1] : __int_as_float(0x7f800000);
+    return;
+  }
+  for (uint32_t i = t; i < len; i += 64) items[i] = make_uint2(top_slot[(size_t)q * 128 + i], __float_as_uint(top_dist[(size_t)q * 128 + i]));
+  for (uint32_t i = t; i < c; i += 64) items[len + i] = cand[(size_t)q * cap + i];
+  __syncthreads();
+  const uint32_t m = len + c;
+  for (uint32_t i = t; i < m; i += 64) {
+    const float d = __uint_as_float(items[i].y);
+    const uint32_t s = items[i].x;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < m; j++) {
+      const float dj = __uint_as_float(items[j].y);
+      rank += (dj < d || (dj == d && items[j].x < s)) ? 1u : 0u;
+    }
+    if (rank < limit) top_slot[(size_t)q * 128 + rank] = s, top_dist[(size_t)q * 128 + rank] = d;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t nl = m < limit ? m : limit;
+    top_len[q] = nl;
+  }
+  __syncthreads();
+  if (t == 0) {
+    __threadfence();
+    thr[q] = (m >= limit) ? top_dist[(size_t)q * 128 + limit - 1] : __int_as_float(0x7f800000);
+  }
+}
+
+int permute_rows_to(const sdb_index *ix, const float *src, float *dst, uint32_t n, hipStream_t stream);
+
+template <bool L2>
+static int launch_flat_scan(const FlatScanArgs &a, uint32_t ng, hipStream_t stream) {
+  const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
+  const size_t lds = ((size_t)kScanRows * (ng * 128 + 4) + 2 * (size_t)kScanQB * ng * 128) * sizeof(float);
+#define SDB_SCAN_CASE(NGV)                                                                                      \
+  case NGV: {                                                                                                   \
+    static bool attr = false;                                                                                   \
+    if (!attr) {                                                                                                \
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan<L2, NGV>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                     \
+      attr = true;                                                                                              \
+    }                                                                                                           \
+    hipLaunchKernelGGL((k_flat_scan<L2, NGV>), grid, dim3(256), lds, stream, a.slab, a.qperm, a);               \
+    break;                                                                                                      \
+  }
+  switch (ng) {
+    SDB_SCAN_CASE(1)
+    SDB_SCAN_CASE(2)
+    SDB_SCAN_CASE(3)
+    default: return fail(SDB_ERR_INVALID, "no streaming scan for %u row groups", ng);
+  }
+#undef SDB_SCAN_CASE
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
 }  // namespace sdb
 
 using namespace sdb;
@@ -201,8 +421,10 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     }
   }
   // ---- buffers: staged queries/outputs for host callers, running top lists, one distance block
-  const uint32_t chunk = filtered ? std::max<uint32_t>(max_f, 1)
-                                  : (uint32_t)std::min<uint64_t>(std::max<uint32_t>(n, 1), (1ull << 28) / nq);
+  uint32_t chunk = filtered ? std::max<uint32_t>(max_f, 1)
+                            : (uint32_t)std::min<uint64_t>(std::max<uint32_t>(n, 1), (1ull << 28) / nq);
+  if (!filtered && !ix->pq && ix->lay.tail == 0 && ix->lay.ng >= 1 && ix->lay.ng <= 3 && n >= 4 * 8192 && nq <= 8192)
+    chunk = std::min<uint32_t>(chunk, 8192);  // with the streaming scan the block path only sees the seed rows
   const uint32_t stride = (chunk + 63) & ~63u;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
@@ -218,6 +440,12 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const size_t o_d = carve((size_t)nq * stride * 4);
   const sdb_pq *pq = ix->pq;
   const size_t o_lut = carve(pq ? (size_t)nq * pq->M * pq->K * 4 : 0);
+  // the streaming scan (k_flat_scan): plain store, no filter, rows of whole 32-float blocks up to 512 floats, a
+  // table worth streaming.  Its first rows still go through the block path below: they seed the thresholds.
+  constexpr uint32_t kSeedRows = 8192, kCandCap = 8192;
+  const bool fast = !filtered && !pq && l.tail == 0 && l.ng >= 1 && l.ng <= 3 && n >= 4 * kSeedRows && nq <= 8192;
+  const size_t o_qp = carve(fast ? (size_t)nq * l.ld * 4 : 0), o_thr = carve(fast ? nq * 4 : 0);
+  const size_t o_cnt = carve(fast ? nq * 4 + 256 : 0), o_cand = carve(fast ? (size_t)nq * kCandCap * 8 : 0);
   char *buf = nullptr;
   SDB_HIP(hipMalloc(&buf, off));
   struct Free {
@@ -254,8 +482,9 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   float *d_dist = (float *)(buf + o_d);
   const size_t lds = (size_t)(l.ng * 128 + 32) * 4;
   const uint32_t total = filtered ? max_f : n;
-  for (uint32_t first = 0; first < total; first += chunk) {
-    const uint32_t rows = std::min<uint32_t>(chunk, total - first);
+  auto block_path = [&](uint32_t begin, uint32_t end) -> int {
+  for (uint32_t first = begin; first < end; first += chunk) {
+    const uint32_t rows = std::min<uint32_t>(chunk, end - first);
     dim3 grid((rows + 63) / 64, (unsigned)nq);
     if (pq) {
       if (first == 0) SDB_TRY(pq_build_lut(pq, dq, nq, (float *)(buf + o_lut), stream));
@@ -275,6 +504,56 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     fa.limit = limit, fa.top_slot = top_slot, fa.top_dist = top_dist, fa.top_len = top_len;
     hipLaunchKernelGGL(k_flat_fold, dim3((unsigned)nq), dim3(64), 0, stream, fa);
     SDB_HIP(hipGetLastError());
+  }
+  return SDB_OK;
+  };
+  if (!fast) {
+    SDB_TRY(block_path(0, total));
+  } else {
+    const uint32_t seed = std::min<uint32_t>(kSeedRows, n);
+    SDB_TRY(block_path(0, seed));
+    float *d_thr = (float *)(buf + o_thr);
+    uint32_t *d_cnt = (uint32_t *)(buf + o_cnt), *d_over = d_cnt + nq;
+    uint2 *d_cand = (uint2 *)(buf + o_cand);
+    SDB_TRY(permute_rows_to(ix, dq, (float *)(buf + o_qp), (uint32_t)nq, stream));
+    SDB_HIP(hipMemsetAsync(d_cnt, 0, nq * 4 + 4, stream));
+    const size_t merge_lds = (size_t)(128 + kCandCap) * sizeof(uint2);
+    static bool merge_attr = false;
+    if (!merge_attr) {
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)merge_lds));
+      merge_attr = true;
+    }
+    // thresholds from the seed rows (no candidates yet: the merge only derives thr from the lists)
+    hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(64), merge_lds, stream, d_cnt, d_cand, kCandCap, limit, top_slot,
+                       top_dist, top_len, d_thr, d_over);
+    SDB_HIP(hipGetLastError());
+    // segments sized so that a query expects far fewer than kCandCap candidates: a row passes with probability
+    // ~ limit / rows-scanned-so-far
+    const uint32_t seg = (uint32_t)std::max<uint64_t>(65536, (uint64_t)seed * kCandCap / ((uint64_t)limit * 8));
+    for (uint32_t first = seed; first < n; first += seg) {
+      FlatScanArgs sa{};
+      sa.slab = ix->d_slab, sa.qperm = (const float *)(buf + o_qp), sa.ids = vw.ids, sa.thr = d_thr, sa.cnt = d_cnt;
+      sa.cand = d_cand, sa.cap = kCandCap, sa.first = first, sa.rows = std::min<uint32_t>(seg, n - first);
+      sa.nq = (uint32_t)nq, sa.ld = l.ld, sa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
+      sa.metric = (int)ix->P.metric;
+      if (ix->P.metric == SDB_METRIC_EUCLIDEAN) SDB_TRY(launch_flat_scan<true>(sa, l.ng, stream));
+      else SDB_TRY(launch_flat_scan<false>(sa, l.ng, stream));
+      hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(64), merge_lds, stream, d_cnt, d_cand, kCandCap, limit,
+                         top_slot, top_dist, top_len, d_thr, d_over);
+      SDB_HIP(hipGetLastError());
+      SDB_HIP(hipMemsetAsync(d_cnt, 0, nq * 4, stream));
+    }
+    // a candidate list that overflowed (a sea of equal distances) lost entries: start over on the block path
+    uint32_t over = 0;
+    SDB_HIP(hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipStreamSynchronize(stream));
+    if (over) {
+      SDB_HIP(hipMemsetAsync(top_slot, 0xFF, nq * 128 * 4, stream));
+      SDB_HIP(hipMemsetAsync(top_dist, 0, nq * 128 * 4, stream));
+      SDB_HIP(hipMemsetAsync(top_len, 0, nq * 4, stream));
+      SDB_TRY(block_path(0, total));
+    }
   }
   hipLaunchKernelGGL(k_flat_emit, dim3((unsigned)nq), dim3(64), 0, stream, top_slot, top_dist, top_len, vw.ids, limit,
                      d_oi, d_od, d_oc);

@@ -72,8 +72,13 @@ __device__ __forceinline__ float dist_regs(const float *r, const float *__restri
     }
     rr[l] = s[0] + s[1];
   }
+  // the tail chain (dot.s:35-43): rt holds the bound vector's tail elements in REGISTERS (31 slots, statically
+  // indexed: a sub-vector shorter than 32 floats -- M = 32 or 192 at d = 768 -- is nothing but this chain, and
+  // fetching its elements from memory once per centroid made the encode 40x slower than at M = 8)
   float t = 0.0f;
-  for (uint32_t i = 0; i < tail; i++) t = chain1<L2>(t, rt[i], u[NB * 32 + i]);
+#pragma unroll
+  for (int i = 0; i < 31; i++)
+    if ((uint32_t)i < tail) t = chain1<L2>(t, rt[i], u[NB * 32 + i]);
   rr[0] = rr[0] + t;
   rr[1] = rr[1] + 0.0f;
   rr[2] = rr[2] + 0.0f;
@@ -315,9 +320,12 @@ __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ quer
 #pragma unroll
   for (int e = 0; e < NB * 32; e++) r[e] = row[e];
   const uint32_t tail = sub_len - NB * 32;
+  float rt[31];
+#pragma unroll
+  for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? row[NB * 32 + e] : 0.0f;
   for (uint32_t q = q0; q < q1; q++) {
     const float *x = queries + (size_t)q * dim + (size_t)i * sub_len;
-    float d = dist_regs<L2, NB>(r, x, row + NB * 32, tail);
+    float d = dist_regs<L2, NB>(r, x, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);
     if (j < K) lut[((size_t)q * M + i) * K + j] = d;
   }
@@ -335,10 +343,13 @@ __global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ v
 #pragma unroll
   for (int e = 0; e < NB * 32; e++) r[e] = sub[e];
   const uint32_t tail = sub_len - NB * 32;
+  float rt[31];
+#pragma unroll
+  for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? sub[NB * 32 + e] : 0.0f;
   float best = FLT_MAX;
   uint32_t best_id = 0;
   for (uint32_t j = 0; j < K; j++) {
-    float d = dist_regs<L2, NB>(r, cent + ((size_t)i * K + j) * sub_len, sub + NB * 32, tail);
+    float d = dist_regs<L2, NB>(r, cent + ((size_t)i * K + j) * sub_len, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);
     if (d < best) best = d, best_id = j;
   }

@@ -113,3 +113,69 @@ def test_flat_over_quantized_store(oracle, metric):
             assert np.array_equal(bits(g_d[i, :len(order)]), bits(dist[order]))
     ix.close()
     gpq.close()
+
+
+@pytest.mark.parametrize("metric,d,n,nq", [("cosine", 64, 40000, 37), ("euclidean", 384, 33000, 19), ("dot", 224, 50000, 130)])
+def test_streaming_scan_equals_the_oracle(oracle, metric, d, n, nq):
+    """Tables of 32 768 rows and more take the streaming scan (k_flat_scan: every row read once, lane-per-row packed
+    FMA chains, thresholded candidates, k_flat_merge): same ids, same distance bits as the oracle's exact scan in
+    storage order, for limits 1 / 10 / 128 and a query count that fills no block of 16 evenly."""
+    from semadb_amd import flat
+    rng = np.random.default_rng(d + n)
+    lat = rng.standard_normal((12, d)).astype(np.float32)
+    base = rng.standard_normal((n, 12)).astype(np.float32) @ lat + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    if metric != "dot":
+        base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    q = base[rng.choice(n, nq, replace=False)] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+    ids = np.arange(7, n + 7, dtype=np.uint64)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, metric), capacity=n + 1)
+    ix.set_vectors(ids, base)
+    for k in (1, 10, 128):
+        g_ids, g_d, g_c = ix.search_batch(q, k)
+        for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, metric, k)):
+            assert int(g_c[i]) == len(e_ids)
+            assert np.array_equal(g_ids[i, :len(e_ids)], e_ids), (k, i)
+            assert np.array_equal(bits(g_d[i, :len(e_ids)]), bits(e_d))
+    ix.close()
+
+
+def test_streaming_scan_with_a_sea_of_ties(oracle):
+    """small-integer data: thousands of rows at exactly the same distance as the k-th best.  The candidate lists
+    overflow (every tie passes `not above the threshold`) and the call starts over on the block path: the answer is
+    still the storage-order one, first seen stays (flat.go:104)."""
+    from semadb_amd import flat
+    rng = np.random.default_rng(5)
+    n, d = 70000, 32
+    base = rng.integers(0, 2, size=(n, d)).astype(np.float32)
+    q = rng.integers(0, 2, size=(9, d)).astype(np.float32)
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, "euclidean"), capacity=n + 1)
+    ix.set_vectors(ids, base)
+    for k in (10, 100):
+        g_ids, g_d, g_c = ix.search_batch(q, k)
+        for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, "euclidean", k)):
+            assert np.array_equal(g_ids[i, :len(e_ids)], e_ids), (k, i)
+            assert np.array_equal(bits(g_d[i, :len(e_ids)]), bits(e_d))
+    ix.close()
+
+
+def test_streaming_scan_skips_the_start_node_and_tombstones(oracle):
+    """on a graph index the exact scan leaves out the start node (not a point) and deleted rows"""
+    from semadb_amd import flat, vamana
+    from tests.helpers import start_vector
+    rng = np.random.default_rng(8)
+    n, d = 36000, 32
+    base = unit_rows(rng, n, d)
+    ix = vamana.NewIndexVamana("fs", vamana.IndexVectorVamanaParameters(d, "cosine", 30, 8, 1.2), strict=False)
+    ix.set_start(start_vector(rng, d))
+    ix.insert_batch(None, base)
+    q = base[:24] + 0.01
+    gone = np.arange(2, 26, dtype=np.uint64)  # the queries' own rows: their exact nearest neighbours
+    ix.delete_batch(gone)
+    keep = np.ones(n, dtype=bool)
+    keep[:24] = False
+    ids = np.arange(2, n + 2, dtype=np.uint64)
+    g_ids, g_d, g_c = flat.flat_search_batch(ix._h, d, q, 10)
+    for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base[keep], ids[keep], "cosine", 10)):
+        assert np.array_equal(g_ids[i], e_ids) and np.array_equal(bits(g_d[i]), bits(e_d))
+    ix.close()

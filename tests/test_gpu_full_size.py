@@ -89,11 +89,11 @@ def test_c3_build_is_deterministic(c2):
 
 def test_c3_build_equals_oracle_schedule(c2, oracle):
     """The batched build of the BASELINE data against the oracle's restatement of the round schedule, edge for
-    edge.  The oracle runs a round's searches and prunes over the host cores; the first 250 000 rows by default,
-    SDB_TEST_C3_ORACLE_ROWS=1000000 for all of C3 (2.5 minutes on the GPU box's 16 host cores; passed at the end
-    of round 1)."""
+    edge.  The oracle runs a round's searches and prunes over the host cores: all 1 000 000 rows of C3 by default
+    (about 2.5 minutes on the GPU box's 16 host cores -- the longest test of the suite); SDB_TEST_C3_ORACLE_ROWS
+    shortens it for a quick run."""
     from semadb_amd import vamana
-    rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 250_000)), c2.n)
+    rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 1_000_000)), c2.n)
     bench = _bench()
     base = c2.base[:rows].cpu().numpy()
     sv = bench.start_vector(c2.d)
