@@ -9,6 +9,14 @@
 // phase 2 folds it into the per-query top list, one wavefront per query.
 #include <cfloat>
 
+// streaming scan shape: waves per workgroup x query pairs per pass.  16 x 1 (four waves per SIMD hide the scalar
+// loads and LDS reads of one another) measured 18.9 ms for 1 024 x 1M x 384; 8 x 2 (half the LDS reads per FMA, two
+// waves per SIMD) 20.8 ms
+#ifndef SDB_SCAN_WAVES
+#define SDB_SCAN_WAVES 16
+#define SDB_SCAN_PAIRS 1
+#endif
+
 #include "pq.h"
 #include "search_kernel.h"
 
@@ -174,32 +182,28 @@ __global__ void k_flat_emit(const uint32_t *__restrict__ top_slot, const float *
 // k-th best distance, taken from the rows scanned so far) is appended to the query's candidate list; k_flat_merge
 // folds the few candidates into the running top list under (distance, slot) order -- the order the reference's
 // walk in storage order with `dist >= tail -> skip` produces (flat.go:104,121-123).
-constexpr int kScanQ = 4;          // queries per pass of a wave
 constexpr uint32_t kScanRows = 64;  // rows per workgroup tile = lanes of a wave
 
 struct FlatScanArgs {
   const float *slab;     // [n][ld] permuted rows
-  const float *qperm;    // [nq][ld] the queries in the same permuted layout
+  const float *queries;  // [nq][dim] the queries as the caller passed them (original layout)
   const uint64_t *ids;   // slot -> id, 0 = deleted
   const float *thr;      // [nq] upper bound of the query's limit-th best distance so far (+inf: list not full)
   uint32_t *cnt;         // [nq] candidates appended in this launch
   uint2 *cand;           // [nq][cap] (slot, distance bits)
   uint32_t cap;
   uint32_t first, rows;  // slab rows [first, first + rows)
-  uint32_t nq, ld, skip_slot;
+  uint32_t nq, ld, dim, nblk, skip_slot;
   int metric;
 };
 
-// LDS: the row tile [64][NG*128 + 4] and two blocks of 16 queries [2][16][NG*128] (four per wave; the next block is
-// fetched into registers while the current one is used, and written to the other buffer before the barrier).  A
-// lane reads its row with ds_read_b128 (padded stride: no bank conflicts) and the query elements with broadcast
-// ds_read_b128 (all lanes one address).
-// Both are laid out for v_pk_fma_f32: inside a 128-float group, float 8j + 2k + h holds element 32(4g + k) + 2j + h,
-// i.e. the partial sums L = 2j and 2j + 1 of block k side by side, so one packed instruction advances two of the
-// reference's 32 partial sums with both operands being natural register pairs -- each half is the reference's own
-// fused multiply-add (VFMADD231PS, dot.s:24-27), in the reference's block order.  The slab's own layout (float
-// 4L + k) is turned into this one while staging.
-constexpr int kScanQB = 16;  // queries per block = 4 waves x kScanQ
+// LDS holds only the row tile, [64][32 nblk + 4] floats in the ORIGINAL element order (the slab's permuted rows are
+// turned back while staging; +16 B per row: lane r starts at bank 4r, so the lanes' ds_read_b128 never collide).
+// The queries are read where the caller left them (original layout) through the scalar cache: element pair
+// (32b + 2j, 32b + 2j + 1) of a query is one SGPR pair, of the lane's row one VGPR pair, and one v_pk_fma_f32
+// advances the reference's partial sums 2j and 2j + 1 of block b -- each half is the reference's own fused
+// multiply-add (VFMADD231PS, dot.s:24-27), blocks in the reference's order.  A wave takes the queries two at a
+// time (64 SGPRs of operands per block); kWaves waves per workgroup share the tile.
 typedef float f2v __attribute__((ext_vector_type(2)));
 template <bool L2>
 __device__ __forceinline__ f2v chain1_pk(f2v acc, f2v x, f2v y) {
@@ -210,82 +214,70 @@ __device__ __forceinline__ f2v chain1_pk(f2v acc, f2v x, f2v y) {
     return __builtin_elementwise_fma(x, y, acc);
   }
 }
-// slab float4 c of a row (c = 32 g + L: blocks 4g..4g+3 of partial sum L) -> its four floats' places in the pair layout
-__device__ __forceinline__ void scatter_pairs(float *dst_row, uint32_t c, const float4 &v) {
-  const uint32_t g = c >> 5, Lx = c & 31;
-  float *d = dst_row + g * 128 + (Lx >> 1) * 8 + (Lx & 1);
-  d[0] = v.x, d[2] = v.y, d[4] = v.z, d[6] = v.w;
-}
-template <bool L2, int NG>
-__global__ __launch_bounds__(256) void k_flat_scan(const float *__restrict__ slab, const float *__restrict__ qperm,
-                                                   const FlatScanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  constexpr uint32_t kStride = NG * 128 + 4;    // floats; +16 B: lane r -> banks 4r.. (no conflict)
-  constexpr uint32_t kRowF4 = NG * 32;          // float4 per row
-  constexpr uint32_t kQF4 = kScanQB * kRowF4;   // float4 per query block
-  constexpr int kPre = (kQF4 + 255) / 256;      // float4 a thread moves per block
-  float *tile = lds_f;
-  float *qbuf = lds_f + (size_t)kScanRows * kStride;  // [2][kScanQB][NG * 128]
+constexpr int kScanWaves = SDB_SCAN_WAVES;
+constexpr int kScanPairs = SDB_SCAN_PAIRS;
+template <bool L2>
+__global__ __launch_bounds__(kScanWaves * 64) void k_flat_scan(const float *__restrict__ slab,
+                                                               const float *__restrict__ queries,
+                                                               const FlatScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][kstride]
+  const uint32_t nblk = a.nblk, kstride = nblk * 32 + 4;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform, and the compiler may know it
   const uint32_t row0 = a.first + blockIdx.x * kScanRows;
   const uint32_t nrows = min(kScanRows, a.first + a.rows - row0);
-  const uint32_t nblocks = (a.nq + kScanQB - 1) / kScanQB;
-  const float4 *q4 = reinterpret_cast<const float4 *>(qperm);
-  const uint32_t q_f4 = a.nq * kRowF4;
-  auto fetch = [&](uint32_t blk, float4(&pre)[kPre]) {
-#pragma unroll
-    for (int j = 0; j < kPre; j++) {
-      uint32_t i = blk * kQF4 + (uint32_t)tid + 256u * j;
-      i = i < q_f4 ? i : q_f4 - 1;  // the last block's overhang: any valid address, never used
-      pre[j] = q4[i];
-    }
-  };
-  auto stash = [&](uint32_t buf, const float4(&pre)[kPre]) {
-#pragma unroll
-    for (int j = 0; j < kPre; j++) {
-      const uint32_t i = (uint32_t)tid + 256u * j;
-      if (i < kQF4) scatter_pairs(qbuf + ((size_t)buf * kScanQB + i / kRowF4) * NG * 128, i % kRowF4, pre[j]);
-    }
-  };
-  float4 pre[kPre];
-  fetch(0, pre);
-  // ---- stage the row tile: consecutive threads read consecutive 16 B of a row
-  for (uint32_t i = tid; i < kScanRows * kRowF4; i += 256) {
-    const uint32_t r = i / kRowF4, c = i % kRowF4;
+  // ---- stage the tile: consecutive threads read consecutive 16 B of a slab row; float4 c = 32 g + L of it holds
+  // blocks 4g..4g+3 of partial sum L, i.e. original elements 32 (4g + k) + L
+  const uint32_t row_f4 = a.ld / 4;
+  for (uint32_t i = tid; i < kScanRows * row_f4; i += kScanWaves * 64) {
+    const uint32_t r = i / row_f4, c = i % row_f4;
     const uint32_t rr = r < nrows ? r : nrows - 1;
-    scatter_pairs(tile + (size_t)r * kStride, c, reinterpret_cast<const float4 *>(slab + (size_t)(row0 + rr) * a.ld)[c]);
+    const float4 v = reinterpret_cast<const float4 *>(slab + (size_t)(row0 + rr) * a.ld)[c];
+    const uint32_t g = c >> 5, Lx = c & 31;
+    float *d = tile + (size_t)r * kstride + 128 * g + Lx;
+    if (4 * g + 0 < nblk) d[0] = v.x;
+    if (4 * g + 1 < nblk) d[32] = v.y;
+    if (4 * g + 2 < nblk) d[64] = v.z;
+    if (4 * g + 3 < nblk) d[96] = v.w;
   }
-  stash(0, pre);
   __syncthreads();
   const uint32_t slot = row0 + (uint32_t)lane;
   const bool live = (uint32_t)lane < nrows && slot != a.skip_slot && a.ids[(uint32_t)lane < nrows ? slot : row0] != 0;
-  const float4 *myrow = reinterpret_cast<const float4 *>(tile) + (size_t)lane * (kStride / 4);
-  for (uint32_t blk = 0; blk < nblocks; blk++) {
-    if (blk + 1 < nblocks) fetch(blk + 1, pre);  // in flight under the arithmetic below
-    const float4 *myq = reinterpret_cast<const float4 *>(qbuf) + ((size_t)(blk & 1) * kScanQB + (size_t)wave * kScanQ) * kRowF4;
-    f2v acc[kScanQ][16];  // [query][j]: partial sums 2j, 2j + 1
+  const float4 *myrow = reinterpret_cast<const float4 *>(tile + (size_t)lane * kstride);
+  // kScanPairs query pairs per pass: the lane's row block is read from LDS once and used for 2 * kScanPairs queries
+  const uint32_t ngroups = (a.nq + 2 * kScanPairs - 1) / (2 * kScanPairs);
+  for (uint32_t grp = (uint32_t)wave; grp < ngroups; grp += kScanWaves) {
+    const float *xq[2 * kScanPairs];
 #pragma unroll
-    for (int k = 0; k < kScanQ; k++)
+    for (int k = 0; k < 2 * kScanPairs; k++) {
+      const uint32_t q = grp * 2 * kScanPairs + k;
+      xq[k] = queries + (size_t)(q < a.nq ? q : a.nq - 1) * a.dim;  // past the end: the last query again, dropped
+    }
+    f2v acc[2 * kScanPairs][16];
+#pragma unroll
+    for (int k = 0; k < 2 * kScanPairs; k++)
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[k][j] = f2v{0.0f, 0.0f};
 #pragma unroll 1
-    for (int g = 0; g < NG; g++) {
+    for (uint32_t b = 0; b < nblk; b++) {
+      float4 y[8];
 #pragma unroll
-      for (int i = 0; i < 32; i++) {  // float4 i of the group: pair j = i / 2, blocks 2 (i % 2) and 2 (i % 2) + 1
-        const float4 y = myrow[g * 32 + i];
+      for (int i = 0; i < 8; i++) y[i] = myrow[b * 8 + i];
 #pragma unroll
-        for (int k = 0; k < kScanQ; k++) {
-          const float4 x = myq[k * kRowF4 + g * 32 + i];
-          f2v t = acc[k][i >> 1];
-          t = chain1_pk<L2>(t, f2v{x.x, x.y}, f2v{y.x, y.y});
-          t = chain1_pk<L2>(t, f2v{x.z, x.w}, f2v{y.z, y.w});
-          acc[k][i >> 1] = t;
+      for (int pp = 0; pp < kScanPairs; pp++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {  // float4 i of the block: pairs j = 2i, 2i + 1
+          const float4 u = reinterpret_cast<const float4 *>(xq[2 * pp] + b * 32)[i];  // wave-uniform: scalar loads
+          const float4 w = reinterpret_cast<const float4 *>(xq[2 * pp + 1] + b * 32)[i];
+          acc[2 * pp][2 * i] = chain1_pk<L2>(acc[2 * pp][2 * i], f2v{u.x, u.y}, f2v{y[i].x, y[i].y});
+          acc[2 * pp][2 * i + 1] = chain1_pk<L2>(acc[2 * pp][2 * i + 1], f2v{u.z, u.w}, f2v{y[i].z, y[i].w});
+          acc[2 * pp + 1][2 * i] = chain1_pk<L2>(acc[2 * pp + 1][2 * i], f2v{w.x, w.y}, f2v{y[i].x, y[i].y});
+          acc[2 * pp + 1][2 * i + 1] = chain1_pk<L2>(acc[2 * pp + 1][2 * i + 1], f2v{w.z, w.w}, f2v{y[i].z, y[i].w});
         }
       }
     }
 #pragma unroll
-    for (int k = 0; k < kScanQ; k++) {
+    for (int k = 0; k < 2 * kScanPairs; k++) {
       // the reduce tree of dot.s:45-53 / euclidean.s:55-63 over acc[L] = acc[k][L / 2][L % 2] (the tail vector
       // {t,0,0,0} is all zero here)
       auto A = [&](int L) { return acc[k][L >> 1][L & 1]; };
@@ -297,14 +289,12 @@ __global__ __launch_bounds__(256) void k_flat_scan(const float *__restrict__ sla
         r4[l] = (s0 + s1) + 0.0f;
       }
       const float dist = metric_finish((r4[0] + r4[1]) + (r4[2] + r4[3]), a.metric);
-      const uint32_t q = blk * kScanQB + (uint32_t)wave * kScanQ + k;
+      const uint32_t q = grp * 2 * kScanPairs + k;
       if (q < a.nq && live && !(dist > a.thr[q])) {  // rare: a handful per query and million rows
         const uint32_t at = atomicAdd(a.cnt + q, 1u);
         if (at < a.cap) a.cand[(size_t)q * a.cap + at] = make_uint2(slot, __float_as_uint(dist));
       }
     }
-    if (blk + 1 < nblocks) stash((blk + 1) & 1, pre);
-    __syncthreads();  // everybody is done with this block's buffer and the next one is complete
   }
 }
 
@@ -353,30 +343,17 @@ __global__ __launch_bounds__(64) void k_flat_merge(const uint32_t *__restrict__ 
   }
 }
 
-int permute_rows_to(const sdb_index *ix, const float *src, float *dst, uint32_t n, hipStream_t stream);
-
 template <bool L2>
-static int launch_flat_scan(const FlatScanArgs &a, uint32_t ng, hipStream_t stream) {
+static int launch_flat_scan(const FlatScanArgs &a, hipStream_t stream) {
   const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
-  const size_t lds = ((size_t)kScanRows * (ng * 128 + 4) + 2 * (size_t)kScanQB * ng * 128) * sizeof(float);
-#define SDB_SCAN_CASE(NGV)                                                                                      \
-  case NGV: {                                                                                                   \
-    static bool attr = false;                                                                                   \
-    if (!attr) {                                                                                                \
-      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan<L2, NGV>),                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                     \
-      attr = true;                                                                                              \
-    }                                                                                                           \
-    hipLaunchKernelGGL((k_flat_scan<L2, NGV>), grid, dim3(256), lds, stream, a.slab, a.qperm, a);               \
-    break;                                                                                                      \
+  const size_t lds = (size_t)kScanRows * (a.nblk * 32 + 4) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan<L2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr = true;
   }
-  switch (ng) {
-    SDB_SCAN_CASE(1)
-    SDB_SCAN_CASE(2)
-    SDB_SCAN_CASE(3)
-    default: return fail(SDB_ERR_INVALID, "no streaming scan for %u row groups", ng);
-  }
-#undef SDB_SCAN_CASE
+  hipLaunchKernelGGL((k_flat_scan<L2>), grid, dim3(kScanWaves * 64), lds, stream, a.slab, a.queries, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }
@@ -423,7 +400,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   // ---- buffers: staged queries/outputs for host callers, running top lists, one distance block
   uint32_t chunk = filtered ? std::max<uint32_t>(max_f, 1)
                             : (uint32_t)std::min<uint64_t>(std::max<uint32_t>(n, 1), (1ull << 28) / nq);
-  if (!filtered && !ix->pq && ix->lay.tail == 0 && ix->lay.ng >= 1 && ix->lay.ng <= 3 && n >= 4 * 8192 && nq <= 8192)
+  if (!filtered && !ix->pq && ix->lay.tail == 0 && ix->lay.nblk >= 1 && ix->lay.nblk <= 19 && n >= 4 * 8192 && nq <= 8192)
     chunk = std::min<uint32_t>(chunk, 8192);  // with the streaming scan the block path only sees the seed rows
   const uint32_t stride = (chunk + 63) & ~63u;
   size_t off = 0;
@@ -443,8 +420,8 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   // the streaming scan (k_flat_scan): plain store, no filter, rows of whole 32-float blocks up to 512 floats, a
   // table worth streaming.  Its first rows still go through the block path below: they seed the thresholds.
   constexpr uint32_t kSeedRows = 8192, kCandCap = 8192;
-  const bool fast = !filtered && !pq && l.tail == 0 && l.ng >= 1 && l.ng <= 3 && n >= 4 * kSeedRows && nq <= 8192;
-  const size_t o_qp = carve(fast ? (size_t)nq * l.ld * 4 : 0), o_thr = carve(fast ? nq * 4 : 0);
+  const bool fast = !filtered && !pq && l.tail == 0 && l.nblk >= 1 && l.nblk <= 19 && n >= 4 * kSeedRows && nq <= 8192;
+  const size_t o_thr = carve(fast ? nq * 4 : 0);
   const size_t o_cnt = carve(fast ? nq * 4 + 256 : 0), o_cand = carve(fast ? (size_t)nq * kCandCap * 8 : 0);
   char *buf = nullptr;
   SDB_HIP(hipMalloc(&buf, off));
@@ -515,7 +492,6 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     float *d_thr = (float *)(buf + o_thr);
     uint32_t *d_cnt = (uint32_t *)(buf + o_cnt), *d_over = d_cnt + nq;
     uint2 *d_cand = (uint2 *)(buf + o_cand);
-    SDB_TRY(permute_rows_to(ix, dq, (float *)(buf + o_qp), (uint32_t)nq, stream));
     SDB_HIP(hipMemsetAsync(d_cnt, 0, nq * 4 + 4, stream));
     const size_t merge_lds = (size_t)(128 + kCandCap) * sizeof(uint2);
     static bool merge_attr = false;
@@ -528,17 +504,17 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(64), merge_lds, stream, d_cnt, d_cand, kCandCap, limit, top_slot,
                        top_dist, top_len, d_thr, d_over);
     SDB_HIP(hipGetLastError());
-    // segments sized so that a query expects far fewer than kCandCap candidates: a row passes with probability
-    // ~ limit / rows-scanned-so-far
-    const uint32_t seg = (uint32_t)std::max<uint64_t>(65536, (uint64_t)seed * kCandCap / ((uint64_t)limit * 8));
-    for (uint32_t first = seed; first < n; first += seg) {
+    // A row passes its query's threshold with probability ~ limit / rows-scanned-so-far, so a segment as long as
+    // everything before it brings about `limit` candidates per query: segments double (8 launches for 1M rows),
+    // the candidate lists stay two orders of magnitude under kCandCap and the merges cost nothing
+    for (uint32_t first = seed, seg = seed; first < n; first += seg, seg = first) {
       FlatScanArgs sa{};
-      sa.slab = ix->d_slab, sa.qperm = (const float *)(buf + o_qp), sa.ids = vw.ids, sa.thr = d_thr, sa.cnt = d_cnt;
+      sa.slab = ix->d_slab, sa.queries = dq, sa.ids = vw.ids, sa.thr = d_thr, sa.cnt = d_cnt;
       sa.cand = d_cand, sa.cap = kCandCap, sa.first = first, sa.rows = std::min<uint32_t>(seg, n - first);
-      sa.nq = (uint32_t)nq, sa.ld = l.ld, sa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
+      sa.nq = (uint32_t)nq, sa.ld = l.ld, sa.dim = l.dim, sa.nblk = l.nblk, sa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
       sa.metric = (int)ix->P.metric;
-      if (ix->P.metric == SDB_METRIC_EUCLIDEAN) SDB_TRY(launch_flat_scan<true>(sa, l.ng, stream));
-      else SDB_TRY(launch_flat_scan<false>(sa, l.ng, stream));
+      if (ix->P.metric == SDB_METRIC_EUCLIDEAN) SDB_TRY(launch_flat_scan<true>(sa, stream));
+      else SDB_TRY(launch_flat_scan<false>(sa, stream));
       hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(64), merge_lds, stream, d_cnt, d_cand, kCandCap, limit,
                          top_slot, top_dist, top_len, d_thr, d_over);
       SDB_HIP(hipGetLastError());

@@ -1041,14 +1041,6 @@ int store_rows_public(sdb_index *ix, uint32_t first, uint32_t n, const float *de
 }  // namespace sdb
 
 namespace sdb {
-// original-layout rows (device) -> the slab's permuted row layout, into any device buffer
-int permute_rows_to(const sdb_index *ix, const float *src, float *dst, uint32_t n, hipStream_t stream) {
-  if (n == 0) return SDB_OK;
-  const RowLayout &l = ix->lay;
-  hipLaunchKernelGGL(k_permute_rows, dim3(n), dim3(128), 0, stream, src, dst, n, l.dim, l.nblk, l.ng, l.tail, l.ld);
-  SDB_HIP(hipGetLastError());
-  return SDB_OK;
-}
 int unpermute_rows_public(const sdb_index *ix, uint32_t first, uint32_t n, float *dst, hipStream_t stream) {
   if (n == 0) return SDB_OK;
   const RowLayout &l = ix->lay;
