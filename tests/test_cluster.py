@@ -154,3 +154,28 @@ def test_topk_merge_with_repeated_items(oracle):
         assert int(o_c[q]) == len(w_ids) == limit
         assert np.array_equal(o_ids[q], w_ids) and np.array_equal(o_d[q], w_d)
         assert np.array_equal(o_s[q].astype(np.int32), w_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["shards", "replicas"])
+def test_bench_two_ranks_over_gloo(mode, tmp_path):
+    """bench.py --gpus 2 end to end with two ranks sharing this GPU (BENCH_BACKEND=gloo; RCCL refuses two ranks on
+    one device): the N > 1 modes of SURVEY 8e produce a valid line whose merged answers recall the exact top-k of
+    the whole database, and `value` is the user-visible rate, not a per-shard sum."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--rows", "120000", "--mode", mode, "--recall-batches", "3", "--timed-batches", "4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["mode"] == mode
+    assert j["config"]["recall_at_10"] >= 0.95 and "invalid" not in j
+    assert abs(j["value"] - 1024 * j["steps"] / (j["ms_per_step"] * j["steps"] * 1e-3)) / j["value"] < 1e-3
+    if mode == "shards":
+        assert j["config"]["per_shard_walk_qps"] == pytest.approx(2 * j["value"], rel=1e-3)
