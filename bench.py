@@ -144,9 +144,23 @@ class Exchange:
         self.cluster, self.dist, self.dev, self.dev_index = cluster, dist, dev, dev_index
         self.world = dist.get_world_size()
         self.native = backend == "nccl"
+        self.note = None
         if self.native:
-            self.cl = cluster.Cluster.from_torch_distributed(dev_index)
-        else:
+            # every rank must end up on the same transport: agree on whether the library's communicator came up
+            ok = 1
+            try:
+                self.cl = cluster.Cluster.from_torch_distributed(dev_index)
+            except Exception as e:  # e.g. an RCCL that refuses the bootstrap: measure over torch's RCCL instead, and say so
+                ok, self.note = 0, "sdb_cluster_create failed on rank %d: %r" % (dist.get_rank(), e)
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if ok:
+                    self.cl.close()
+                self.native = False
+                self.note = self.note or "sdb_cluster_create failed on another rank"
+                log("exchange falls back to torch.distributed all_gather_into_tensor:", self.note)
+        if not self.native:
             self.stream = torch.cuda.Stream(device=dev)
 
     def search(self, ix, q, k, L):
@@ -462,6 +476,10 @@ def run_c2(a, ctx):
         },
         "build_roofline": broof,
     }
+    if ex is not None and world > 1 and not split:
+        result["config"]["exchange"] = ("libsemadb_amd.so: sdb_cluster_search_batch (ncclAllGather on the library's stream)"
+                                        if ex.native else "torch.distributed all_gather_into_tensor (%s) + sdb_topk_merge%s" %
+                                        (ctx["backend"], "; " + ex.note if ex.note else ""))
     if recall < 0.95:  # the metric is recall-gated: a line below the gate is not a measurement of it
         result["invalid"] = "recall@10 %.4f is below the metric's 0.95 gate" % recall
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

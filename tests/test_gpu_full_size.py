@@ -358,3 +358,53 @@ def test_c4_quantized_search(c4, oracle):
         assert np.array_equal(bits(want), bits(d[i])), "query %d" % i
     # the quantized walk does far fewer HBM bytes per query than the full-precision one, on the same graph
     assert nd.mean() * c4.M < 0.05 * c4.full[3].mean() * c4.d * 4
+
+
+C5_ROWS = int(os.environ.get("SDB_TEST_C5_ROWS", 12_500_000))
+
+
+def test_c5_one_rank_at_size():
+    """BASELINE configs[4] is 8 shards x 12.5M x 384, one per MI355X; a 1-GPU box holds one of them.  One rank's shard
+    at full size (19.2 GB slab; seed 20250620 + rank): built on the device, graph invariants checked where
+    the graph lies (degree bound, no dangling / self edges: export without vectors), 1 024 queries: rows sorted, ids
+    unique, every returned distance bit-equal to K1's recomputation from the stored row, recall@10 >= 0.95 against the
+    exact scan of the same 12.5M rows (k_flat_scan), per-shard limit of the 8-shard cluster rule applied."""
+    import torch
+    from semadb_amd import cluster, flat, vamana
+    bench = _bench()
+    rank, d, n = 3, 384, C5_ROWS
+    base = bench.gen_rows(n, d, 20250620 + rank, "latent:24", "cuda:0")
+    queries = bench.gen_rows(1024, d, 20250621, "latent:24", "cuda:0")
+    ix = vamana.NewIndexVamana("c5", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), capacity=n + 1)
+    ix.set_start(bench.start_vector(d))
+    ix.insert_batch(None, base)
+    torch.cuda.synchronize()
+    del base
+    torch.cuda.empty_cache()
+    nn, ne, mx = ix.stats()
+    assert nn == n + 1 and mx == n + 1 and ne / nn > 0.9 * R
+    ids, _, off, edges = ix.export(with_vectors=False)
+    deg = np.diff(off.astype(np.int64))
+    assert deg.min() >= 1 and deg.max() <= R and int(edges.min()) >= 1 and int(edges.max()) <= n + 1
+    src = np.repeat(np.arange(n + 1, dtype=np.int64), deg)
+    assert not (src == edges.astype(np.int64) - 1).any(), "self loop"
+    del ids, off, edges, src, deg
+    per_shard = cluster.shard_limit(K, 8)  # actions.go:291-299 for the 8-shard collection
+    g_ids, g_d, g_c, _ = ix.search_batch(queries, per_shard, L)
+    f_ids, f_d, f_c = flat.flat_search_batch(ix._h, d, queries, per_shard)
+    torch.cuda.synchronize()
+    gi, gd = g_ids.cpu().numpy().view(np.uint64), g_d.cpu().numpy()
+    assert (g_c.cpu().numpy() == per_shard).all()
+    assert (np.diff(gd, axis=1) >= 0).all(), "rows not sorted by distance"
+    assert all(len(set(row)) == per_shard for row in gi[:128])
+    hits = (g_ids.to(torch.int64).unsqueeze(2) == f_ids.to(torch.int64).unsqueeze(1)).any(2).float().mean().item()
+    assert hits >= 0.95, hits
+    # every returned distance is what K1 computes from the stored row (bit for bit)
+    k1 = ix.distance_batch(queries[:64], gi[:64])
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(k1.cpu().numpy()), bits(gd[:64]))
+    # and the exact scan's own distances likewise
+    k1f = ix.distance_batch(queries[:64], f_ids[:64].cpu().numpy().view(np.uint64))
+    assert np.array_equal(bits(k1f.cpu().numpy()), bits(f_d[:64].cpu().numpy()))
+    ix.close()
+    torch.cuda.empty_cache()
