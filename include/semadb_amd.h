@@ -248,6 +248,12 @@ int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids, const 
 int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes);
 /* number of nodes (start node included) / edges */
 int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id);
+/* Storage rows: in use (live nodes + tombstones of deleted / updated points) and of those dead.  A deleted point's
+ * row stays behind as a tombstone (id 0, no edges, unreachable) and inserts always append, so under an update-heavy
+ * load `rows` grows until the host rebuilds the index from the bucket (what a SemaDB cache eviction + reload does
+ * anyway: shard/cache/manager.go evicts whole shards); per-search cost depends on live nodes only, except for the
+ * bitset fallback's clear, which is sized by `rows`.  Rebuild when dead / rows passes a threshold of your choosing. */
+int sdb_index_row_usage(const sdb_index *ix, uint64_t *rows, uint64_t *dead);
 /* Copy the graph back out in bucket order (what flush() writes, vamana.go:265-276): ids[n],
  * vectors[n*dim] (NULL to skip), offsets[n+1], edges[n_edges] as node ids.  Host memory. */
 int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets,

@@ -978,6 +978,13 @@ int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, u
   return SDB_OK;
 }
 
+int sdb_index_row_usage(const sdb_index *ix, uint64_t *rows, uint64_t *dead) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (rows) *rows = ix->n;
+  if (dead) *dead = ix->n_dead;
+  return SDB_OK;
+}
+
 int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets, uint64_t *edges) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");

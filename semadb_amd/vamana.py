@@ -145,6 +145,12 @@ class IndexVamana:
             check(lib().sdb_index_exists_batch(self._h, ids_a.size, _buf.np_ptr(ids_a), _buf.np_ptr(out)))
         return out.astype(bool)
 
+    def row_usage(self):
+        """(storage rows in use, of which tombstones) -- sdb_index_row_usage"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().sdb_index_row_usage(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_profiling(self, enabled=True):
         check(lib().sdb_index_set_profiling(self._h, 1 if enabled else 0))
 

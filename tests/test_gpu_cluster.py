@@ -100,6 +100,7 @@ def test_exists_batch_tuning_and_build_stats():
     assert e.tolist() == [True, True, True, False, False, False]
     ix.delete_batch(np.array([2], dtype=np.uint64))
     assert ix.exists_batch([2, 3]).tolist() == [False, True] and not ix.exists(2)
+    assert ix.row_usage() == (1501, 1) and ix.stats()[0] == 1500  # the tombstone still occupies a row
     st = ix.build_stats()
     assert st["rounds"] > 0 and st["search_n_dist"] > 1500 and st["prune_pairs"] > 0
     assert st["requests"] > 0 and st["requests"] >= st["appends"]
