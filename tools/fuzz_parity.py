@@ -113,6 +113,9 @@ def explain(g, o, tag):
 
 def check_graph(g, o):
     assert_same_graph(g, o)
+    # outside a transaction the committed copy and the writer's copy of the graph are the same rows: a write path
+    # that forgot to flag a row it changed shows up here
+    assert g.version_diff() == 0, "graph versions differ after a committed write"
 
 
 def trial(rng, t):
