@@ -217,6 +217,12 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
 #define SDB_BUILD_STATS 11
 int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap);
 
+/* vecStore.GetMany (shard/vectorstore/plain.go:26-45 over ItemCache.GetMany, shard/cache/itemcache.go:109-128):
+ * the stored float32 vectors of n ids, in request order, out[i * dim ..]; found[i] = 0 (and a zero row) for an id
+ * that is not stored -- the reference silently skips those, the flag lets the caller do the same.  Get = n of 1;
+ * ForEach = sdb_index_export.  Committed state, like a search.  out / found are host memory. */
+int sdb_index_get_vectors(const sdb_index *ix, uint64_t n, const uint64_t *ids, float *out, uint8_t *found);
+
 /* vecStore.Exists (shard/vectorstore/plain.go:21-24) for n ids at once: out[i] = 1 if the id is stored
  * (the start node counts), else 0.  Host-side table lookup, no device work. */
 int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *out);
@@ -252,8 +258,14 @@ int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, u
  * row stays behind as a tombstone (id 0, no edges, unreachable) and inserts always append, so under an update-heavy
  * load `rows` grows until the host rebuilds the index from the bucket (what a SemaDB cache eviction + reload does
  * anyway: shard/cache/manager.go evicts whole shards); per-search cost depends on live nodes only, except for the
- * bitset fallback's clear, which is sized by `rows`.  Rebuild when dead / rows passes a threshold of your choosing. */
+ * bitset fallback's clear, which is sized by `rows`.  sdb_index_compact squeezes the tombstones out. */
 int sdb_index_row_usage(const sdb_index *ix, uint64_t *rows, uint64_t *dead);
+/* Drop the tombstones: the live rows move down in storage order (so everything that depends on storage order --
+ * the exact scan's tie rule, straggler re-attachment -- is unchanged), adjacency is renumbered, ids, graph and every
+ * later answer stay what they were.  The reference frees deleted nodes when it flushes (node.go:129-134); call
+ * this from the same place when dead / rows is worth it.  A maintenance call: no write transaction open; searches
+ * wait for it (tens of milliseconds per million rows).  Needs room for a second copy of the index while it runs. */
+int sdb_index_compact(sdb_index *ix);
 /* Copy the graph back out in bucket order (what flush() writes, vamana.go:265-276): ids[n],
  * vectors[n*dim] (NULL to skip), offsets[n+1], edges[n_edges] as node ids.  Host memory. */
 int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets,

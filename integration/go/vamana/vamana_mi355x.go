@@ -162,6 +162,27 @@ func (v *IndexVamana) exists(ids []uint64) []bool {
 	return out
 }
 
+// getMany: vecStore.GetMany (plain.go:26-45) -- stored vectors of ids in request order, missing ids skipped
+func (v *IndexVamana) getMany(ids []uint64) [][]float32 {
+	if len(ids) == 0 {
+		return nil
+	}
+	d := int(v.parameters.VectorSize)
+	flat := make([]float32, len(ids)*d)
+	found := make([]C.uint8_t, len(ids))
+	if rc := C.sdb_index_get_vectors(v.h, C.uint64_t(len(ids)), (*C.uint64_t)(unsafe.Pointer(&ids[0])),
+		(*C.float)(unsafe.Pointer(&flat[0])), &found[0]); rc != C.SDB_OK {
+		return nil
+	}
+	out := make([][]float32, 0, len(ids))
+	for i := range ids {
+		if found[i] != 0 {
+			out = append(out, flat[i*d:(i+1)*d])
+		}
+	}
+	return out
+}
+
 // Search has the reference's signature (vamana.go:278).  Concurrent callers -- one goroutine per request,
 // shard/cache/manager.go:163 -- are coalesced into device batches by the batcher.
 func (v *IndexVamana) Search(ctx context.Context, q models.SearchVectorVamanaOptions, filter *roaring64.Bitmap) (*roaring64.Bitmap, []models.SearchResult, error) {

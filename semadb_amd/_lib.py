@@ -58,6 +58,7 @@ SIGNATURES = {
                                            C.c_int, C.c_void_p]),
     "sdb_index_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     "sdb_index_build_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "sdb_index_get_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdb_index_exists_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "sdb_index_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "sdb_index_last_search_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "sdb_index_set_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     "sdb_index_size_in_memory": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "sdb_index_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "sdb_index_compact": (C.c_int, [C.c_void_p]),
     "sdb_index_row_usage": (C.c_int, [C.c_void_p, u64p, u64p]),
     "sdb_index_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdb_topk_merge": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,

@@ -115,6 +115,46 @@ __global__ void k_unpermute_rows(const float *__restrict__ src, float *__restric
   }
 }
 
+// slab rows by slot list -> original-layout rows (kNoSlot: a zero row)
+__global__ void k_gather_rows(const float *__restrict__ slab, const uint32_t *__restrict__ slots, float *__restrict__ dst,
+                              uint32_t n, uint32_t dim, uint32_t nblk, uint32_t ng, uint32_t ld) {
+  const uint32_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint32_t slot = slots[i];
+  const float *s = slab + (size_t)slot * ld;
+  float *d = dst + (size_t)i * dim;
+  for (uint32_t e = threadIdx.x; e < dim; e += blockDim.x) {
+    const uint32_t b = e / 32, Lx = e % 32;
+    d[e] = slot == kNoSlot ? 0.0f : (b < nblk ? s[(b / 4) * 128 + Lx * 4 + (b % 4)] : s[ng * 128 + Lx]);
+  }
+}
+
+// sdb_index_compact: new row j <- old row live[j], adjacency renumbered through map[]
+__global__ __launch_bounds__(64) void k_compact_rows(const uint32_t *__restrict__ live, const uint32_t *__restrict__ map,
+                                                     uint32_t ld, const float *__restrict__ slab, float *__restrict__ nslab,
+                                                     const uint32_t *__restrict__ adj, uint32_t *__restrict__ nadj,
+                                                     const float *__restrict__ adjdist, float *__restrict__ nadjdist,
+                                                     const uint32_t *__restrict__ deg, uint32_t *__restrict__ ndeg,
+                                                     const uint32_t *__restrict__ clean, uint32_t *__restrict__ nclean,
+                                                     const uint32_t *__restrict__ dcount, uint32_t *__restrict__ ndcount,
+                                                     const uint64_t *__restrict__ ids, uint64_t *__restrict__ nids,
+                                                     const uint8_t *__restrict__ codes, uint8_t *__restrict__ ncodes,
+                                                     uint32_t M, uint32_t *__restrict__ lost) {
+  const uint32_t j = blockIdx.x, s = live[j];
+  const int lane = threadIdx.x;
+  const float4 *src = reinterpret_cast<const float4 *>(slab + (size_t)s * ld);
+  float4 *dst = reinterpret_cast<float4 *>(nslab + (size_t)j * ld);
+  for (uint32_t i = lane; i < ld / 4; i += 64) dst[i] = src[i];
+  const uint32_t e = adj[(size_t)s * kAdjStride + lane];
+  const uint32_t ne = e == kNoSlot ? kNoSlot : map[e];
+  if (e != kNoSlot && ne == kNoSlot) atomicAdd(lost, 1u);  // an edge into a tombstone: delete_batch never leaves one
+  nadj[(size_t)j * kAdjStride + lane] = ne;
+  nadjdist[(size_t)j * kAdjStride + lane] = adjdist[(size_t)s * kAdjStride + lane];
+  if (lane == 0) ndeg[j] = deg[s], nclean[j] = clean[s], ndcount[j] = dcount[s], nids[j] = ids[s];
+  if (codes)
+    for (uint32_t i = lane; i < M; i += 64) ncodes[(size_t)j * M + i] = codes[(size_t)s * M + i];
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -904,6 +944,40 @@ int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) {
   return SDB_OK;
 }
 
+int sdb_index_get_vectors(const sdb_index *ix, uint64_t n, const uint64_t *ids, float *out, uint8_t *found) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (n == 0) return SDB_OK;
+  if (!ids || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (n > 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many ids");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
+  DeviceGuard dg(ix->P.device);
+  const RowLayout &l = ix->lay;
+  std::vector<uint32_t> slots(n);
+  {
+    std::shared_lock<std::shared_mutex> rl(ix->view_mu);  // the committed id tables
+    for (uint64_t i = 0; i < n; i++) {
+      const int64_t s = ix->slot_of_committed(ids[i], ix->view.n);
+      slots[i] = s < 0 ? kNoSlot : (uint32_t)s;
+      if (found) found[i] = s < 0 ? 0 : 1;
+    }
+  }
+  uint32_t *d_slots = nullptr;
+  float *d_out = nullptr;
+  SDB_HIP(hipMalloc(&d_slots, n * 4));
+  hipError_t e = hipMalloc(&d_out, n * l.dim * 4);
+  if (e == hipSuccess) e = hipMemcpy(d_slots, slots.data(), n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {  // slab rows are immutable once written: no version to pick
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(128), 0, nullptr, ix->d_slab, d_slots, d_out, (uint32_t)n,
+                       l.dim, l.nblk, l.ng, l.ld);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, n * l.dim * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_slots);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "get_vectors failed: %s", hipGetErrorString(e));
+  return SDB_OK;
+}
+
 int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *out) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
@@ -982,6 +1056,114 @@ int sdb_index_row_usage(const sdb_index *ix, uint64_t *rows, uint64_t *dead) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (rows) *rows = ix->n;
   if (dead) *dead = ix->n_dead;
+  return SDB_OK;
+}
+
+int sdb_index_compact(sdb_index *ix) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
+  if (ix->in_tx) return fail(SDB_ERR_STATE, "a write transaction is open");
+  if (ix->n_dead == 0) return SDB_OK;
+  DeviceGuard dg(ix->P.device);
+  std::unique_lock<std::shared_mutex> wl(ix->view_mu);  // searches wait: every buffer they read is replaced
+  SDB_HIP(hipDeviceSynchronize());
+  const uint32_t n = ix->n, cap = ix->cap, ld = ix->lay.ld;
+  const uint32_t M = ix->pq ? ix->pq->M : 0;
+  std::vector<uint32_t> map(n, kNoSlot), live;
+  live.reserve(n - ix->n_dead);
+  for (uint32_t s = 0; s < n; s++)
+    if (ix->h_ids[s] != 0) map[s] = (uint32_t)live.size(), live.push_back(s);
+  const uint32_t nn = (uint32_t)live.size();
+  // ---- every allocation first: a failure leaves the index as it was
+  struct Bufs {
+    std::vector<void *> p;
+    bool keep = false;
+    ~Bufs() {
+      if (!keep)
+        for (void *x : p)
+          if (x) (void)hipFree(x);
+    }
+    int get(void **out, size_t bytes) {
+      SDB_HIP(hipMalloc(out, bytes));
+      p.push_back(*out);
+      return SDB_OK;
+    }
+  } nb, tmp;
+  float *nslab = nullptr, *nad = nullptr;
+  uint32_t *nadj = nullptr, *nradj = nullptr, *ndeg = nullptr, *nclean = nullptr, *ndc = nullptr;
+  uint64_t *nids = nullptr, *nrids = nullptr;
+  uint8_t *ncodes = nullptr;
+  uint32_t *d_live = nullptr, *d_map = nullptr, *d_lost = nullptr;
+  SDB_TRY(nb.get((void **)&nslab, (size_t)cap * ld * 4));
+  SDB_TRY(nb.get((void **)&nadj, (size_t)cap * kAdjStride * 4));
+  SDB_TRY(nb.get((void **)&nradj, (size_t)cap * kAdjStride * 4));
+  SDB_TRY(nb.get((void **)&nad, (size_t)cap * kAdjStride * 4));
+  SDB_TRY(nb.get((void **)&ndeg, (size_t)cap * 4));
+  SDB_TRY(nb.get((void **)&nclean, (size_t)cap * 4));
+  SDB_TRY(nb.get((void **)&ndc, (size_t)cap * 4));
+  SDB_TRY(nb.get((void **)&nids, (size_t)cap * 8));
+  SDB_TRY(nb.get((void **)&nrids, (size_t)cap * 8));
+  if (M) SDB_TRY(nb.get((void **)&ncodes, (size_t)cap * M));
+  SDB_TRY(tmp.get((void **)&d_live, (size_t)nn * 4 + 4));
+  SDB_TRY(tmp.get((void **)&d_map, (size_t)n * 4));
+  SDB_TRY(tmp.get((void **)&d_lost, 4));
+  SDB_HIP(hipMemcpy(d_live, live.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+  SDB_HIP(hipMemcpy(d_map, map.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  SDB_HIP(hipMemset(d_lost, 0, 4));
+  SDB_HIP(hipMemset(nadj, 0xFF, (size_t)cap * kAdjStride * 4));
+  SDB_HIP(hipMemset(ndeg, 0, (size_t)cap * 4));
+  SDB_HIP(hipMemset(nclean, 0, (size_t)cap * 4));
+  SDB_HIP(hipMemset(ndc, 0, (size_t)cap * 4));
+  hipLaunchKernelGGL(k_compact_rows, dim3(nn), dim3(64), 0, nullptr, d_live, d_map, ld, ix->d_slab, nslab, ix->d_adj, nadj,
+                     ix->d_adjdist, nad, ix->d_deg, ndeg, ix->d_clean, nclean, ix->d_dcount, ndc, ix->d_ids, nids,
+                     ix->d_codes, ncodes, M, d_lost);
+  SDB_HIP(hipGetLastError());
+  SDB_HIP(hipMemcpy(nradj, nadj, (size_t)cap * kAdjStride * 4, hipMemcpyDeviceToDevice));
+  SDB_HIP(hipMemcpy(nrids, nids, (size_t)nn * 8, hipMemcpyDeviceToDevice));
+  uint32_t lost = 0;
+  SDB_HIP(hipMemcpy(&lost, d_lost, 4, hipMemcpyDeviceToHost));
+  if (lost) return fail(SDB_ERR_STATE, "%u edges point at deleted rows: the graph is inconsistent, nothing was changed", lost);
+  // ---- swap in (nothing below can fail)
+  for (void *x : {(void *)ix->d_slab, (void *)ix->d_adj, (void *)ix->r_adj, (void *)ix->d_adjdist, (void *)ix->d_deg,
+                  (void *)ix->d_clean, (void *)ix->d_dcount, (void *)ix->d_ids, (void *)ix->r_ids})
+    (void)hipFree(x);
+  if (M) (void)hipFree(ix->d_codes);
+  nb.keep = true;
+  ix->d_slab = nslab, ix->d_adj = nadj, ix->r_adj = nradj, ix->d_adjdist = nad, ix->d_deg = ndeg, ix->d_clean = nclean;
+  ix->d_dcount = ndc, ix->d_ids = nids, ix->r_ids = nrids;
+  if (M) ix->d_codes = ncodes;
+  (void)hipMemset(ix->d_dirty, 0, cap);
+  std::vector<uint64_t> h(nn);
+  bool dense = true;
+  for (uint32_t j = 0; j < nn; j++) {
+    h[j] = ix->h_ids[live[j]];
+    if (j && h[j] != h[0] + j) dense = false;
+  }
+  ix->h_ids.swap(h);
+  ix->id2slot.clear();
+  ix->dense_ids = dense;
+  if (!dense) {
+    ix->id2slot.reserve((size_t)nn * 2);
+    for (uint32_t j = 0; j < nn; j++) ix->id2slot.emplace(ix->h_ids[j], j);
+  }
+  ix->start_slot = (int64_t)map[(uint32_t)ix->start_slot];
+  for (auto &t : ix->h_start_ext) t = map[t];
+  ix->n = nn, ix->n_dead = 0;
+  const uint32_t need = (uint32_t)((ix->h_start_ext.size() + 63) / 64 * 64);
+  if (need) {  // both copies of the overflow list, renumbered
+    std::vector<uint32_t> padded(need, kNoSlot);
+    std::copy(ix->h_start_ext.begin(), ix->h_start_ext.end(), padded.begin());
+    (void)hipMemcpy(ix->d_start_ext, padded.data(), (size_t)need * 4, hipMemcpyHostToDevice);
+    if (need > ix->r_start_ext_cap) {
+      if (ix->r_start_ext) (void)hipFree(ix->r_start_ext);
+      ix->r_start_ext = nullptr, ix->r_start_ext_cap = 0;
+      if (hipMalloc(&ix->r_start_ext, (size_t)need * 2 * 4) == hipSuccess) ix->r_start_ext_cap = need * 2;
+    }
+    if (ix->r_start_ext) (void)hipMemcpy(ix->r_start_ext, padded.data(), (size_t)need * 4, hipMemcpyHostToDevice);
+  }
+  ix->view.n = nn, ix->view.adj = ix->r_adj, ix->view.ids = ix->r_ids, ix->view.start_ext = ix->r_start_ext;
+  ix->view.start_ext_n = (uint32_t)ix->h_start_ext.size();
+  (void)hipDeviceSynchronize();
   return SDB_OK;
 }
 

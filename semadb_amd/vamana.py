@@ -137,6 +137,15 @@ class IndexVamana:
         check(lib().sdb_index_build_stats(self._h, _buf.np_ptr(out), out.size))
         return dict(zip(self.BUILD_STATS, (int(v) for v in out)))
 
+    def GetMany(self, ids):
+        """vecStore.GetMany (plain.go:26-45): (vectors of the ids that are stored, in request order; found mask)"""
+        ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
+        out = np.zeros((ids_a.size, self.parameters.VectorSize), dtype=np.float32)
+        found = np.zeros(ids_a.size, dtype=np.uint8)
+        if ids_a.size:
+            check(lib().sdb_index_get_vectors(self._h, ids_a.size, _buf.np_ptr(ids_a), _buf.np_ptr(out), _buf.np_ptr(found)))
+        return out[found.astype(bool)], found.astype(bool)
+
     def exists_batch(self, ids):
         """vecStore.Exists (plain.go:21-24) for many ids: host-side table lookup, no device work"""
         ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
@@ -150,6 +159,10 @@ class IndexVamana:
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(lib().sdb_index_row_usage(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def compact(self):
+        """drop the tombstones of deleted / updated points (sdb_index_compact); ids, graph and answers are unchanged"""
+        check(lib().sdb_index_compact(self._h))
 
     def set_profiling(self, enabled=True):
         check(lib().sdb_index_set_profiling(self._h, 1 if enabled else 0))

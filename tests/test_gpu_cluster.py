@@ -101,6 +101,13 @@ def test_exists_batch_tuning_and_build_stats():
     ix.delete_batch(np.array([2], dtype=np.uint64))
     assert ix.exists_batch([2, 3]).tolist() == [False, True] and not ix.exists(2)
     assert ix.row_usage() == (1501, 1) and ix.stats()[0] == 1500  # the tombstone still occupies a row
+    # GetMany (plain.go:26-45): request order, missing ids skipped, bit-exact rows; d = 48 has a tail chain region
+    want_ids = [7, 10 ** 9, 3, 1500, 2, 1]
+    vecs, found = ix.GetMany(want_ids)
+    assert found.tolist() == [True, False, True, True, False, True] and vecs.shape == (4, 48)
+    assert np.array_equal(vecs[0].view(np.uint32), base[7 - 2].view(np.uint32))
+    assert np.array_equal(vecs[1].view(np.uint32), base[3 - 2].view(np.uint32))
+    assert np.array_equal(vecs[2].view(np.uint32), base[1500 - 2].view(np.uint32))
     st = ix.build_stats()
     assert st["rounds"] > 0 and st["search_n_dist"] > 1500 and st["prune_pairs"] > 0
     assert st["requests"] > 0 and st["requests"] >= st["appends"]

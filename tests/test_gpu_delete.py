@@ -404,3 +404,51 @@ def test_edge_scan_matches_the_reference_rule(oracle):
     w_tp, w_ts = oracle.edge_scan(ids, off, edges, dele2)
     assert sorted(int(v) for v in tp) == w_tp and sorted(int(v) for v in ts) == w_ts
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d", [("cosine", 48), ("euclidean", 33)])
+def test_compact_changes_nothing_but_the_rows(oracle, metric, d):
+    """sdb_index_compact squeezes the tombstones out (the reference frees deleted nodes at flush, node.go:129-134):
+    the exported graph, every search (ids, distance bits, visit order, counters) and everything the write path
+    remembers per row are as before -- later inserts and deletes still build the oracle's graph edge for edge."""
+    from semadb_amd import vamana
+    from tests.helpers import assert_same_graph, build_oracle_index
+    rng = np.random.default_rng(d * 3)
+    n, R, L = 1800, 16, 40
+    base = unit_rows(rng, n + 600, d)
+    o = build_oracle_index(oracle, base[:n], metric, R=R, L=L, seed=9)
+    ix = vamana.NewIndexVamana("cp", vamana.IndexVectorVamanaParameters(d, metric, L, R, 1.2), strict=False)
+    ix.set_start(start_vector(np.random.default_rng(9), d))
+    ix.insert_batch(np.arange(2, n + 2, dtype=np.uint64), base[:n], round_size=1)
+    gone = rng.choice(np.arange(2, n + 2), 500, replace=False).astype(np.uint64)
+    ix.delete_batch(gone)
+    assert o.delete(gone) == 0
+    assert ix.row_usage() == (n + 1, 500)
+    q = unit_rows(rng, 24, d)
+    before = ix.search_batch(q, 10, L, trace=True, visit_cap=512)
+    g0 = ix.export()
+    ix.compact()
+    assert ix.row_usage() == (n + 1 - 500, 0) and ix.version_diff() == 0
+    g1 = ix.export()
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    after = ix.search_batch(q, 10, L, trace=True, visit_cap=512)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(bits(before[1]), bits(after[1]))
+    assert np.array_equal(before[3].visit_ids, after[3].visit_ids) and np.array_equal(before[3].n_dist, after[3].n_dist)
+    assert_same_graph(ix, o)
+    assert not ix.exists_batch(gone[:5]).any() and ix.exists(int(sorted(set(range(2, n + 2)) - set(int(g) for g in gone))[0]))
+    # the write path carries on from the compacted state exactly as the oracle does from its own
+    new_ids = np.concatenate([gone[:100], np.arange(n + 2, n + 502, dtype=np.uint64)])  # freed ids come back (idcounter.go)
+    for k, i in enumerate(new_ids):
+        assert o.insert(int(i), base[n + k]) == 0
+    ix.insert_batch(new_ids, base[n:n + 600], round_size=1)
+    assert_same_graph(ix, o)
+    gone2 = rng.choice(new_ids, 150, replace=False).astype(np.uint64)
+    ix.delete_batch(gone2)
+    assert o.delete(gone2) == 0
+    assert_same_graph(ix, o)
+    ix.compact()
+    assert_same_graph(ix, o)
+    ix.compact()  # nothing to do
+    assert ix.row_usage()[1] == 0
+    ix.close()

@@ -235,6 +235,9 @@ def trial(rng, t):
                 for k, i in enumerate(upds):
                     assert o.insert(i, upd_vecs[k]) == 0
             live = sorted((set(live) - set(dels)) | set(new_ids))
+            if rng.integers(0, 3) == 0:  # tombstones squeezed out: nothing observable may change
+                g.compact()
+                assert g.row_usage()[1] == 0
             check_graph(g, o)
             compare_searches(rng, g, o, d, kind, L, live, "after write batch %d" % step, None if quantized else metric)
     finally:
