@@ -293,7 +293,18 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 	if err := v.fit(); err != nil { // vecStore.Fit (:257-260)
 		return fmt.Errorf("could not fit vector store: %w", err)
 	}
-	return v.flushToBucket(delIds) // :265-276
+	if err := v.flushToBucket(delIds); err != nil { // :265-276
+		return err
+	}
+	// the reference frees deleted nodes at flush (node.go:129-134); here their rows stay behind as tombstones
+	// until they are worth squeezing out
+	var rows, dead C.uint64_t
+	if C.sdb_index_row_usage(v.h, &rows, &dead) == C.SDB_OK && dead*4 > rows {
+		if rc := C.sdb_index_compact(v.h); rc != C.SDB_OK {
+			return lastErr("could not compact the index", rc)
+		}
+	}
+	return nil
 }
 
 // EdgeScan (node.go:142-199), same signature: nodes with an edge into deleteSet, and valid nodes nobody

@@ -561,7 +561,13 @@ class IndexVamana {
     if (any)
       if (int rc = sdb_index_commit(h_, nullptr)) return Error::wrap("could not commit the write", rc);
     if (Error e = fit()) return Error("could not fit vector store: " + e.msg);  // vamana.go:257-260
-    return flush();
+    if (Error e = flush()) return e;
+    // the reference frees deleted nodes at flush (node.go:129-134); here their rows stay behind as tombstones
+    // until they are worth squeezing out
+    uint64_t rows = 0, dead = 0;
+    if (sdb_index_row_usage(h_, &rows, &dead) == SDB_OK && dead * 4 > rows)
+      if (int rc = sdb_index_compact(h_)) return Error::wrap("could not compact the index", rc);
+    return Error();
   }
 
   // productQuantizer.Fit (product.go:175-236): once, when the store holds TriggerThreshold points (the start
