@@ -907,7 +907,10 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   if (a.big_count) SDB_HIP(hipMemsetAsync(a.big_count, 0, 4, stream));  // word 1 = BuildArgs::flags, kept
   hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
   SDB_HIP(hipGetLastError());
-  if (a.big_count && ((size_t)a.nnew * 64 >= a.big_min || a.start_ext_n)) {  // the hubs of this round, if any (bigprune.inc)
+  // the hubs of this round, if any (bigprune.inc).  A target gets at most one request per new node, so a round of
+  // fewer than big_min points cannot have one and the host need not wait for the count (the early rounds -- two
+  // thirds of all rounds of a 1M build -- then run without a host round trip each)
+  if (a.big_count && (a.nnew >= a.big_min || a.start_ext_n)) {
     uint32_t nbig = 0;
     SDB_HIP(hipMemcpyAsync(&nbig, a.big_count, 4, hipMemcpyDeviceToHost, stream));
     SDB_HIP(hipStreamSynchronize(stream));
