@@ -494,6 +494,25 @@ def run_c2(a, ctx):
 
     if rank == 0 and world == 1:
         cfg = result["config"]
+        # not the metric (one batch at a time): the same batches with two of them in flight on two streams, the way a
+        # serving process (the host batcher) runs -- a second batch fills the SIMDs the first one's finished walks left
+        try:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream())
+            reps = max(a.steps, 20)
+            for i in range(4):
+                with torch.cuda.stream(streams[i % 2]):
+                    step(tb[i % len(tb)])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(reps):
+                with torch.cuda.stream(streams[i % 2]):
+                    step(tb[a.warmup + i % a.steps])
+            torch.cuda.synchronize()
+            cfg["two_batches_in_flight_qps"] = round(nq * reps / (time.perf_counter() - t2), 1)
+        except Exception as e:
+            cfg["two_batches_in_flight_qps"] = repr(e)
         if not a.no_host_rates:
             try:
                 cfg.update(host_rates(a, ix, queries[nb_recall:], k, L, last))

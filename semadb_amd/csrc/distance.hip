@@ -152,8 +152,13 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
   hipStream_t stream = as_stream(stream_);
   const RowLayout &l = ix->lay;
   std::vector<uint32_t> slots(nq * nc);
+  // a read like a search: ids resolve against the committed state (index.h graph versions); the slab rows
+  // themselves never change once written.  The lock is kept until the kernel is enqueued (reserve() swaps
+  // the slab pointer under it).
+  std::shared_lock<std::shared_mutex> rl(ix->view_mu);
+  const uint32_t view_n = ix->view.n;
   for (size_t i = 0; i < slots.size(); i++) {
-    int64_t s = ix->slot_of(cand_ids[i]);
+    int64_t s = ix->slot_of_committed(cand_ids[i], view_n);
     slots[i] = s < 0 ? kNoSlot : (uint32_t)s;
   }
   uint32_t *dslots = nullptr;
