@@ -506,12 +506,38 @@ __device__ __forceinline__ void add_with_limit_lanes(uint32_t (&cid)[NREG], floa
 template <int NREG>
 __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap,
                                                      uint32_t idreg, float mydist, uint64_t pd, int lane,
-                                                     uint32_t *scratch) {
-  if (len != cap) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+                                                     uint32_t *scratch
+#ifdef SDB_STAMPS
+                                                     , unsigned long long *mst = nullptr
+#endif
+) {
+#ifdef SDB_STAMPS
+  unsigned long long m_t0 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define SDB_MST(i)                                              \
+  if (mst) {                                                    \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    mst[i] += _t - m_t0;                                        \
+    m_t0 = _t;                                                  \
+  }
+#else
+#define SDB_MST(i)
+#endif
+  if (len != cap) {
+    return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  }
   const float tail0 = list_tail(cd, cap);
   const uint64_t cm = __ballot(!(mydist > tail0)) & pd;  // the points the replay would look at first
-  if (__popcll(cm) < 2 || (__ballot(mydist != mydist) & pd))
-    return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  SDB_MST(0)
+  if (__popcll(cm) < 2 || (__ballot(mydist != mydist) & pd)) {
+    add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+#ifdef SDB_STAMPS
+    asm volatile("" ::"v"(cd[0]));
+#endif
+    SDB_MST(1)
+    return;
+  }
   const bool inC = (cm >> lane) & 1ull;
   // The pass over the points is the hot part (about a dozen points per hop): per point one readlane, and per
   // array register one compare-and-count each way.  Ties are not looked for here; they show up afterwards
@@ -533,6 +559,10 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
     if (lane == j) rl_me = below;
     rc_me += dj < mydist ? 1u : 0u;
   }
+#ifdef SDB_STAMPS
+  asm volatile("" ::"v"(rc_me), "v"(up[0]));
+#endif
+  SDB_MST(2)
   // positions; with no two equal distances they are a permutation and exactly `cap` of them lie below `cap`
   const uint32_t np_me = rl_me + rc_me;
   uint32_t kept = (uint32_t)__popcll(__ballot(inC && np_me < (uint32_t)cap));
@@ -544,7 +574,9 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
     kept += (uint32_t)__popcll(__ballot(e < cap && (uint32_t)e + up[r] < (uint32_t)cap));
     if (e < cap) s_id[e] = kNoSlot;  // a position nobody lands on stays marked
   }
-  if (kept != (uint32_t)cap) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  if (kept != (uint32_t)cap) {
+    return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  }
   wave_lds_sync();
 #pragma unroll
   for (int r = 0; r < NREG; r++) {
@@ -565,9 +597,15 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
   }
   wave_lds_sync();
   // an unfilled position = two elements shared another one = equal distances: replay one by one
-  if (__ballot(hole)) return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  if (__ballot(hole)) {
+    return add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
+  }
 #pragma unroll
   for (int r = 0; r < NREG; r++) cid[r] = nid[r], cd[r] = nd[r];
+#ifdef SDB_STAMPS
+  asm volatile("" ::"v"(cd[0]));
+#endif
+  SDB_MST(3)
 }
 
 // roaring Contains on this query's ascending slot list: 64-ary search, all lanes probe at once
@@ -758,6 +796,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 
 #ifdef SDB_STAMPS  // diagnostic build only: where does a hop spend its cycles (never in the shipped library)
   unsigned long long st_adj = 0, st_atom = 0, st_vec = 0, st_ins = 0, st_t0 = 0;
+  unsigned long long st_m[4] = {0, 0, 0, 0};  // inside the merge: preamble, <2-candidates path, per-point pass, scatter
 #define SDB_STAMP(acc)                                              \
   {                                                                 \
     unsigned long long _t = __builtin_amdgcn_s_memtime();           \
@@ -832,7 +871,11 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         SDB_STAMP(st_vec)
         // AddWithLimit over the new neighbours, in edge order distset.go:184-198
         if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
+#ifdef SDB_STAMPS
+        else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter, st_m);
+#else
         else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
+#endif
         SDB_STAMP(st_ins)
       }
       if (__builtin_expect(ext_left == 0, 1)) break;
@@ -858,6 +901,9 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     a.tr_visit[(size_t)q * a.visit_cap + 1] = st_atom;
     a.tr_visit[(size_t)q * a.visit_cap + 2] = st_vec;
     a.tr_visit[(size_t)q * a.visit_cap + 3] = st_ins;
+    if constexpr (!Dist::kHasStamps)
+      if (a.visit_cap >= 8)
+        for (int i = 0; i < 4; i++) a.tr_visit[(size_t)q * a.visit_cap + 4 + i] = st_m[i];
     if constexpr (Dist::kHasStamps)
       if (a.visit_cap >= 8) {
         a.tr_visit[(size_t)q * a.visit_cap + 4] = dist.st[0];
