@@ -647,6 +647,10 @@ struct BitVisited {
 constexpr uint32_t kHashCap = 8192;    // plain store: 32 KB per wave -> 4 waves per CU
 constexpr uint32_t kHashLimit = 6000;  // keys a table may hold before it spills (any CAP: limit * CAP / 8192)
 constexpr uint32_t kHashCapPQ = 7417;  // quantized store: a prime, 29 KB, leaves room for the 8 KB LUT (M = 8)
+#ifndef SDB_HASH_PROBES
+#define SDB_HASH_PROBES 4  // 6 and 8 measured the same (tools/kernel_ab.py: 0.947 / 0.947 / 0.946 ms plain, 0.315 / 0.312 / 0.317 ms quantized)
+#endif
+constexpr int kProbes = SDB_HASH_PROBES;  // probe positions a round of the visited-set test reads at once
 // CAP is a power of two (mask) or a prime (conditional subtract): either way every probe stride in
 // [1, CAP) reaches every slot.
 template <uint32_t CAP>
@@ -693,20 +697,28 @@ struct HashVisited {
       else if (x >= CAP) x -= CAP;
       return x;
     };
-    // A round reads FOUR consecutive probe positions at once (one LDS round trip), takes the first that is
+    // A round reads kProbes consecutive probe positions at once (one LDS round trip), takes the first that is
     // empty or already holds the key -- nothing is ever removed, so a key that is present sits before the
     // first empty position of its chain -- and only then spends the atomic: almost every lane finishes in one
     // round, where a compare-and-swap per probe made the whole wave wait for its longest chain.
     while (__ballot(!done)) {
-      const uint32_t h0 = h, h1 = next(h0), h2 = next(h1), h3 = next(h2);
-      const uint32_t k0 = tab[h0], k1 = tab[h1], k2 = tab[h2], k3 = tab[h3];
-      const bool s0 = k0 == slot || k0 == kNoSlot, s1 = k1 == slot || k1 == kNoSlot;
-      const bool s2 = k2 == slot || k2 == kNoSlot, s3 = k3 == slot || k3 == kNoSlot;
-      const uint32_t hs = s0 ? h0 : s1 ? h1 : s2 ? h2 : h3;
-      const uint32_t ks = s0 ? k0 : s1 ? k1 : s2 ? k2 : k3;
+      uint32_t hp[kProbes], kp[kProbes];
+      hp[0] = h;
+#pragma unroll
+      for (int i = 1; i < kProbes; i++) hp[i] = next(hp[i - 1]);
+#pragma unroll
+      for (int i = 0; i < kProbes; i++) kp[i] = tab[hp[i]];
+      bool any = false;
+      uint32_t hs = hp[kProbes - 1], ks = kp[kProbes - 1];
+#pragma unroll
+      for (int i = kProbes - 1; i >= 0; i--) {
+        const bool si = kp[i] == slot || kp[i] == kNoSlot;
+        hs = si ? hp[i] : hs, ks = si ? kp[i] : ks;
+        any |= si;
+      }
       if (!done) {
-        if (!(s0 || s1 || s2 || s3)) {
-          h = next(h3);
+        if (!any) {
+          h = next(hp[kProbes - 1]);
         } else if (ks == slot) {
           done = true;
         } else {
