@@ -8,4 +8,4 @@ export TMPDIR=/tmp
 echo "rc=$?"
 f=$(ls $out/prof/*kernel_stats.csv $out/prof/*/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then cp "$f" $out/kernel_stats.csv; head -30 "$f" | cut -c1-260; else echo "no kernel_stats.csv"; ls -R $out | head -20; fi
-find $out -name "*kernel_trace.csv" -size +20M -delete
+for f in $(find $out -name "*kernel_trace.csv"); do head -1 $f > $f.tmp; grep -E "k_greedy_search" $f >> $f.tmp; mv $f.tmp $f; done
