@@ -258,18 +258,36 @@ int sdb_index::reserve(uint32_t rows) {
   if (rows <= cap) return SDB_OK;
   uint32_t ncap = cap ? cap : 1024;
   while (ncap < rows) ncap = ncap < (1u << 30) ? ncap * 2 : rows;
-  float *nslab = nullptr;
-  uint32_t *nadj = nullptr, *nradj = nullptr, *ndeg = nullptr, *nclean = nullptr;
+  // every new buffer first; if one allocation fails the ones before it are returned and the index is as it was
+  struct Fresh {
+    std::vector<void *> p;
+    bool keep = false;
+    ~Fresh() {
+      if (!keep)
+        for (void *x : p)
+          if (x) (void)hipFree(x);
+    }
+    int get(void **out, size_t bytes) {
+      SDB_HIP(hipMalloc(out, bytes));
+      p.push_back(*out);
+      return SDB_OK;
+    }
+  } fresh;
+  float *nslab = nullptr, *nad = nullptr;
+  uint32_t *nadj = nullptr, *nradj = nullptr, *ndeg = nullptr, *nclean = nullptr, *ndc = nullptr;
   uint64_t *nids = nullptr, *nrids = nullptr;
-  uint8_t *ndirty = nullptr;
-  SDB_HIP(hipMalloc(&nslab, (size_t)ncap * lay.ld * sizeof(float)));
-  SDB_HIP(hipMalloc(&nadj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
-  SDB_HIP(hipMalloc(&nradj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
-  SDB_HIP(hipMalloc(&ndeg, (size_t)ncap * sizeof(uint32_t)));
-  SDB_HIP(hipMalloc(&nclean, (size_t)ncap * sizeof(uint32_t)));
-  SDB_HIP(hipMalloc(&nids, (size_t)ncap * sizeof(uint64_t)));
-  SDB_HIP(hipMalloc(&nrids, (size_t)ncap * sizeof(uint64_t)));
-  SDB_HIP(hipMalloc(&ndirty, (size_t)ncap));
+  uint8_t *ndirty = nullptr, *ncodes = nullptr;
+  SDB_TRY(fresh.get((void **)&nslab, (size_t)ncap * lay.ld * sizeof(float)));
+  SDB_TRY(fresh.get((void **)&nadj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
+  SDB_TRY(fresh.get((void **)&nradj, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
+  SDB_TRY(fresh.get((void **)&ndeg, (size_t)ncap * sizeof(uint32_t)));
+  SDB_TRY(fresh.get((void **)&nclean, (size_t)ncap * sizeof(uint32_t)));
+  SDB_TRY(fresh.get((void **)&nids, (size_t)ncap * sizeof(uint64_t)));
+  SDB_TRY(fresh.get((void **)&nrids, (size_t)ncap * sizeof(uint64_t)));
+  SDB_TRY(fresh.get((void **)&ndirty, (size_t)ncap));
+  SDB_TRY(fresh.get((void **)&nad, (size_t)ncap * kAdjStride * sizeof(float)));  // edge-distance cache of the write path (index.h)
+  SDB_TRY(fresh.get((void **)&ndc, (size_t)ncap * sizeof(uint32_t)));
+  if (pq) SDB_TRY(fresh.get((void **)&ncodes, (size_t)ncap * pq->M));  // the code rows of a quantized store grow with it
   // the old buffers are freed below: nothing may still be walking them (searches run on streams of their own)
   if (cap) SDB_HIP(hipDeviceSynchronize());
   SDB_HIP(hipMemset(nadj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
@@ -287,19 +305,11 @@ int sdb_index::reserve(uint32_t rows) {
     SDB_HIP(hipMemcpy(nrids, r_ids, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(ndirty, d_dirty, (size_t)n, hipMemcpyDeviceToDevice));
   }
-  float *nad = nullptr;  // edge-distance cache of the write path (index.h); a row without cached distances has d_dcount 0
-  uint32_t *ndc = nullptr;
-  SDB_HIP(hipMalloc(&nad, (size_t)ncap * kAdjStride * sizeof(float)));
-  SDB_HIP(hipMalloc(&ndc, (size_t)ncap * sizeof(uint32_t)));
-  SDB_HIP(hipMemset(ndc, 0, (size_t)ncap * sizeof(uint32_t)));
+  SDB_HIP(hipMemset(ndc, 0, (size_t)ncap * sizeof(uint32_t)));  // a row without cached distances has d_dcount 0
   if (n) {
     SDB_HIP(hipMemcpy(nad, d_adjdist, (size_t)n * kAdjStride * sizeof(float), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(ndc, d_dcount, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-  }
-  uint8_t *ncodes = nullptr;
-  if (pq) {  // the code rows of a quantized store grow with it
-    SDB_HIP(hipMalloc(&ncodes, (size_t)ncap * pq->M));
-    if (n) SDB_HIP(hipMemcpy(ncodes, d_codes, (size_t)n * pq->M, hipMemcpyDeviceToDevice));
+    if (pq) SDB_HIP(hipMemcpy(ncodes, d_codes, (size_t)n * pq->M, hipMemcpyDeviceToDevice));
   }
   SDB_HIP(hipDeviceSynchronize());
   {
@@ -311,6 +321,7 @@ int sdb_index::reserve(uint32_t rows) {
     d_slab = nslab, d_adj = nadj, r_adj = nradj, d_deg = ndeg, d_clean = nclean, d_ids = nids, r_ids = nrids;
     d_dirty = ndirty, d_adjdist = nad, d_dcount = ndc;
     if (pq) d_codes = ncodes;
+    fresh.keep = true;
     cap = ncap;
     view.adj = r_adj, view.ids = r_ids;
   }
