@@ -246,9 +246,14 @@ int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *queries, uint
                           const uint64_t *filter_offsets, const uint64_t *filter_ids, uint64_t *out_ids,
                           float *out_dists, uint32_t *out_counts, int mem, void *stream);
 
-/* vecStore.Set without graph maintenance -- what IndexFlat.InsertUpdateDelete does for an insert
- * (flat.go:46-49).  ids == NULL assigns max_id+1.. ; existing ids are rejected (updates are host-side). */
+/* vecStore.Set without graph maintenance -- what IndexFlat.InsertUpdateDelete does for a point with a vector
+ * (flat.go:46-49): insert, or replace the stored vector of an id that exists (the old row becomes a tombstone, the
+ * new one is appended).  ids == NULL assigns max_id+1.. .  On an index WITH a graph an existing id is rejected: a
+ * graph update is delete_batch + insert_batch.  An id may appear once per call. */
 int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem);
+/* vecStore.Delete as IndexFlat.InsertUpdateDelete calls it for a point without a vector (flat.go:50-52); ids that are
+ * not stored are skipped.  Only for an index without a graph. */
+int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids);
 
 /* cache.Cachable.SizeInMemory (vamana.go:83-85): bytes of HBM held */
 int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes);

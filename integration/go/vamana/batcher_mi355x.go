@@ -13,7 +13,7 @@ import (
 	"time"
 	"unsafe"
 
-	"github.com/RoaringBitmap/roaring/v2/roaring64"
+	"github.com/RoaringBitmap/roaring/roaring64"
 )
 
 // One REST request carries one query (httpapi/v2/handlers.go:435-489) and the reference answers it on its own

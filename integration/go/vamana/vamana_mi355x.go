@@ -22,7 +22,7 @@ import (
 	"time"
 	"unsafe"
 
-	"github.com/RoaringBitmap/roaring/v2/roaring64"
+	"github.com/RoaringBitmap/roaring/roaring64"
 	"github.com/semafind/semadb/diskstore"
 	"github.com/semafind/semadb/models"
 )

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sdb_index_flat_search": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sdb_index_set_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
+    "sdb_index_remove_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "sdb_index_size_in_memory": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "sdb_index_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "sdb_index_compact": (C.c_int, [C.c_void_p]),

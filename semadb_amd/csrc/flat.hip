@@ -554,15 +554,96 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
 namespace sdb {
 int store_rows_public(sdb_index *ix, uint32_t first, uint32_t n, const float *dev_vectors, hipStream_t stream);
 }
+namespace sdb {
+// vecStore.Delete on an index without a graph: the row becomes a tombstone (id 0), like a deleted graph node's
+__global__ void k_flat_tombstone(uint64_t *ids, uint8_t *dirty, const uint32_t *dead, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[dead[i]] = 0, dirty[dead[i]] = 1;
+}
+}  // namespace sdb
+
+// rows of a flat index (no graph) leave the store; part of the open transaction (the caller commits)
+static int flat_tombstone(sdb_index *ix, std::vector<uint32_t> &slots) {
+  if (slots.empty()) return SDB_OK;
+  std::sort(slots.begin(), slots.end());
+  slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+  uint32_t *d_dead = nullptr;
+  SDB_HIP(hipMalloc(&d_dead, slots.size() * 4));
+  hipError_t e = hipMemcpy(d_dead, slots.data(), slots.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(sdb::k_flat_tombstone, dim3((unsigned)((slots.size() + 255) / 256)), dim3(256), 0, nullptr, ix->d_ids,
+                       ix->d_dirty, d_dead, (uint32_t)slots.size());
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(d_dead);
+  if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "tombstone failed: %s", hipGetErrorString(e));
+  std::unique_lock<std::shared_mutex> wl(ix->view_mu);  // searches translate filter ids with these tables
+  if (ix->dense_ids) {  // the dense id -> slot shortcut does not survive holes
+    ix->id2slot.clear();
+    ix->id2slot.reserve((size_t)ix->n * 2);
+    for (uint32_t s = 0; s < ix->n; s++)
+      if (ix->h_ids[s] != 0) ix->id2slot.emplace(ix->h_ids[s], s);
+    ix->dense_ids = false;
+  }
+  for (uint32_t s : slots) {
+    ix->tx_deleted[ix->h_ids[s]] = s;  // until commit a search on the committed rows still finds it
+    ix->id2slot.erase(ix->h_ids[s]);
+    ix->h_ids[s] = 0;
+  }
+  ix->n_dead += (uint32_t)slots.size();
+  return SDB_OK;
+}
+
+// vecStore.Delete as IndexFlat.InsertUpdateDelete calls it for a point without a vector (flat.go:50-52): ids that are
+// not stored are skipped (ItemCache.Delete of a missing key is not an error).  Only for an index without a graph
+// (no start node); a graph index deletes through sdb_index_delete_batch.
+extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (n == 0) return SDB_OK;
+  if (!ids) return fail(SDB_ERR_INVALID, "ids is NULL");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
+  if (ix->start_slot >= 0) return fail(SDB_ERR_STATE, "the index has a graph: delete through sdb_index_delete_batch");
+  std::vector<uint32_t> slots;
+  for (uint64_t i = 0; i < n; i++) {
+    const int64_t s = ix->slot_of(ids[i]);
+    if (s >= 0) slots.push_back((uint32_t)s);
+  }
+  if (slots.empty()) return SDB_OK;
+  DeviceGuard dg(ix->P.device);
+  SDB_TRY(ix->begin_write());
+  SDB_TRY(flat_tombstone(ix, slots));
+  if (!ix->tx_explicit) {
+    SDB_TRY(ix->commit(nullptr));
+    SDB_HIP(hipDeviceSynchronize());
+  }
+  return SDB_OK;
+}
+
 extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem) {
   if (!ix || !vectors) return fail(SDB_ERR_INVALID, "NULL argument");
   if (n == 0) return SDB_OK;
   if ((uint64_t)ix->n + n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many nodes");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   std::vector<uint64_t> new_ids(n);
+  std::vector<uint32_t> replaced;  // rows of ids that are stored already: vecStore.Set overwrites (plain.go:58-65)
   for (uint64_t i = 0; i < n; i++) {
     new_ids[i] = ids ? ids[i] : std::max<uint64_t>(ix->max_node_id, SDB_STARTID) + 1 + i;
-    if (ix->slot_of(new_ids[i]) >= 0)
-      return fail(SDB_ERR_EXISTS, "point %llu exists: updates are not on the device path", (unsigned long long)new_ids[i]);
+    if (new_ids[i] == 0) return fail(SDB_ERR_INVALID, "invalid point id: 0");
+    const int64_t s = ix->slot_of(new_ids[i]);
+    if (s >= 0) {
+      // on a graph index a stored id is an update, which is delete_batch + insert_batch; a flat index simply
+      // replaces the vector: the old row becomes a tombstone, the new one is appended (rows are never rewritten
+      // in place -- a search that runs meanwhile reads whole rows)
+      if (ix->start_slot >= 0)
+        return fail(SDB_ERR_EXISTS, "point %llu exists: updates are not on the device path", (unsigned long long)new_ids[i]);
+      replaced.push_back((uint32_t)s);
+    }
+  }
+  {  // the same id twice in one call: the last vector wins, like consecutive Set calls
+    std::unordered_map<uint64_t, uint64_t> last;
+    for (uint64_t i = 0; i < n; i++) last[new_ids[i]] = i;
+    if (last.size() != n) return fail(SDB_ERR_INVALID, "an id appears twice in one set_vectors call");
   }
   DeviceGuard dg(ix->P.device);
   const RowLayout &l = ix->lay;
@@ -586,6 +667,7 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   if (rc != SDB_OK) return rc;
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "id copy failed: %s", hipGetErrorString(e));
   SDB_TRY(ix->begin_write());  // appended rows become visible to searches at commit
+  SDB_TRY(flat_tombstone(ix, replaced));
   std::unique_lock<std::shared_mutex> wl(ix->view_mu);
   bool dense = ix->dense_ids;
   for (uint64_t i = 0; i < n; i++) {

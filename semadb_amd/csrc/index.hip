@@ -1157,7 +1157,7 @@ int sdb_index_compact(sdb_index *ix) {
     ix->id2slot.reserve((size_t)nn * 2);
     for (uint32_t j = 0; j < nn; j++) ix->id2slot.emplace(ix->h_ids[j], j);
   }
-  ix->start_slot = (int64_t)map[(uint32_t)ix->start_slot];
+  if (ix->start_slot >= 0) ix->start_slot = (int64_t)map[(uint32_t)ix->start_slot];  // a flat index has none
   for (auto &t : ix->h_start_ext) t = map[t];
   ix->n = nn, ix->n_dead = 0;
   const uint32_t need = (uint32_t)((ix->h_start_ext.size() + 63) / 64 * 64);

@@ -72,20 +72,57 @@ class IndexFlat:
             pass
 
     def InsertUpdateDelete(self, points):
-        """flat.go:41-74: Set for points with a vector; deletes/updates are the host path."""
-        ids, vecs = [], []
+        """flat.go:41-74: vecStore.Set for a point with a vector (insert or replace), vecStore.Delete for one
+        without, in the order given; one write transaction."""
+        ops = []  # runs of consecutive sets / deletes keep the reference's order between the two kinds
         for ch in points:
-            if ch.Vector is None:
-                raise SemaDBError(3, "delete is not on the device path")
-            ids.append(ch.Id)
-            vecs.append(np.asarray(ch.Vector, dtype=np.float32))
-        if ids:
-            self.set_vectors(np.array(ids, dtype=np.uint64), np.stack(vecs))
+            kind = "del" if ch.Vector is None else "set"
+            if ops and ops[-1][0] == kind and (kind == "del" or ch.Id not in ops[-1][3]):
+                ops[-1][1].append(ch.Id)
+                ops[-1][3].add(ch.Id)
+            else:
+                ops.append([kind, [ch.Id], [], {ch.Id}])
+            if kind == "set":
+                ops[-1][2].append(np.asarray(ch.Vector, dtype=np.float32))
+        if not ops:
+            return
+        check(lib().sdb_index_begin_write(self._h))
+        for kind, ids, vecs, _ in ops:
+            if kind == "set":
+                self.set_vectors(np.array(ids, dtype=np.uint64), np.stack(vecs))
+            else:
+                self.remove_vectors(ids)
+        check(lib().sdb_index_commit(self._h, None))
 
     def set_vectors(self, ids, vectors):
         k, vp, mem, shape = _buf.as_f32(vectors)
         ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
         check(lib().sdb_index_set_vectors(self._h, shape[0], _buf.np_ptr(ids_a), vp, mem))
+
+    def remove_vectors(self, ids):
+        ids_a = np.ascontiguousarray(ids, dtype=np.uint64)
+        if ids_a.size:
+            check(lib().sdb_index_remove_vectors(self._h, ids_a.size, _buf.np_ptr(ids_a)))
+
+    def begin_write(self):
+        check(lib().sdb_index_begin_write(self._h))
+
+    def commit(self):
+        check(lib().sdb_index_commit(self._h, None))
+
+    def row_usage(self):
+        """(storage rows in use, of which tombstones)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().sdb_index_row_usage(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def compact(self):
+        check(lib().sdb_index_compact(self._h))
+
+    def version_diff(self):
+        v = C.c_uint64(0)
+        check(lib().sdb_index_version_diff(self._h, C.byref(v)))
+        return v.value
 
     def Search(self, options: SearchVectorFlatOptions, filter=None):
         vec = np.ascontiguousarray(options.Vector, dtype=np.float32).reshape(1, -1)

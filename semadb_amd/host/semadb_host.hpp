@@ -185,6 +185,16 @@ struct IndexVectorVamanaParameters {
   float Alpha = 1.2f;
   std::optional<models::Quantizer> Quantizer;  // models/index.go:281
 };
+struct IndexVectorFlatParameters {  // models/index.go:238-246
+  uint32_t VectorSize = 0;
+  std::string DistanceMetric;
+  std::optional<models::Quantizer> Quantizer;
+};
+struct SearchVectorFlatOptions {  // models/search.go:308-314
+  std::vector<float> Vector;
+  int Limit = 10;
+  std::optional<float> Weight;
+};
 struct SearchVectorVamanaOptions {
   std::vector<float> Vector;
   int SearchSize = 75;
@@ -739,4 +749,134 @@ inline std::pair<std::unique_ptr<IndexVamana>, Error> NewIndexVamana(const std::
   return IndexVamana::NewIndexVamana(name, params, bucket, device, start_vector);
 }
 }  // namespace vamana
+
+// ---------------------------------------------------------------------------------------------------
+namespace flat {  // shard/index/flat/flat.go
+// flat.IndexFlat: a vector store and an exact scan, nothing else.  The plain store only (a quantized flat index is
+// a configuration the BASELINE does not name).  InsertUpdateDelete is vecStore.Set / vecStore.Delete in the order
+// given, then Flush (flat.go:41-74); Search is the scan of flat.go:76-132 on the device.
+class IndexFlat {
+ public:
+  using Filter = std::set<uint64_t>;
+  struct SearchReturn {
+    std::set<uint64_t> set;
+    std::vector<models::SearchResult> results;
+    Error err;
+  };
+  static std::pair<std::unique_ptr<IndexFlat>, Error> NewIndexFlat(const models::IndexVectorFlatParameters &params,
+                                                                  diskstore::Bucket *bucket, int device = 0) {
+    const int mc = metric_code(params.DistanceMetric);
+    if (mc < 0) return {nullptr, Error("failed to create vector store: unknown float32 distance function: " + params.DistanceMetric)};
+    if (params.Quantizer && params.Quantizer->Type != models::QuantizerNone)
+      return {nullptr, Error("failed to create vector store: a quantized flat index is not on the MI355X path")};
+    std::unique_ptr<IndexFlat> f(new IndexFlat());
+    f->parameters_ = params, f->bucket_ = bucket;
+    sdb_index_params p{};
+    p.dim = params.VectorSize, p.metric = (uint32_t)mc, p.search_size = 75, p.degree_bound = 64, p.alpha = 1.2f, p.device = device;
+    if (int rc = sdb_index_create(&p, &f->h_)) return {nullptr, Error::wrap("failed to create vector store", rc)};
+    if (bucket) {  // plainPoint.ReadFrom for every stored point (plain.go:125-141)
+      std::vector<uint64_t> ids;
+      std::vector<float> vecs;
+      Error e = bucket->ForEach([&](const std::string &k, const std::string &val) {
+        uint64_t id;
+        if (!conversion::NodeIdFromKey(k, 'v', &id)) return Error();
+        if (val.size() != (size_t)params.VectorSize * 4) return Error("vector of point " + std::to_string(id) + " has the wrong length");
+        ids.push_back(id);
+        auto v = conversion::BytesToFloat32(val);
+        vecs.insert(vecs.end(), v.begin(), v.end());
+        return Error();
+      });
+      if (e) return {nullptr, e};
+      if (!ids.empty())
+        if (int rc = sdb_index_set_vectors(f->h_, ids.size(), ids.data(), vecs.data(), SDB_MEM_HOST))
+          return {nullptr, Error::wrap("failed to load vector store", rc)};
+    }
+    return {std::move(f), Error()};
+  }
+  ~IndexFlat() {
+    if (h_) sdb_index_destroy(h_);
+  }
+  int64_t SizeInMemory() const {  // flat.go:34-36
+    int64_t b = 0;
+    sdb_index_size_in_memory(h_, &b);
+    return b;
+  }
+  void UpdateBucket(diskstore::Bucket *b) { bucket_ = b; }  // flat.go:38-40
+
+  // flat.go:41-74
+  Error InsertUpdateDelete(const std::vector<vamana::IndexVectorChange> &points) {
+    std::lock_guard<std::mutex> wl(write_mu_);
+    if (points.empty()) return Error();
+    const size_t d = parameters_.VectorSize;
+    if (int rc = sdb_index_begin_write(h_)) return Error::wrap("failed to insert/update/delete", rc);
+    // runs of consecutive sets / deletes, so that the two kinds keep the order the caller gave them
+    size_t i = 0;
+    while (i < points.size()) {
+      const bool del = points[i].Vector.empty();
+      std::vector<uint64_t> ids;
+      std::vector<float> vecs;
+      std::set<uint64_t> seen;
+      while (i < points.size() && points[i].Vector.empty() == del && (del || !seen.count(points[i].Id))) {
+        if (!del && points[i].Vector.size() != d) return Error("failed to insert/update/delete: vector length mismatch");
+        ids.push_back(points[i].Id), seen.insert(points[i].Id);
+        vecs.insert(vecs.end(), points[i].Vector.begin(), points[i].Vector.end());
+        i++;
+      }
+      const int rc = del ? sdb_index_remove_vectors(h_, ids.size(), ids.data())
+                         : sdb_index_set_vectors(h_, ids.size(), ids.data(), vecs.data(), SDB_MEM_HOST);
+      if (rc) return Error::wrap("failed to insert/update/delete", rc);
+      if (bucket_)  // vecStore.Flush: plainPoint.WriteTo / DeleteFrom (plain.go:112-123,143-148)
+        for (size_t k = 0; k < ids.size(); k++) {
+          if (del) bucket_->Delete(conversion::NodeKey(ids[k], 'v'));
+          else bucket_->Put(conversion::NodeKey(ids[k], 'v'), conversion::Float32ToBytes(vecs.data() + k * d, d));
+        }
+    }
+    if (int rc = sdb_index_commit(h_, nullptr)) return Error::wrap("failed to insert/update/delete", rc);
+    uint64_t rows = 0, dead = 0;
+    if (sdb_index_row_usage(h_, &rows, &dead) == SDB_OK && dead * 4 > rows)
+      if (int rc = sdb_index_compact(h_)) return Error::wrap("could not compact the store", rc);
+    return Error();
+  }
+
+  // flat.go:76-132
+  SearchReturn Search(const models::SearchVectorFlatOptions &q, const Filter *filter = nullptr) {
+    SearchReturn out;
+    if (q.Vector.size() != parameters_.VectorSize) {
+      out.err = Error("query vector length mismatch");
+      return out;
+    }
+    const uint32_t limit = (uint32_t)q.Limit;
+    std::vector<uint64_t> ids(limit), f_off, f_ids;
+    std::vector<float> dists(limit);
+    uint32_t count = 0;
+    if (filter) {
+      f_off = {0, (uint64_t)filter->size()};
+      f_ids.assign(filter->begin(), filter->end());
+      if (f_ids.empty()) f_ids.push_back(0);
+    }
+    if (int rc = sdb_index_flat_search(h_, 1, q.Vector.data(), limit, filter ? f_off.data() : nullptr,
+                                       filter ? f_ids.data() : nullptr, ids.data(), dists.data(), &count, SDB_MEM_HOST,
+                                       nullptr)) {
+      out.err = Error::wrap("failed to iterate over points", rc);
+      return out;
+    }
+    const float weight = q.Weight ? *q.Weight : 1.0f;
+    for (uint32_t i = 0; i < count; i++) {
+      models::SearchResult sr;
+      sr.NodeId = ids[i], sr.Distance = dists[i];
+      sr.HybridScore = (-1 * weight * dists[i]);  // flat.go:114
+      out.results.push_back(sr);
+      out.set.insert(ids[i]);
+    }
+    return out;
+  }
+
+ private:
+  IndexFlat() = default;
+  models::IndexVectorFlatParameters parameters_;
+  diskstore::Bucket *bucket_ = nullptr;
+  sdb_index *h_ = nullptr;
+  std::mutex write_mu_;
+};
+}  // namespace flat
 }  // namespace semadb

@@ -296,6 +296,67 @@ static void test_quantized_index() {
   }
 }
 
+// flat.IndexFlat (flat.go): insert, replace, delete and the exact scan, with the bucket written through and a cold
+// reader seeing the same points (shard_vector_test.go runs its cases over both index types)
+static void test_flat_index() {
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<float> U(0, 1);
+  models::IndexVectorFlatParameters p;
+  p.VectorSize = 8, p.DistanceMetric = "euclidean";
+  diskstore::MemBucket bucket;
+  auto [ix, err] = flat::IndexFlat::NewIndexFlat(p, &bucket);
+  CHECK(!err);
+  std::vector<vamana::IndexVectorChange> pts;
+  for (int i = 0; i < 200; i++) {
+    std::vector<float> v(8);
+    for (auto &x : v) x = U(rng);
+    pts.push_back({(uint64_t)(i + 1), v});
+  }
+  CHECK(!ix->InsertUpdateDelete(pts));
+  // every point finds itself at distance 0
+  for (int i = 0; i < 200; i += 17) {
+    models::SearchVectorFlatOptions q;
+    q.Vector = pts[i].Vector, q.Limit = 3;
+    auto r = ix->Search(q);
+    CHECK(!r.err && r.results.size() == 3 && r.results[0].NodeId == pts[i].Id && r.results[0].Distance == 0);
+    CHECK(r.results[0].HybridScore == 0 && r.results[1].HybridScore == -r.results[1].Distance);
+  }
+  // move point 1 onto point 2's vector shifted, delete point 2, delete a missing id
+  std::vector<float> moved = pts[1].Vector;
+  moved[0] += 0.001f;
+  CHECK(!ix->InsertUpdateDelete({{1, moved}, {2, {}}, {777, {}}}));
+  models::SearchVectorFlatOptions q;
+  q.Vector = pts[1].Vector, q.Limit = 128;  // the device scan serves limits up to 128
+  auto r = ix->Search(q);
+  CHECK(!r.err && r.results.size() == 128 && r.results[0].NodeId == 1 && !r.set.count(2));
+  // filter
+  flat::IndexFlat::Filter f = {3, 4, 2, 900};
+  auto rf = ix->Search(q, &f);
+  CHECK(!rf.err && rf.results.size() == 2 && rf.set.count(3) && rf.set.count(4));
+  // the bucket holds exactly the live points; a cold index answers the same
+  size_t nv = 0;
+  bucket.ForEach([&](const std::string &k, const std::string &) {
+    uint64_t id;
+    if (conversion::NodeIdFromKey(k, 'v', &id)) nv++;
+    return Error();
+  });
+  CHECK(nv == 199);
+  auto [cold, err2] = flat::IndexFlat::NewIndexFlat(p, &bucket);
+  CHECK(!err2);
+  auto rc = cold->Search(q);
+  CHECK(rc.results.size() == r.results.size());
+  std::set<std::pair<float, uint64_t>> a, b;  // equal as sets of (distance, id): the bucket order is the key order
+  for (auto &x : r.results) a.insert({x.Distance, x.NodeId});
+  for (auto &x : rc.results) b.insert({x.Distance, x.NodeId});
+  CHECK(a == b);
+  // wrong metric / wrong length
+  models::IndexVectorFlatParameters bad = p;
+  bad.DistanceMetric = "manhattan";
+  CHECK((bool)flat::IndexFlat::NewIndexFlat(bad, nullptr).second);
+  q.Vector.pop_back();
+  CHECK((bool)ix->Search(q).err);
+}
+
 int main() {
   int ndev = 0;
   if (sdb_device_count(&ndev) != SDB_OK) {
@@ -309,6 +370,7 @@ int main() {
   test_self_retrieval_and_concurrency();
   test_create_update_delete();
   test_quantized_index();
+  test_flat_index();
   if (g_fail) {
     std::printf("%d HOST CHECKS FAILED\n", g_fail);
     return 1;

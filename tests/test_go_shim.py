@@ -137,6 +137,44 @@ def test_helpers_are_defined_and_surface_is_complete():
         assert "C." + fn in clu
 
 
+def test_imports_are_the_reference_modules():
+    """import paths: the standard library or what the reference's go.mod (go 1.22; roaring v1.9.4) and its own tree
+    provide -- a path from another major version would not resolve in the reference's module"""
+    allowed = {"context", "fmt", "hash/fnv", "math", "math/rand/v2", "sync", "time", "unsafe", "sort", "errors",
+               "github.com/RoaringBitmap/roaring/roaring64", "github.com/semafind/semadb/conversion",
+               "github.com/semafind/semadb/diskstore", "github.com/semafind/semadb/models",
+               "github.com/semafind/semadb/shard/index/vamana"}
+    for path, text in go_sources().items():
+        block = re.search(r"\nimport \((.*?)\n\)", text, flags=re.S)
+        if not block:
+            continue
+        for imp in re.findall(r'"([^"]+)"', block.group(1)):
+            assert imp in allowed, "%s imports %s" % (os.path.basename(path), imp)
+
+
+def test_flat_package_surface():
+    """shard/index/flat's exported surface with the reference's signatures (flat.go:17,21,33,37,41,76), every helper
+    it calls defined in the package, and the write path made of the calls the header documents for a flat index"""
+    text = _go_code(open(os.path.join(ROOT, "integration", "go", "flat", "flat_mi355x.go")).read())
+    for sig in [r"type IndexFlat struct",
+                r"func NewIndexFlat\(params models\.IndexVectorFlatParameters, bucket diskstore\.Bucket\) \(inf IndexFlat, err error\)",
+                r"func \(inf IndexFlat\) SizeInMemory\(\) int64",
+                r"func \(inf IndexFlat\) UpdateBucket\(bucket diskstore\.Bucket\)",
+                r"func \(inf IndexFlat\) InsertUpdateDelete\(ctx context\.Context, points <-chan vamana\.IndexVectorChange\) <-chan error",
+                r"func \(inf IndexFlat\) Search\(ctx context\.Context, options models\.SearchVectorFlatOptions, filter \*roaring64\.Bitmap\) \(\*roaring64\.Bitmap, \[\]models\.SearchResult, error\)"]:
+        assert re.search(sig, text), "missing from the flat package: %s" % sig
+    defined = set(re.findall(r"^func (?:\([a-z]+ \*?[A-Za-z]+\) )?([A-Za-z_][A-Za-z0-9_]*)\(", text, flags=re.M))
+    builtin = {"make", "append", "len", "copy", "close", "float32", "uint64", "uint32", "int", "int64", "string", "func",
+               "go", "defer", "if", "for", "switch", "return", "range", "error"}
+    for name in set(re.findall(r"(?<![\w.])([a-z][A-Za-z0-9_]*)\(", text)):
+        assert name in defined or name in builtin, "flat package calls %s(), not defined in it" % name
+    for name in set(re.findall(r"\b(?:s|inf\.s)\.([a-z][A-Za-z0-9_]*)\(", text)):
+        assert name in defined, "method %s() is not defined in the flat package" % name
+    for fn in ["sdb_index_begin_write", "sdb_index_set_vectors", "sdb_index_remove_vectors", "sdb_index_commit",
+               "sdb_index_flat_search", "sdb_index_compact"]:
+        assert "C." + fn in text
+
+
 def test_every_file_has_the_build_tag_and_balanced_braces():
     for path, text in go_sources().items():
         assert text.startswith("//go:build mi355x\n"), path

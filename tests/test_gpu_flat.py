@@ -179,3 +179,122 @@ def test_streaming_scan_skips_the_start_node_and_tombstones(oracle):
     for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base[keep], ids[keep], "cosine", 10)):
         assert np.array_equal(g_ids[i], e_ids) and np.array_equal(bits(g_d[i]), bits(e_d))
     ix.close()
+
+
+class _Store:
+    """the storage-order model of the device store: Set of a stored id drops its row and appends the new one, Delete
+    drops the row, compaction keeps the order"""
+
+    def __init__(self):
+        self.ids, self.rows = [], []
+
+    def set(self, i, v):
+        self.delete(i)
+        self.ids.append(int(i)), self.rows.append(np.asarray(v, dtype=np.float32))
+
+    def delete(self, i):
+        if int(i) in self.ids:
+            k = self.ids.index(int(i))
+            del self.ids[k], self.rows[k]
+
+    def arrays(self):
+        return np.array(self.ids, dtype=np.uint64), np.stack(self.rows)
+
+
+def _check_flat(oracle, ix, store, q, metric, ks=(1, 10)):
+    ids, base = store.arrays()
+    for k in ks:
+        g_ids, g_d, g_c = ix.search_batch(q, k)
+        for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, metric, k)):
+            assert int(g_c[i]) == len(e_ids)
+            assert np.array_equal(g_ids[i, :len(e_ids)], e_ids), (k, i)
+            assert np.array_equal(bits(g_d[i, :len(e_ids)]), bits(e_d))
+
+
+@pytest.mark.parametrize("metric,d,n", [("euclidean", 2, 400), ("cosine", 33, 900), ("dot", 128, 36000)])
+def test_flat_insert_update_delete(oracle, metric, d, n):
+    """flat.go:41-74 on the device path: vecStore.Set replaces the vector of a stored id, vecStore.Delete removes the
+    point, a delete of a missing id does nothing, the same id may appear more than once in one call (the last one
+    wins).  After every call the exact scan equals the oracle's over the points that are left -- for the table of
+    36 000 rows through the streaming scan, whose kernel skips tombstones -- and after compaction as well."""
+    from semadb_amd import flat
+    rng = np.random.default_rng(n)
+    mk = (lambda m: unit_rows(rng, m, d)) if d > 2 else (lambda m: rng.integers(0, 6, size=(m, d)).astype(np.float32))
+    base = mk(n)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, metric))
+    st = _Store()
+    ix.InsertUpdateDelete([flat.IndexVectorChange(i + 3, base[i]) for i in range(n)])
+    for i in range(n):
+        st.set(i + 3, base[i])
+    q = np.concatenate([base[:6] + np.float32(0.01), mk(5)])
+    _check_flat(oracle, ix, st, q, metric)
+    # one mixed call: updates (among them the queries' nearest rows), deletes, a missing id, new points,
+    # a point set twice and a point deleted and set again
+    upd = mk(40)
+    new = mk(30)
+    ch = [flat.IndexVectorChange(3 + i, upd[i]) for i in range(20)]
+    ch += [flat.IndexVectorChange(40 + i, None) for i in range(25)] + [flat.IndexVectorChange(10 ** 7, None)]
+    ch += [flat.IndexVectorChange(n + 100 + i, new[i]) for i in range(30)]
+    ch += [flat.IndexVectorChange(3, upd[20]), flat.IndexVectorChange(41, upd[21])]
+    ch += [flat.IndexVectorChange(n + 100, None), flat.IndexVectorChange(n + 100, upd[22])]
+    ix.InsertUpdateDelete(ch)
+    for c in ch:
+        st.delete(c.Id) if c.Vector is None else st.set(c.Id, c.Vector)
+    assert ix.version_diff() == 0
+    _check_flat(oracle, ix, st, q, metric)
+    rows, dead = ix.row_usage()
+    assert rows - dead == len(st.ids) and dead == 20 + 25 + 1 + 1  # updates, deletes, the second Set of 3, the deleted new point
+    # a filter naming a deleted and an updated id
+    allowed = [{45, 3, 4, 200, n + 100} for _ in range(q.shape[0])]
+    g_ids, g_d, g_c = ix.search_batch(q, 10, filters=allowed)
+    ids, rows_ = st.arrays()
+    for i, (e_ids, e_d) in enumerate(_expected(oracle, q, rows_, ids, metric, 10, allowed)):
+        assert int(g_c[i]) == len(e_ids) == 4
+        assert np.array_equal(g_ids[i, :4], e_ids) and np.array_equal(bits(g_d[i, :4]), bits(e_d))
+    ix.compact()
+    assert ix.row_usage() == (len(st.ids), 0) and ix.version_diff() == 0
+    _check_flat(oracle, ix, st, q, metric)
+    # the store keeps working after compaction
+    ix.InsertUpdateDelete([flat.IndexVectorChange(5, upd[23]), flat.IndexVectorChange(6, None)])
+    st.set(5, upd[23]), st.delete(6)
+    _check_flat(oracle, ix, st, q, metric)
+    ix.close()
+
+
+def test_flat_writes_are_invisible_until_commit(oracle):
+    """a flat search between begin_write and commit answers from the committed rows"""
+    from semadb_amd import flat
+    rng = np.random.default_rng(2)
+    d, n = 48, 500
+    base = unit_rows(rng, n, d)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, "cosine"))
+    st = _Store()
+    ix.set_vectors(np.arange(1, n + 1, dtype=np.uint64), base)
+    for i in range(n):
+        st.set(i + 1, base[i])
+    q = base[:8] + np.float32(0.01)
+    ix.begin_write()
+    ix.set_vectors(np.arange(1, 5, dtype=np.uint64), unit_rows(rng, 4, d))
+    ix.remove_vectors([5, 6, 7])
+    ix.set_vectors(np.array([9000], dtype=np.uint64), q[:1])
+    _check_flat(oracle, ix, st, q, "cosine")  # nothing of it is visible
+    ix.commit()
+    g_ids, g_d, _ = ix.search_batch(q, 1)
+    assert int(g_ids[0, 0]) == 9000 and not ({int(v) for v in g_ids[:, 0]} & {5, 6, 7})
+    assert ix.version_diff() == 0
+    ix.close()
+
+
+def test_flat_set_rules():
+    from semadb_amd import flat
+    from semadb_amd._lib import SemaDBError
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(4, "euclidean"))
+    v = np.ones((2, 4), dtype=np.float32)
+    with pytest.raises(SemaDBError):
+        ix.set_vectors(np.array([0, 1], dtype=np.uint64), v)  # id 0 is no point
+    with pytest.raises(SemaDBError):
+        ix.set_vectors(np.array([7, 7], dtype=np.uint64), v)  # twice in one call: which one wins is the caller's order
+    ix.set_vectors(np.array([7, 8], dtype=np.uint64), v)
+    ix.remove_vectors([7, 7, 99])  # twice and unknown: one tombstone
+    assert ix.row_usage() == (2, 1)
+    ix.close()
