@@ -198,11 +198,14 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        default 6000 (also the maximum)
  *   SDB_TUNE_NO_HASH     != 0: the visited set is the HBM bitset from the start
  *   SDB_TUNE_NO_TILE     != 0: a new node's robustPrune reads candidate rows from global memory instead of
- *                        staging them in LDS */
+ *                        staging them in LDS
+ *   SDB_TUNE_NO_MFMA     != 0: the exact scan of dot / cosine tables runs on the packed-FMA kernel (the one
+ *                        euclidean uses) instead of the matrix cores */
 #define SDB_TUNE_HUB_MIN 1
 #define SDB_TUNE_HASH_LIMIT 2
 #define SDB_TUNE_NO_HASH 3
 #define SDB_TUNE_NO_TILE 4
+#define SDB_TUNE_NO_MFMA 5
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
 
 /* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts

@@ -298,9 +298,175 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_flat_scan(const float *__re
   }
 }
 
-// fold a launch's candidates into the running top list of one query (64 threads): the `limit` smallest of
+// ---- the same scan on the matrix cores (dot and cosine) ------------------------------------------------------
+// The scan is a GEMM with a prescribed summation order: pair (row, query) keeps the reference's 32 partial sums,
+// partial sum L = 8a + t taking elements 32b + L in the order of b, each step one fused multiply-add
+// (VFMADD231PS, dot.s:24-27).  v_mfma_f32_16x16x1_4b_f32 is exactly that step for 4 x 16 x 16 independent
+// accumulators at once: D[blk][i][j] = fma(A[blk][i], B[blk][j], D[blk][i][j]) -- one product, one rounding, denormals
+// kept (tools/probes/mfma_exact.hip: 5.2 M outputs against fmaf(), none different; 154 TFLOP/s, the packed-FP32 rate,
+// with two register operands per 1 024 FMAs instead of LDS/scalar operands per 128).  The four blocks of the
+// instruction are given to the four quarters t mod 4 = blk of the partial sums, so that a wave's tile is 16 rows x 16
+// queries and the whole reduce tree of dot.s:45-53 stays inside the lane:
+//   A lane 16 blk + i = row i,   element 32b + 8a + 4tt + blk        accumulator set k = 2a + tt (8 sets x 16 registers)
+//   B lane 16 blk + j = query j, the same element                    D register 4 blk + i4, lane l: row 4 (l / 16) + i4,
+//                                                                     query l % 16, partial sum t = blk + 4tt
+//   S_tt = ((c(0,tt) + c(1,tt)) + c(2,tt)) + c(3,tt)   r4[blk] = (S_0 + S_1) + 0   dist = (r4[0] + r4[1]) + (r4[2] + r4[3])
+// A wave keeps its 16 rows in registers for the whole launch (32 floats per slab group and lane: the slab's permuted
+// layout puts elements 32 (4g + kk) + L, kk = 0..3, side by side, one 16-byte load) and walks the queries 16 at a time;
+// the queries arrive through LDS in the operand order (k_flat_swizzle_queries lays them out once per call), double
+// buffered, shared by the 4 waves = 64 rows of the workgroup.  Euclidean is not of this shape ((x - y) is rounded per
+// pair before the multiply, euclidean.s:27) and stays on k_flat_scan.
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr uint32_t kMfmaMaxGroups = 4;  // slab groups of 4 blocks a wave holds in registers: d <= 512
+
+// [G = q / 16][b][h][l][c]: query 16 G + l % 16, element 32 b + 8 (2h + c / 2) + 4 (c % 2) + l / 16
+__global__ void k_flat_swizzle_queries(const float *__restrict__ q, float *__restrict__ out, uint32_t nq, uint32_t dim,
+                                       uint32_t nblk, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t c = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, gb = i >> 9;
+  const uint32_t b = gb % nblk, G = gb / nblk;
+  const uint32_t k = 4 * h + c, e = 32 * b + 8 * (k >> 1) + 4 * (k & 1) + (l >> 4), qi = 16 * G + (l & 15);
+  out[i] = qi < nq ? q[(size_t)qi * dim + e] : 0.0f;
+}
+
+// Rows of up to 12 blocks leave room for two workgroups per CU (256 registers per wave: 128 accumulators, 8 NBLK row
+// operands); longer rows run one workgroup per CU.
+template <int NBLK>
+__global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_flat_scan_mfma(const float *__restrict__ slab, const float *__restrict__ qsw,
+                                                        const FlatScanArgs a) {
+  constexpr int NG = (NBLK + 3) / 4;
+  constexpr uint32_t kGrpF4 = NBLK * 128;         // float4 per query group
+  extern __shared__ __attribute__((aligned(16))) float bs[];  // [2][NBLK][2][64][4], then the nq thresholds
+  float *thr_s = bs + 2 * kGrpF4 * 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t row0 = a.first + blockIdx.x * kScanRows, end = a.first + a.rows;
+  // ---- the wave's 16 rows: lane 16 blk + i holds, per slab group g and accumulator set k, the float4 at
+  // 128 g + 4 (8a + 4tt + blk) = elements 32 (4g + kk) + 8a + 4tt + blk, kk = 0..3
+  f4v A[NG][8];
+  {
+    const uint32_t r = row0 + 16 * wave + (lane & 15);
+    const float *src = slab + (size_t)(r < end ? r : end - 1) * a.ld + 4 * (lane >> 4);
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        A[g][k] = *reinterpret_cast<const f4v *>(src + 128 * g + 4 * (8 * (k >> 1) + 4 * (k & 1)));
+  }
+  // rows 4 (lane / 16) + i4 of the wave's tile are the ones this lane emits
+  const uint32_t slot0 = row0 + 16 * wave + 4 * (lane >> 4);
+  uint32_t live = 0;
+#pragma unroll
+  for (int i4 = 0; i4 < 4; i4++)
+    if (slot0 + i4 < end && slot0 + i4 != a.skip_slot && a.ids[slot0 + i4] != 0) live |= 1u << i4;
+  const uint32_t ngroups = (a.nq + 15) / 16;
+  // a query group's operands (2 NBLK KB) go from the swizzled image straight into LDS (global_load_lds_dwordx4: a wave
+  // instruction moves 64 x 16 B = 1 KB, no registers in between); a group past the end: the last one again
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  auto dma = [&](uint32_t G) __attribute__((always_inline)) {
+    const char *src = reinterpret_cast<const char *>(qsw) + (size_t)min(G, ngroups - 1) * (kGrpF4 * 16) + wave * 1024;
+    char *dst = reinterpret_cast<char *>(bs) + (size_t)(G & 1) * (kGrpF4 * 16) + wave * 1024;
+    const uint32_t lane_off = lane * 16;  // the only per-lane part of the address
+#pragma unroll
+    for (int piece = 0; piece < (2 * NBLK + 3) / 4; piece++)
+      if (4 * piece + wave < 2 * NBLK)
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + piece * 4096 + lane_off), (lds_void *)(dst + piece * 4096), 16, 0, 0);
+  };
+  // 8 NBLK matrix instructions: the wave's 16 rows against query group G, operands of block b + 1 on their way from
+  // LDS while block b is multiplied
+  auto multiply = [&](f16v (&acc)[8], uint32_t G) __attribute__((always_inline)) {
+    const f4v *bq = reinterpret_cast<const f4v *>(bs) + (size_t)(G & 1) * kGrpF4 + lane;
+    f4v b0 = bq[0], b1 = bq[64];
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+      f4v n0 = b0, n1 = b1;
+      if (b + 1 < NBLK) n0 = bq[(b + 1) * 128], n1 = bq[(b + 1) * 128 + 64];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        f16v c = acc[k];
+        if (b == 0)
+#pragma unroll
+          for (int r = 0; r < 16; r++) c[r] = 0.0f;
+        acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(A[b / 4][k][b % 4], k < 4 ? b0[k & 3] : b1[k & 3], c, 0, 0, 0);
+      }
+      b0 = n0, b1 = n1;
+    }
+  };
+  // the reduce tree of dot.s:45-53 in the lane, then the threshold test of the lane's 4 (row, query) pairs
+  auto reduce = [&](const f16v (&acc)[8], float (&dist)[4]) __attribute__((always_inline)) {
+    const f16v s0 = ((acc[0] + acc[2]) + acc[4]) + acc[6];
+    const f16v s1 = ((acc[1] + acc[3]) + acc[5]) + acc[7];
+    const f16v r4 = (s0 + s1) + 0.0f;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++) {
+      dist[i4] = (r4[i4] + r4[4 + i4]) + (r4[8 + i4] + r4[12 + i4]);  // metric_finish in emit
+      asm volatile("" : "+v"(dist[i4]));  // keeps the adds here, next to the matrix instructions, not behind emit's branch
+    }
+  };
+  auto threshold = [&](uint32_t G) __attribute__((always_inline)) { return thr_s[min(16 * G + (lane & 15), a.nq - 1)]; };
+  // distance.go:19-25 without a branch per pair: cosine 1 - x, dot -x (the metric is the same for the whole launch)
+  const bool cosine = a.metric == SDB_METRIC_COSINE;
+  auto emit = [&](const float (&dist)[4], uint32_t G, float thr) __attribute__((always_inline)) {
+    float d[4];
+    uint32_t hit = 0;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++) {
+      const float one_minus = 1.0f - dist[i4], neg = -dist[i4];
+      d[i4] = cosine ? one_minus : neg;
+      hit |= (!(d[i4] > thr) ? 1u : 0u) << i4;
+    }
+    hit &= live;
+    if (16 * G + (lane & 15) >= a.nq) hit = 0;
+    if (hit == 0) return;  // nearly always
+    uint32_t *cnt_g = a.cnt + 16 * G;                       // uniform base, the lane's part is a 32-bit offset
+    uint2 *cand_g = a.cand + (size_t)(16 * G) * a.cap;
+    const uint32_t j = lane & 15;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++)
+      if ((hit >> i4) & 1u) {
+        const uint32_t at = atomicAdd(cnt_g + j, 1u);
+        if (at < a.cap) cand_g[j * a.cap + at] = make_uint2(slot0 + i4, __float_as_uint(d[i4]));
+      }
+  };
+  // the order of issue: block b + 1's operands are asked for after the second matrix instruction of block b, six
+  // instructions (192 cycles of the matrix pipe) before the first one that needs them
+  auto pipeline = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // block 0's operands and the group's threshold
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (k == 2 && b + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    }
+  };
+  dma(0);
+  for (uint32_t i = tid; i < a.nq; i += 256) thr_s[i] = a.thr[i];
+  __syncthreads();  // waits for this wave's DMAs (vmcnt) and for everybody else's
+  f16v acc[8];
+  float dist[4];
+  // One barrier per group: LDS buffer (G + 1) & 1 was read by multiply(G - 1) before the previous barrier, is refilled
+  // with group G + 1 now, and is read by multiply(G + 1) after this one.  Two workgroups share a CU (256 registers
+  // per wave): while one wave reduces and emits, the matrix pipe of its SIMD works for the other.
+  for (uint32_t G = 0; G < ngroups; G++) {
+    dma(G + 1);
+    const float thr = threshold(G);
+    multiply(acc, G);
+    pipeline();
+    reduce(acc, dist);
+    emit(dist, G, thr);
+    __syncthreads();
+  }
+}
+
+constexpr int kMergeThreads = 256;
+// fold a launch's candidates into the running top list of one query (256 threads): the `limit` smallest of
 // (list U candidates) under (distance, slot) order; then the new threshold.  cnt > cap: the list was cut -- flag it.
-__global__ __launch_bounds__(64) void k_flat_merge(const uint32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
+__global__ __launch_bounds__(kMergeThreads) void k_flat_merge(const uint32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
                                                    uint32_t cap, uint32_t limit, uint32_t *__restrict__ top_slot,
                                                    float *__restrict__ top_dist, uint32_t *__restrict__ top_len,
                                                    float *__restrict__ thr, uint32_t *__restrict__ overflow) {
@@ -317,11 +483,11 @@ __global__ __launch_bounds__(64) void k_flat_merge(const uint32_t *__restrict__ 
     if (t == 0) thr[q] = len >= limit ? top_dist[(size_t)q * 128 + limit - 1] : __int_as_float(0x7f800000);
     return;
   }
-  for (uint32_t i = t; i < len; i += 64) items[i] = make_uint2(top_slot[(size_t)q * 128 + i], __float_as_uint(top_dist[(size_t)q * 128 + i]));
-  for (uint32_t i = t; i < c; i += 64) items[len + i] = cand[(size_t)q * cap + i];
+  for (uint32_t i = t; i < len; i += kMergeThreads) items[i] = make_uint2(top_slot[(size_t)q * 128 + i], __float_as_uint(top_dist[(size_t)q * 128 + i]));
+  for (uint32_t i = t; i < c; i += kMergeThreads) items[len + i] = cand[(size_t)q * cap + i];
   __syncthreads();
   const uint32_t m = len + c;
-  for (uint32_t i = t; i < m; i += 64) {
+  for (uint32_t i = t; i < m; i += kMergeThreads) {
     const float d = __uint_as_float(items[i].y);
     const uint32_t s = items[i].x;
     uint32_t rank = 0;
@@ -356,6 +522,33 @@ static int launch_flat_scan(const FlatScanArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL((k_flat_scan<L2>), grid, dim3(kScanWaves * 64), lds, stream, a.slab, a.queries, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
+}
+
+template <int NBLK>
+static int launch_flat_scan_mfma_nb(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
+  const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
+  const size_t lds = (size_t)2 * NBLK * 512 * sizeof(float) + (size_t)a.nq * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan_mfma<NBLK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_flat_scan_mfma<NBLK>), grid, dim3(256), lds, stream, a.slab, qsw, a);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+static int launch_flat_scan_mfma(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
+  switch (a.nblk) {
+#define SDB_MFMA_CASE(NB) \
+  case NB:                \
+    return launch_flat_scan_mfma_nb<NB>(a, qsw, stream);
+    SDB_MFMA_CASE(1) SDB_MFMA_CASE(2) SDB_MFMA_CASE(3) SDB_MFMA_CASE(4) SDB_MFMA_CASE(5) SDB_MFMA_CASE(6) SDB_MFMA_CASE(7)
+    SDB_MFMA_CASE(8) SDB_MFMA_CASE(9) SDB_MFMA_CASE(10) SDB_MFMA_CASE(11) SDB_MFMA_CASE(12) SDB_MFMA_CASE(13)
+    SDB_MFMA_CASE(14) SDB_MFMA_CASE(15) SDB_MFMA_CASE(16)
+#undef SDB_MFMA_CASE
+  }
+  return fail(SDB_ERR_INVALID, "row too long for the matrix-core scan");
 }
 
 }  // namespace sdb
@@ -400,8 +593,8 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   // ---- buffers: staged queries/outputs for host callers, running top lists, one distance block
   uint32_t chunk = filtered ? std::max<uint32_t>(max_f, 1)
                             : (uint32_t)std::min<uint64_t>(std::max<uint32_t>(n, 1), (1ull << 28) / nq);
-  if (!filtered && !ix->pq && ix->lay.tail == 0 && ix->lay.nblk >= 1 && ix->lay.nblk <= 19 && n >= 4 * 8192 && nq <= 8192)
-    chunk = std::min<uint32_t>(chunk, 8192);  // with the streaming scan the block path only sees the seed rows
+  if (!filtered && !ix->pq && ix->lay.tail == 0 && ix->lay.nblk >= 1 && ix->lay.nblk <= 19 && n >= 32768 && nq <= 8192)
+    chunk = std::min<uint32_t>(chunk, 4096);  // with the streaming scan the block path only sees the seed rows
   const uint32_t stride = (chunk + 63) & ~63u;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
@@ -419,10 +612,14 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const size_t o_lut = carve(pq ? (size_t)nq * pq->M * pq->K * 4 : 0);
   // the streaming scan (k_flat_scan): plain store, no filter, rows of whole 32-float blocks up to 512 floats, a
   // table worth streaming.  Its first rows still go through the block path below: they seed the thresholds.
-  constexpr uint32_t kSeedRows = 8192, kCandCap = 8192;
-  const bool fast = !filtered && !pq && l.tail == 0 && l.nblk >= 1 && l.nblk <= 19 && n >= 4 * kSeedRows && nq <= 8192;
+  constexpr uint32_t kSeedRows = 4096, kMinSegment = 32768, kCandCap = 8192;
+  const bool fast = !filtered && !pq && l.tail == 0 && l.nblk >= 1 && l.nblk <= 19 && n >= kMinSegment && nq <= 8192;
   const size_t o_thr = carve(fast ? nq * 4 : 0);
   const size_t o_cnt = carve(fast ? nq * 4 + 256 : 0), o_cand = carve(fast ? (size_t)nq * kCandCap * 8 : 0);
+  // dot / cosine rows of up to 512 floats: the scan runs on the matrix cores, queries in its operand order
+  const bool mfma = fast && ix->P.metric != SDB_METRIC_EUCLIDEAN && l.nblk <= 4 * kMfmaMaxGroups && !ix->tune_no_mfma;
+  const uint32_t qsw_floats = mfma ? (uint32_t)((nq + 15) / 16) * l.nblk * 512 : 0;
+  const size_t o_qsw = carve((size_t)qsw_floats * 4);
   char *buf = nullptr;
   SDB_HIP(hipMalloc(&buf, off));
   struct Free {
@@ -501,21 +698,30 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
       merge_attr = true;
     }
     // thresholds from the seed rows (no candidates yet: the merge only derives thr from the lists)
-    hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(64), merge_lds, stream, d_cnt, d_cand, kCandCap, limit, top_slot,
+    hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(kMergeThreads), merge_lds, stream, d_cnt, d_cand, kCandCap, limit, top_slot,
                        top_dist, top_len, d_thr, d_over);
     SDB_HIP(hipGetLastError());
     // A row passes its query's threshold with probability ~ limit / rows-scanned-so-far, so a segment as long as
-    // everything before it brings about `limit` candidates per query: segments double (8 launches for 1M rows),
-    // the candidate lists stay two orders of magnitude under kCandCap and the merges cost nothing
-    for (uint32_t first = seed, seg = seed; first < n; first += seg, seg = first) {
+    // everything before it brings about `limit` candidates per query.  The first segment is 32 768 rows (one
+    // workgroup tile for each of the 512 resident workgroups; ~8 limit candidates after the 4 096 seed rows), then
+    // the segments double: 6 launches for 1M rows, candidate lists far under kCandCap, merges that cost nothing
+    for (uint32_t first = seed, seg = kMinSegment - seed; first < n; first += seg, seg = first) {
       FlatScanArgs sa{};
       sa.slab = ix->d_slab, sa.queries = dq, sa.ids = vw.ids, sa.thr = d_thr, sa.cnt = d_cnt;
       sa.cand = d_cand, sa.cap = kCandCap, sa.first = first, sa.rows = std::min<uint32_t>(seg, n - first);
       sa.nq = (uint32_t)nq, sa.ld = l.ld, sa.dim = l.dim, sa.nblk = l.nblk, sa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
       sa.metric = (int)ix->P.metric;
-      if (ix->P.metric == SDB_METRIC_EUCLIDEAN) SDB_TRY(launch_flat_scan<true>(sa, stream));
+      if (mfma) {
+        if (first == seed) {
+          hipLaunchKernelGGL(k_flat_swizzle_queries, dim3((qsw_floats + 255) / 256), dim3(256), 0, stream, dq,
+                             (float *)(buf + o_qsw), (uint32_t)nq, l.dim, l.nblk, qsw_floats);
+          SDB_HIP(hipGetLastError());
+        }
+        SDB_TRY(launch_flat_scan_mfma(sa, (const float *)(buf + o_qsw), stream));
+
+      } else if (ix->P.metric == SDB_METRIC_EUCLIDEAN) SDB_TRY(launch_flat_scan<true>(sa, stream));
       else SDB_TRY(launch_flat_scan<false>(sa, stream));
-      hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(64), merge_lds, stream, d_cnt, d_cand, kCandCap, limit,
+      hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(kMergeThreads), merge_lds, stream, d_cnt, d_cand, kCandCap, limit,
                          top_slot, top_dist, top_len, d_thr, d_over);
       SDB_HIP(hipGetLastError());
       SDB_HIP(hipMemsetAsync(d_cnt, 0, nq * 4, stream));
@@ -640,7 +846,7 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
       replaced.push_back((uint32_t)s);
     }
   }
-  {  // the same id twice in one call: the last vector wins, like consecutive Set calls
+  if (ids) {  // the same id twice in one call: the last vector wins, like consecutive Set calls
     std::unordered_map<uint64_t, uint64_t> last;
     for (uint64_t i = 0; i < n; i++) last[new_ids[i]] = i;
     if (last.size() != n) return fail(SDB_ERR_INVALID, "an id appears twice in one set_vectors call");

@@ -936,6 +936,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
     case SDB_TUNE_NO_TILE:
       ix->tune_no_tile = (uint32_t)(value > 2 ? 1 : value);
       return SDB_OK;
+    case SDB_TUNE_NO_MFMA:
+      ix->tune_no_mfma = value != 0;
+      return SDB_OK;
     default:
       return fail(SDB_ERR_INVALID, "unknown tuning key %d", key);
   }
