@@ -366,6 +366,14 @@ def run_c2(a, ctx):
     t_ids = exact_topk(queries[0], base, k)[1] + 2
     truth_agree = float((f_ids.to(torch.int64).unsqueeze(2) == t_ids.unsqueeze(1)).any(2).float().mean().item())
     log("flat scan vs matmul ground truth agreement: %.4f" % truth_agree)
+    # the exact scan as a measured point of its own (IndexFlat.Search of one query batch over this rank's rows)
+    torch.cuda.synchronize()
+    t_f = time.perf_counter()
+    for _ in range(3):
+        flat.flat_search_batch(ix._h, d, queries[0], k, device=dev_index)
+    torch.cuda.synchronize()
+    flat_ms = (time.perf_counter() - t_f) / 3 * 1e3
+    log("flat exact scan: %.2f ms per %d queries over %d rows" % (flat_ms, nq, n))
 
     # ---- timed region: batches the recall phase never walked, trace counters OFF, one batch at a time
     tb = [nb_recall + (i % nb_timed) for i in range(a.warmup + a.steps)]
@@ -446,6 +454,9 @@ def run_c2(a, ctx):
             "recall_gate": 0.95,
             "ground_truth": "exact brute force over the whole database (torch matmul top-k); agreement with the "
                             "device flat scan %.4f" % truth_agree,
+            "flat_scan_ms": round(flat_ms, 2),
+            "flat_scan": "IndexFlat.Search (exact scan, same distance bits) of one %d-query batch over %d rows: "
+                         "%.1f G pairs/s, %.1f useful TFLOP/s" % (nq, n, nq * n / flat_ms / 1e6, 2.0 * nq * n * d / flat_ms / 1e9),
             "search_size": L,
             "parallelism": par,
             "value_definition": "user-visible queries answered per second (each query counted once, after the "

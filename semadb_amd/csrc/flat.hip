@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_flat_scan(const float *__re
 // pair before the multiply, euclidean.s:27) and stays on k_flat_scan.
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
-constexpr uint32_t kMfmaMaxGroups = 4;  // slab groups of 4 blocks a wave holds in registers: d <= 512
+constexpr uint32_t kMfmaMaxGroups = 8;  // slab groups of 4 blocks a wave holds in registers: d <= 1024
 
 // [G = q / 16][b][h][l][c]: query 16 G + l % 16, element 32 b + 8 (2h + c / 2) + 4 (c % 2) + l / 16
 __global__ void k_flat_swizzle_queries(const float *__restrict__ q, float *__restrict__ out, uint32_t nq, uint32_t dim,
@@ -545,7 +545,10 @@ static int launch_flat_scan_mfma(const FlatScanArgs &a, const float *qsw, hipStr
     return launch_flat_scan_mfma_nb<NB>(a, qsw, stream);
     SDB_MFMA_CASE(1) SDB_MFMA_CASE(2) SDB_MFMA_CASE(3) SDB_MFMA_CASE(4) SDB_MFMA_CASE(5) SDB_MFMA_CASE(6) SDB_MFMA_CASE(7)
     SDB_MFMA_CASE(8) SDB_MFMA_CASE(9) SDB_MFMA_CASE(10) SDB_MFMA_CASE(11) SDB_MFMA_CASE(12) SDB_MFMA_CASE(13)
-    SDB_MFMA_CASE(14) SDB_MFMA_CASE(15) SDB_MFMA_CASE(16)
+    SDB_MFMA_CASE(14) SDB_MFMA_CASE(15) SDB_MFMA_CASE(16) SDB_MFMA_CASE(17) SDB_MFMA_CASE(18) SDB_MFMA_CASE(19)
+    SDB_MFMA_CASE(20) SDB_MFMA_CASE(21) SDB_MFMA_CASE(22) SDB_MFMA_CASE(23) SDB_MFMA_CASE(24) SDB_MFMA_CASE(25)
+    SDB_MFMA_CASE(26) SDB_MFMA_CASE(27) SDB_MFMA_CASE(28) SDB_MFMA_CASE(29) SDB_MFMA_CASE(30) SDB_MFMA_CASE(31)
+    SDB_MFMA_CASE(32)
 #undef SDB_MFMA_CASE
   }
   return fail(SDB_ERR_INVALID, "row too long for the matrix-core scan");
@@ -593,8 +596,16 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   // ---- buffers: staged queries/outputs for host callers, running top lists, one distance block
   uint32_t chunk = filtered ? std::max<uint32_t>(max_f, 1)
                             : (uint32_t)std::min<uint64_t>(std::max<uint32_t>(n, 1), (1ull << 28) / nq);
-  if (!filtered && !ix->pq && ix->lay.tail == 0 && ix->lay.nblk >= 1 && ix->lay.nblk <= 19 && n >= 32768 && nq <= 8192)
-    chunk = std::min<uint32_t>(chunk, 4096);  // with the streaming scan the block path only sees the seed rows
+  // the streaming scans: plain store, no filter, rows of whole 32-float blocks, a table worth streaming.  Dot and
+  // cosine rows of up to 1 024 floats run on the matrix cores (k_flat_scan_mfma; its query operands and thresholds
+  // must fit LDS), euclidean rows -- and the others when the matrix-core scan is switched off -- of up to 608 floats
+  // on the packed-FMA kernel (k_flat_scan).  The first rows still go through the block path: they seed the thresholds.
+  constexpr uint32_t kSeedRows = 4096, kMinSegment = 32768, kCandCap = 8192;
+  const bool streamable = !filtered && !ix->pq && l.tail == 0 && l.nblk >= 1 && n >= kMinSegment && nq <= 8192;
+  const bool mfma = streamable && ix->P.metric != SDB_METRIC_EUCLIDEAN && l.nblk <= 4 * kMfmaMaxGroups && !ix->tune_no_mfma &&
+                    (size_t)2 * l.nblk * 2048 + nq * 4 <= 160 * 1024;
+  const bool fast = mfma || (streamable && l.nblk <= 19);
+  if (fast) chunk = std::min<uint32_t>(chunk, kSeedRows);  // the block path only sees the seed rows
   const uint32_t stride = (chunk + 63) & ~63u;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
@@ -610,14 +621,8 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const size_t o_d = carve((size_t)nq * stride * 4);
   const sdb_pq *pq = ix->pq;
   const size_t o_lut = carve(pq ? (size_t)nq * pq->M * pq->K * 4 : 0);
-  // the streaming scan (k_flat_scan): plain store, no filter, rows of whole 32-float blocks up to 512 floats, a
-  // table worth streaming.  Its first rows still go through the block path below: they seed the thresholds.
-  constexpr uint32_t kSeedRows = 4096, kMinSegment = 32768, kCandCap = 8192;
-  const bool fast = !filtered && !pq && l.tail == 0 && l.nblk >= 1 && l.nblk <= 19 && n >= kMinSegment && nq <= 8192;
   const size_t o_thr = carve(fast ? nq * 4 : 0);
   const size_t o_cnt = carve(fast ? nq * 4 + 256 : 0), o_cand = carve(fast ? (size_t)nq * kCandCap * 8 : 0);
-  // dot / cosine rows of up to 512 floats: the scan runs on the matrix cores, queries in its operand order
-  const bool mfma = fast && ix->P.metric != SDB_METRIC_EUCLIDEAN && l.nblk <= 4 * kMfmaMaxGroups && !ix->tune_no_mfma;
   const uint32_t qsw_floats = mfma ? (uint32_t)((nq + 15) / 16) * l.nblk * 512 : 0;
   const size_t o_qsw = carve((size_t)qsw_floats * 4);
   char *buf = nullptr;

@@ -304,15 +304,15 @@ def test_flat_set_rules():
 def test_matrix_core_scan_equals_the_packed_fma_scan(oracle, metric):
     """dot / cosine tables are scanned on the matrix cores (k_flat_scan_mfma: one v_mfma_f32_16x16x1 = one fused
     multiply-add of the reference's chain for 1 024 (row, query, partial sum) triples).  Every row length the kernel is
-    instantiated for (1..16 blocks of 32 floats) gives the same ids and the same distance bits as the packed-FMA
-    scan (SDB_TUNE_NO_MFMA), values that underflow to denormals included; three of the lengths are also held to the
-    oracle directly."""
+    instantiated for (1..32 blocks of 32 floats) gives the same ids and the same distance bits as the scan without
+    them (SDB_TUNE_NO_MFMA: the packed-FMA kernel up to 19 blocks, the block path beyond), values that underflow to
+    denormals included; five of the lengths are also held to the oracle directly."""
     import ctypes as C
     from semadb_amd import flat
     from semadb_amd._lib import lib, check
     rng = np.random.default_rng(77)
     n, nq = 33000, 21
-    for nblk in range(1, 17):
+    for nblk in range(1, 33):
         d = 32 * nblk
         base = rng.standard_normal((n, d)).astype(np.float32)
         base[::7] *= np.float32(1e-22)   # products of two such values are denormal or underflow
@@ -329,7 +329,7 @@ def test_matrix_core_scan_equals_the_packed_fma_scan(oracle, metric):
         ref = ix.search_batch(q, 10)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), d
         assert np.array_equal(got[2], ref[2])
-        if nblk in (1, 12, 16):
+        if nblk in (1, 12, 16, 24, 32):
             for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, metric, 10)):
                 assert np.array_equal(got[0][i], e_ids) and np.array_equal(bits(got[1][i]), bits(e_d)), (d, i)
         ix.close()
