@@ -105,6 +105,10 @@ def build_index(a, base, dev_index, name="bench"):
     ix.set_start(start_vector(d))
     if os.environ.get("BENCH_NO_TILE"):  # measurement only (tools/pmc_build.sh): the one-wave prune of new nodes
         ix.set_tuning("no_tile", int(os.environ["BENCH_NO_TILE"]))
+    for kv in filter(None, os.environ.get("BENCH_TUNE", "").split(",")):  # measurement only: "wide_hash=1,hash_limit=3000"
+        key, value = kv.split("=")
+        ix.set_tuning(key, int(value))
+        log("tuning %s = %s (A/B measurement, not the shipped default)" % (key, value))
     torch.cuda.synchronize()
     t1 = time.time()
     ix.insert_batch(None, base)  # ids 2..n+1 ; K4 on device

@@ -200,12 +200,15 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *   SDB_TUNE_NO_TILE     != 0: a new node's robustPrune reads candidate rows from global memory instead of
  *                        staging them in LDS
  *   SDB_TUNE_NO_MFMA     != 0: the exact scan of dot / cosine tables runs on the packed-FMA kernel (the one
- *                        euclidean uses) instead of the matrix cores */
+ *                        euclidean uses) instead of the matrix cores
+ *   SDB_TUNE_WIDE_HASH   != 0: searches over a quantized store keep their visited ids in 32-bit LDS cells (four
+ *                        walks per CU) instead of the 16-bit cells used for stores of up to 2^24 rows (six) */
 #define SDB_TUNE_HUB_MIN 1
 #define SDB_TUNE_HASH_LIMIT 2
 #define SDB_TUNE_NO_HASH 3
 #define SDB_TUNE_NO_TILE 4
 #define SDB_TUNE_NO_MFMA 5
+#define SDB_TUNE_WIDE_HASH 6
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
 
 /* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts

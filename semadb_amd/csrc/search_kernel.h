@@ -65,6 +65,7 @@ struct SearchArgs {
   uint32_t dcache_shift;
   unsigned long long *totals;  // build path: [0] += n_dist, [1] += n_edges of every query (sdb_index_build_stats)
   uint32_t prefer_bitset;  // != 0: never use the LDS hash visited set (large build rounds)
+  uint32_t wide_hash;      // != 0: quantized store keeps the 32-bit-cell set (HashVisited) instead of HashVisited16
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
 
@@ -735,6 +736,110 @@ struct HashVisited {
   }
 };
 
+// The same exact set in half the LDS, for stores of up to 2^24 rows: 16-bit cells.  h = slot * odd mod 2^24 is a
+// bijection of the 24-bit universe; its top 12 bits name a bucket -- one 32-bit LDS word, two cells -- and its low
+// 12 bits are the remainder a cell stores, next to the number (0..14) of the probe that placed the key: probe i of
+// a key looks at bucket (b + i * (2 rem + 1)) mod 4096, double hashing over buckets with a stride the cell itself
+// gives back.  Position and content of a cell therefore identify its key exactly -- nothing is a fingerprint --
+// and spill() rebuilds every key.  The cells of a bucket fill low half first and nothing is ever removed, so a key
+// that is present sits before the first bucket of its sequence that is not full.  A key that finds 15 full buckets
+// (probability ~1e-7 at 60 % load), or a table past its limit, spills to the HBM bitset like HashVisited does.
+// 8 192 cells = 16 KB: with the 8 KB LUT of M = 8 six walks fit a CU instead of four.
+constexpr uint32_t inverse24(uint32_t a) {  // a * x = 1 mod 2^24, Newton steps double the correct bits
+  uint32_t x = a;
+  for (int i = 0; i < 5; i++) x *= 2u - a * x;
+  return x & 0xFFFFFFu;
+}
+constexpr uint32_t kHash16Mul = 0x9E3779B1u & 0xFFFFFFu, kHash16Inv = inverse24(kHash16Mul);
+static_assert(((kHash16Mul * kHash16Inv) & 0xFFFFFFu) == 1u, "kHash16Inv must invert kHash16Mul mod 2^24");
+struct HashVisited16 {
+  static constexpr uint32_t kBuckets = 4096, kCells = 2 * kBuckets;
+  static constexpr uint32_t kWords = kBuckets;  // 32-bit LDS words
+  static constexpr uint32_t kMaxProbe = 14;     // (probe 15, remainder 0xFFF) is the empty cell
+  uint32_t *tab;
+  uint32_t *bits;
+  uint32_t words, count, limit;
+  bool spilled;
+  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
+    tab = lds, bits = bitset, words = nwords;
+    count = 0, spilled = false;
+    limit = (uint32_t)(((uint64_t)lim * kCells) >> 13);  // 6 000 of 8 192 cells by default
+    uint4 *t4 = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __syncthreads();
+  }
+  __device__ __forceinline__ void spill(int lane) {
+    for (uint32_t i = lane; i < words; i += 64) bits[i] = 0u;  // ClearAll distset.go:101
+    __threadfence();
+    for (uint32_t c = lane; c < kCells; c += 64) {
+      const uint32_t v = (tab[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu;
+      if (v != 0xFFFFu) {
+        const uint32_t rem = v & 0xFFFu, probe = v >> 12;
+        const uint32_t b = ((c >> 1) - probe * (2u * rem + 1u)) & (kBuckets - 1);
+        const uint32_t k = (((b << 12) | rem) * kHash16Inv) & 0xFFFFFFu;
+        atomicOr(&bits[k >> 5], 1u << (k & 31));
+      }
+    }
+    __threadfence();
+    spilled = true;
+  }
+  __device__ __forceinline__ bool bit_test_and_set(bool active, uint32_t slot) {
+    if (!active) return false;
+    const uint32_t bit = 1u << (slot & 31);
+    return !(atomicOr(&bits[slot >> 5], bit) & bit);
+  }
+  __device__ __forceinline__ bool test_and_set(bool active, uint32_t slot, int lane) {
+    if (spilled) return bit_test_and_set(active, slot);
+    const uint32_t h = (slot * kHash16Mul) & 0xFFFFFFu;
+    const uint32_t rem = h & 0xFFFu, step = 2u * rem + 1u;
+    uint32_t bucket = h >> 12, probe = 0;
+    bool isnew = false, done = !active, stuck = false;
+    // a round reads kProbes buckets of the sequence at once and takes the first that holds the key or has room
+    while (__ballot(!done)) {
+      uint32_t bp[kProbes], wp[kProbes];
+      bp[0] = bucket;
+#pragma unroll
+      for (int i = 1; i < kProbes; i++) bp[i] = (bp[i - 1] + step) & (kBuckets - 1);
+#pragma unroll
+      for (int i = 0; i < kProbes; i++) wp[i] = tab[bp[i]];
+      int hit = -1;  // first bucket of this round that ends the search
+      bool present = false;
+#pragma unroll
+      for (int i = kProbes - 1; i >= 0; i--) {
+        const uint32_t target = rem | ((probe + i) << 12);
+        const bool has = (wp[i] & 0xFFFFu) == target || (wp[i] >> 16) == target;
+        const bool room = (wp[i] >> 16) == 0xFFFFu;
+        if ((has || room) && probe + i <= kMaxProbe) hit = i, present = has;
+      }
+      if (!done) {
+        if (hit < 0) {
+          probe += kProbes;
+          if (probe > kMaxProbe) done = stuck = true;
+          else bucket = (bp[kProbes - 1] + step) & (kBuckets - 1);
+        } else if (present) {
+          done = true;
+        } else {
+          uint32_t old = wp[0], at = bp[0];
+#pragma unroll
+          for (int i = 1; i < kProbes; i++)
+            if (hit == i) old = wp[i], at = bp[i];
+          const uint32_t target = rem | ((probe + (uint32_t)hit) << 12);
+          const uint32_t neu = (old & 0xFFFFu) == 0xFFFFu ? ((old & 0xFFFF0000u) | target) : ((old & 0xFFFFu) | (target << 16));
+          if (atomicCAS(tab + at, old, neu) == old) isnew = true, done = true;
+          else probe += (uint32_t)hit, bucket = at;  // another lane's key took a cell of that bucket: look at it again
+        }
+      }
+    }
+    count += (uint32_t)__popcll(__ballot(isnew));
+    const uint64_t st = __ballot(stuck);
+    if (st || count > limit) {
+      spill(lane);
+      if (stuck) isnew = bit_test_and_set(true, slot);  // after the replay: the set is the bitset now
+    }
+    return isnew;
+  }
+};
+
 // greedySearch for one query by one wavefront.
 template <class Dist, int NREG, bool FILT, class Visited>
 __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist,
@@ -963,7 +1068,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 // HASH: visited set in LDS, spilling to the HBM bitset when it fills (plain store, unfiltered); otherwise the
 // HBM bitset from the start.
 // HCAP != 0: capacity of the LDS hash visited set (it sits first in dynamic LDS, the distance policy's
-// tile / LUT after it); HCAP == 0: HBM bitset from the start.
+// tile / LUT after it), kHash16: the 16-bit-cell set; HCAP == 0: HBM bitset from the start.
+constexpr uint32_t kHash16 = 0xFFFFFFFFu;  // HCAP value that selects HashVisited16
 template <class Dist, int NREG, bool FILT, uint32_t HCAP>
 __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   const int lane = threadIdx.x;
@@ -971,7 +1077,12 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   Dist dist;
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
-  if constexpr (HCAP != 0) {
+  if constexpr (HCAP == kHash16) {
+    dist.init(a, q, lane, lds_f + HashVisited16::kWords);
+    HashVisited16 hv;
+    hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
+  } else if constexpr (HCAP != 0) {
     dist.init(a, q, lane, lds_f + HashVisited<HCAP>::kWords);
     HashVisited<HCAP> hv;
     hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);

@@ -315,3 +315,50 @@ def test_quantizer_attached_to_a_device_built_graph(oracle, monkeypatch, metric,
     assert_same_graph(ix, o)
     ix.close()
     gpq.close()
+
+
+def test_quantized_walk_is_the_same_under_every_visited_set(oracle):
+    """The walk over a quantized store keeps its visited ids in 16-bit LDS cells (HashVisited16: bucket + remainder
+    of a 24-bit bijection, six walks per CU), or -- by tuning -- in 32-bit cells, or in the HBM bitset, or spills
+    from the cells to the bitset after a handful of ids.  All of them are exact sets: a graph of 120 000 nodes
+    walked with searchSize 96 (spilling early and mid-walk through the limit knob) gives the same ids,
+    distance bits, hop and distance counts under each, and the first queries agree with the oracle."""
+    from semadb_amd import vamana, vectorstore as vs
+    from tests.helpers import start_vector
+    rng = np.random.default_rng(31)
+    n, d, M, K, R, L = 120000, 32, 8, 256, 48, 96
+    lat = rng.standard_normal((10, d)).astype(np.float32)
+    base = rng.standard_normal((n, 10)).astype(np.float32) @ lat + 0.2 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    ix = vamana.NewIndexVamana("vs", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), strict=False)
+    ix.set_start(start_vector(np.random.default_rng(3), d))
+    ix.insert_batch(None, base)
+    ids, vecs, off, edges = ix.export()
+    first = rng.integers(0, 5000, M)
+    gpq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(K, M), d)
+    codes = gpq.Fit(vecs[1:5001].copy(), first, alias=True)
+    vs.attach(ix, gpq)
+    q = base[rng.choice(n, 96, replace=False)] + 0.05 * rng.standard_normal((96, d)).astype(np.float32)
+    ref = ix.search_batch(q, 10, L, trace=True, visit_cap=1024)
+    assert int(ref[3].n_dist.max()) > 1200, int(ref[3].n_dist.max())
+    for key, value in [("wide_hash", 1), ("no_hash", 1), ("hash_limit", 40), ("hash_limit", 600)]:
+        ix.set_tuning("wide_hash", 0), ix.set_tuning("no_hash", 0), ix.set_tuning("hash_limit", 0)
+        ix.set_tuning(key, value)
+        got = ix.search_batch(q, 10, L, trace=True, visit_cap=1024)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), key
+        assert np.array_equal(got[3].n_dist, ref[3].n_dist) and np.array_equal(got[3].n_hop, ref[3].n_hop), key
+        assert np.array_equal(got[3].visit_ids, ref[3].visit_ids), key
+    # and the walk is the reference's: the oracle over the exported graph with the same codes
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=oracle.IMPL_ASM)
+    o.load(ids, vecs, off, edges)
+    opq = oracle.PQ(d, "cosine", M, K)
+    ocodes = opq.fit(vecs[1:5001].copy(), first, alias=True)
+    assert np.array_equal(ocodes, codes)
+    all_codes = np.stack([opq.encode(v) for v in vecs])
+    assert o.attach_pq(opq, all_codes) == 0
+    for k in range(6):
+        o_ids, o_d, o_vis, o_tr = o.search(q[k], 10, L)
+        assert np.array_equal(ref[0][k, :len(o_ids)], o_ids) and np.array_equal(bits(ref[1][k, :len(o_ids)]), bits(o_d))
+        assert int(ref[3].n_dist[k]) == o_tr.n_dist
+    ix.close()
+    gpq.close()
