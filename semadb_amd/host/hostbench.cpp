@@ -62,6 +62,10 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
         }
       }
     }
+    // `done` flags are raised before the batcher takes client.mu to count and notify: a request can be harvested
+    // while its wake-up is still on its way.  The client (a stack object) may only go away once every wake-up has
+    // been delivered, i.e. once the count under the lock has reached what was submitted.
+    SearchBatcher::waitFor(&client, submitted);
   };
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> pool;

@@ -296,7 +296,8 @@ class SearchBatcher {
     }
     if (wake) qcv_.notify_one();
   }
-  // block the client until at least `target` of its requests have completed
+  // block the client until at least `target` of its requests have completed.  A Client must outlive its wake-ups:
+  // before it is destroyed, wait for the count of everything it submitted (Request::done alone is raised earlier)
   static void waitFor(Client *c, uint64_t target) {
     std::unique_lock<std::mutex> lk(c->mu);
     c->cv.wait(lk, [&] { return c->completed >= target; });
