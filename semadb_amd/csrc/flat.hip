@@ -798,7 +798,9 @@ static int flat_tombstone(sdb_index *ix, std::vector<uint32_t> &slots) {
     ix->dense_ids = false;
   }
   for (uint32_t s : slots) {
-    ix->tx_deleted[ix->h_ids[s]] = s;  // until commit a search on the committed rows still finds it
+    // until commit a search on the committed rows still finds it; a row this transaction appended itself was never
+    // visible, and an id keeps the committed row it had when the transaction began (first record wins)
+    if (s < ix->tx_n0) ix->tx_deleted.emplace(ix->h_ids[s], s);
     ix->id2slot.erase(ix->h_ids[s]);
     ix->h_ids[s] = 0;
   }

@@ -370,7 +370,7 @@ int sdb_index::begin_write() {
 
 int64_t sdb_index::slot_of_committed(uint64_t id, uint32_t view_n) const {
   int64_t s = slot_of(id);
-  if (s < 0 && in_tx) {  // removed by the open transaction: still there for a search on the committed graph
+  if ((s < 0 || (uint32_t)s >= view_n) && in_tx) {  // removed or replaced by the open transaction: the committed row is still there for a search on the committed graph
     auto it = tx_deleted.find(id);
     if (it != tx_deleted.end()) s = (int64_t)it->second;
   }

@@ -34,4 +34,5 @@ def test_fuzz_short_soak(oracle, monkeypatch, seed):
         rng = np.random.default_rng([seed, t])
         fz.merge_trial(rng)
         fz.pq_trial(rng)
+        fz.flat_trial(rng)
         fz.trial(rng, t)

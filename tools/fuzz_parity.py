@@ -308,6 +308,104 @@ def pq_trial(rng):
         gpq.close()
 
 
+def flat_trial(rng):
+    """flat.IndexFlat (shard/index/flat/flat.go): random Set / replace / Delete sequences, explicit transactions with
+    a search in between (which must not see them), compaction, and exact searches with random limits and filters
+    against the oracle's distances over a storage-order model of the store (Set of a stored id drops its row and
+    appends the new one).  One trial in four is a table of 33 000+ rows of whole 32-float blocks: the streaming
+    scans (matrix cores for dot / cosine, packed FMAs for euclidean), tombstones included."""
+    from semadb_amd import flat
+    metric = str(rng.choice(METRICS))
+    kind = str(rng.choice(["unit", "latent", "grid", "dups"]))
+    big = rng.integers(0, 4) == 0
+    d = int(rng.choice([32, 64, 96, 128, 384])) if big else int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 128, 200, 384, 768]))
+    n0 = int(rng.integers(33000, 42000)) if big else int(rng.integers(1, max(2, min(3000, 200000 // d))))
+    CURRENT.clear()
+    CURRENT.update(dict(flat_trial=True, d=d, metric=metric, kind=kind, n0=n0))
+    ids, rows = [], []
+
+    def m_set(i, v):
+        m_del(i)
+        ids.append(int(i)), rows.append(np.asarray(v, dtype=np.float32))
+
+    def m_del(i):
+        if int(i) in pos_of():
+            k = ids.index(int(i))
+            del ids[k], rows[k]
+
+    def pos_of():
+        return set(ids)
+
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, metric))
+    try:
+        base = draw_rows(rng, n0, d, kind)
+        first_ids = rng.permutation(np.arange(1, 3 * n0 + 1))[:n0].astype(np.uint64) if rng.integers(0, 2) else \
+            np.arange(5, n0 + 5, dtype=np.uint64)
+        ix.set_vectors(first_ids, base)
+        ids.extend(int(v) for v in first_ids), rows.extend(base)
+        next_id = int(first_ids.max()) + 1
+
+        def check(tag):
+            if not ids:
+                return
+            nq = int(rng.integers(1, 20))
+            q = draw_rows(rng, nq, d, kind)
+            limit = int(rng.choice([1, 3, 10, 75, 128]))
+            I, B = np.array(ids, dtype=np.uint64), np.stack(rows)
+            dm = orc.distance_matrix(q, B, metric, orc.IMPL_ASM)
+            allowed = None
+            if rng.integers(0, 3) == 0:
+                pool = np.concatenate([I, np.array([10 ** 9 + 1], dtype=np.uint64)])
+                allowed = [set(int(v) for v in rng.choice(pool, size=min(len(pool), int(rng.integers(1, 60))), replace=False))
+                           for _ in range(nq)]
+            g_ids, g_d, g_c = ix.search_batch(q, limit, filters=allowed)
+            for i in range(nq):
+                idx = np.arange(len(I)) if allowed is None else np.array([j for j in range(len(I)) if int(I[j]) in allowed[i]], dtype=np.int64)
+                order = idx[np.argsort(dm[i, idx], kind="stable")][:limit]
+                assert int(g_c[i]) == len(order), (tag, "flat count", i, int(g_c[i]), len(order))
+                assert np.array_equal(g_ids[i, :len(order)], I[order]), (tag, "flat ids", i)
+                assert np.array_equal(bits(g_d[i, :len(order)]), bits(dm[i, order])), (tag, "flat distances", i)
+
+        check("initial")
+        for step in range(int(rng.integers(2, 6))):
+            ch = []
+            live = list(ids)
+            for _ in range(int(rng.integers(1, 40))):
+                op = int(rng.integers(0, 5))
+                if op <= 1:  # new point
+                    ch.append(flat.IndexVectorChange(next_id, draw_rows(rng, 1, d, kind)[0]))
+                    next_id += 1
+                elif op == 2 and live:  # replace
+                    ch.append(flat.IndexVectorChange(int(rng.choice(live)), draw_rows(rng, 1, d, kind)[0]))
+                elif op == 3 and live:  # delete
+                    ch.append(flat.IndexVectorChange(int(rng.choice(live)), None))
+                else:  # delete of a missing id
+                    ch.append(flat.IndexVectorChange(next_id + 10 ** 6, None))
+            explicit = rng.integers(0, 3) == 0
+            if explicit:  # the same changes by hand inside one transaction, with a search that must not see them
+                ix.begin_write()
+                for c in ch:
+                    if c.Vector is None:
+                        ix.remove_vectors([c.Id])
+                    else:
+                        ix.set_vectors(np.array([c.Id], dtype=np.uint64), c.Vector.reshape(1, -1))
+                check("inside transaction %d" % step)
+                ix.commit()
+            else:
+                ix.InsertUpdateDelete(ch)
+            for c in ch:
+                m_del(c.Id) if c.Vector is None else m_set(c.Id, c.Vector)
+            assert ix.version_diff() == 0, ("flat version diff", step)
+            r_rows, r_dead = ix.row_usage()
+            assert r_rows - r_dead == len(ids), ("flat row usage", step, r_rows, r_dead, len(ids))
+            if rng.integers(0, 3) == 0:
+                ix.compact()
+                assert ix.row_usage() == (len(ids), 0), ("flat compaction", step)
+            check("after step %d" % step)
+    finally:
+        ix.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=100)
@@ -329,6 +427,7 @@ def main():
             t2 = time.time()
             pq_trial(rng)
             pq_desc = dict(CURRENT)
+            flat_trial(rng)
             t3 = time.time()
             desc = trial(rng, t)
             if time.time() - t1 > 20:
