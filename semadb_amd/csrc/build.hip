@@ -553,7 +553,10 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
   // flight before the first LDS write
   const uint32_t d_bytes = ((uint32_t)(nc * nc) * 4u + 15u) & ~15u;
   float *tile = reinterpret_cast<float *>(lds_raw + kTileFixedBytes + d_bytes);
-  const int fit = (int)((kTileLdsBytes - kTileFixedBytes - d_bytes - 1024u) / (a.ld * 4u));  // 1 KB: DMA overhang
+  // rows sit 16 bytes further apart than they are long: a column of 16-byte pieces (what the matrix-core phase A
+  // reads: the same piece of 16 rows) then falls on different banks instead of all on one
+  const uint32_t tpitch = a.ld * 4u + 16u;
+  const int fit = (int)((kTileLdsBytes - kTileFixedBytes - d_bytes - 1024u) / tpitch);  // 1 KB: DMA overhang
   const int nt = nc < fit ? nc : fit;
   {
     // LDS-DMA (global_load_lds_dwordx4): a wave instruction moves 64 x 16 B straight into 1 KB of the tile, no
@@ -562,12 +565,14 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
     // come from LDS: an ordinary global load in this loop would make the compiler drain the DMAs at every use.
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
-    const uint32_t rowb = a.ld * 4u, total = (uint32_t)nt * rowb;
+    const uint32_t rowb = a.ld * 4u, total = (uint32_t)nt * tpitch;
     char *tile_b = reinterpret_cast<char *>(tile);
     for (uint32_t piece = (uint32_t)wave; piece * 1024u < total; piece += NW) {
       uint32_t o = piece * 1024u + (uint32_t)lane * 16u;
       if (o >= total) o = total - 16u;  // the last piece's overhang lands in unused LDS behind the tile
-      const uint32_t r = o / rowb, c = o - r * rowb;
+      const uint32_t r = o / tpitch;
+      uint32_t c = o - r * tpitch;
+      if (c >= rowb) c = 0;  // the 16 bytes between two rows: any valid source
       const char *src = reinterpret_cast<const char *>(a.slab) + (size_t)s_slot[r] * rowb + c;
       __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(tile_b + piece * 1024u), 16, 0, 0);
     }
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
         ok[u] = k < n;
         jj[u] = i + 1 + (ok[u] ? k : 0);  // past the end: the row's first pair again, computed and dropped
         if (ALLT || jj[u] < nt) {
-          const char *row = tileL + (uint32_t)jj[u] * rowb;
+          const char *row = tileL + (uint32_t)jj[u] * tpitch;
 #pragma unroll
           for (int g = 0; g < NG; g++) y[u][g] = *reinterpret_cast<const float4 *>(row + g * 512);
           if constexpr (TAIL) yt[u] = *reinterpret_cast<const float *>(row + NG * 512 - L * 12);
@@ -622,17 +627,70 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
         if (L == 0 && ok[u]) D[i * nc + jj[u]] = raw[u];  // the raw sum; phase B applies the metric (distance.go:19-25)
     }
   };
+  // dot / cosine rows of whole blocks, all in the tile: phase A on the matrix cores.  d(c_i, c_j) for a 16 x 16 block of
+  // pairs is the same product of partial-sum chains as the exact scan's (flat.hip, k_flat_scan_mfma): one
+  // v_mfma_f32_16x16x1 = one fused multiply-add of every chain of 256 pairs, its four blocks the quarters t mod 4 of
+  // the 32 partial sums, the reduce tree in the lane.  Both operands come from the tile (the same 16-byte piece of 16
+  // rows per read); blocks of pairs (I <= J) are dealt to the waves in turn.
+  bool by_mfma = false;
+  if constexpr (!L2 && !TAIL && NG <= 4) by_mfma = nt == nc;
+  if (by_mfma) {
+    if constexpr (!L2 && !TAIL && NG <= 4) {
+      typedef float f16v __attribute__((ext_vector_type(16)));
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const int nb16 = (nc + 15) >> 4;
+      const uint32_t nblk = a.nblk;
+      const uint32_t lane_off = 16u * (uint32_t)(lane >> 4);  // the quarter's 16-byte piece inside a (a, tt) pair of pieces
+      int p = 0;
+      for (int I = 0; I < nb16; I++)
+        for (int J = I; J < nb16; J++, p++) {
+          if (p % NW != wave) continue;  // wave-uniform
+          const int ri = min(16 * I + (lane & 15), nc - 1), rj = min(16 * J + (lane & 15), nc - 1);
+          const char *pa = reinterpret_cast<const char *>(tile) + (uint32_t)ri * tpitch + lane_off;
+          const char *pb = reinterpret_cast<const char *>(tile) + (uint32_t)rj * tpitch + lane_off;
+          f16v acc[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            f4v A[8], B[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {  // accumulator set k = 2a + tt: partial sums 8a + 4tt + quarter
+              A[k] = *reinterpret_cast<const f4v *>(pa + g * 512 + (k >> 1) * 128 + (k & 1) * 64);
+              B[k] = *reinterpret_cast<const f4v *>(pb + g * 512 + (k >> 1) * 128 + (k & 1) * 64);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+              if ((uint32_t)(4 * g + kk) < nblk) {  // uniform
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(A[k][kk], B[k][kk], acc[k], 0, 0, 0);
+              }
+          }
+          const f16v s0 = ((acc[0] + acc[2]) + acc[4]) + acc[6];
+          const f16v s1 = ((acc[1] + acc[3]) + acc[5]) + acc[7];
+          const f16v r4 = (s0 + s1) + 0.0f;
+#pragma unroll
+          for (int i4 = 0; i4 < 4; i4++) {
+            const int row_i = 16 * I + 4 * (lane >> 4) + i4, col_j = 16 * J + (lane & 15);
+            const float raw = (r4[i4] + r4[4 + i4]) + (r4[8 + i4] + r4[12 + i4]);
+            if (row_i < col_j && col_j < nc) D[row_i * nc + col_j] = raw;  // the raw sum; phase B applies the metric
+          }
+        }
+    }
+  } else
   for (int b = 0; NW * b < nc - 1; b++) {
     const int i = NW * b + ((b & 1) ? NW - 1 - wave : wave);
     if (i >= nc - 1) continue;  // wave-uniform
     float4 xq[NG];
     float xt = 0.0f;
     {
-      const char *prow = i < nt ? tileL + (uint32_t)i * rowb : slabL + (size_t)s_slot[i] * rowb;
+      const char *prow = i < nt ? tileL + (uint32_t)i * tpitch : slabL + (size_t)s_slot[i] * rowb;
       if (i < nt) {
 #pragma unroll
-        for (int g = 0; g < NG; g++) xq[g] = *reinterpret_cast<const float4 *>(tileL + (uint32_t)i * rowb + g * 512);
-        if constexpr (TAIL) xt = *reinterpret_cast<const float *>(tileL + (uint32_t)i * rowb + NG * 512 - L * 12);
+        for (int g = 0; g < NG; g++) xq[g] = *reinterpret_cast<const float4 *>(tileL + (uint32_t)i * tpitch + g * 512);
+        if constexpr (TAIL) xt = *reinterpret_cast<const float *>(tileL + (uint32_t)i * tpitch + NG * 512 - L * 12);
       } else {
 #pragma unroll
         for (int g = 0; g < NG; g++) xq[g] = *reinterpret_cast<const float4 *>(prow + g * 512);
