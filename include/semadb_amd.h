@@ -197,8 +197,9 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *   SDB_TUNE_HASH_LIMIT  ids a query's LDS visited hash set may hold before it spills to the HBM bitset;
  *                        default 6000 (also the maximum)
  *   SDB_TUNE_NO_HASH     != 0: the visited set is the HBM bitset from the start
- *   SDB_TUNE_NO_TILE     != 0: a new node's robustPrune reads candidate rows from global memory instead of
- *                        staging them in LDS
+ *   SDB_TUNE_NO_TILE     1: a new node's robustPrune reads candidate rows from global memory instead of
+ *                        staging them in LDS; 2: staged, four waves per node instead of eight; 3: staged, the
+ *                        selection loop inside the staging kernel instead of a kernel of its own
  *   SDB_TUNE_NO_MFMA     != 0: the exact scan of dot / cosine tables runs on the packed-FMA kernel (the one
  *                        euclidean uses) instead of the matrix cores
  *   SDB_TUNE_WIDE_HASH   != 0: searches over a quantized store keep their visited ids in 32-bit LDS cells (four

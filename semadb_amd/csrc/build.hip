@@ -62,7 +62,10 @@ struct BuildArgs {
   const uint32_t *start_ext;
   uint32_t start_ext_n;
   uint32_t no_tile;           // != 0: new nodes are pruned by k_prune_new (rows from global memory), a test knob
-  uint32_t *prune_done;       // [nnew] set by k_prune_new_tiled for the nodes it pruned; NULL: k_prune_new takes all
+  uint32_t *prune_done;       // [nnew] 0: left to k_prune_new, 2: pair table ready for k_prune_select, 1: pruned; NULL: k_prune_new takes all
+  float *pair_tab;            // [nnew][kTileMaxCand^2] the tiled kernel's pair table of a node (row stride = its list length)
+  uint32_t *pair_slots;       // [nnew][kTileMaxCand] its sorted visit list
+  float *pair_dists;
   uint8_t *dirty;             // [n] set for every row whose adjacency this call writes (index.h graph versions)
   unsigned long long *stats;  // sdb_index_build_stats counters (index.h d_bstats), or NULL
   uint32_t *flags;            // [0] bit 0: a search's visit log did not fit vis_cap
@@ -701,6 +704,16 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
     else row_pairs(std::false_type{}, i, xq, xt);
   }
   __syncthreads();
+  if (a.pair_tab) {
+    // phase B runs in a kernel of its own (k_prune_select): one wave per node and no LDS, so that its 52 dependent
+    // steps per node overlap across a few thousand nodes instead of holding a whole CU's LDS for one
+    float *gD = a.pair_tab + (size_t)q * (kTileMaxCand * kTileMaxCand);
+    for (int x = tid; x < nc * nc; x += NW * 64) gD[x] = D[x];
+    if (tid < nc) a.pair_slots[(size_t)q * kTileMaxCand + tid] = s_slot[tid], a.pair_dists[(size_t)q * kTileMaxCand + tid] = s_dist[tid];
+    if (tid == 0) a.prune_done[q] = 2u;
+    if (wave == 0) stat_add(a, kStStagedRows, (unsigned long long)nt, lane);
+    return;
+  }
   if (wave != 0) return;
   // ---- phase B: the selection loop, candidate j = 64 c + lane in registers
   constexpr int NCH = kTileMaxCand / 64;
@@ -753,6 +766,72 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
       (lane < cnt) ? ((uint64_t)my_out << 32) | ((uint64_t)q << 6) | (uint64_t)lane : kNoKey;
   stat_add(a, kStPrunePairs, n_eval, lane);
   stat_add(a, kStStagedRows, (unsigned long long)nt, lane);
+}
+
+
+// Phase B of the tiled prune for every node whose pair table k_prune_new_tiled left in BuildArgs::pair_tab: the
+// selection loop of robustPrune (search.go:113-137), one wave per node, the list in registers, one row of the table per
+// selected candidate straight from global memory (written a moment ago: L2 / Infinity Cache).
+__global__ __launch_bounds__(64) void k_prune_select(const BuildArgs a) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  if (a.prune_done[q] != 2u) return;
+  const uint32_t self = a.first_slot + q;
+  const int nc = (int)a.vis_count[q];
+  const float *__restrict__ D = a.pair_tab + (size_t)q * (kTileMaxCand * kTileMaxCand);
+  constexpr int NCH = kTileMaxCand / 64;
+  float sd[NCH];
+  uint32_t ss[NCH];
+  bool rem[NCH];  // pruneRemoved (distset.go:124); lanes past the list count as removed
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int j = c * 64 + lane;
+    sd[c] = j < nc ? a.pair_dists[(size_t)q * kTileMaxCand + j] : 0.0f;
+    ss[c] = j < nc ? a.pair_slots[(size_t)q * kTileMaxCand + j] : kNoSlot;
+    rem[c] = j >= nc;
+  }
+  uint32_t my_out = kNoSlot;
+  float my_outd = 0.0f;
+  int cnt = 0, i = 0;
+  uint32_t n_eval = 0;
+  while (true) {
+    int found = -1;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const uint64_t m = __ballot(c * 64 + lane >= i && !rem[c] && ss[c] != self);  // :115-117
+      if (found < 0 && m) found = c * 64 + __ffsll((unsigned long long)m) - 1;
+    }
+    if (found < 0) break;
+    uint32_t p = 0;
+    float pd = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if ((found >> 6) == c) p = rl(ss[c], found & 63), pd = rlf(sd[c], found & 63);
+    if (lane == cnt) my_out = p, my_outd = pd;  // node.AddNeighbour :118
+    cnt++;
+    if (cnt >= (int)a.R) break;  // :119-121
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const int j = c * 64 + lane;
+      const bool live = j > found && !rem[c];
+      n_eval += live ? 1u : 0u;  // the pairs the reference's walk evaluates
+      if (live && a.alpha * metric_finish(D[found * nc + j], a.metric) < sd[c]) rem[c] = true;  // :132
+    }
+    i = found + 1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o);
+  // ---- node.edges of the new node, kNoSlot padded; a freshly pruned row is clean and carries its distances
+  a.adj[(size_t)self * kAdjStride + lane] = lane < cnt ? my_out : kNoSlot;
+  a.adjdist[(size_t)self * kAdjStride + lane] = my_outd;
+  if (lane == 0) {
+    a.deg[self] = (uint32_t)cnt, a.clean[self] = (uint32_t)cnt, a.dcount[self] = (uint32_t)cnt;
+    a.prune_done[q] = 1u;
+    if (a.dirty) a.dirty[self] = 1;
+  }
+  a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
+      (lane < cnt) ? ((uint64_t)my_out << 32) | ((uint64_t)q << 6) | (uint64_t)lane : kNoKey;
+  stat_add(a, kStPrunePairs, n_eval, lane);
 }
 
 }  // namespace sdb
@@ -950,6 +1029,10 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
       else if (a.no_tile == 2) hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, false, 4>), dim3(a.nnew), dim3(256), kTileLdsBytes, stream, a);
       else hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, false, 8>), dim3(a.nnew), dim3(512), kTileLdsBytes, stream, a);
       SDB_HIP(hipGetLastError());
+      if (a.pair_tab) {
+        hipLaunchKernelGGL(k_prune_select, dim3(a.nnew), dim3(64), 0, stream, a);
+        SDB_HIP(hipGetLastError());
+      }
       a1.prune_done = a.prune_done;
     }
   }
@@ -1127,6 +1210,17 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   uint32_t *prune_done = nullptr;
   SDB_HIP(hipMalloc(&prune_done, (size_t)max_round * 4));
   cleanup.ptrs.push_back(prune_done);
+  // the tiled prune's pair tables, handed from its all-pairs phase to the selection kernel (64 KB per point of a round)
+  float *pair_tab = nullptr, *pair_dists = nullptr;
+  uint32_t *pair_slots = nullptr;
+  if (!pq && ix->tune_no_tile != 3) {
+    SDB_HIP(hipMalloc(&pair_tab, (size_t)max_round * kTileMaxCand * kTileMaxCand * 4));
+    cleanup.ptrs.push_back(pair_tab);
+    SDB_HIP(hipMalloc(&pair_slots, (size_t)max_round * kTileMaxCand * 4));
+    cleanup.ptrs.push_back(pair_slots);
+    SDB_HIP(hipMalloc(&pair_dists, (size_t)max_round * kTileMaxCand * 4));
+    cleanup.ptrs.push_back(pair_dists);
+  }
   BigScratch big_scratch;
   // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
   constexpr uint32_t kDcacheBits = SDB_DCACHE_BITS;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
@@ -1237,6 +1331,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.start_ext = ix->d_start_ext, ba.start_ext_n = (uint32_t)ix->h_start_ext.size();
     ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
     ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done, ba.dirty = ix->d_dirty;
+    ba.pair_tab = pair_tab, ba.pair_slots = pair_slots, ba.pair_dists = pair_dists;
     bool start_pruned = false;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN

@@ -108,7 +108,7 @@ struct sdb_index {
   bool tune_no_hash = false;
   bool tune_wide_hash = false;  // quantized searches with 32-bit visited-set cells (4 walks per CU) instead of 16-bit ones (6)
   bool tune_no_mfma = false;  // exact scan of dot/cosine rows on the packed-FMA kernel instead of the matrix cores
-  uint32_t tune_no_tile = 0;  // 0: LDS-tiled prune of new nodes, 1: one-wave kernel only, 2: tiled with 4 waves instead of 8 (measurement)
+  uint32_t tune_no_tile = 0;  // 0: LDS-tiled prune of new nodes, 1: one-wave kernel only, 2: tiled with 4 waves instead of 8, 3: tiled without the separate selection kernel (measurement)
   // a write that failed after it had started to change the graph leaves it unusable: every later call fails
   // until the host rebuilds the index from the bucket -- the reference scraps its cache on any error inside a
   // write transaction the same way (shard/cache/manager.go:231-240)

@@ -943,7 +943,7 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       ix->tune_no_hash = value != 0;
       return SDB_OK;
     case SDB_TUNE_NO_TILE:
-      ix->tune_no_tile = (uint32_t)(value > 2 ? 1 : value);
+      ix->tune_no_tile = (uint32_t)(value > 3 ? 1 : value);  // 3: tiled, selection loop inside the tiled kernel (no k_prune_select)
       return SDB_OK;
     case SDB_TUNE_NO_MFMA:
       ix->tune_no_mfma = value != 0;

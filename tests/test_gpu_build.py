@@ -311,7 +311,7 @@ def test_new_node_prune_tiled_and_untiled_agree(oracle, metric, d, n, R, L, sear
                 assert o.insert(int(ids[i]), base[i]) == 0
         else:
             assert o.insert_rounds(ids, base, round_size=0) == 0
-        for no_tile in (0, 1):
+        for no_tile in (0, 1, 3):  # 3: tiled with the selection loop inside the tiled kernel (no k_prune_select)
             ix = _new_gpu(d, metric, R, L)
             ix.set_tuning("no_tile", no_tile)
             ix.set_start(sv)
@@ -319,5 +319,5 @@ def test_new_node_prune_tiled_and_untiled_agree(oracle, metric, d, n, R, L, sear
             assert_same_graph(ix, o)
             st = ix.build_stats()
             # rows wider than 4 KB leave no room for a useful tile: those dimensions keep the one-wave kernel
-            assert (st["staged_rows"] > 0) == (no_tile == 0 and d <= 1024)
+            assert (st["staged_rows"] > 0) == (no_tile != 1 and d <= 1024)
             ix.close()
