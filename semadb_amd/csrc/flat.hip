@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void k_flat_dist(const float *__restrict__ sla
   for (int u = 0; u < U; u++) {
     const uint32_t c = c0 + u, c2 = c0 + U + u;
     live[u] = c < nrows, live2[u] = c2 < nrows;
-    const uint32_t cc = live[u] ? c : 0, cc2 = live2[u] ? c2 : 0;
-    slot[u] = myslots ? myslots[cc] : first_row + cc;
-    slot2[u] = myslots ? myslots[cc2] : first_row + cc2;
+    // a candidate past the end of the list is computed and dropped: on row 0, never on whatever follows the list
+    // (a query whose filter names no stored id has an EMPTY list; found by tools/fuzz_parity.py, seed 31337 trial 233)
+    slot[u] = live[u] ? (myslots ? myslots[c] : first_row + c) : 0u;
+    slot2[u] = live2[u] ? (myslots ? myslots[c2] : first_row + c2) : 0u;
   }
   float res[U], res2[U];
   chunk_dist_lds<L2, U>(slab, ld, ng, tail, qs, slot, res, lane);
@@ -193,7 +194,7 @@ struct FlatScanArgs {
   uint2 *cand;           // [nq][cap] (slot, distance bits)
   uint32_t cap;
   uint32_t first, rows;  // slab rows [first, first + rows)
-  uint32_t nq, ld, dim, nblk, skip_slot;
+  uint32_t nq, ld, dim, nblk, tail, skip_slot;
   int metric;
 };
 
@@ -320,26 +321,42 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr uint32_t kMfmaMaxGroups = 8;  // slab groups of 4 blocks a wave holds in registers: d <= 1024
 
-// [G = q / 16][b][h][l][c]: query 16 G + l % 16, element 32 b + 8 (2h + c / 2) + 4 (c % 2) + l / 16
+// A query group's image: [b][h][l][c] = query 16 G + l % 16, element 32 b + 8 (2h + c / 2) + 4 (c % 2) + l / 16 for the
+// nblk whole blocks; then, when the rows have a tail of d % 32 elements, [j][kTailPitch]: the tail elements of query
+// 16 G + j in order, zero padded (768 floats = three 1 KB pieces)
+constexpr uint32_t kTailPitch = 36;        // floats per row / query of tail elements in LDS: 16-byte aligned, lane j at bank 4j
+constexpr uint32_t kTailImgFloats = 768;   // 16 x 36 = 576, rounded up to whole 1 KB pieces
 __global__ void k_flat_swizzle_queries(const float *__restrict__ q, float *__restrict__ out, uint32_t nq, uint32_t dim,
-                                       uint32_t nblk, uint32_t total) {
+                                       uint32_t nblk, uint32_t tail, uint32_t total) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const uint32_t c = i & 3, l = (i >> 2) & 63, h = (i >> 8) & 1, gb = i >> 9;
-  const uint32_t b = gb % nblk, G = gb / nblk;
+  const uint32_t grp = nblk * 512 + (tail ? kTailImgFloats : 0);
+  const uint32_t G = i / grp, o = i % grp;
+  if (o >= nblk * 512) {  // the tail section
+    const uint32_t t = o - nblk * 512, j = t / kTailPitch, m = t % kTailPitch, qi = 16 * G + j;
+    out[i] = (j < 16 && m < tail && qi < nq) ? q[(size_t)qi * dim + 32 * nblk + m] : 0.0f;
+    return;
+  }
+  const uint32_t c = o & 3, l = (o >> 2) & 63, h = (o >> 8) & 1, b = o >> 9;
   const uint32_t k = 4 * h + c, e = 32 * b + 8 * (k >> 1) + 4 * (k & 1) + (l >> 4), qi = 16 * G + (l & 15);
   out[i] = qi < nq ? q[(size_t)qi * dim + e] : 0.0f;
 }
 
 // Rows of up to 12 blocks leave room for two workgroups per CU (256 registers per wave: 128 accumulators, 8 NBLK row
 // operands); longer rows run one workgroup per CU.
-template <int NBLK>
-__global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_flat_scan_mfma(const float *__restrict__ slab, const float *__restrict__ qsw,
+// TAIL: rows of d % 32 != 0.  The tail elements form one more chain per pair (dot.s:35-43: t = fma(x, y, t) over them in
+// order), added to r[0] of the reduce tree (dot.s:50): a ninth accumulator set whose block 0 holds the pairs' tail chains
+// (lanes of the other blocks multiply zeros: fma(0, 0, 0) = +0, the {t, 0, 0, 0} vector of the reference), one matrix
+// instruction per tail element, operands from LDS ([row][36] and [query][36], four elements per 16-byte read).
+template <int NBLK, bool TAIL>
+__global__ __launch_bounds__(256, (NBLK <= 12 && !TAIL) ? 2 : 1) void k_flat_scan_mfma(const float *__restrict__ slab, const float *__restrict__ qsw,
                                                         const FlatScanArgs a) {
   constexpr int NG = (NBLK + 3) / 4;
-  constexpr uint32_t kGrpF4 = NBLK * 128;         // float4 per query group
-  extern __shared__ __attribute__((aligned(16))) float bs[];  // [2][NBLK][2][64][4], then the nq thresholds
-  float *thr_s = bs + 2 * kGrpF4 * 4;
+  constexpr uint32_t kGrpF4 = NBLK * 128 + (TAIL ? kTailImgFloats / 4 : 0);  // float4 per query group
+  constexpr int kPieces = (int)(kGrpF4 / 64);                               // 1 KB pieces of a group's image
+  extern __shared__ __attribute__((aligned(16))) float bs[];  // [2][group image], [64][kTailPitch] row tails, the nq thresholds
+  float *rowtail = bs + 2 * kGrpF4 * 4;
+  float *thr_s = rowtail + (TAIL ? kScanRows * kTailPitch : 0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t row0 = a.first + blockIdx.x * kScanRows, end = a.first + a.rows;
@@ -371,14 +388,28 @@ __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_flat_scan_mfma(cons
     char *dst = reinterpret_cast<char *>(bs) + (size_t)(G & 1) * (kGrpF4 * 16) + wave * 1024;
     const uint32_t lane_off = lane * 16;  // the only per-lane part of the address
 #pragma unroll
-    for (int piece = 0; piece < (2 * NBLK + 3) / 4; piece++)
-      if (4 * piece + wave < 2 * NBLK)
+    for (int piece = 0; piece < (kPieces + 3) / 4; piece++)
+      if (4 * piece + wave < kPieces)
         __builtin_amdgcn_global_load_lds((glb_void *)(src + piece * 4096 + lane_off), (lds_void *)(dst + piece * 4096), 16, 0, 0);
   };
   // 8 NBLK matrix instructions: the wave's 16 rows against query group G, operands of block b + 1 on their way from
   // LDS while block b is multiplied
-  auto multiply = [&](f16v (&acc)[8], uint32_t G) __attribute__((always_inline)) {
+  auto multiply = [&](f16v (&acc)[8], f16v &T, uint32_t G) __attribute__((always_inline)) {
     const f4v *bq = reinterpret_cast<const f4v *>(bs) + (size_t)(G & 1) * kGrpF4 + lane;
+    if constexpr (TAIL) {  // the tail chains first: block 0 of the instruction, lanes 0..15 = row i / query j
+#pragma unroll
+      for (int r = 0; r < 16; r++) T[r] = 0.0f;
+      const float *ta = rowtail + (16 * wave + (lane & 15)) * kTailPitch;
+      const float *tb = bs + (size_t)(G & 1) * kGrpF4 * 4 + NBLK * 512 + (lane & 15) * kTailPitch;
+      const bool low = lane < 16;
+      for (uint32_t m = 0; m < a.tail; m += 4) {
+        const f4v x4 = *reinterpret_cast<const f4v *>(ta + m), y4 = *reinterpret_cast<const f4v *>(tb + m);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          if (m + c < a.tail)  // uniform: exactly `tail` steps, like the reference's loop
+            T = __builtin_amdgcn_mfma_f32_16x16x1f32(low ? x4[c] : 0.0f, low ? y4[c] : 0.0f, T, 0, 0, 0);
+      }
+    }
     f4v b0 = bq[0], b1 = bq[64];
 #pragma unroll
     for (int b = 0; b < NBLK; b++) {
@@ -396,10 +427,12 @@ __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_flat_scan_mfma(cons
     }
   };
   // the reduce tree of dot.s:45-53 in the lane, then the threshold test of the lane's 4 (row, query) pairs
-  auto reduce = [&](const f16v (&acc)[8], float (&dist)[4]) __attribute__((always_inline)) {
+  auto reduce = [&](const f16v (&acc)[8], const f16v &T, float (&dist)[4]) __attribute__((always_inline)) {
     const f16v s0 = ((acc[0] + acc[2]) + acc[4]) + acc[6];
     const f16v s1 = ((acc[1] + acc[3]) + acc[5]) + acc[7];
-    const f16v r4 = (s0 + s1) + 0.0f;
+    f16v r4;
+    if constexpr (TAIL) r4 = (s0 + s1) + T;  // r[0] + tail chain, r[1..3] + 0 (dot.s:50)
+    else r4 = (s0 + s1) + 0.0f;
 #pragma unroll
     for (int i4 = 0; i4 < 4; i4++) {
       dist[i4] = (r4[i4] + r4[4 + i4]) + (r4[8 + i4] + r4[12 + i4]);  // metric_finish in emit
@@ -446,8 +479,15 @@ __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_flat_scan_mfma(cons
   };
   dma(0);
   for (uint32_t i = tid; i < a.nq; i += 256) thr_s[i] = a.thr[i];
+  if constexpr (TAIL) {  // the 64 rows' tail elements: slab floats [ld - 32, ld - 32 + tail)
+    for (uint32_t i = tid; i < kScanRows * 32; i += 256) {
+      const uint32_t r = i >> 5, m = i & 31, row = row0 + r;
+      rowtail[r * kTailPitch + m] = m < a.tail ? slab[(size_t)(row < end ? row : end - 1) * a.ld + (a.ld - 32) + m] : 0.0f;
+    }
+    for (uint32_t i = tid; i < kScanRows * 4; i += 256) rowtail[(i >> 2) * kTailPitch + 32 + (i & 3)] = 0.0f;
+  }
   __syncthreads();  // waits for this wave's DMAs (vmcnt) and for everybody else's
-  f16v acc[8];
+  f16v acc[8], T;
   float dist[4];
   // One barrier per group: LDS buffer (G + 1) & 1 was read by multiply(G - 1) before the previous barrier, is refilled
   // with group G + 1 now, and is read by multiply(G + 1) after this one.  Two workgroups share a CU (256 registers
@@ -455,9 +495,9 @@ __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_flat_scan_mfma(cons
   for (uint32_t G = 0; G < ngroups; G++) {
     dma(G + 1);
     const float thr = threshold(G);
-    multiply(acc, G);
-    pipeline();
-    reduce(acc, dist);
+    multiply(acc, T, G);
+    if constexpr (!TAIL) pipeline();
+    reduce(acc, T, dist);
     emit(dist, G, thr);
     __syncthreads();
   }
@@ -524,19 +564,27 @@ static int launch_flat_scan(const FlatScanArgs &a, hipStream_t stream) {
   return SDB_OK;
 }
 
-template <int NBLK>
-static int launch_flat_scan_mfma_nb(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
+static size_t flat_mfma_lds_bytes(uint32_t nblk, uint32_t tail, uint64_t nq) {
+  return (size_t)2 * (nblk * 512 + (tail ? kTailImgFloats : 0)) * sizeof(float) +
+         (tail ? (size_t)kScanRows * kTailPitch * sizeof(float) : 0) + (size_t)nq * sizeof(float);
+}
+template <int NBLK, bool TAIL>
+static int launch_flat_scan_mfma_nbt(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
   const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
-  const size_t lds = (size_t)2 * NBLK * 512 * sizeof(float) + (size_t)a.nq * sizeof(float);
+  const size_t lds = flat_mfma_lds_bytes(NBLK, TAIL ? 1 : 0, a.nq);
   static bool attr = false;
   if (!attr) {
-    SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan_mfma<NBLK>),
+    SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan_mfma<NBLK, TAIL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL((k_flat_scan_mfma<NBLK>), grid, dim3(256), lds, stream, a.slab, qsw, a);
+  hipLaunchKernelGGL((k_flat_scan_mfma<NBLK, TAIL>), grid, dim3(256), lds, stream, a.slab, qsw, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
+}
+template <int NBLK>
+static int launch_flat_scan_mfma_nb(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
+  return a.tail ? launch_flat_scan_mfma_nbt<NBLK, true>(a, qsw, stream) : launch_flat_scan_mfma_nbt<NBLK, false>(a, qsw, stream);
 }
 static int launch_flat_scan_mfma(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
   switch (a.nblk) {
@@ -601,10 +649,10 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   // must fit LDS), euclidean rows -- and the others when the matrix-core scan is switched off -- of up to 608 floats
   // on the packed-FMA kernel (k_flat_scan).  The first rows still go through the block path: they seed the thresholds.
   constexpr uint32_t kSeedRows = 4096, kMinSegment = 32768, kCandCap = 8192;
-  const bool streamable = !filtered && !ix->pq && l.tail == 0 && l.nblk >= 1 && n >= kMinSegment && nq <= 8192;
+  const bool streamable = !filtered && !ix->pq && l.nblk >= 1 && n >= kMinSegment && nq <= 8192;
   const bool mfma = streamable && ix->P.metric != SDB_METRIC_EUCLIDEAN && l.nblk <= 4 * kMfmaMaxGroups && !ix->tune_no_mfma &&
-                    (size_t)2 * l.nblk * 2048 + nq * 4 <= 160 * 1024;
-  const bool fast = mfma || (streamable && l.nblk <= 19);
+                    flat_mfma_lds_bytes(l.nblk, l.tail, nq) <= 160 * 1024;
+  const bool fast = mfma || (streamable && l.tail == 0 && l.nblk <= 19);
   if (fast) chunk = std::min<uint32_t>(chunk, kSeedRows);  // the block path only sees the seed rows
   const uint32_t stride = (chunk + 63) & ~63u;
   size_t off = 0;
@@ -623,7 +671,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const size_t o_lut = carve(pq ? (size_t)nq * pq->M * pq->K * 4 : 0);
   const size_t o_thr = carve(fast ? nq * 4 : 0);
   const size_t o_cnt = carve(fast ? nq * 4 + 256 : 0), o_cand = carve(fast ? (size_t)nq * kCandCap * 8 : 0);
-  const uint32_t qsw_floats = mfma ? (uint32_t)((nq + 15) / 16) * l.nblk * 512 : 0;
+  const uint32_t qsw_floats = mfma ? (uint32_t)((nq + 15) / 16) * (l.nblk * 512 + (l.tail ? kTailImgFloats : 0)) : 0;
   const size_t o_qsw = carve((size_t)qsw_floats * 4);
   char *buf = nullptr;
   SDB_HIP(hipMalloc(&buf, off));
@@ -714,12 +762,12 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
       FlatScanArgs sa{};
       sa.slab = ix->d_slab, sa.queries = dq, sa.ids = vw.ids, sa.thr = d_thr, sa.cnt = d_cnt;
       sa.cand = d_cand, sa.cap = kCandCap, sa.first = first, sa.rows = std::min<uint32_t>(seg, n - first);
-      sa.nq = (uint32_t)nq, sa.ld = l.ld, sa.dim = l.dim, sa.nblk = l.nblk, sa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
+      sa.nq = (uint32_t)nq, sa.ld = l.ld, sa.dim = l.dim, sa.nblk = l.nblk, sa.tail = l.tail, sa.skip_slot = ix->start_slot >= 0 ? (uint32_t)ix->start_slot : kNoSlot;
       sa.metric = (int)ix->P.metric;
       if (mfma) {
         if (first == seed) {
           hipLaunchKernelGGL(k_flat_swizzle_queries, dim3((qsw_floats + 255) / 256), dim3(256), 0, stream, dq,
-                             (float *)(buf + o_qsw), (uint32_t)nq, l.dim, l.nblk, qsw_floats);
+                             (float *)(buf + o_qsw), (uint32_t)nq, l.dim, l.nblk, l.tail, qsw_floats);
           SDB_HIP(hipGetLastError());
         }
         SDB_TRY(launch_flat_scan_mfma(sa, (const float *)(buf + o_qsw), stream));

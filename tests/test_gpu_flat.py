@@ -333,3 +333,59 @@ def test_matrix_core_scan_equals_the_packed_fma_scan(oracle, metric):
             for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, metric, 10)):
                 assert np.array_equal(got[0][i], e_ids) and np.array_equal(bits(got[1][i]), bits(e_d)), (d, i)
         ix.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_matrix_core_scan_with_a_tail(oracle, metric):
+    """rows of d % 32 != 0: the tail elements are one more chain per pair (dot.s:35-43), run as a ninth accumulator
+    set with one matrix instruction per tail element.  Same ids and distance bits as the block path (SDB_TUNE_NO_MFMA)
+    for tails of 1, 18, 4, 12, 15, 8 and 31 elements, denormal products and all-zero rows included, and as the oracle."""
+    from semadb_amd import flat
+    from semadb_amd._lib import lib, check
+    rng = np.random.default_rng(78)
+    n, nq = 33100, 19
+    for d in (33, 50, 100, 300, 527, 1000, 1055):
+        base = rng.standard_normal((n, d)).astype(np.float32)
+        base[::7] *= np.float32(1e-22)
+        base[5::11, ::3] = 0.0
+        base[9::500] = 0.0  # all-zero rows: distances of exactly zero, whose sign the extra chain must not change
+        if metric == "cosine":
+            nz = np.linalg.norm(base, axis=1) > 0
+            base[nz] = base[nz] / np.linalg.norm(base[nz], axis=1, keepdims=True)
+        q = base[rng.choice(n, nq, replace=False)] * np.float32(1.0 + 1e-3)
+        q[3] *= np.float32(1e-20)
+        q[4] = 0.0
+        ids = np.arange(3, n + 3, dtype=np.uint64)
+        ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, metric), capacity=n + 1)
+        ix.set_vectors(ids, base)
+        got = ix.search_batch(q, 10)
+        check(lib().sdb_index_set_tuning(ix._h, 5, 1))  # SDB_TUNE_NO_MFMA
+        ref = ix.search_batch(q, 10)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), d
+        if d in (33, 300, 1055):
+            for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, metric, 10)):
+                assert np.array_equal(got[0][i], e_ids) and np.array_equal(bits(got[1][i]), bits(e_d)), (d, i)
+        ix.close()
+
+
+def test_flat_filter_that_names_no_stored_id(oracle):
+    """a query whose filter holds only ids that are not stored has an empty candidate list: no answer for it, the other
+    queries unaffected -- also when it is the last query, or when every query is like that (found by
+    tools/fuzz_parity.py, seed 31337 trial 233: the distance kernel computed a dropped candidate on the slot word that
+    follows the list, i.e. on whatever lies behind the buffer)"""
+    from semadb_amd import flat
+    rng = np.random.default_rng(12)
+    n, d = 700, 2
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    ids = rng.permutation(np.arange(1, 3 * n + 1))[:n].astype(np.uint64)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, "dot"))
+    ix.set_vectors(ids, base)
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    some = set(int(v) for v in ids[:25])
+    for filters in ([some, {10 ** 9 + 1}, some, set(), some, {10 ** 9 + 1, 10 ** 9 + 2}],
+                    [{10 ** 9 + 1}] * 6):
+        g_ids, g_d, g_c = ix.search_batch(q, 10, filters=filters)
+        for i, (e_ids, e_d) in enumerate(_expected(oracle, q, base, ids, "dot", 10, filters)):
+            assert int(g_c[i]) == len(e_ids) == (10 if filters[i] is some else 0)
+            assert np.array_equal(g_ids[i, :len(e_ids)], e_ids) and np.array_equal(bits(g_d[i, :len(e_ids)]), bits(e_d))
+    ix.close()

@@ -95,6 +95,7 @@ def compare_searches(rng, g, o, d, kind, L, live, tag, metric=None):
 
 
 CURRENT = {}
+VERBOSE = False
 BUDGET = 300000
 
 
@@ -322,6 +323,8 @@ def flat_trial(rng):
     n0 = int(rng.integers(33000, 42000)) if big else int(rng.integers(1, max(2, min(3000, 200000 // d))))
     CURRENT.clear()
     CURRENT.update(dict(flat_trial=True, d=d, metric=metric, kind=kind, n0=n0))
+    if VERBOSE:
+        print("  flat:", CURRENT, file=sys.stderr, flush=True)
     ids, rows = [], []
 
     def m_set(i, v):
@@ -346,11 +349,15 @@ def flat_trial(rng):
         next_id = int(first_ids.max()) + 1
 
         def check(tag):
+            if VERBOSE:
+                print("  flat check", tag, len(ids), file=sys.stderr, flush=True)
             if not ids:
                 return
             nq = int(rng.integers(1, 20))
             q = draw_rows(rng, nq, d, kind)
             limit = int(rng.choice([1, 3, 10, 75, 128]))
+            if VERBOSE:
+                print("    nq %d limit %d" % (nq, limit), file=sys.stderr, flush=True)
             I, B = np.array(ids, dtype=np.uint64), np.stack(rows)
             dm = orc.distance_matrix(q, B, metric, orc.IMPL_ASM)
             allowed = None
@@ -358,6 +365,8 @@ def flat_trial(rng):
                 pool = np.concatenate([I, np.array([10 ** 9 + 1], dtype=np.uint64)])
                 allowed = [set(int(v) for v in rng.choice(pool, size=min(len(pool), int(rng.integers(1, 60))), replace=False))
                            for _ in range(nq)]
+            if VERBOSE:
+                print("    filtered %s" % (allowed is not None), file=sys.stderr, flush=True)
             g_ids, g_d, g_c = ix.search_batch(q, limit, filters=allowed)
             for i in range(nq):
                 idx = np.arange(len(I)) if allowed is None else np.array([j for j in range(len(I)) if int(I[j]) in allowed[i]], dtype=np.int64)
@@ -382,6 +391,8 @@ def flat_trial(rng):
                 else:  # delete of a missing id
                     ch.append(flat.IndexVectorChange(next_id + 10 ** 6, None))
             explicit = rng.integers(0, 3) == 0
+            if VERBOSE:
+                print("  flat step %d: %d changes, explicit %s: %s" % (step, len(ch), explicit, [(c.Id, c.Vector is None) for c in ch]), file=sys.stderr, flush=True)
             if explicit:  # the same changes by hand inside one transaction, with a search that must not see them
                 ix.begin_write()
                 for c in ch:
@@ -399,6 +410,8 @@ def flat_trial(rng):
             r_rows, r_dead = ix.row_usage()
             assert r_rows - r_dead == len(ids), ("flat row usage", step, r_rows, r_dead, len(ids))
             if rng.integers(0, 3) == 0:
+                if VERBOSE:
+                    print("  flat compact", ix.row_usage(), file=sys.stderr, flush=True)
                 ix.compact()
                 assert ix.row_usage() == (len(ids), 0), ("flat compaction", step)
             check("after step %d" % step)
@@ -412,10 +425,12 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0, help="stop after this much wall time (0 = run all trials)")
     ap.add_argument("--only", type=int, default=-1, help="run just this trial number")
+    ap.add_argument("--verbose", action="store_true", help="print every trial and stage as it starts (to find a crash)")
     ap.add_argument("--budget", type=int, default=300000, help="rows * dim of a trial's index at most (and 3000 rows per 300000)")
     a = ap.parse_args()
-    global BUDGET
+    global BUDGET, VERBOSE
     BUDGET = a.budget
+    VERBOSE = a.verbose
     t0 = time.time()
     done = 0
     dims = set()
@@ -423,12 +438,20 @@ def main():
         rng = np.random.default_rng([a.seed, t])
         try:
             t1 = time.time()
+            if a.verbose:
+                print("trial %d: merge" % t, file=sys.stderr, flush=True)
             merge_trial(rng)
             t2 = time.time()
+            if a.verbose:
+                print("trial %d: pq" % t, file=sys.stderr, flush=True)
             pq_trial(rng)
             pq_desc = dict(CURRENT)
+            if a.verbose:
+                print("trial %d: flat %s" % (t, pq_desc), file=sys.stderr, flush=True)
             flat_trial(rng)
             t3 = time.time()
+            if a.verbose:
+                print("trial %d: index %s" % (t, CURRENT), file=sys.stderr, flush=True)
             desc = trial(rng, t)
             if time.time() - t1 > 20:
                 print("slow trial %d: merge %.1fs, pq %.1fs %s, index %.1fs %s" % (
