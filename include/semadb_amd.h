@@ -203,13 +203,17 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *   SDB_TUNE_NO_MFMA     != 0: the exact scan of dot / cosine tables runs on the packed-FMA kernel (the one
  *                        euclidean uses) instead of the matrix cores
  *   SDB_TUNE_WIDE_HASH   != 0: searches over a quantized store keep their visited ids in 32-bit LDS cells (four
- *                        walks per CU) instead of the 16-bit cells used for stores of up to 2^24 rows (six) */
+ *                        walks per CU) instead of the 16-bit cells used for stores of up to 2^24 rows (six)
+ *   SDB_TUNE_HASH16_PROBES  buckets a key of the 16-bit-cell set may try before the walk spills to the HBM bitset
+ *                        (0 = all 15; 1..15).  With 15 that spill is a one-in-ten-million event; a test sets 1 or 2
+ *                        to walk through it */
 #define SDB_TUNE_HUB_MIN 1
 #define SDB_TUNE_HASH_LIMIT 2
 #define SDB_TUNE_NO_HASH 3
 #define SDB_TUNE_NO_TILE 4
 #define SDB_TUNE_NO_MFMA 5
 #define SDB_TUNE_WIDE_HASH 6
+#define SDB_TUNE_HASH16_PROBES 7
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
 
 /* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts

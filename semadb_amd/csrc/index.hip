@@ -847,7 +847,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   a.start_ext = vw.start_ext, a.start_ext_n = vw.start_ext_n;
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
   a.hash_limit = ix->tune_hash_limit, a.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
-  a.wide_hash = ix->tune_wide_hash ? 1u : 0u;
+  a.wide_hash = ix->tune_wide_hash ? 1u : 0u, a.hash16_probes = ix->tune_hash16_probes;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
@@ -950,6 +950,10 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       return SDB_OK;
     case SDB_TUNE_WIDE_HASH:
       ix->tune_wide_hash = value != 0;
+      return SDB_OK;
+    case SDB_TUNE_HASH16_PROBES:
+      if (value > 15) return fail(SDB_ERR_INVALID, "at most 15 probes");
+      ix->tune_hash16_probes = (uint32_t)value;
       return SDB_OK;
     default:
       return fail(SDB_ERR_INVALID, "unknown tuning key %d", key);

@@ -66,6 +66,7 @@ struct SearchArgs {
   unsigned long long *totals;  // build path: [0] += n_dist, [1] += n_edges of every query (sdb_index_build_stats)
   uint32_t prefer_bitset;  // != 0: never use the LDS hash visited set (large build rounds)
   uint32_t wide_hash;      // != 0: quantized store keeps the 32-bit-cell set (HashVisited) instead of HashVisited16
+  uint32_t hash16_probes;  // test knob: buckets a key of HashVisited16 may try (0 = all 15); fewer make the `stuck` spill common
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
 };
 
@@ -758,11 +759,12 @@ struct HashVisited16 {
   static constexpr uint32_t kMaxProbe = 14;     // (probe 15, remainder 0xFFF) is the empty cell
   uint32_t *tab;
   uint32_t *bits;
-  uint32_t words, count, limit;
+  uint32_t words, count, limit, maxp;
   bool spilled;
-  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
+  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim, uint32_t probes = 0) {
     tab = lds, bits = bitset, words = nwords;
     count = 0, spilled = false;
+    maxp = (probes >= 1 && probes <= kMaxProbe) ? probes - 1 : kMaxProbe;  // last probe number a key may use
     limit = (uint32_t)(((uint64_t)lim * kCells) >> 13);  // 6 000 of 8 192 cells by default
     uint4 *t4 = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -809,12 +811,12 @@ struct HashVisited16 {
         const uint32_t target = rem | ((probe + i) << 12);
         const bool has = (wp[i] & 0xFFFFu) == target || (wp[i] >> 16) == target;
         const bool room = (wp[i] >> 16) == 0xFFFFu;
-        if ((has || room) && probe + i <= kMaxProbe) hit = i, present = has;
+        if ((has || room) && probe + i <= maxp) hit = i, present = has;
       }
       if (!done) {
         if (hit < 0) {
           probe += kProbes;
-          if (probe > kMaxProbe) done = stuck = true;
+          if (probe > maxp) done = stuck = true;
           else bucket = (bp[kProbes - 1] + step) & (kBuckets - 1);
         } else if (present) {
           done = true;
@@ -1080,7 +1082,7 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   if constexpr (HCAP == kHash16) {
     dist.init(a, q, lane, lds_f + HashVisited16::kWords);
     HashVisited16 hv;
-    hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
     search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
   } else if constexpr (HCAP != 0) {
     dist.init(a, q, lane, lds_f + HashVisited<HCAP>::kWords);

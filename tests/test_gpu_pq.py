@@ -341,8 +341,12 @@ def test_quantized_walk_is_the_same_under_every_visited_set(oracle):
     q = base[rng.choice(n, 96, replace=False)] + 0.05 * rng.standard_normal((96, d)).astype(np.float32)
     ref = ix.search_batch(q, 10, L, trace=True, visit_cap=1024)
     assert int(ref[3].n_dist.max()) > 1200, int(ref[3].n_dist.max())
-    for key, value in [("wide_hash", 1), ("no_hash", 1), ("hash_limit", 40), ("hash_limit", 600)]:
+    # hash16_probes 1 / 2: a key whose first (two) bucket(s) are full sends the walk to the bitset -- the `stuck` spill,
+    # a one-in-ten-million event with the full budget of 15 buckets
+    for key, value in [("wide_hash", 1), ("no_hash", 1), ("hash_limit", 40), ("hash_limit", 600), ("hash16_probes", 1),
+                       ("hash16_probes", 2)]:
         ix.set_tuning("wide_hash", 0), ix.set_tuning("no_hash", 0), ix.set_tuning("hash_limit", 0)
+        ix.set_tuning("hash16_probes", 0)
         ix.set_tuning(key, value)
         got = ix.search_batch(q, 10, L, trace=True, visit_cap=1024)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), key
