@@ -185,10 +185,11 @@ class IndexVamana:
         return v.value
 
     # ---- InsertUpdateDelete vamana.go:127-263 (insert branch on device) --------------------------
-    def InsertUpdateDelete(self, points, round_size=0):
+    def InsertUpdateDelete(self, points, round_size=0, _between=None):
         """points: iterable of IndexVectorChange.  Same classification and order as vamana.go:149-251: new
         ids are inserted first; then the inbound edges of deleted AND updated ids are removed in one scan
-        and the deleted nodes dropped; then the updated points are re-inserted one by one."""
+        and the deleted nodes dropped; then the updated points are re-inserted one by one.  `_between` (tests): called
+        after every step inside the open transaction."""
         ins_ids, ins_vecs, upd_ids, upd_vecs, del_ids = [], [], [], [], []
         known = set()
         points = list(points)
@@ -216,10 +217,16 @@ class IndexVamana:
         self.begin_write()  # one transaction, like the shard's (searches see it whole or not at all)
         if ins_ids:
             self.insert_batch(np.array(ins_ids, dtype=np.uint64), np.stack(ins_vecs), round_size)
+            if _between:
+                _between("inserts")
         if del_ids or upd_ids:
             self.delete_batch(np.array(del_ids + upd_ids, dtype=np.uint64))  # removeInboundEdges :223-233
+            if _between:
+                _between("deletes")
         for i, v in zip(upd_ids, upd_vecs):  # :247-251 re-inserted sequentially
             self.insert_batch(np.array([i], dtype=np.uint64), v.reshape(1, -1), 1)
+        if _between and upd_ids:
+            _between("updates")
         self.commit()
         self.Fit()  # vamana.go:257-260
 

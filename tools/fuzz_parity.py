@@ -224,7 +224,33 @@ def trial(rng, t):
                     assert o.insert(i, upd_vecs[k]) == 0
                     explain(g, o, "re-insert of %d" % i)
             else:
-                g.InsertUpdateDelete(ch, round_size=wr)
+                between = None
+                if rng.integers(0, 3) == 0:
+                    # snapshot isolation: answers computed before the write must come back unchanged after every step
+                    # inside the open transaction -- plain and filtered walks, the exact scan, K1; the filters and the
+                    # K1 candidates name ids the transaction deletes, updates and (not yet visibly) inserts
+                    sq = draw_rows(rng, 6, d, kind)
+                    named = [int(v) for v in rng.choice(live, size=min(len(live), 20), replace=False)] + dels[:5] + upds + new_ids[:3]
+                    sf = [set(named) for _ in range(6)]
+                    cand = np.tile(np.array(named, dtype=np.uint64), (6, 1))
+                    from semadb_amd import flat as _flat
+
+                    def snapshot():
+                        a1 = g.search_batch(sq, 5, L)
+                        a2 = g.search_batch(sq, 5, L, filters=sf)
+                        out = [a1[0].copy(), bits(a1[1]).copy(), a2[0].copy(), bits(a2[1]).copy()]
+                        if not quantized:
+                            a3 = _flat.flat_search_batch(g._h, d, sq, min(5, len(live)))
+                            out += [a3[0].copy(), bits(a3[1]).copy(), bits(g.distance_batch(sq, cand)).copy()]
+                        return out
+
+                    pre = snapshot()
+
+                    def between(tag):
+                        now = snapshot()
+                        for x, y in zip(pre, now):
+                            assert np.array_equal(x, y), ("a search inside the transaction saw it", tag)
+                g.InsertUpdateDelete(ch, round_size=wr, _between=between)
                 if wr == 1:
                     for k, i in enumerate(new_ids):
                         assert o.insert(i, new_vecs[k]) == 0
