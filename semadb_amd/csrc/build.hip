@@ -1015,15 +1015,14 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
     // (always at d <= 1024 and searchSize 75); what the tiled kernel leaves is pruned by k_prune_new
     const uint32_t worst = kTileFixedBytes + 80 * 80 * 4 + 1024;
     if (a.no_tile != 1 && a.prune_done && worst + 24 * a.ld * 4 <= kTileLdsBytes) {
-      static bool attr_set = false;  // per instantiation
+      static std::atomic<uint64_t> attr_set{0};  // per instantiation, a bit per device
       auto setattr = [](const void *f) {
         return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLdsBytes);
       };
-      if (!attr_set) {
+      if (first_use_on_this_device(attr_set)) {
         SDB_HIP(setattr(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2, false, 4>)));
         SDB_HIP(setattr(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2, true, 4>)));
         SDB_HIP(setattr(reinterpret_cast<const void *>(&k_prune_new_tiled<NG, L2, false, 8>)));
-        attr_set = true;
       }
       // 8 waves (two per SIMD) for the common no-tail rows: one wave's LDS waits run under the other's arithmetic
       // (1M x 384 build: 2.25 s with the one-wave kernel, 2.10 s tiled with 4 waves, 1.98 s with 8)

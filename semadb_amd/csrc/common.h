@@ -1,6 +1,7 @@
 // common.h -- shared host-side plumbing for the C ABI (error reporting, device guards).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdint>
@@ -70,5 +71,14 @@ struct RowLayout {
 };
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute applies to the function on the CURRENT device: a process that drives several GPUs
+// (sdb_cluster_create_local) has to set a kernel's attribute once per device, not once per process.
+inline bool first_use_on_this_device(std::atomic<uint64_t> &seen) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return !(seen.fetch_or(bit) & bit);
+}
 
 }  // namespace sdb

@@ -553,12 +553,10 @@ template <bool L2>
 static int launch_flat_scan(const FlatScanArgs &a, hipStream_t stream) {
   const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
   const size_t lds = (size_t)kScanRows * (a.nblk * 32 + 4) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_use_on_this_device(attr))
     SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan<L2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    attr = true;
-  }
   hipLaunchKernelGGL((k_flat_scan<L2>), grid, dim3(kScanWaves * 64), lds, stream, a.slab, a.queries, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
@@ -572,12 +570,10 @@ template <int NBLK, bool TAIL>
 static int launch_flat_scan_mfma_nbt(const FlatScanArgs &a, const float *qsw, hipStream_t stream) {
   const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
   const size_t lds = flat_mfma_lds_bytes(NBLK, TAIL ? 1 : 0, a.nq);
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (first_use_on_this_device(attr))
     SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan_mfma<NBLK, TAIL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
   hipLaunchKernelGGL((k_flat_scan_mfma<NBLK, TAIL>), grid, dim3(256), lds, stream, a.slab, qsw, a);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
@@ -744,12 +740,10 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     uint2 *d_cand = (uint2 *)(buf + o_cand);
     SDB_HIP(hipMemsetAsync(d_cnt, 0, nq * 4 + 4, stream));
     const size_t merge_lds = (size_t)(128 + kCandCap) * sizeof(uint2);
-    static bool merge_attr = false;
-    if (!merge_attr) {
+    static std::atomic<uint64_t> merge_attr{0};
+    if (first_use_on_this_device(merge_attr))
       SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)merge_lds));
-      merge_attr = true;
-    }
     // thresholds from the seed rows (no candidates yet: the merge only derives thr from the lists)
     hipLaunchKernelGGL(k_flat_merge, dim3((unsigned)nq), dim3(kMergeThreads), merge_lds, stream, d_cnt, d_cand, kCandCap, limit, top_slot,
                        top_dist, top_len, d_thr, d_over);
