@@ -339,13 +339,13 @@ def flat_trial(rng):
     """flat.IndexFlat (shard/index/flat/flat.go): random Set / replace / Delete sequences, explicit transactions with
     a search in between (which must not see them), compaction, and exact searches with random limits and filters
     against the oracle's distances over a storage-order model of the store (Set of a stored id drops its row and
-    appends the new one).  One trial in four is a table of 33 000+ rows of whole 32-float blocks: the streaming
-    scans (matrix cores for dot / cosine, packed FMAs for euclidean), tombstones included."""
+    appends the new one).  One trial in four is a table of 33 000+ rows: the streaming scans (matrix cores for dot /
+    cosine, with and without a tail; packed FMAs for euclidean rows of whole blocks), tombstones included."""
     from semadb_amd import flat
     metric = str(rng.choice(METRICS))
     kind = str(rng.choice(["unit", "latent", "grid", "dups"]))
     big = rng.integers(0, 4) == 0
-    d = int(rng.choice([32, 64, 96, 128, 384])) if big else int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 128, 200, 384, 768]))
+    d = int(rng.choice([32, 33, 64, 96, 100, 128, 300, 384])) if big else int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 128, 200, 384, 768]))
     n0 = int(rng.integers(33000, 42000)) if big else int(rng.integers(1, max(2, min(3000, 200000 // d))))
     CURRENT.clear()
     CURRENT.update(dict(flat_trial=True, d=d, metric=metric, kind=kind, n0=n0))
