@@ -308,7 +308,10 @@ __global__ void k_pq_lut(const float *__restrict__ queries, uint32_t dim, const 
 // Register-tiled forms of the two kernels above for sub_len < 32 * (kRegBlocksMax + 1).
 // LUT: thread = centroid j (its row in registers), the block walks kLutQT queries whose sub-vectors
 // are wave-uniform -- the centroid table is read once per 16 queries instead of once per query.
-constexpr uint32_t kLutQT = 16;
+#ifndef SDB_LUT_QT
+#define SDB_LUT_QT 16
+#endif
+constexpr uint32_t kLutQT = SDB_LUT_QT;
 template <bool L2, int NB>
 __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ queries, uint32_t nq, uint32_t dim,
                                                   const float *__restrict__ cent, uint32_t M, uint32_t K,
@@ -378,6 +381,56 @@ static void launch_encode_t(const sdb_pq *pq, const float *d_vecs, uint64_t n, u
                        pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
 }
 
+// The same table on the matrix cores, for dot / cosine sub-vectors of whole 32-float blocks and K a multiple of 16: per
+// sub-quantizer the table is queries x centroids^T with the reference's summation order, and one v_mfma_f32_16x16x1 is one
+// fused multiply-add of that order for 16 queries x 16 centroids x 4 partial-sum quarters (the mapping of flat.hip's
+// k_flat_scan_mfma: accumulator set k = 2a + tt, block = quarter, reduce tree in the lane).  A wave takes 16 queries x 16
+// centroids; lane 16 blk + i reads query i and centroid i at elements 32b + 8a + 4tt + blk straight from global memory (the
+// centroid table is L2-resident); a lane's four results are 16 consecutive centroids across the lanes: 64-byte stores.
+typedef float pq_f16v __attribute__((ext_vector_type(16)));
+template <int NB>
+__global__ __launch_bounds__(256) void k_pq_lut_mfma(const float *__restrict__ queries, uint32_t nq, uint32_t dim,
+                                                     const float *__restrict__ cent, uint32_t M, uint32_t K,
+                                                     int metric, float *__restrict__ lut) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t m = blockIdx.y, c0 = blockIdx.x * 16, q0 = (blockIdx.z * 4 + wave) * 16;
+  if (q0 >= nq) return;
+  constexpr uint32_t sub_len = NB * 32;
+  const uint32_t blk = lane >> 4;
+  const float *qrow = queries + (size_t)min(q0 + (lane & 15), nq - 1) * dim + (size_t)m * sub_len + blk;
+  const float *crow = cent + ((size_t)m * K + c0 + (lane & 15)) * sub_len + blk;
+  pq_f16v acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    float x[8], y[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = qrow[32 * b + 4 * k], y[k] = crow[32 * b + 4 * k];  // 8a + 4tt = 4k
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(x[k], y[k], acc[k], 0, 0, 0);
+  }
+  const pq_f16v s0 = ((acc[0] + acc[2]) + acc[4]) + acc[6];
+  const pq_f16v s1 = ((acc[1] + acc[3]) + acc[5]) + acc[7];
+  const pq_f16v r4 = (s0 + s1) + 0.0f;
+#pragma unroll
+  for (int i4 = 0; i4 < 4; i4++) {
+    const uint32_t q = q0 + 4 * blk + i4;
+    const float d = metric_finish((r4[i4] + r4[4 + i4]) + (r4[8 + i4] + r4[12 + i4]), metric);
+    if (q < nq) lut[((size_t)q * M + m) * K + c0 + (lane & 15)] = d;
+  }
+}
+template <int NB>
+static void launch_lut_mfma(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
+  if constexpr (NB >= 1) {
+    const dim3 grid(pq->K / 16, pq->M, (unsigned)((nq + 63) / 64));
+    hipLaunchKernelGGL((k_pq_lut_mfma<NB>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim, pq->d_centroids, pq->M,
+                       pq->K, pq->metric, d_lut);
+  }
+}
+
 #define SDB_NB_SWITCH(fn, ...)                 \
   switch (pq->sub_len / 32) {                  \
     case 0: fn<0>(__VA_ARGS__); break;         \
@@ -422,7 +475,10 @@ __global__ void k_scatter_labels(const uint8_t *__restrict__ labels, uint8_t *__
 
 int pq_build_lut(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
   if (nq == 0) return SDB_OK;
-  if (pq->sub_len < 32 * (kRegBlocksMax + 1)) {
+  if (pq->metric != SDB_METRIC_EUCLIDEAN && pq->sub_len % 32 == 0 && pq->sub_len >= 32 && pq->sub_len <= 32 * kRegBlocksMax &&
+      pq->K % 16 == 0) {
+    SDB_NB_SWITCH(launch_lut_mfma, pq, d_queries, nq, d_lut, stream)
+  } else if (pq->sub_len < 32 * (kRegBlocksMax + 1)) {
     SDB_NB_SWITCH(launch_lut_t, pq, d_queries, nq, d_lut, stream)
   } else {
     const uint32_t MK = pq->M * pq->K;

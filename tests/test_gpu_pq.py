@@ -45,7 +45,9 @@ def test_kmeans_reference_kat():
 @pytest.mark.parametrize("d,M,K,n", [(4, 2, 256, 5), (32, 8, 16, 600), (96, 2, 32, 400), (768, 8, 64, 700),
                                      (64, 16, 256, 1200),
                                      # sub-vector lengths 100 (3 blocks + tail), 256 (8 blocks), 320 (generic kernel)
-                                     (200, 2, 16, 300), (512, 2, 8, 200), (640, 2, 8, 200)])
+                                     (200, 2, 16, 300), (512, 2, 8, 200), (640, 2, 8, 200),
+                                     # whole 32-float blocks and K % 16 == 0: the LUT of dot / cosine is built on the matrix cores
+                                     (256, 8, 256, 1300), (512, 2, 16, 300), (768, 8, 256, 1300)])
 def test_pq_matches_oracle(oracle, metric, d, M, K, n):
     from semadb_amd import vectorstore as vs
     rng = np.random.default_rng(d + M + K)
