@@ -50,9 +50,27 @@ __device__ __forceinline__ float dist_serial_metric(const float *x, const float 
 // reduce tree consumes them, so only a handful are live at a time.  rt = the register operand's tail
 // elements in memory (sub_len % 32 of them), chained sequentially as the asm does.
 constexpr int kRegBlocksMax = 8;  // sub-vectors of up to 8 * 32 + 31 floats take the register path
+typedef float pq_f2v __attribute__((ext_vector_type(2)));
 template <bool L2, int NB>
 __device__ __forceinline__ float dist_regs(const float *r, const float *__restrict__ u, const float *__restrict__ rt,
                                            uint32_t tail) {
+  // partial sums 2p and 2p + 1 advance together: one v_pk_fma_f32 (and, for euclidean, one packed subtract, rounded per
+  // element like VSUBPS) per pair of elements -- each half is the reference's own operation on its own chain
+  pq_f2v acc2[16];
+#pragma unroll
+  for (int p = 0; p < 16; p++) acc2[p] = pq_f2v{0.0f, 0.0f};
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      const pq_f2v x = {r[32 * b + 2 * p], r[32 * b + 2 * p + 1]}, y = {u[32 * b + 2 * p], u[32 * b + 2 * p + 1]};
+      if constexpr (L2) {
+        const pq_f2v d = x - y;
+        acc2[p] = __builtin_elementwise_fma(d, d, acc2[p]);
+      } else {
+        acc2[p] = __builtin_elementwise_fma(x, y, acc2[p]);
+      }
+    }
   float rr[4];
 #pragma unroll
   for (int l = 0; l < 4; l++) {
@@ -63,10 +81,7 @@ __device__ __forceinline__ float dist_regs(const float *r, const float *__restri
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int L = l + 4 * h + 8 * k;
-        float acc = 0.0f;
-#pragma unroll
-        for (int b = 0; b < NB; b++) acc = chain1<L2>(acc, r[32 * b + L], u[32 * b + L]);
-        part[k] = acc;
+        part[k] = acc2[L >> 1][L & 1];
       }
       s[h] = ((part[0] + part[1]) + part[2]) + part[3];
     }
