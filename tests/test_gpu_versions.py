@@ -169,3 +169,109 @@ def test_searches_run_while_a_writer_inserts(oracle):
     assert during >= 1 and seen_pre >= 1 and seen_post >= 1
     assert ix.version_diff() == 0
     ix.close()
+
+
+def test_random_writes_under_concurrent_readers(oracle):
+    """One writer applies 120 random write batches (inserts in rounds, deletes, updates, now and then a compaction)
+    while three reader threads keep asking: graph walks with and without filters, the exact scan, K1.  Every answer a
+    reader gets must be the answer of ONE committed version -- the oracle replays the same batches one by one and the
+    answers to the fixed questions after each commit are the allowed set -- and nothing may crash, hang or tear.  At
+    the end the device graph equals the oracle's edge for edge."""
+    from semadb_amd import flat, vamana
+    from tests.helpers import assert_same_graph
+    rng = np.random.default_rng(909)
+    d, n0, R, L, k = 24, 3000, 24, 40, 5
+    lat = rng.standard_normal((6, d)).astype(np.float32)
+    base0 = _rows(rng, n0, d, lat)
+    q = _rows(rng, 16, d, lat)
+    sv = start_vector(np.random.default_rng(5), d)
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    ids0 = np.arange(2, n0 + 2, dtype=np.uint64)
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=impl)
+    o.set_start(sv)
+    for i in range(n0):
+        assert o.insert(int(ids0[i]), base0[i]) == 0
+    ix = vamana.NewIndexVamana("rw", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), strict=False)
+    ix.set_start(sv)
+    ix.insert_batch(ids0, base0, round_size=1)
+    filt = [set(int(v) for v in rng.choice(ids0, 25, replace=False)) for _ in range(16)]
+
+    def o_version():
+        plain = tuple((tuple(int(v) for v in a), tuple(int(v) for v in bits(b))) for a, b in _oracle_answers(o, q, k, L))
+        filtered = tuple((tuple(int(v) for v in a), tuple(int(v) for v in bits(b))) for a, b in _oracle_answers(o, q, 3, L, filt))
+        return plain, filtered
+
+    # ---- the write batches, replayed on the oracle first: the answers of every committed version
+    batches, versions = [], [o_version()]
+    live = [int(v) for v in ids0]
+    nxt = n0 + 2
+    for b in range(120):
+        n_ins, n_del, n_upd = int(rng.integers(0, 30)), int(rng.integers(0, 12)), int(rng.integers(0, 4))
+        dels = [int(v) for v in rng.choice(live, n_del, replace=False)] if n_del else []
+        rest = [v for v in live if v not in set(dels)]
+        upds = [int(v) for v in rng.choice(rest, n_upd, replace=False)] if n_upd else []
+        new_ids = list(range(nxt, nxt + n_ins))
+        nxt += n_ins
+        nv, uv = _rows(rng, max(1, n_ins), d, lat), _rows(rng, max(1, n_upd), d, lat)
+        ch = [vamana.IndexVectorChange(i, nv[j]) for j, i in enumerate(new_ids)]
+        ch += [vamana.IndexVectorChange(i, None) for i in dels]
+        ch += [vamana.IndexVectorChange(i, uv[j]) for j, i in enumerate(upds)]
+        batches.append((ch, b % 9 == 8))
+        for j, i in enumerate(new_ids):
+            assert o.insert(i, nv[j]) == 0
+        if dels or upds:
+            assert o.delete(np.array(dels + upds, dtype=np.uint64)) == 0
+        for j, i in enumerate(upds):
+            assert o.insert(i, uv[j]) == 0
+        live = sorted((set(live) - set(dels)) | set(new_ids))
+        versions.append(o_version())
+    plain_ok, filt_ok = set(v[0] for v in versions), set(v[1] for v in versions)
+
+    state = {"done": False, "err": None, "asked": 0}
+
+    def writer():
+        try:
+            for ch, compact in batches:
+                ix.InsertUpdateDelete(ch, round_size=1)
+                if compact:
+                    ix.compact()
+        except Exception as e:  # pragma: no cover
+            state["err"] = e
+        state["done"] = True
+
+    def reader(kind):
+        try:
+            while not state["done"]:
+                if kind == 0:
+                    g = ix.search_batch(q, k, L)
+                    got = tuple((tuple(int(v) for v in g[0][i, :int(g[2][i])]), tuple(int(v) for v in bits(g[1][i, :int(g[2][i])])))
+                                for i in range(16))
+                    assert got in plain_ok, "a walk answered with no committed version's answers"
+                elif kind == 1:
+                    g = ix.search_batch(q, 3, L, filters=filt)
+                    got = tuple((tuple(int(v) for v in g[0][i, :int(g[2][i])]), tuple(int(v) for v in bits(g[1][i, :int(g[2][i])])))
+                                for i in range(16))
+                    assert got in filt_ok, "a filtered walk answered with no committed version's answers"
+                else:
+                    f_ids, f_d, f_c = flat.flat_search_batch(ix._h, d, q, 4)
+                    assert (np.asarray(f_c) == 4).all() and np.isfinite(np.asarray(f_d)).all()
+                    assert (np.diff(np.asarray(f_d), axis=1) >= 0).all(), "the exact scan tore"
+                    ix.distance_batch(q, np.tile(ids0[:8], (16, 1)))
+                state["asked"] += 1
+        except Exception as e:
+            state["err"] = e
+            state["done"] = True
+
+    threads = [threading.Thread(target=writer)] + [threading.Thread(target=reader, args=(kind,)) for kind in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a thread hung"
+    if state["err"] is not None:
+        raise state["err"]
+    print("questions answered while the writer ran: %d" % state["asked"])
+    assert state["asked"] >= 10
+    assert ix.version_diff() == 0
+    assert_same_graph(ix, o)
+    ix.close()
