@@ -389,3 +389,76 @@ def test_flat_filter_that_names_no_stored_id(oracle):
             assert int(g_c[i]) == len(e_ids) == (10 if filters[i] is some else 0)
             assert np.array_equal(g_ids[i, :len(e_ids)], e_ids) and np.array_equal(bits(g_d[i, :len(e_ids)]), bits(e_d))
     ix.close()
+
+
+def test_flat_writes_under_a_concurrent_reader(oracle):
+    """a writer thread applies 150 random Set / replace / Delete batches (and compactions) to a flat index while a reader
+    thread keeps scanning: every answer is the exact answer over ONE committed state of the store"""
+    import threading
+    from semadb_amd import flat
+    rng = np.random.default_rng(4)
+    d, n0 = 24, 2500
+    base = unit_rows(rng, n0, d)
+    q = unit_rows(rng, 12, d)
+    ix = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, "cosine"))
+    st = _Store()
+    ids0 = np.arange(1, n0 + 1, dtype=np.uint64)
+    ix.set_vectors(ids0, base)
+    for i in range(n0):
+        st.set(i + 1, base[i])
+
+    def answers():
+        ids, rows = st.arrays()
+        return tuple((tuple(int(v) for v in a), tuple(int(v) for v in bits(b))) for a, b in _expected(oracle, q, rows, ids, "cosine", 5))
+
+    batches, allowed = [], {answers()}
+    nxt = n0 + 1
+    for b in range(150):
+        ch = []
+        for _ in range(int(rng.integers(1, 12))):
+            op = int(rng.integers(0, 3))
+            if op == 0:
+                ch.append(flat.IndexVectorChange(nxt, unit_rows(rng, 1, d)[0]))
+                nxt += 1
+            elif op == 1:
+                ch.append(flat.IndexVectorChange(int(rng.choice(st.ids)), unit_rows(rng, 1, d)[0]))
+            else:
+                ch.append(flat.IndexVectorChange(int(rng.choice(st.ids)), None))
+        batches.append((ch, b % 20 == 19))
+        for c in ch:
+            st.delete(c.Id) if c.Vector is None else st.set(c.Id, c.Vector)
+        allowed.add(answers())
+    state = {"done": False, "err": None, "asked": 0}
+
+    def writer():
+        try:
+            for ch, compact in batches:
+                ix.InsertUpdateDelete(ch)
+                if compact:
+                    ix.compact()
+        except Exception as e:  # pragma: no cover
+            state["err"] = e
+        state["done"] = True
+
+    def reader():
+        try:
+            while not state["done"]:
+                g = ix.search_batch(q, 5)
+                got = tuple((tuple(int(v) for v in g[0][i]), tuple(int(v) for v in bits(g[1][i]))) for i in range(12))
+                assert got in allowed, "an exact scan answered with no committed state's answers"
+                state["asked"] += 1
+        except Exception as e:
+            state["err"] = e
+            state["done"] = True
+
+    ts = [threading.Thread(target=writer), threading.Thread(target=reader)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a thread hung"
+    if state["err"] is not None:
+        raise state["err"]
+    assert state["asked"] >= 5 and ix.version_diff() == 0
+    _check_flat(oracle, ix, st, q, "cosine")
+    ix.close()
