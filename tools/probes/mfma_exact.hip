@@ -87,7 +87,7 @@ int main() {
       case 1: u &= 0x807FFFFFu; memcpy(&f, &u, 4); break;                                          // denormal
       case 2: f = std::ldexp((float)(int32_t)rng() / 2147483648.f, -(int)(rng() % 30) - 60); break; // products underflow
       case 3: f = (float)((int)(rng() % 7) - 3); break;                                            // small ints, zeros
-      default: memcpy(&f, &u, 4); if (std::isnan(f) || std::isinf(f)) f = 1.5f; break;             // any bits
+      default: memcpy(&f, &u, 4); if (rng() % 16 == 0) f = (rng() & 1) ? INFINITY : -INFINITY; break;  // any bits: NaNs and infinities too
     }
     return f;
   };
@@ -106,7 +106,7 @@ int main() {
     if (shape == 0) hipLaunchKernelGGL(k4, dim3(T), dim3(64), 0, 0, da, db, dc, dd);
     else hipLaunchKernelGGL(k16, dim3(T), dim3(64), 0, 0, da, db, dc, dd);
     hipMemcpy(d.data(), dd, d.size() * 4, hipMemcpyDeviceToHost);
-    long bad_fused = 0, bad_unfused = 0, total = 0, differ = 0, bad_den = 0, den_total = 0;
+    long bad_fused = 0, bad_unfused = 0, total = 0, differ = 0, bad_den = 0, den_total = 0, nan_class = 0;
     for (int t = 0; t < T; t++)
       for (int l = 0; l < 64; l++)
         for (int r = 0; r < R; r++) {
@@ -120,6 +120,7 @@ int main() {
           const float got = d[(t * 64 + l) * R + r];
           total++;
           if (bitsof(want) != bitsof(unf)) differ++;
+          if (std::isnan(got) != std::isnan(want)) nan_class++;
           if (bitsof(got) != bitsof(want) && !(std::isnan(got) && std::isnan(want))) {
             bad_fused++;
             if (bad_fused <= 5) std::printf("  shape %d: a=%a b=%a c=%a got=%a fmaf=%a\n", R, x, y, z, got, want);
@@ -129,6 +130,7 @@ int main() {
                            (std::fpclassify(z) == FP_SUBNORMAL) || (std::fpclassify(want) == FP_SUBNORMAL);
           if (den) { den_total++; if (bitsof(got) != bitsof(want)) bad_den++; }
         }
+    std::printf("  (a NaN where fmaf has none or the other way round: %ld)\n", nan_class);
     std::printf("mfma_f32_%dx%dx1: %ld outputs, %ld where fused != unfused; mismatches vs fmaf %ld (of them with denormals %ld / %ld), vs unfused %ld\n",
                 R, R, total, differ, bad_fused, bad_den, den_total, bad_unfused);
   }
