@@ -164,30 +164,23 @@ class Exchange:
                 self.native = False
                 self.note = self.note or "sdb_cluster_create failed on another rank"
                 log("exchange falls back to torch.distributed all_gather_into_tensor:", self.note)
-        if not self.native:
-            self.stream = torch.cuda.Stream(device=dev)
+        self.seq = 0
 
     def search(self, ix, q, k, L):
         """ClusterNode.SearchPoints for this rank's shard -> merged (ids, dists, shards, counts) on device,
         valid after join()"""
         if self.native:
             return self.cl.search_batch(ix, q, k, L)
+        # the torch.distributed transport: same block, same tags, same check + merge (blocking)
         per = self.cluster.shard_limit(k, self.world, 75)
         blk = self.cluster.PackedTopK(q.shape[0], per, self.dev)
         ix.search_batch(q, per, L, out=blk.out())
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
-            blk.buf.record_stream(self.stream)
-            g = blk.allgather()
-            return self.cluster.topk_merge(*g, k, device=self.dev_index)
+        self.seq += 1
+        return blk.exchange(k, seq=self.seq, ticket=self.seq, queries=q)
 
     def join(self):
         if self.native:
             self.cl.synchronize()
-        else:
-            self.stream.synchronize()
 
     def close(self):
         if self.native:
@@ -493,7 +486,7 @@ def run_c2(a, ctx):
     }
     if ex is not None and world > 1 and not split:
         result["config"]["exchange"] = ("libsemadb_amd.so: sdb_cluster_search_batch (ncclAllGather on the library's stream)"
-                                        if ex.native else "torch.distributed all_gather_into_tensor (%s) + sdb_topk_merge%s" %
+                                        if ex.native else "torch.distributed all_gather_into_tensor (%s) + sdb_cluster_merge_gathered (tag check + merge)%s" %
                                         (ctx["backend"], "; " + ex.note if ex.note else ""))
     if recall < 0.95:  # the metric is recall-gated: a line below the gate is not a measurement of it
         result["invalid"] = "recall@10 %.4f is below the metric's 0.95 gate" % recall

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SDB_ABI_VERSION 1
+#define SDB_ABI_VERSION 2
 
 typedef enum {
   SDB_OK = 0,
@@ -146,6 +146,13 @@ int sdb_index_delete_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, void 
  * cache after any error inside a transaction the same way (manager.go:231-240). */
 int sdb_index_begin_write(sdb_index *ix);
 int sdb_index_commit(sdb_index *ix, void *stream);
+/* Leave a transaction without committing it -- the error path of a host's InsertUpdateDelete (a bad point found
+ * after begin_write, a failed insert call).  If the transaction has not changed anything yet it just closes and the
+ * index is what it was at begin_write (SDB_OK).  If it has, there is no rollback: the handle becomes unusable and
+ * SDB_ERR_STATE says so; the host reloads from the bucket, as the reference's cache manager scraps a shard after any
+ * error inside a transaction (shard/cache/manager.go:231-240).  Without an open transaction: SDB_OK.  Insert / delete
+ * calls that fail before their first change close the transaction they opened for themselves the same way. */
+int sdb_index_abort_write(sdb_index *ix);
 /* test support: rows on which the committed and the writer's copy of the graph differ (0 outside a transaction) */
 int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows);
 
@@ -316,7 +323,12 @@ int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit
  * others over whatever channel the host already has (SemaDB: its cluster RPC; the tests:
  * torch.distributed / a pipe); every rank then calls sdb_cluster_create, which blocks until all
  * `world` ranks have arrived.  One process per GPU or one thread per GPU in one process (the shape
- * of a Go server that owns the whole node) -- sdb_cluster_create_local sets the latter up in one call. */
+ * of a Go server that owns the whole node) -- sdb_cluster_create_local sets the latter up in one call.
+ * Transports: distinct devices exchange through RCCL (ncclAllGather over xGMI).  When create_local is given the
+ * SAME device for every rank -- several shards of a collection living on one GPU, which is also how a one-GPU box
+ * runs the whole N-shard protocol -- the ranks exchange through device memory copies behind a host rendezvous
+ * (the last rank to arrive enqueues the copies and merges for all); everything else (tickets, tags, error
+ * propagation, merge) is the same code.  A mix of repeated and distinct devices is rejected. */
 #define SDB_CLUSTER_ID_BYTES 128
 typedef struct sdb_cluster sdb_cluster;
 int sdb_cluster_unique_id(uint8_t *id /* [SDB_CLUSTER_ID_BYTES] */);
@@ -329,38 +341,92 @@ int sdb_cluster_info(const sdb_cluster *c, int *rank, int *world, int *device);
 /* Layout of one shard's result block for nq queries x per_shard results, the all-gather message:
  *   [0, off_dists)            uint64 ids   [nq][per_shard]
  *   [off_dists, off_counts)   float  dists [nq][per_shard]
- *   [off_counts, ...)         uint32 counts[nq]            padded to `bytes` (a multiple of 16)
+ *   [off_counts, off_tag)     uint32 counts[nq]            (padded to 16 bytes)
+ *   [off_tag, bytes)          sdb_block_tag, SDB_BLOCK_TAG_BYTES: written by the library, compared after the gather
  * sdb_index_search_batch can write straight into it (out_ids = block, out_dists = block + off_dists,
  * out_counts = block + off_counts). */
-int sdb_cluster_block_layout(uint64_t nq, uint32_t per_shard, size_t *off_dists, size_t *off_counts,
+#define SDB_BLOCK_TAG_BYTES 64
+typedef struct {
+  uint32_t magic;      /* SDB_BLOCK_MAGIC                                                                   */
+  uint32_t status;     /* sdb_status of this rank's shard search: != 0 fails the request on every rank      */
+  uint64_t seq;        /* position of the call in this rank's sequence of collectives (ticket order)         */
+  uint64_t ticket;     /* the caller's request ticket (0: none)                                              */
+  uint64_t nq;         /* the shape every rank must agree on                                                  */
+  uint32_t per_shard;
+  uint32_t limit;
+  uint64_t query_hash; /* order-independent 64-bit hash of the nq x dim query floats (search_batch; else 0)  */
+  uint32_t rank;
+  uint32_t reserved[3];
+} sdb_block_tag;
+#define SDB_BLOCK_MAGIC 0x53444254u /* "SDBT" */
+int sdb_cluster_block_layout(uint64_t nq, uint32_t per_shard, size_t *off_dists, size_t *off_counts, size_t *off_tag,
                              size_t *bytes);
 
+/* Collective calls, order and failure.  The reference fans one request out to its shards from one goroutine each,
+ * and requests run concurrently (cluster/actions.go:316-351): shard A may see request 1 before request 2 and shard B
+ * the other way round, which is harmless over RPC (every reply names its request) and fatal for a collective -- equal
+ * sized all-gathers would pair request 1's block of one rank with request 2's of another and merge them into
+ * plausible, wrong answers.  Three guards:
+ *   (1) `ticket`: a request number the fan-out draws once per request (1, 2, 3, ... without gaps, shared by all ranks
+ *       of the node) and passes to every rank's call.  A rank's calls then ENTER the exchange in ticket order whatever
+ *       order its threads arrive in: a call whose ticket is not next waits for its predecessors.  ticket 0 = no
+ *       ordering by the library (a single caller thread per rank that issues in the same order everywhere).
+ *   (2) every block carries a tag (above): sequence number, ticket, shape and -- for search_batch -- a hash of the
+ *       queries the rank searched.  After the gather every rank compares all tags; on any difference NO answer is
+ *       produced (counts 0) and the call fails with SDB_ERR_STATE on every rank, naming the ranks that disagree.
+ *   (3) a rank whose own shard search fails (index unusable after a failed write, no start node, out of memory)
+ *       still enters the exchange with status != 0 in its tag and empty counts, so that its peers are not left
+ *       waiting inside the all-gather; every rank then returns that error for this request and the next request is
+ *       served normally -- the reference returns an error for the request and keeps serving (actions.go:339-353).
+ * Device-memory calls are asynchronous: their verdict is delivered by sdb_cluster_synchronize (first failure since the
+ * last call, SDB_ERR_STATE), and a failed request's out_counts are all zero. */
+
 /* The exchange step of SearchPoints (actions.go:316-376) for a block this rank's shard produced:
- * all-gather of `block` (device memory, layout above, written by work already enqueued on `stream`)
- * over all ranks, then the merge (sdb_topk_merge rule) to the original `limit` on this rank's GPU.
- * Collective: every rank calls it with the same nq / per_shard, in the same order.
+ * all-gather of `block` (device memory, layout above, written by work already enqueued on `stream`; the library
+ * writes its tag) over all ranks, then the merge (sdb_topk_merge rule) to the original `limit` on this rank's GPU.
+ * Collective: every rank calls it with the same ticket / nq / per_shard / limit.
  * The exchange runs on the cluster's own stream, ordered after `stream`'s work at the time of the
  * call, so the caller's next search overlaps it.  `block` must stay untouched and the outputs are
  * not valid until sdb_cluster_wait(c, stream) (a stream-side wait, no host block) or
  * sdb_cluster_synchronize(c).  out_* follow `mem`; SDB_MEM_HOST outputs are copied back and the
  * call synchronises.  out_shards (optional) = rank of the shard each result came from. */
-int sdb_cluster_allgather_merge(sdb_cluster *c, uint64_t nq, uint32_t per_shard, const void *block,
-                                uint32_t limit, uint64_t *out_ids, float *out_dists,
-                                uint32_t *out_shards, uint32_t *out_counts, int mem, void *stream);
+int sdb_cluster_allgather_merge(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32_t per_shard, void *block,
+                                uint32_t limit, uint64_t *out_ids, float *out_dists, uint32_t *out_shards,
+                                uint32_t *out_counts, int mem, void *stream);
 
 /* ClusterNode.SearchPoints for this rank's shard, whole: per-shard limit (actions.go:291-299;
  * the query's own Limit / SearchSize are not rewritten per shard, :301-314) -> IndexVamana.Search
  * of all nq queries on `ix` into a block of the cluster's ring -> all-gather -> merge to `limit`.
  * Collective like sdb_cluster_allgather_merge.  `queries` and out_* follow `mem`; with
  * SDB_MEM_DEVICE the search is enqueued on `stream`, the exchange on the cluster's stream, and up
- * to 4 batches may be in flight before the caller waits (sdb_cluster_wait / _synchronize). */
-int sdb_cluster_search_batch(sdb_cluster *c, sdb_index *ix, uint64_t nq, const float *queries,
+ * to SDB_CLUSTER_RING batches may be in flight before the caller waits (sdb_cluster_wait / _synchronize).
+ * SDB_MEM_HOST calls block until their own answer is there, and up to SDB_CLUSTER_RING of them may be in flight
+ * on one rank from different threads (each has its own staging; the exchange of one runs under the walk of the
+ * next). */
+#define SDB_CLUSTER_RING 8
+int sdb_cluster_search_batch(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries,
                              uint32_t limit, uint32_t search_size, uint64_t *out_ids,
                              float *out_dists, uint32_t *out_shards, uint32_t *out_counts, int mem,
                              void *stream);
-/* make `stream` wait (on the device) for every exchange enqueued so far / block the host for them */
+/* make `stream` wait (on the device) for every exchange enqueued so far / block the host for them.
+ * synchronize also reports: SDB_ERR_STATE (with the ranks and fields that disagreed, or the failing shard's status)
+ * if any device-memory exchange since the previous synchronize failed its tag check. */
 int sdb_cluster_wait(sdb_cluster *c, void *stream);
 int sdb_cluster_synchronize(sdb_cluster *c);
+/* the next ticket this rank will let into the exchange (tickets below it have entered) */
+int sdb_cluster_next_ticket(const sdb_cluster *c, uint64_t *ticket);
+
+/* The tag check + merge on a gathered buffer [world][bytes] that some other transport delivered (the tests' gloo
+ * path; a host that moves the blocks over its own RPC): sdb_cluster_stamp_block writes this rank's tag into its
+ * block before it is sent (query_hash over `queries` when given; device memory, asynchronous on `stream`),
+ * sdb_cluster_merge_gathered compares the tags of all blocks and merges, blocking; on a tag mismatch or a failed
+ * shard it returns SDB_ERR_STATE and leaves all counts zero.  Buffers are device memory. */
+int sdb_cluster_stamp_block(void *block, uint64_t nq, uint32_t per_shard, uint32_t limit, uint32_t rank, uint64_t seq,
+                            uint64_t ticket, uint32_t status, const float *queries, uint32_t dim, int device,
+                            void *stream);
+int sdb_cluster_merge_gathered(uint32_t world, uint64_t nq, uint32_t per_shard, const void *gathered, uint32_t limit,
+                               uint64_t *out_ids, float *out_dists, uint32_t *out_shards, uint32_t *out_counts,
+                               int device, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * utils/kmeans.go + shard/vectorstore/product.go  (K5..K8)

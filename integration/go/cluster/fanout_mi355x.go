@@ -6,6 +6,16 @@
 // call that searches its shard, exchanges the per-shard top-k blocks with a single RCCL all-gather over xGMI and
 // merges them on its GPU (sdb_cluster_search_batch).  Every goroutine gets the merged answer; the caller takes
 // shard 0's.
+//
+// Order.  REST requests are concurrent (httpapi/v2/handlers.go:435-489) and each fans out to its shards from
+// goroutines of its own (actions.go:316-351), so without further care shard 0 may see request A before B and shard 1
+// B before A -- harmless over RPC, fatal for a collective, whose all-gathers would pair A's block with B's.  Every
+// request therefore draws ONE ticket (1, 2, 3, ... from a counter shared by all ranks) and hands it to every rank's
+// call; the library lets a rank's calls into the exchange in ticket order whichever goroutine arrives first, stamps
+// each block with (sequence, ticket, shape, hash of the queries) and refuses to merge blocks whose stamps differ
+// (SDB_ERR_STATE on every rank, no answer) -- see include/semadb_amd.h "Collective calls, order and failure".  Up to
+// SDB_CLUSTER_RING requests are in flight per rank: the exchange of one runs under the graph walk of the next.
+// C++ twin, compiled and run on the GPU by tests/host/test_host.cpp: semadb::cluster::GpuFanout (semadb_host.hpp).
 package cluster
 
 /*
@@ -25,6 +35,8 @@ import (
 type gpuFanout struct {
 	ranks   []*C.sdb_cluster
 	indexes []*C.sdb_index // the shard indexes, in rank order (device r)
+	mu      sync.Mutex     // guards ticket
+	ticket  uint64         // the last ticket handed out; every request takes the next one, for all ranks
 }
 
 func fanoutErr(what string, rc C.int) error {
@@ -40,7 +52,22 @@ func newGpuFanout(indexes []*C.sdb_index) (*gpuFanout, error) {
 	if rc := C.sdb_cluster_create_local(C.int(n), nil, &f.ranks[0]); rc != C.SDB_OK {
 		return nil, fanoutErr("could not create the shard exchange", rc)
 	}
+	var next C.uint64_t
+	if rc := C.sdb_cluster_next_ticket(f.ranks[0], &next); rc != C.SDB_OK {
+		f.close()
+		return nil, fanoutErr("could not read the exchange's ticket counter", rc)
+	}
+	f.ticket = uint64(next) - 1
 	return f, nil
+}
+
+// nextTicket: one per request, without gaps -- a ticket that never reaches some rank would hold up every later one
+// there, so searchPoints below presents its ticket to every rank unconditionally (a cancelled request still runs).
+func (f *gpuFanout) nextTicket() uint64 {
+	f.mu.Lock()
+	defer f.mu.Unlock()
+	f.ticket++
+	return f.ticket
 }
 
 func (f *gpuFanout) close() {
@@ -54,6 +81,7 @@ func (f *gpuFanout) close() {
 // node ids), shards[nq*limit] (which shard each id belongs to), dists and counts.
 func (f *gpuFanout) searchPoints(queries []float32, nq, limit, searchSize int) (ids []uint64, shards []uint32, dists []float32, counts []uint32, err error) {
 	n := len(f.ranks)
+	ticket := f.nextTicket()
 	type out struct {
 		ids    []uint64
 		shards []uint32
@@ -70,16 +98,18 @@ func (f *gpuFanout) searchPoints(queries []float32, nq, limit, searchSize int) (
 			o := &outs[r]
 			o.ids, o.shards = make([]uint64, nq*limit), make([]uint32, nq*limit)
 			o.dists, o.counts = make([]float32, nq*limit), make([]uint32, nq)
-			o.rc = C.sdb_cluster_search_batch(f.ranks[r], f.indexes[r], C.uint64_t(nq), (*C.float)(unsafe.Pointer(&queries[0])),
-				C.uint32_t(limit), C.uint32_t(searchSize), (*C.uint64_t)(unsafe.Pointer(&o.ids[0])),
+			o.rc = C.sdb_cluster_search_batch(f.ranks[r], f.indexes[r], C.uint64_t(ticket), C.uint64_t(nq),
+				(*C.float)(unsafe.Pointer(&queries[0])), C.uint32_t(limit), C.uint32_t(searchSize), (*C.uint64_t)(unsafe.Pointer(&o.ids[0])),
 				(*C.float)(unsafe.Pointer(&o.dists[0])), (*C.uint32_t)(unsafe.Pointer(&o.shards[0])),
 				(*C.uint32_t)(unsafe.Pointer(&o.counts[0])), C.SDB_MEM_HOST, nil)
 		}(r)
 	}
 	wg.Wait()
+	// a shard that failed its search has said so inside the exchange: every rank returns an error for this request
+	// and the next request is served (the reference: "could not search points", actions.go:339-353)
 	for r := range outs {
 		if outs[r].rc != C.SDB_OK {
-			return nil, nil, nil, nil, fanoutErr("shard could not search points", outs[r].rc)
+			return nil, nil, nil, nil, fmt.Errorf("shard %d could not search points (status %d)", r, int(outs[r].rc))
 		}
 	}
 	o := outs[0] // every rank holds the same merged answer

@@ -179,6 +179,12 @@ func (s *flatState) insertUpdateDelete(ctx context.Context, points <-chan vamana
 	if rc := C.sdb_index_begin_write(s.h); rc != C.SDB_OK {
 		return lastErr("could not start the write", rc)
 	}
+	committed := false
+	defer func() { // every error return below leaves the transaction: the next write must not find it open
+		if !committed {
+			C.sdb_index_abort_write(s.h)
+		}
+	}()
 	for _, r := range runs {
 		var rc C.int
 		if r.del { // vecStore.Delete (flat.go:50-52); a missing id is skipped
@@ -208,6 +214,7 @@ func (s *flatState) insertUpdateDelete(ctx context.Context, points <-chan vamana
 	if rc := C.sdb_index_commit(s.h, nil); rc != C.SDB_OK {
 		return lastErr("could not commit the write", rc)
 	}
+	committed = true
 	// rows of replaced and deleted points are tombstones until the store is compacted
 	var rows, dead C.uint64_t
 	if rc := C.sdb_index_row_usage(s.h, &rows, &dead); rc == C.SDB_OK && dead*4 > rows {

@@ -269,6 +269,16 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 	if rc := C.sdb_index_begin_write(v.h); rc != C.SDB_OK {
 		return lastErr("could not start the write", rc)
 	}
+	committed := false
+	defer func() {
+		// An error inside the transaction: leave it, so that the next write is not refused with "a transaction is
+		// already open".  If the graph had been changed already the handle is unusable from here on (abort_write
+		// says so) and the cache manager, which scraps a shard after any error inside a write (manager.go:231-240),
+		// rebuilds this index from the bucket.
+		if !committed {
+			C.sdb_index_abort_write(v.h)
+		}
+	}()
 	if len(insIds) > 0 {
 		if rc := C.sdb_index_insert_batch(v.h, C.uint64_t(len(insIds)), (*C.uint64_t)(unsafe.Pointer(&insIds[0])),
 			(*C.float)(unsafe.Pointer(&insVecs[0])), C.SDB_MEM_HOST, 0, nil); rc != C.SDB_OK {
@@ -290,6 +300,7 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 	if rc := C.sdb_index_commit(v.h, nil); rc != C.SDB_OK {
 		return lastErr("could not commit the write", rc)
 	}
+	committed = true
 	if err := v.fit(); err != nil { // vecStore.Fit (:257-260)
 		return fmt.Errorf("could not fit vector store: %w", err)
 	}

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sdb_index_delete_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "sdb_index_begin_write": (C.c_int, [C.c_void_p]),
     "sdb_index_commit": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sdb_index_abort_write": (C.c_int, [C.c_void_p]),
     "sdb_index_version_diff": (C.c_int, [C.c_void_p, u64p]),
     "sdb_index_edge_scan": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p,
                                       C.c_uint64, u64p, C.c_void_p]),
@@ -81,13 +82,19 @@ SIGNATURES = {
     "sdb_cluster_destroy": (C.c_int, [C.c_void_p]),
     "sdb_cluster_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sdb_cluster_block_layout": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
-                                           C.POINTER(C.c_size_t)]),
-    "sdb_cluster_allgather_merge": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
-                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "sdb_cluster_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "sdb_cluster_allgather_merge": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sdb_cluster_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32,
+                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p]),
     "sdb_cluster_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sdb_cluster_synchronize": (C.c_int, [C.c_void_p]),
+    "sdb_cluster_next_ticket": (C.c_int, [C.c_void_p, u64p]),
+    "sdb_cluster_stamp_block": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                          C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "sdb_cluster_merge_gathered": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sdb_kmeans_fit": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, u32p, C.c_int, C.c_int, C.c_void_p]),
     "sdb_pq_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),

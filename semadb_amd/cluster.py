@@ -5,14 +5,24 @@ and sorts/truncates them (actions.go:316-376).  On one 8 x MI355X node the shard
 the gather step is a single RCCL all-gather over xGMI of the fixed-size per-shard top-k blocks and the
 merge runs on device (merge.hip).
 
-Two transports for the gather step:
+Transports for the gather step:
   Cluster        the product path: a binding of sdb_cluster_* (csrc/cluster.hip), where the library itself
-                 owns the RCCL communicator and the exchange stream -- what a Go host calls.
-  allgather_topk / PackedTopK.allgather
+                 owns the exchange stream and the transport -- RCCL between GPUs (create / create_local with
+                 distinct devices), device copies behind a host rendezvous for shards that share one GPU
+                 (create_local with the same device repeated) -- what a Go host calls.
+  allgather_topk / PackedTopK.allgather / PackedTopK.exchange
                  the same exchange over any torch.distributed backend; exists so that the N > 1 logic
-                 (block layout, shard-major gather, merge rule) runs under gloo on machines without
-                 N GPUs (tests/test_cluster.py, BENCH_BACKEND=gloo).
+                 (block layout, tags, shard-major gather, merge rule) runs under gloo on machines without
+                 N GPUs (tests/test_cluster.py, BENCH_BACKEND=gloo).  PackedTopK.exchange stamps the block's tag
+                 and runs the library's tag check + merge on the gathered buffer (sdb_cluster_stamp_block /
+                 sdb_cluster_merge_gathered), so a mis-ordered collective is refused on this path too.
+
+Order: collective calls take a `ticket` (1, 2, 3, ... drawn once per request by whoever fans it out, see Fanout):
+a rank's calls enter the exchange in ticket order whichever thread arrives first, and the tags every block carries
+are compared after the gather (include/semadb_amd.h "Collective calls, order and failure").
 """
+import threading
+
 import ctypes as C
 
 import numpy as np
@@ -96,10 +106,11 @@ class PackedTopK:
         import torch
         self.nq, self.per = nq, per_shard
         self.b_ids, self.b_d, self.b_c = nq * per_shard * 8, nq * per_shard * 4, nq * 4
-        off_d, off_c, total = block_layout(nq, per_shard)  # the layout the C ABI defines (semadb_amd.h)
-        assert off_d == self.b_ids and off_c == self.b_ids + self.b_d
-        # the search kernel writes every element (short rows are zero-padded by the kernel); the 16-byte
-        # padding behind the counts travels too, so the buffer starts out cleared
+        off_d, off_c, off_t, total = block_layout(nq, per_shard)  # the layout the C ABI defines (semadb_amd.h)
+        assert off_d == self.b_ids and off_c == self.b_ids + self.b_d and total == off_t + 64
+        self.off_tag = off_t
+        # the search kernel writes every element (short rows are zero-padded by the kernel); the padding
+        # behind the counts and the tag travel too, so the buffer starts out cleared
         self.buf = torch.zeros(total, dtype=torch.uint8, device=device)
         self.ids = self.buf[:self.b_ids].view(torch.int64).view(nq, per_shard)
         self.dists = self.buf[self.b_ids:self.b_ids + self.b_d].view(torch.float32).view(nq, per_shard)
@@ -122,11 +133,46 @@ class PackedTopK:
         return ids, d, c
 
 
+    def exchange(self, limit, seq, ticket=0, queries=None, status=0):
+        """The torch.distributed form of sdb_cluster_search_batch's exchange step with the library's guards: stamp
+        this block's tag (sequence number, ticket, shape, hash of the queries this rank searched), all-gather the
+        blocks, then tag check + merge on this rank's GPU.  Raises SemaDBError(SDB_ERR_STATE) when the gathered blocks
+        belong to different requests or a shard reported a failure.  Blocking.  CUDA buffers only."""
+        import torch
+        import torch.distributed as dist
+        dev = self.buf.device
+        stream = _buf.current_stream(MEM_DEVICE)
+        qp, dim = None, 0
+        if queries is not None:
+            queries = queries.contiguous()
+            qp, dim = C.c_void_p(queries.data_ptr()), queries.shape[1]
+        check(lib().sdb_cluster_stamp_block(C.c_void_p(self.buf.data_ptr()), self.nq, self.per, limit, dist.get_rank(),
+                                            seq, ticket, status, qp, dim, dev.index or 0, stream))
+        world = dist.get_world_size()
+        if dist.get_backend() == "gloo":  # gloo moves host tensors
+            mine = self.buf.cpu()
+            g = torch.empty(world * mine.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(g, mine)
+            g = g.to(dev)
+        else:
+            g = torch.empty(world * self.buf.numel(), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(g, self.buf)
+        o_ids = torch.zeros((self.nq, limit), dtype=torch.int64, device=dev)
+        o_d = torch.zeros((self.nq, limit), dtype=torch.float32, device=dev)
+        o_s = torch.zeros((self.nq, limit), dtype=torch.int32, device=dev)
+        o_c = torch.zeros((self.nq,), dtype=torch.int32, device=dev)
+        check(lib().sdb_cluster_merge_gathered(world, self.nq, self.per, C.c_void_p(g.data_ptr()), limit,
+                                               C.c_void_p(o_ids.data_ptr()), C.c_void_p(o_d.data_ptr()),
+                                               C.c_void_p(o_s.data_ptr()), C.c_void_p(o_c.data_ptr()), dev.index or 0,
+                                               stream))
+        return o_ids, o_d, o_s, o_c
+
+
 def block_layout(nq, per_shard):
-    """(off_dists, off_counts, bytes) of one shard's result block, sdb_cluster_block_layout"""
-    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-    check(lib().sdb_cluster_block_layout(nq, per_shard, C.byref(a), C.byref(b), C.byref(c)))
-    return a.value, b.value, c.value
+    """(off_dists, off_counts, off_tag, bytes) of one shard's result block, sdb_cluster_block_layout"""
+    a, b, t, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    check(lib().sdb_cluster_block_layout(nq, per_shard, C.byref(a), C.byref(b), C.byref(t), C.byref(c)))
+    return a.value, b.value, t.value, c.value
 
 
 class Cluster:
@@ -185,24 +231,30 @@ class Cluster:
         o_c, p_c = _buf.empty_like_mem(mem, (nq,), "uint32", self.device)
         return (o_ids, o_d, o_s, o_c), (p_ids, p_d, p_s, p_c)
 
-    def allgather_merge(self, block, limit, host_out=False):
+    def allgather_merge(self, block, limit, host_out=False, ticket=0):
         """block: PackedTopK on this rank's GPU, written by work on the current stream.  Returns merged
         (ids, dists, shards, counts): device tensors valid after wait()/synchronize(), or numpy if host_out."""
         mem = 0 if host_out else MEM_DEVICE
         outs, ptrs = self._outs(block.nq, limit, mem)
-        check(lib().sdb_cluster_allgather_merge(self._h, block.nq, block.per, C.c_void_p(block.buf.data_ptr()), limit,
-                                                ptrs[0], ptrs[1], ptrs[2], ptrs[3], mem,
+        check(lib().sdb_cluster_allgather_merge(self._h, ticket, block.nq, block.per, C.c_void_p(block.buf.data_ptr()),
+                                                limit, ptrs[0], ptrs[1], ptrs[2], ptrs[3], mem,
                                                 _buf.current_stream(MEM_DEVICE)))
         return outs
 
-    def search_batch(self, ix, queries, limit, search_size):
+    def search_batch(self, ix, queries, limit, search_size, ticket=0):
         """ClusterNode.SearchPoints for this rank's shard: search -> all-gather -> merge.  numpy queries ->
-        numpy results (synchronous); torch CUDA queries -> device results, valid after wait()/synchronize()."""
+        numpy results (synchronous); torch CUDA queries -> device results, valid after wait()/synchronize()
+        (synchronize raises if the exchange failed its tag check)."""
         k, qp, mem, shape = _buf.as_f32(queries)
         outs, ptrs = self._outs(shape[0], limit, mem)
-        check(lib().sdb_cluster_search_batch(self._h, ix._h, shape[0], qp, limit, search_size, ptrs[0], ptrs[1],
+        check(lib().sdb_cluster_search_batch(self._h, ix._h, ticket, shape[0], qp, limit, search_size, ptrs[0], ptrs[1],
                                              ptrs[2], ptrs[3], mem, _buf.current_stream(mem)))
         return outs
+
+    def next_ticket(self):
+        t = C.c_uint64(0)
+        check(lib().sdb_cluster_next_ticket(self._h, C.byref(t)))
+        return t.value
 
     def wait(self):
         """the current torch stream waits (on the device) for every exchange enqueued so far"""
@@ -211,3 +263,43 @@ class Cluster:
     def synchronize(self):
         check(lib().sdb_cluster_synchronize(self._h))
 
+
+
+class Fanout:
+    """ClusterNode.SearchPoints for the shards of one process (cluster/actions.go:316-376): one request = one ticket,
+    handed to every rank's sdb_cluster_search_batch from a thread of its own (the calls are collective and, with
+    host memory, blocking).  The Python twin of integration/go/cluster/fanout_mi355x.go and of
+    semadb::cluster::GpuFanout (semadb_host.hpp); requests may be issued from many threads at once."""
+
+    def __init__(self, ranks, indexes):
+        assert len(ranks) == len(indexes)
+        self.ranks, self.indexes = ranks, indexes
+        self._mu = threading.Lock()
+        self._next = ranks[0].next_ticket()
+
+    def _ticket(self):
+        with self._mu:
+            t = self._next
+            self._next += 1
+            return t
+
+    def search_points(self, queries, limit, search_size):
+        """numpy queries [nq, dim] -> merged (ids, dists, shards, counts) as numpy; raises the first rank's error"""
+        ticket = self._ticket()
+        outs, errs = [None] * len(self.ranks), [None] * len(self.ranks)
+
+        def run(r):
+            try:
+                outs[r] = self.ranks[r].search_batch(self.indexes[r], queries, limit, search_size, ticket=ticket)
+            except SemaDBError as e:  # every rank sees the failure of any rank
+                errs[r] = e
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(len(self.ranks))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return outs[0]  # every rank holds the same merged answer

@@ -1234,23 +1234,53 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   // ---- from here on the call writes, into the writer's copy of the graph (index.h graph versions): searches
   // issued meanwhile keep walking the last committed version.  Rows beyond ix->n first.
   SDB_TRY(ix->begin_write());
-  SDB_HIP(hipMemsetAsync(ix->d_bstats, 0, bstats_bytes, stream));
-  SDB_HIP(hipMemsetAsync(big_count, 0, 8, stream));
+  uint64_t done = 0;
+  // Every exit below this line goes through one of two doors.  write_failed: nothing of this call has reached the
+  // graph or the host tables yet when done == 0 (rows past ix->n are invisible) -- the transaction this call opened
+  // for itself closes again and the index is as it was; with rounds already applied the rows they appended and the
+  // back-edges they wrote have no committed counterpart and no rollback, so the handle becomes unusable (index.h
+  // `broken`), never a half-open transaction that wedges the next writer.  round_failed: the round's kernels had
+  // started, which is the same as "applied".
+  auto round_failed = [&](int rc) {
+    ix->broken = true;
+    ix->tx_dirty = true;
+    return rc;
+  };
+  auto write_failed = [&](int rc) {
+    if (done > 0) return round_failed(rc);
+    if (!ix->tx_explicit && !ix->tx_dirty) ix->in_tx = false;
+    return rc;
+  };
+#define SDB_W_TRY(expr)                          \
+  do {                                           \
+    int _rc = (expr);                            \
+    if (_rc != SDB_OK) return write_failed(_rc); \
+  } while (0)
+#define SDB_W_HIP(expr)                                                                                         \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess)                                                                                       \
+      return write_failed(sdb::fail(SDB_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                                    __LINE__));                                                                 \
+  } while (0)
+  SDB_W_HIP(hipMemsetAsync(ix->d_bstats, 0, bstats_bytes, stream));
+  SDB_W_HIP(hipMemsetAsync(big_count, 0, 8, stream));
   const float *dvec = vectors;  // the vectors (original layout) on device; they double as the search queries
   if (staging) {
-    SDB_HIP(hipMemcpyAsync(staging, vectors, n * l.dim * sizeof(float), hipMemcpyHostToDevice, stream));
+    SDB_W_HIP(hipMemcpyAsync(staging, vectors, n * l.dim * sizeof(float), hipMemcpyHostToDevice, stream));
     dvec = staging;
   }
   // vecStore.Set for the whole batch (insert.go:17): rows are unreachable until they get in-edges
-  SDB_TRY(store_rows_public(ix, n0, (uint32_t)n, dvec, stream));
+  SDB_W_TRY(store_rows_public(ix, n0, (uint32_t)n, dvec, stream));
   // a fitted quantizer encodes on Set (product.go:161-169); from here on every distance of the insert is a
   // table distance: LUT for the search (DistanceFromFloat), centroid pairs for the prunes (DistanceFromPoint)
-  if (pq) SDB_TRY(pq_encode_device(pq, dvec, n, ix->d_codes + (size_t)n0 * pq->M, stream));
-  SDB_HIP(hipMemcpyAsync(ix->d_ids + n0, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+  if (pq) SDB_W_TRY(pq_encode_device(pq, dvec, n, ix->d_codes + (size_t)n0 * pq->M, stream));
+  SDB_W_HIP(hipMemcpyAsync(ix->d_ids + n0, new_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
   // host-side id bookkeeping of the points of one completed round: h_ids / id2slot / max_node_id move together
   // with ix->n, so that an error return never leaves ids that resolve to slots past the rows in use
   auto commit = [&](uint64_t from, uint64_t to) {
-    std::unique_lock<std::shared_mutex> wl(ix->view_mu);  // searches translate filter ids with these tables
+    std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // searches translate filter ids with these tables
+    ix->tx_dirty = true;
     bool dense = ix->dense_ids;
     for (uint64_t i = from; i < to; i++) {
       if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
@@ -1265,12 +1295,6 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ix->dense_ids = dense;
     ix->n = n0 + (uint32_t)to;
   };
-  // a round that fails after its kernels have started may have written back-edges that point at rows the
-  // host never committed: the graph is unusable from then on (index.h `broken`)
-  auto round_failed = [&](int rc) {
-    ix->broken = true;
-    return rc;
-  };
   auto check_flags = [&]() -> int {
     uint32_t fl = 0;
     SDB_HIP(hipMemcpyAsync(&fl, big_count + 1, 4, hipMemcpyDeviceToHost, stream));
@@ -1281,7 +1305,6 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     return SDB_OK;
   };
 
-  uint64_t done = 0;
   uint64_t n_rounds = 0;
   while (done < n) {
     const uint32_t cur = n0 + (uint32_t)done;  // rows in storage so far = slot of the round's first point
@@ -1306,16 +1329,16 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.wide_hash = ix->tune_wide_hash ? 1u : 0u, sa.hash16_probes = ix->tune_hash16_probes;
     sa.totals = reinterpret_cast<unsigned long long *>(ix->d_bstats);  // [0] n_dist, [1] n_edges
     if (dcache) {
-      SDB_HIP(hipMemsetAsync(dcache, 0xFF, ((size_t)rs << kDcacheBits) * sizeof(uint2), stream));  // no slot is ~0
+      SDB_W_HIP(hipMemsetAsync(dcache, 0xFF, ((size_t)rs << kDcacheBits) * sizeof(uint2), stream));  // no slot is ~0
       sa.dcache = dcache, sa.dcache_shift = 32 - kDcacheBits;
     }
     if (pq) {
-      SDB_TRY(pq_build_lut(pq, sa.queries, rs, lut, stream));
+      SDB_W_TRY(pq_build_lut(pq, sa.queries, rs, lut, stream));
       sa.pq_lut = lut, sa.pq_codes = ix->d_codes, sa.pq_M = pq->M, sa.pq_K = pq->K;
       sa.pq_lut_in_lds = (lut_row <= 64 * 1024) ? 1u : 0u;
     }
-    if (!search_uses_hash(sa, rs)) SDB_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
-    SDB_TRY(launch_greedy_search(sa, rs, stream));  // read-only on the graph: a failure here changes nothing
+    if (!search_uses_hash(sa, rs)) SDB_W_HIP(hipMemsetAsync(bitsets, 0, (size_t)rs * words * 4, stream));
+    SDB_W_TRY(launch_greedy_search(sa, rs, stream));  // read-only on the graph: a failure here adds nothing to what the rounds before it did
     // ---- robustPrune + back-edges
     BuildArgs ba{};
     ba.slab = ix->d_slab, ba.adj = ix->d_adj, ba.deg = ix->d_deg, ba.clean = ix->d_clean;
@@ -1346,14 +1369,16 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   }
   {
     const unsigned long long nr = n_rounds;
-    SDB_HIP(hipMemcpyAsync(ix->d_bstats + kStRounds, &nr, 8, hipMemcpyHostToDevice, stream));
+    SDB_W_HIP(hipMemcpyAsync(ix->d_bstats + kStRounds, &nr, 8, hipMemcpyHostToDevice, stream));
   }
   if (int rc = check_flags()) return round_failed(rc);
   if (!ix->tx_explicit) {  // the call is its own transaction: publish
     if (int rc = ix->commit(stream)) return round_failed(rc);
-    SDB_HIP(hipStreamSynchronize(stream));
+    SDB_W_HIP(hipStreamSynchronize(stream));
   }
   return SDB_OK;
+#undef SDB_W_TRY
+#undef SDB_W_HIP
 }
 
 #include "delete.inc"

@@ -155,7 +155,7 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
   // a read like a search: ids resolve against the committed state (index.h graph versions); the slab rows
   // themselves never change once written.  The lock is kept until the kernel is enqueued (reserve() swaps
   // the slab pointer under it).
-  std::shared_lock<std::shared_mutex> rl(ix->view_mu);
+  std::shared_lock<sdb::ViewMutex> rl(ix->view_mu);
   const uint32_t view_n = ix->view.n;
   for (size_t i = 0; i < slots.size(); i++) {
     int64_t s = ix->slot_of_committed(cand_ids[i], view_n);

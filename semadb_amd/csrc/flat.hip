@@ -618,7 +618,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const RowLayout &l = ix->lay;
   // the scan sees the last committed version like a graph search does (index.h graph versions); the shared lock
   // is kept until everything is enqueued
-  std::shared_lock<std::shared_mutex> rl(ix->view_mu);
+  std::shared_lock<sdb::ViewMutex> rl(ix->view_mu);
   const sdb_index::View vw = ix->view;
   const uint32_t n = vw.n;
   // ---- filtered: per-query candidate slots, ascending (filter.Contains(point.Id()), flat.go:100)
@@ -669,6 +669,15 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   const size_t o_cnt = carve(fast ? nq * 4 + 256 : 0), o_cand = carve(fast ? (size_t)nq * kCandCap * 8 : 0);
   const uint32_t qsw_floats = mfma ? (uint32_t)((nq + 15) / 16) * (l.nblk * 512 + (l.tail ? kTailImgFloats : 0)) : 0;
   const size_t o_qsw = carve((size_t)qsw_floats * 4);
+  // The workspace carries the event a commit waits for before it hands the copy this scan reads to the writer.  It
+  // stays this call's own until the stream has been synchronised (`fr` below is destroyed first): released earlier, a
+  // scan on another stream could take it and re-record the event, and the commit would wait for that scan only.
+  struct WsHold {
+    const sdb_index *ix;
+    Workspace *ws;
+    hipStream_t s;
+    ~WsHold() { ix->release_ws(ws, s, false); }
+  } hold{ix, ix->acquire_ws(stream, false), stream};
   char *buf = nullptr;
   SDB_HIP(hipMalloc(&buf, off));
   struct Free {
@@ -788,11 +797,10 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
                      d_oi, d_od, d_oc);
   SDB_HIP(hipGetLastError());
   {  // a commit must wait for this scan before it hands the copy it reads to the writer
-    Workspace *ws = ix->acquire_ws(stream, false);
+    Workspace *ws = hold.ws;
     if (!ws->launched) (void)hipEventCreateWithFlags(&ws->launched, hipEventDisableTiming);
     if (ws->launched && hipEventRecord(ws->launched, stream) == hipSuccess) ws->launched_valid = true;
     else (void)hipStreamSynchronize(stream);
-    ix->release_ws(ws, stream, false);
   }
   rl.unlock();
   if (mem == SDB_MEM_HOST) {
@@ -831,7 +839,7 @@ static int flat_tombstone(sdb_index *ix, std::vector<uint32_t> &slots) {
   if (e == hipSuccess) e = hipDeviceSynchronize();
   (void)hipFree(d_dead);
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "tombstone failed: %s", hipGetErrorString(e));
-  std::unique_lock<std::shared_mutex> wl(ix->view_mu);  // searches translate filter ids with these tables
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // searches translate filter ids with these tables
   if (ix->dense_ids) {  // the dense id -> slot shortcut does not survive holes
     ix->id2slot.clear();
     ix->id2slot.reserve((size_t)ix->n * 2);
@@ -867,7 +875,11 @@ extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_
   if (slots.empty()) return SDB_OK;
   DeviceGuard dg(ix->P.device);
   SDB_TRY(ix->begin_write());
-  SDB_TRY(flat_tombstone(ix, slots));
+  ix->tx_dirty = true;
+  if (int rc = flat_tombstone(ix, slots)) {  // device rows may be half-marked: no way back (index.h `broken`)
+    ix->broken = true;
+    return rc;
+  }
   if (!ix->tx_explicit) {
     SDB_TRY(ix->commit(nullptr));
     SDB_HIP(hipDeviceSynchronize());
@@ -922,8 +934,12 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   if (rc != SDB_OK) return rc;
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "id copy failed: %s", hipGetErrorString(e));
   SDB_TRY(ix->begin_write());  // appended rows become visible to searches at commit
-  SDB_TRY(flat_tombstone(ix, replaced));
-  std::unique_lock<std::shared_mutex> wl(ix->view_mu);
+  ix->tx_dirty = true;
+  if (int rc = flat_tombstone(ix, replaced)) {
+    ix->broken = true;
+    return rc;
+  }
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
   bool dense = ix->dense_ids;
   for (uint64_t i = 0; i < n; i++) {
     if (dense && !ix->h_ids.empty() && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {

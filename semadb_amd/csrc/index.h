@@ -3,6 +3,7 @@
 #pragma once
 #include <map>
 #include <shared_mutex>
+#include <thread>
 #include <unordered_map>
 
 #include "common.h"
@@ -37,6 +38,28 @@ struct Workspace {
 };
 
 struct PQState;  // pq.hip
+
+// The lock around an index's committed view.  Searches take it shared for the few microseconds between reading the
+// view and recording their event; commit / compact / reserve / attach_pq take it exclusively.  glibc's rwlock prefers
+// readers, and two always-busy batcher workers can keep a shared lock held back to back for as long as they like --
+// a writer would starve.  So a waiting writer raises a flag and new readers stand aside until it has had its turn.
+class ViewMutex {
+  std::shared_mutex m_;
+  std::atomic<int> writers_{0};
+
+ public:
+  void lock() {
+    writers_.fetch_add(1, std::memory_order_acq_rel);
+    m_.lock();
+    writers_.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  void unlock() { m_.unlock(); }
+  void lock_shared() {
+    while (writers_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    m_.lock_shared();
+  }
+  void unlock_shared() { m_.unlock_shared(); }
+};
 
 }  // namespace sdb
 
@@ -95,8 +118,9 @@ struct sdb_index {
   } view;
   // readers: shared from taking `view` until their kernels are enqueued and their event recorded; writers:
   // exclusive while they change the host-side id tables or publish a view
-  mutable std::shared_mutex view_mu;
+  mutable sdb::ViewMutex view_mu;
   bool in_tx = false, tx_explicit = false;
+  bool tx_dirty = false;  // the open transaction has changed the writer's copy or the host tables (sdb_index_abort_write)
   uint32_t tx_n0 = 0;  // rows at the start of the open transaction
   std::unordered_map<uint64_t, uint32_t> tx_deleted;  // ids the open transaction has removed -> their slots
   int begin_write();

@@ -321,7 +321,7 @@ int sdb_index::reserve(uint32_t rows) {
   }
   SDB_HIP(hipDeviceSynchronize());
   {
-    std::unique_lock<std::shared_mutex> wl(view_mu);  // searches pick their pointers up under this lock
+    std::unique_lock<sdb::ViewMutex> wl(view_mu);  // searches pick their pointers up under this lock
     for (void *p : {(void *)d_slab, (void *)d_adj, (void *)r_adj, (void *)d_deg, (void *)d_clean, (void *)d_ids,
                     (void *)r_ids, (void *)d_dirty, (void *)d_adjdist, (void *)d_dcount})
       if (p) (void)hipFree(p);
@@ -364,7 +364,7 @@ __global__ void k_count_version_diff(const uint32_t *a_adj, const uint32_t *b_ad
 }  // namespace sdb
 
 int sdb_index::begin_write() {
-  if (!in_tx) in_tx = true, tx_n0 = n;
+  if (!in_tx) in_tx = true, tx_n0 = n, tx_dirty = false;
   return SDB_OK;
 }
 
@@ -381,7 +381,7 @@ int sdb_index::commit(hipStream_t stream) {
   if (!in_tx) return SDB_OK;
   const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
   {
-    std::unique_lock<std::shared_mutex> wl(view_mu);
+    std::unique_lock<sdb::ViewMutex> wl(view_mu);
     // every search that took the old view has enqueued its kernels and recorded its event by now (it held the
     // shared lock until then): the writer's stream waits for them before it touches the copy they walk
     {
@@ -396,7 +396,7 @@ int sdb_index::commit(hipStream_t stream) {
     view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
     view.start_ext_n = (uint32_t)h_start_ext.size();
     tx_deleted.clear();
-    in_tx = false, tx_explicit = false;
+    in_tx = false, tx_explicit = false, tx_dirty = false;
   }
   // the writer's copy is now the one the last version's searches walked: bring it up to date
   if (n) {
@@ -419,7 +419,7 @@ int sdb_index::commit(hipStream_t stream) {
 
 int sdb_index::publish_full() {
   SDB_HIP(hipDeviceSynchronize());
-  std::unique_lock<std::shared_mutex> wl(view_mu);
+  std::unique_lock<sdb::ViewMutex> wl(view_mu);
   if (n) {
     SDB_HIP(hipMemcpy(r_adj, d_adj, (size_t)n * kAdjStride * 4, hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(r_ids, d_ids, (size_t)n * 8, hipMemcpyDeviceToDevice));
@@ -438,7 +438,7 @@ int sdb_index::publish_full() {
   view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
   view.start_ext_n = (uint32_t)h_start_ext.size();
   tx_deleted.clear();
-  in_tx = false, tx_explicit = false;
+  in_tx = false, tx_explicit = false, tx_dirty = false;
   return SDB_OK;
 }
 
@@ -735,6 +735,24 @@ int sdb_index_commit(sdb_index *ix, void *stream_) {
   return SDB_OK;
 }
 
+// The way out of a transaction that will not be committed (a host that found a bad point after begin_write, an
+// insert call that failed).  Nothing changed yet: the transaction simply closes and the index is what it was at
+// begin_write.  Something changed: there is no rollback (the header says so), the handle is marked unusable like
+// after any failed write and the host reloads from the bucket -- what the reference's cache manager does with a
+// shard after an error inside a transaction (shard/cache/manager.go:231-240).
+int sdb_index_abort_write(sdb_index *ix) {
+  if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (!ix->in_tx) return SDB_OK;
+  if (ix->tx_dirty || ix->broken) {
+    ix->broken = true;
+    return fail(SDB_ERR_STATE, "the aborted transaction had already changed the graph: the index is unusable, reload it from the bucket");
+  }
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+  ix->tx_deleted.clear();
+  ix->in_tx = false, ix->tx_explicit = false;
+  return SDB_OK;
+}
+
 // test support: the number of rows on which the two graph copies differ (0 whenever no transaction is open)
 int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows) {
   if (!ix || !rows) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -798,7 +816,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   const RowLayout &l = ix->lay;
   // the graph version this batch walks: the last committed one, whatever a writer is doing meanwhile.  The shared
   // lock is held until the kernels are enqueued and their event recorded (sdb_index::commit counts on that).
-  std::shared_lock<std::shared_mutex> rl(ix->view_mu);
+  std::shared_lock<sdb::ViewMutex> rl(ix->view_mu);
   const sdb_index::View vw = ix->view;
   const uint32_t words = ((vw.n + 31) / 32 + 31) & ~31u;  // per-query bitset, 128-byte multiple
   const size_t bs_bytes = (size_t)nq * words * sizeof(uint32_t);
@@ -983,28 +1001,29 @@ int sdb_index_get_vectors(const sdb_index *ix, uint64_t n, const uint64_t *ids, 
   DeviceGuard dg(ix->P.device);
   const RowLayout &l = ix->lay;
   std::vector<uint32_t> slots(n);
-  {
-    std::shared_lock<std::shared_mutex> rl(ix->view_mu);  // the committed id tables
-    for (uint64_t i = 0; i < n; i++) {
-      const int64_t s = ix->slot_of_committed(ids[i], ix->view.n);
-      slots[i] = s < 0 ? kNoSlot : (uint32_t)s;
-      if (found) found[i] = s < 0 ? 0 : 1;
+  struct Bufs {
+    uint32_t *slots = nullptr;
+    float *out = nullptr;
+    ~Bufs() {
+      if (slots) (void)hipFree(slots);
+      if (out) (void)hipFree(out);
     }
+  } b;
+  SDB_HIP(hipMalloc(&b.slots, n * 4));
+  SDB_HIP(hipMalloc(&b.out, n * l.dim * 4));
+  // the shared lock is held until the rows are on the host: compact and reserve replace the slab (and renumber the
+  // rows) under the exclusive lock, and a slot resolved before that must not be read after it
+  std::shared_lock<sdb::ViewMutex> rl(ix->view_mu);
+  for (uint64_t i = 0; i < n; i++) {
+    const int64_t s = ix->slot_of_committed(ids[i], ix->view.n);
+    slots[i] = s < 0 ? kNoSlot : (uint32_t)s;
+    if (found) found[i] = s < 0 ? 0 : 1;
   }
-  uint32_t *d_slots = nullptr;
-  float *d_out = nullptr;
-  SDB_HIP(hipMalloc(&d_slots, n * 4));
-  hipError_t e = hipMalloc(&d_out, n * l.dim * 4);
-  if (e == hipSuccess) e = hipMemcpy(d_slots, slots.data(), n * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {  // slab rows are immutable once written: no version to pick
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(128), 0, nullptr, ix->d_slab, d_slots, d_out, (uint32_t)n,
-                       l.dim, l.nblk, l.ng, l.ld);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpy(out, d_out, n * l.dim * 4, hipMemcpyDeviceToHost);
-  (void)hipFree(d_slots);
-  if (d_out) (void)hipFree(d_out);
-  if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "get_vectors failed: %s", hipGetErrorString(e));
+  SDB_HIP(hipMemcpy(b.slots, slots.data(), n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(128), 0, nullptr, ix->d_slab, b.slots, b.out, (uint32_t)n, l.dim,
+                     l.nblk, l.ng, l.ld);
+  SDB_HIP(hipGetLastError());
+  SDB_HIP(hipMemcpy(out, b.out, n * l.dim * 4, hipMemcpyDeviceToHost));
   return SDB_OK;
 }
 
@@ -1012,6 +1031,7 @@ int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids,
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
   if (!ids || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+  std::shared_lock<sdb::ViewMutex> rl(ix->view_mu);  // a writer rehashes the id tables under the exclusive lock
   for (uint64_t i = 0; i < n; i++) out[i] = ix->slot_of(ids[i]) >= 0 ? 1 : 0;
   return SDB_OK;
 }
@@ -1095,7 +1115,7 @@ int sdb_index_compact(sdb_index *ix) {
   if (ix->in_tx) return fail(SDB_ERR_STATE, "a write transaction is open");
   if (ix->n_dead == 0) return SDB_OK;
   DeviceGuard dg(ix->P.device);
-  std::unique_lock<std::shared_mutex> wl(ix->view_mu);  // searches wait: every buffer they read is replaced
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // searches wait: every buffer they read is replaced
   SDB_HIP(hipDeviceSynchronize());
   const uint32_t n = ix->n, cap = ix->cap, ld = ix->lay.ld;
   const uint32_t M = ix->pq ? ix->pq->M : 0;
@@ -1294,27 +1314,40 @@ extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream
     const int want = ix->P.metric == SDB_METRIC_COSINE ? SDB_METRIC_EUCLIDEAN : (int)ix->P.metric;
     if (pq->metric != want) return fail(SDB_ERR_INVALID, "quantizer metric does not match the index metric");
   }
+  if (ix->in_tx) return fail(SDB_ERR_STATE, "a write transaction is open");
   DeviceGuard dg(ix->P.device);
   hipStream_t stream = as_stream(stream_);
-  if (ix->d_codes) (void)hipFree(ix->d_codes);
-  ix->d_codes = nullptr;
-  SDB_HIP(hipMalloc(&ix->d_codes, (size_t)ix->cap * pq->M));
+  // The hosts run Fit after a commit while their batcher keeps searching.  The new code rows are encoded into a
+  // buffer of their own while searches go on with what they have (full precision, or the previous quantizer's
+  // codes); then (quantizer, codes) change hands together under the exclusive lock, once the walks that were
+  // launched with the old pair have drained -- a search sees either pair whole, never the new tables over
+  // half-written codes, never freed rows.
+  uint8_t *ncodes = nullptr;
+  SDB_HIP(hipMalloc(&ncodes, (size_t)ix->cap * pq->M));
   const uint32_t chunk = 1u << 18;
   float *tmp = nullptr;
-  SDB_HIP(hipMalloc(&tmp, (size_t)std::min<uint32_t>(chunk, std::max<uint32_t>(ix->n, 1)) * ix->lay.dim * sizeof(float)));
+  if (hipMalloc(&tmp, (size_t)std::min<uint32_t>(chunk, std::max<uint32_t>(ix->n, 1)) * ix->lay.dim * sizeof(float)) != hipSuccess) {
+    (void)hipFree(ncodes);
+    return fail(SDB_ERR_DEVICE, "out of device memory for the encode staging");
+  }
   int rc = SDB_OK;
   for (uint32_t first = 0; first < ix->n && rc == SDB_OK; first += chunk) {
     const uint32_t m = std::min<uint32_t>(chunk, ix->n - first);
     rc = unpermute_rows_public(ix, first, m, tmp, stream);
-    if (rc == SDB_OK) rc = pq_encode_device(pq, tmp, m, ix->d_codes + (size_t)first * pq->M, stream);
+    if (rc == SDB_OK) rc = pq_encode_device(pq, tmp, m, ncodes + (size_t)first * pq->M, stream);
   }
   (void)hipStreamSynchronize(stream);
   (void)hipFree(tmp);
-  if (rc == SDB_OK) {
-    ix->pq = pq;
-    rc = forget_prune_state(ix);
+  if (rc != SDB_OK) {
+    (void)hipFree(ncodes);
+    return rc;
   }
-  return rc;
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+  (void)hipDeviceSynchronize();  // walks launched with the old (quantizer, codes) pair
+  if (ix->d_codes) (void)hipFree(ix->d_codes);
+  ix->d_codes = ncodes;
+  ix->pq = pq;
+  return forget_prune_state(ix);
 }
 
 // Centroid ids that do NOT come from encode(): the k-means labels productQuantizer.Fit leaves on its
@@ -1326,11 +1359,15 @@ extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *id
   if (!ids || !codes) return fail(SDB_ERR_INVALID, "NULL argument");
   const uint32_t M = ix->pq->M;
   DeviceGuard dg(ix->P.device);
+  for (uint64_t i = 0; i < n; i++)  // nothing is written unless every id resolves
+    if (ix->slot_of(ids[i]) < 0) return fail(SDB_ERR_NOT_FOUND, "point %llu not found", (unsigned long long)ids[i]);
+  // code rows are rewritten in place: searches stand aside (exclusive lock) and the walks in flight drain first
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+  SDB_HIP(hipDeviceSynchronize());
   // group runs of consecutive slots into one copy each (ids in storage order give one run)
   uint64_t i = 0;
   while (i < n) {
     const int64_t s0 = ix->slot_of(ids[i]);
-    if (s0 < 0) return fail(SDB_ERR_NOT_FOUND, "point %llu not found", (unsigned long long)ids[i]);
     uint64_t j = i + 1;
     while (j < n && ix->slot_of(ids[j]) == s0 + (int64_t)(j - i)) j++;
     SDB_HIP(hipMemcpy(ix->d_codes + (size_t)s0 * M, codes + i * M, (j - i) * M, hipMemcpyHostToDevice));

@@ -3,10 +3,55 @@
 // In the 8-GPU layout every GPU holds one shard and answers every query; the per-shard top-k
 // lists are all-gathered over xGMI (RCCL, driven by the host process) and merged here.
 #include "common.h"
+#include "exchange.h"
 
 namespace sdb {
 
 constexpr int kMergeMaxItems = 2048;  // n_shards * per_shard
+
+// The tags of all gathered blocks against rank 0's (semadb_amd.h "Collective calls, order and failure").  Every
+// workgroup of the merge runs it -- n_shards x 64 bytes out of L2 -- so that a failed check yields no answer for ANY
+// query; workgroup 0 also leaves the verdict where the host reads it (pinned host memory).
+__device__ __forceinline__ bool tags_agree(uint32_t n_shards, const char *tags_b, size_t tag_stride, ExchangeVerdict *verdict,
+                                           bool report) {
+  __shared__ uint32_t s_bad_rank, s_fields, s_status;
+  const int t = threadIdx.x;
+  if (t == 0) s_bad_rank = 0xFFFFFFFFu, s_fields = 0, s_status = 0;
+  __syncthreads();
+  const sdb_block_tag *t0 = reinterpret_cast<const sdb_block_tag *>(tags_b);
+  if ((uint32_t)t < n_shards) {
+    const sdb_block_tag *tg = reinterpret_cast<const sdb_block_tag *>(tags_b + (size_t)t * tag_stride);
+    uint32_t f = 0;
+    if (tg->magic != SDB_BLOCK_MAGIC) f |= kTagMagic;
+    if (tg->seq != t0->seq) f |= kTagSeq;
+    if (tg->ticket != t0->ticket) f |= kTagTicket;
+    if (tg->nq != t0->nq) f |= kTagNq;
+    if (tg->per_shard != t0->per_shard) f |= kTagPerShard;
+    if (tg->limit != t0->limit) f |= kTagLimit;
+    if (tg->query_hash != t0->query_hash) f |= kTagQueryHash;
+    if (tg->rank != (uint32_t)t) f |= kTagRank;
+    const uint32_t st = tg->status;
+    if (f || st) {
+      atomicMin(&s_bad_rank, (uint32_t)t);
+      atomicOr(&s_fields, f);
+    }
+    if (st) atomicMax(&s_status, st | ((uint32_t)t << 8));  // any failed shard (the highest-numbered one is named)
+  }
+  __syncthreads();
+  const bool ok = s_bad_rank == 0xFFFFFFFFu;
+  if (report && t == 0 && verdict) {
+    verdict->bad_rank = ok ? 0 : s_bad_rank;
+    verdict->fields = s_fields;
+    verdict->status = s_status & 0xFFu;
+    verdict->status_rank = s_status >> 8;
+    verdict->seq = t0->seq;
+    verdict->ticket = t0->ticket;
+    __threadfence_system();
+    verdict->state = ok ? kVerdictOk : (s_status ? kVerdictShardFailed : kVerdictMismatch);
+    __threadfence_system();
+  }
+  return ok;
+}
 
 // one 64-thread block per query; rank-by-counting under the total order (dist, shard, id, position) -- the
 // position only matters for a caller that hands in the same (dist, shard, id) twice: every item still gets a
@@ -21,13 +66,18 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
                                                    const char *__restrict__ counts_b, size_t counts_stride,
                                                    uint32_t limit, uint64_t *__restrict__ out_ids,
                                                    float *__restrict__ out_dists, uint32_t *__restrict__ out_shards,
-                                                   uint32_t *__restrict__ out_counts) {
+                                                   uint32_t *__restrict__ out_counts, const char *__restrict__ tags_b,
+                                                   size_t tag_stride, ExchangeVerdict *verdict) {
   __shared__ float s_d[kMergeMaxItems];
   __shared__ uint64_t s_id[kMergeMaxItems];
   __shared__ uint16_t s_sh[kMergeMaxItems];
   __shared__ uint32_t s_off[65];
   const uint64_t q = blockIdx.x;
   const int t = threadIdx.x;
+  if (tags_b && !tags_agree(n_shards, tags_b, tag_stride, verdict, q == 0)) {
+    if (t == 0) out_counts[q] = 0;  // no answer rather than the merge of two different requests
+    return;
+  }
   if (t == 0) {
     uint32_t o = 0;
     for (uint32_t s = 0; s < n_shards; s++) {
@@ -74,11 +124,11 @@ __global__ __launch_bounds__(64) void k_topk_merge(uint32_t n_shards, uint64_t n
 int launch_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const void *ids, size_t ids_stride,
                       const void *dists, size_t dists_stride, const void *counts, size_t counts_stride, uint32_t limit,
                       uint64_t *out_ids, float *out_dists, uint32_t *out_shards, uint32_t *out_counts,
-                      hipStream_t stream) {
+                      hipStream_t stream, const void *tags, size_t tag_stride, ExchangeVerdict *verdict) {
   hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(64), 0, stream, n_shards, nq, per_shard,
                      static_cast<const char *>(ids), ids_stride, static_cast<const char *>(dists), dists_stride,
                      static_cast<const char *>(counts), counts_stride, limit, out_ids, out_dists, out_shards,
-                     out_counts);
+                     out_counts, static_cast<const char *>(tags), tag_stride, verdict);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }

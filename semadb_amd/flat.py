@@ -86,13 +86,27 @@ class IndexFlat:
                 ops[-1][2].append(np.asarray(ch.Vector, dtype=np.float32))
         if not ops:
             return
-        check(lib().sdb_index_begin_write(self._h))
+        # everything the caller can get wrong is checked before the transaction opens (ragged vectors raise here)
+        batches = []
         for kind, ids, vecs, _ in ops:
             if kind == "set":
-                self.set_vectors(np.array(ids, dtype=np.uint64), np.stack(vecs))
+                m = np.stack(vecs)
+                if m.ndim != 2 or m.shape[1] != self.parameters.VectorSize:
+                    raise SemaDBError(1, "failed to insert/update/delete: vector length mismatch")
+                batches.append((kind, np.array(ids, dtype=np.uint64), m))
             else:
-                self.remove_vectors(ids)
-        check(lib().sdb_index_commit(self._h, None))
+                batches.append((kind, ids, None))
+        check(lib().sdb_index_begin_write(self._h))
+        try:
+            for kind, ids, m in batches:
+                if kind == "set":
+                    self.set_vectors(ids, m)
+                else:
+                    self.remove_vectors(ids)
+            check(lib().sdb_index_commit(self._h, None))
+        except Exception:
+            self.abort_write()  # never leave the transaction open: the next write would be refused
+            raise
 
     def set_vectors(self, ids, vectors):
         k, vp, mem, shape = _buf.as_f32(vectors)
@@ -109,6 +123,11 @@ class IndexFlat:
 
     def commit(self):
         check(lib().sdb_index_commit(self._h, None))
+
+    def abort_write(self):
+        """leave an open transaction without committing; True if the index is unchanged, False if it had already
+        been changed and is now unusable (reload it from the bucket)"""
+        return lib().sdb_index_abort_write(self._h) == 0
 
     def row_usage(self):
         """(storage rows in use, of which tombstones)"""

@@ -214,20 +214,29 @@ class IndexVamana:
                 known.add(ch.Id)
         if not (ins_ids or del_ids or upd_ids):
             return
+        # what the caller can get wrong is checked before the transaction opens (models/index.go:182-184)
+        for v in ins_vecs + upd_vecs:
+            if v.ndim != 1 or v.shape[0] != self.parameters.VectorSize:
+                raise SemaDBError(1, "vector length mismatch: expected %d" % self.parameters.VectorSize)
+        ins_mat = np.stack(ins_vecs) if ins_ids else None
         self.begin_write()  # one transaction, like the shard's (searches see it whole or not at all)
-        if ins_ids:
-            self.insert_batch(np.array(ins_ids, dtype=np.uint64), np.stack(ins_vecs), round_size)
-            if _between:
-                _between("inserts")
-        if del_ids or upd_ids:
-            self.delete_batch(np.array(del_ids + upd_ids, dtype=np.uint64))  # removeInboundEdges :223-233
-            if _between:
-                _between("deletes")
-        for i, v in zip(upd_ids, upd_vecs):  # :247-251 re-inserted sequentially
-            self.insert_batch(np.array([i], dtype=np.uint64), v.reshape(1, -1), 1)
-        if _between and upd_ids:
-            _between("updates")
-        self.commit()
+        try:
+            if ins_ids:
+                self.insert_batch(np.array(ins_ids, dtype=np.uint64), ins_mat, round_size)
+                if _between:
+                    _between("inserts")
+            if del_ids or upd_ids:
+                self.delete_batch(np.array(del_ids + upd_ids, dtype=np.uint64))  # removeInboundEdges :223-233
+                if _between:
+                    _between("deletes")
+            for i, v in zip(upd_ids, upd_vecs):  # :247-251 re-inserted sequentially
+                self.insert_batch(np.array([i], dtype=np.uint64), v.reshape(1, -1), 1)
+            if _between and upd_ids:
+                _between("updates")
+            self.commit()
+        except Exception:
+            self.abort_write()  # never leave the transaction open: the next write would be refused
+            raise
         self.Fit()  # vamana.go:257-260
 
     def Fit(self):
@@ -264,6 +273,12 @@ class IndexVamana:
 
     def commit(self):
         check(lib().sdb_index_commit(self._h, None))
+
+    def abort_write(self):
+        """leave an open transaction without committing (the error path of InsertUpdateDelete); True if the index is
+        what it was at begin_write, False if the transaction had already changed it -- the handle is then unusable
+        and is rebuilt from the bucket, as the reference scraps a shard's cache (manager.go:231-240)"""
+        return lib().sdb_index_abort_write(self._h) == 0
 
     def version_diff(self):
         """test support: rows on which the committed and the writer's copy differ"""

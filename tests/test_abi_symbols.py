@@ -48,7 +48,7 @@ def test_python_signature_table_matches_header():
 def test_abi_version_and_error_channel():
     from semadb_amd import _lib
     L = _lib.lib()
-    assert L.sdb_abi_version() == 1
+    assert L.sdb_abi_version() == 2
     out = C.c_uint32(0)
     assert L.sdb_shard_limit(10, 8, 75, C.byref(out)) == 0 and out.value == 10  # actions.go:291-299
     assert L.sdb_shard_limit(10, 0, 75, C.byref(out)) != 0

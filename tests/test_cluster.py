@@ -179,3 +179,69 @@ def test_bench_two_ranks_over_gloo(mode, tmp_path):
     assert abs(j["value"] - 1024 * j["steps"] / (j["ms_per_step"] * j["steps"] * 1e-3)) / j["value"] < 1e-3
     if mode == "shards":
         assert j["config"]["per_shard_walk_qps"] == pytest.approx(2 * j["value"], rel=1e-3)
+
+
+def _gloo_exchange_worker(rank, world, port, q):
+    """two processes share the GPU; gloo carries the blocks, the library stamps and checks the tags"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError
+    torch.cuda.set_device(0)
+    nq, per, limit, dim = 16, 10, 10, 24
+    ids, d, c = _shard_results(rank, nq, per)
+    blk = cluster.PackedTopK(nq, per, "cuda:0")
+    blk.ids.copy_(torch.from_numpy(ids)); blk.dists.copy_(torch.from_numpy(d)); blk.counts.copy_(torch.from_numpy(c))
+    same = torch.arange(nq * dim, dtype=torch.float32, device="cuda:0").view(nq, dim)
+    out = {"rank": rank}
+    m = blk.exchange(limit, seq=0, ticket=1, queries=same)  # every rank searched the same queries: merged
+    torch.cuda.synchronize()
+    out["ok_ids"], out["ok_counts"] = m[0].cpu().numpy(), m[3].cpu().numpy()
+    mine = same + (1.0 if rank == 1 else 0.0)  # rank 1 was handed another request's queries
+    try:
+        blk.exchange(limit, seq=1, ticket=2, queries=mine)
+        out["mismatch"] = None
+    except SemaDBError as e:
+        out["mismatch"] = (e.code, str(e))
+    try:  # a shard that failed its search says so in its tag
+        blk.exchange(limit, seq=2, ticket=3, queries=same, status=3 if rank == 0 else 0)
+        out["failed"] = None
+    except SemaDBError as e:
+        out["failed"] = (e.code, str(e))
+    try:  # out of step by one request
+        blk.exchange(limit, seq=3 + rank, ticket=4 + rank, queries=same)
+        out["seq"] = None
+    except SemaDBError as e:
+        out["seq"] = (e.code, str(e))
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_tag_check_fires_across_two_gloo_ranks(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, nq, per, limit = 2, 16, 10, 10
+    procs = [ctx.Process(target=_gloo_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [_shard_results(r, nq, per) for r in range(world)]
+    g_ids = np.stack([e[0] for e in expect]).astype(np.uint64); g_d = np.stack([e[1] for e in expect]); g_c = np.stack([e[2] for e in expect])
+    for o in got:
+        for qi in range(nq):
+            w_ids, w_d, w_s = oracle.cluster_merge(g_ids[:, qi, :], g_d[:, qi, :], g_c[:, qi], limit)
+            assert int(o["ok_counts"][qi]) == len(w_ids)
+            assert np.array_equal(o["ok_ids"][qi, :len(w_ids)].view(np.uint64), w_ids)
+        assert o["mismatch"] is not None and o["mismatch"][0] == 3 and "query hash" in o["mismatch"][1]
+        assert o["failed"] is not None and o["failed"][0] == 3 and "shard 0" in o["failed"][1]
+        assert o["seq"] is not None and o["seq"][0] == 3 and "sequence number" in o["seq"][1] and "ticket" in o["seq"][1]

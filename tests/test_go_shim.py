@@ -55,6 +55,81 @@ def header_functions():
     return out
 
 
+def header_param_types():
+    """name -> list of parameter kinds: ("ptr", pointee C type) or ("val", C type)"""
+    text = _strip_c_comments(open(HEADER).read())
+    out = {}
+    for m in re.finditer(r"\b(sdb_[a-z0-9_]+)\s*\(", text):
+        end = _balanced(text, m.end() - 1)
+        params = text[m.end():end - 1].strip()
+        kinds = []
+        if params not in ("", "void"):
+            for p in _split_top_level(params):
+                p = re.sub(r"\bconst\b", "", p).strip()
+                mm = re.match(r"^(.*?)(\**)\s*([A-Za-z_][A-Za-z0-9_]*)?(\[[^\]]*\])?$", p)
+                base, stars = mm.group(1).strip(), mm.group(2)
+                if p.endswith("]") or stars:
+                    kinds.append(("ptr", base if len(stars) <= 1 and not (stars and p.endswith("]")) else base + "*"))
+                else:
+                    kinds.append(("val", base))
+        out[m.group(1)] = kinds
+    return out
+
+
+def _arg_kind(expr):
+    """what a Go argument expression visibly is: ("ptr", pointee or None), ("val", C type or None) or None (an
+    identifier whose type this test cannot see)"""
+    e = expr.strip()
+    if e == "nil":
+        return ("ptr", None)
+    m = re.match(r"^\(\*C\.([A-Za-z0-9_]+)\)\(", e)
+    if m:
+        return ("ptr", m.group(1))
+    m = re.match(r"^\(\*\*C\.([A-Za-z0-9_]+)\)\(", e)
+    if m:
+        return ("ptr", m.group(1) + "*")
+    if e.startswith("unsafe.Pointer("):
+        return ("ptr", "void")
+    if e.startswith("&"):
+        return ("ptr", None)
+    m = re.match(r"^C\.([a-z][A-Za-z0-9_]*)\(", e)
+    if m:
+        return ("val", m.group(1))
+    if re.match(r"^C\.SDB_[A-Z0-9_]+$", e) or re.match(r"^-?\d+$", e):
+        return ("val", None)
+    return None
+
+
+def test_every_c_call_passes_arguments_of_the_declared_kind():
+    """pointer where the header wants a pointer (and to the same C type when the cast names one), C.<type>(...) of the
+    declared width where it wants a scalar -- the mistakes cgo would refuse to compile"""
+    decl = header_param_types()
+    widths = {"int": "int", "uint32_t": "uint32_t", "uint64_t": "uint64_t", "float": "float", "size_t": "size_t",
+              "int32_t": "int32_t", "uint8_t": "uint8_t", "int64_t": "int64_t"}
+    checked = 0
+    for path, text in go_sources().items():
+        code = _go_code(text)
+        for m in re.finditer(r"\bC\.(sdb_[a-z0-9_]+)\s*\(", code):
+            name = m.group(1)
+            end = _balanced(code, m.end() - 1)
+            inner = code[m.end():end - 1].strip()
+            args = [] if inner == "" else _split_top_level(inner)
+            for i, (arg, (kind, ctype)) in enumerate(zip(args, decl[name])):
+                got = _arg_kind(arg)
+                where = "%s: argument %d of C.%s (%s)" % (os.path.basename(path), i + 1, name, arg.strip())
+                if got is None:
+                    continue
+                assert got[0] == kind, "%s is a %s, the header wants a %s" % (where, got[0], kind)
+                if got[1] is None or ctype == "void":
+                    continue
+                if kind == "ptr" and got[1] != "void":
+                    assert got[1] == ctype, "%s points at %s, the header says %s" % (where, got[1], ctype)
+                if kind == "val":
+                    assert widths.get(got[1], got[1]) == ctype, "%s is a %s, the header says %s" % (where, got[1], ctype)
+                checked += 1
+    assert checked >= 60
+
+
 def header_constants():
     text = open(HEADER).read()
     names = set(re.findall(r"#define\s+(SDB_[A-Z0-9_]+)", text))
@@ -130,11 +205,18 @@ def test_helpers_are_defined_and_surface_is_complete():
                 r"func \(v \*IndexVamana\) SizeInMemory\(\) int64",
                 r"func \(v \*IndexVamana\) EdgeScan\(deleteSet map\[uint64\]struct\{\}\) \(toPrune, toSave \[\]uint64, err error\)"]:
         assert re.search(sig, vam), "missing from the vamana package: %s" % sig
+    # the distance package keeps the AVX2 assembly for pair-wise calls (distance_amd64.go:19-27): no override of the
+    # package-level function variables with a kernel launch per pair, only a batched entry point
     dist = "\n".join(by_pkg["distance"])
-    assert "dotProductImpl =" in dist and "euclideanDistance =" in dist and "func init()" in dist
+    assert "dotProductImpl =" not in dist and "euclideanDistance =" not in dist
+    assert re.search(r"func BatchDistance\(name string, dim int, queries, candidates \[\]float32, device int\) \(\[\]float32, error\)", dist)
+    assert "C.sdb_distance_batch" in dist
     clu = "\n".join(by_pkg["cluster"])
-    for fn in ["sdb_cluster_create_local", "sdb_cluster_search_batch", "sdb_cluster_destroy", "sdb_shard_limit"]:
+    for fn in ["sdb_cluster_create_local", "sdb_cluster_search_batch", "sdb_cluster_destroy", "sdb_shard_limit",
+               "sdb_cluster_next_ticket"]:
         assert "C." + fn in clu
+    # one ticket per request, drawn under a lock, handed to every rank's call
+    assert re.search(r"ticket := f\.nextTicket\(\)", clu) and re.search(r"C\.sdb_cluster_search_batch\(f\.ranks\[r\], f\.indexes\[r\], C\.uint64_t\(ticket\)", clu)
 
 
 def test_imports_are_the_reference_modules():

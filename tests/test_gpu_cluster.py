@@ -1,6 +1,9 @@
-"""The RCCL exchange behind the C ABI (csrc/cluster.hip: sdb_cluster_*), driven with a single rank -- all a 1-GPU
-box can hold; RCCL refuses two ranks on one device -- plus the CPU-side checks of its layout and argument
-handling.  The N > 1 logic (shard-major gather, merge rule) is covered under gloo in tests/test_cluster.py."""
+"""The shard exchange behind the C ABI (csrc/cluster.hip: sdb_cluster_*).  RCCL is driven with a single rank -- all a
+1-GPU box can hold; RCCL refuses two ranks on one device.  The whole N > 1 protocol -- tickets, tags, a failing shard,
+several host batches in flight per rank, the merge over several shards -- runs on one GPU over the library's
+shared-device transport (sdb_cluster_create_local with the same device for every rank), which differs from the RCCL
+path in the gather call alone.  The torch.distributed form of the exchange is covered in tests/test_cluster.py."""
+import threading
 import ctypes as C
 
 import numpy as np
@@ -9,13 +12,13 @@ import pytest
 
 def test_block_layout_is_what_the_header_says():
     from semadb_amd import cluster
-    off_d, off_c, total = cluster.block_layout(1024, 10)
+    off_d, off_c, off_t, total = cluster.block_layout(1024, 10)
     assert off_d == 1024 * 10 * 8 and off_c == off_d + 1024 * 10 * 4
-    assert total >= off_c + 1024 * 4 and total % 16 == 0
-    # odd sizes still put the next shard's uint64 ids on an 8-byte boundary
+    assert off_t >= off_c + 1024 * 4 and off_t % 16 == 0 and total == off_t + 64
+    # odd sizes still put the next shard's uint64 ids on an 8-byte boundary, and the tag on a 16-byte one
     for nq, per in [(1, 1), (3, 7), (5, 11), (1023, 13)]:
-        a, b, t = cluster.block_layout(nq, per)
-        assert a == nq * per * 8 and b == a + nq * per * 4 and t % 16 == 0 and t >= b + nq * 4
+        a, b, tg, t = cluster.block_layout(nq, per)
+        assert a == nq * per * 8 and b == a + nq * per * 4 and tg % 16 == 0 and tg >= b + nq * 4 and t == tg + 64
 
 
 def test_cluster_calls_fail_loudly_without_a_gpu():
@@ -144,3 +147,249 @@ def test_host_batcher_answers_equal_direct_calls():
     want_ids, _, want_c, _ = ix.search_batch(q, k, 50)
     assert np.array_equal(first_c, want_c) and np.array_equal(first_ids, want_ids)
     ix.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 on one GPU: the shared-device transport
+# ---------------------------------------------------------------------------------------------------------------
+def _shards(rng, world, n=1500, d=48, nq=64):
+    from semadb_amd import vamana
+    from tests.helpers import start_vector, unit_rows
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    ixs, bases = [], []
+    for s in range(world):
+        x = rng.standard_normal((n, 8)).astype(np.float32) @ lat + 0.1 * rng.standard_normal((n, d)).astype(np.float32)
+        base = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+        ix = vamana.NewIndexVamana("sh%d" % s, vamana.IndexVectorVamanaParameters(d, "cosine", 50, 32, 1.2), strict=False)
+        ix.set_start(start_vector(rng, d))
+        ix.insert_batch(None, base)
+        ixs.append(ix)
+        bases.append(base)
+    qs = [unit_rows(rng, nq, d) for _ in range(6)]
+    return ixs, bases, qs
+
+
+def _expected(oracle, ixs, q, limit, L):
+    """the reference's rule on the shards' own answers: per-shard limit (actions.go:291-299), then the merge (:357-376)"""
+    from semadb_amd import cluster
+    per = cluster.shard_limit(limit, len(ixs), 75)
+    res = [ix.search_batch(q, per, L) for ix in ixs]
+    ids = np.stack([r[0] for r in res]); d = np.stack([r[1] for r in res]); c = np.stack([r[2] for r in res])
+    out = []
+    for i in range(q.shape[0]):
+        out.append(oracle.cluster_merge(ids[:, i, :], d[:, i, :], c[:, i].astype(np.int32), limit))
+    return out
+
+
+def _check(got, want):
+    ids, d, sh, c = got
+    for i, (w_ids, w_d, w_s) in enumerate(want):
+        n = len(w_ids)
+        assert int(c[i]) == n
+        assert np.array_equal(ids[i, :n], w_ids) and np.array_equal(d[i, :n].view(np.uint32), w_d.view(np.uint32))
+        assert np.array_equal(sh[i, :n].astype(np.int32), w_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_shards_on_one_gpu_fanout_equals_reference_merge(oracle, world):
+    """ClusterNode.SearchPoints over `world` shards that share the GPU: requests from racing threads, one ticket each,
+    every rank's blocking host-memory call on a thread of its own -- every answer is the reference's merge of the
+    shards' own answers, whatever order the threads ran in."""
+    from semadb_amd import cluster
+    rng = np.random.default_rng(40 + world)
+    ixs, bases, qs = _shards(rng, world)
+    ranks = cluster.Cluster.create_local([0] * world)
+    assert [(r.rank, r.world) for r in ranks] == [(i, world) for i in range(world)]
+    fan = cluster.Fanout(ranks, ixs)
+    want = [_expected(oracle, ixs, q, 10, 50) for q in qs]
+    results, errors = {}, []
+
+    def client(j):
+        try:
+            for rep in range(3):
+                b = (j + rep) % len(qs)
+                results[(j, rep)] = (b, fan.search_points(qs[b], 10, 50))
+        except Exception as e:  # pragma: no cover - reported below
+            errors.append(e)
+
+    ts = [threading.Thread(target=client, args=(j,)) for j in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 18
+    for b, got in results.values():
+        _check(got, want[b])
+    assert ranks[0].next_ticket() == 19 and ranks[-1].next_ticket() == 19
+    for r in ranks:
+        r.close()
+    for ix in ixs:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_misordered_collectives_are_refused_not_merged(oracle):
+    """The race the reference's fan-out allows (requests A and B reach shard 0 as A,B and shard 1 as B,A) with the
+    ordering switched off (ticket 0): the all-gathers pair A's block with B's.  The tags disagree on the query hash,
+    so NO rank returns an answer -- every call fails with SDB_ERR_STATE -- and the handles stay in step: the next,
+    ordered request is answered."""
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError
+    rng = np.random.default_rng(77)
+    ixs, bases, qs = _shards(rng, 2)
+    ranks = cluster.Cluster.create_local([0, 0])
+    A, B = qs[0], qs[1]
+    errs = {}
+
+    def run(r, order):
+        for name, q in order:
+            try:
+                ranks[r].search_batch(ixs[r], q, 10, 50)
+                errs[(r, name)] = None
+            except SemaDBError as e:
+                errs[(r, name)] = e
+
+    t0 = threading.Thread(target=run, args=(0, [("A", A), ("B", B)]))
+    t1 = threading.Thread(target=run, args=(1, [("B", B), ("A", A)]))
+    t0.start(); t1.start(); t0.join(); t1.join()
+    assert len(errs) == 4
+    for key, e in errs.items():
+        assert e is not None and e.code == 3, key  # SDB_ERR_STATE
+        assert "query hash" in str(e) and "different requests" in str(e)
+    # in step again: an ordered request goes through
+    fan = cluster.Fanout(ranks, ixs)
+    _check(fan.search_points(A, 10, 50), _expected(oracle, ixs, A, 10, 50))
+    # the same race with tickets cannot happen: whichever thread arrives first, ticket order wins
+    t = ranks[0].next_ticket()
+    outs = {}
+
+    def run_t(r, order):
+        for name, q, tk in order:
+            outs[(r, name)] = ranks[r].search_batch(ixs[r], q, 10, 50, ticket=tk)
+
+    t0 = threading.Thread(target=run_t, args=(0, [("A", A, t), ("B", B, t + 1)]))
+    t1 = threading.Thread(target=run_t, args=(1, [("B", B, t + 1)]))
+    t2 = threading.Thread(target=run_t, args=(1, [("A", A, t)]))
+    t1.start()  # rank 1's B arrives first and must wait for rank 1's A
+    import time
+    time.sleep(0.2)
+    t0.start(); t2.start()
+    for th in (t0, t1, t2):
+        th.join()
+    wa, wb = _expected(oracle, ixs, A, 10, 50), _expected(oracle, ixs, B, 10, 50)
+    for r in (0, 1):
+        _check(outs[(r, "A")], wa)
+        _check(outs[(r, "B")], wb)
+    # a ticket that has already entered is refused
+    with pytest.raises(SemaDBError):
+        ranks[0].search_batch(ixs[0], A, 10, 50, ticket=t)
+    for r in ranks:
+        r.close()
+    for ix in ixs:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_failing_shard_enters_the_exchange_and_fails_the_request_everywhere(oracle):
+    """One shard cannot search (no start node: sdb_index_search_batch returns SDB_ERR_STATE).  Its rank still joins the
+    all-gather with the status in its tag, so the other rank is not left waiting inside the collective; both calls
+    return an error for THIS request (actions.go:339-353) and the next request, on healthy shards, is served."""
+    from semadb_amd import cluster, vamana
+    from semadb_amd._lib import SemaDBError
+    rng = np.random.default_rng(91)
+    ixs, bases, qs = _shards(rng, 2)
+    bad = vamana.NewIndexVamana("bad", vamana.IndexVectorVamanaParameters(48, "cosine", 50, 32, 1.2), strict=False)
+    ranks = cluster.Cluster.create_local([0, 0])
+    fan = cluster.Fanout(ranks, [ixs[0], bad])
+    with pytest.raises(SemaDBError) as ei:
+        fan.search_points(qs[0], 10, 50)
+    assert ei.value.code == 3
+    # each rank on its own: the healthy one names the failing shard, the failing one reports its own error
+    out = {}
+
+    def run(r, ix, tk):
+        try:
+            ranks[r].search_batch(ix, qs[0], 10, 50, ticket=tk)
+            out[r] = None
+        except SemaDBError as e:
+            out[r] = e
+
+    tk = ranks[0].next_ticket()
+    ths = [threading.Thread(target=run, args=(0, ixs[0], tk)), threading.Thread(target=run, args=(1, bad, tk))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert out[0] is not None and "shard 1" in str(out[0]) and "status 3" in str(out[0])
+    assert out[1] is not None and "start point" in str(out[1])
+    good = cluster.Fanout(ranks, ixs)
+    _check(good.search_points(qs[1], 10, 50), _expected(oracle, ixs, qs[1], 10, 50))
+    for r in ranks:
+        r.close()
+    for ix in ixs + [bad]:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_device_memory_exchanges_in_flight_and_their_verdicts(oracle):
+    """Asynchronous (device-memory) calls over two shards driven from ONE thread, several batches in flight; the
+    verdict of a mis-paired exchange arrives with synchronize(), the counts of that request are zero."""
+    import torch
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError
+    rng = np.random.default_rng(123)
+    ixs, bases, qs = _shards(rng, 2)
+    ranks = cluster.Cluster.create_local([0, 0])
+    qd = [torch.from_numpy(q).cuda() for q in qs]
+    outs = []
+    for b in range(5):
+        outs.append([ranks[r].search_batch(ixs[r], qd[b], 10, 50) for r in range(2)])
+    for r in ranks:
+        r.synchronize()
+    for b in range(5):
+        want = _expected(oracle, ixs, qs[b], 10, 50)
+        for r in range(2):
+            o = outs[b][r]
+            _check((o[0].cpu().numpy().view(np.uint64), o[1].cpu().numpy(), o[2].cpu().numpy().view(np.uint32),
+                    o[3].cpu().numpy().view(np.uint32)), want)
+    # mis-paired: rank 0 searches batch 0, rank 1 batch 1
+    o0 = ranks[0].search_batch(ixs[0], qd[0], 10, 50)
+    o1 = ranks[1].search_batch(ixs[1], qd[1], 10, 50)
+    for r in ranks:
+        with pytest.raises(SemaDBError) as ei:
+            r.synchronize()
+        assert ei.value.code == 3 and "query hash" in str(ei.value)
+    assert not o0[3].cpu().numpy().any() and not o1[3].cpu().numpy().any()
+    for r in ranks:
+        r.synchronize()  # reported once
+    # the caller's own block through allgather_merge, two shards
+    per = cluster.shard_limit(10, 2, 75)
+    blks = []
+    for r in range(2):
+        blk = cluster.PackedTopK(qs[2].shape[0], per, "cuda:0")
+        ixs[r].search_batch(qd[2], per, 50, out=blk.out())
+        blks.append(blk)
+    ms = [ranks[r].allgather_merge(blks[r], 10) for r in range(2)]
+    for r in ranks:
+        r.synchronize()
+    want = _expected(oracle, ixs, qs[2], 10, 50)
+    for m in ms:
+        _check((m[0].cpu().numpy().view(np.uint64), m[1].cpu().numpy(), m[2].cpu().numpy().view(np.uint32),
+                m[3].cpu().numpy().view(np.uint32)), want)
+    for r in ranks:
+        r.close()
+    for ix in ixs:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_mixed_device_lists_are_rejected():
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError, device_count
+    if device_count() < 2:
+        with pytest.raises(SemaDBError):
+            cluster.Cluster.create_local([0, 1])  # device 1 does not exist here
+    with pytest.raises(SemaDBError):
+        cluster.Cluster.create_local([0, 0, 1] if device_count() >= 2 else [0, 0, 7])
