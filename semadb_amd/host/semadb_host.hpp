@@ -8,6 +8,8 @@
 //   semadb::distance     <-> distance/              (GetFloatDistanceFn)
 //   semadb::models       <-> models/                (IndexVectorVamanaParameters, SearchVectorVamanaOptions, SearchResult)
 //   semadb::vamana       <-> shard/index/vamana/    (STARTID, IndexVectorChange, NewIndexVamana, IndexVamana)
+//   semadb::flat         <-> shard/index/flat/      (IndexFlat)
+//   semadb::cluster      <-> cluster/actions.go     (the in-node fan-out of SearchPoints: GpuFanout, PerShardLimit)
 //
 // IndexVamana keeps its state in HBM and treats the bucket as the source of truth exactly like the
 // reference's ItemCache: NewIndexVamana fills HBM from the 'n<id>v' / 'n<id>e' keys (plain.go:125-141,
@@ -21,6 +23,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -895,4 +898,162 @@ class IndexFlat {
   std::mutex write_mu_;
 };
 }  // namespace flat
+// ---------------------------------------------------------------------------------------------------
+namespace cluster {  // cluster/actions.go:275-379, the part that stays inside one server
+// per-shard limit, actions.go:291-299
+inline int PerShardLimit(int limit, int nShards, int maxSearchLimit = 75) {
+  uint32_t out = 0;
+  sdb_shard_limit((uint32_t)limit, (uint32_t)nShards, (uint32_t)maxSearchLimit, &out);
+  return (int)out;
+}
+
+// ClusterNode.SearchPoints for the shards of this server (actions.go:316-376): instead of one RPCSearchPoints per
+// shard and a host-side sort, every shard's rank makes ONE collective call that searches its shard, exchanges the
+// per-shard top-k blocks (RCCL all-gather between GPUs; device copies when the shards share a GPU) and merges them
+// on its GPU.  The compiled twin of integration/go/cluster/fanout_mi355x.go.
+//
+// Requests arrive concurrently (one goroutine per REST request in the reference, httpapi/v2/handlers.go:435-489).
+// Each draws ONE ticket under a lock and presents it to every rank; the library lets a rank's calls into the exchange
+// in ticket order whichever worker arrives first and refuses to merge blocks whose tags differ, so two racing
+// requests can neither be paired up wrongly nor deadlock the collective.  Each rank has `workers` threads: that
+// many requests are in flight per rank, the exchange of one under the graph walk of the next.
+class GpuFanout {
+ public:
+  struct Result {
+    std::vector<uint64_t> ids;    // [nq * limit] shard-local node ids
+    std::vector<uint32_t> shards; // [nq * limit] which shard each id belongs to
+    std::vector<float> dists;
+    std::vector<uint32_t> counts; // [nq]
+    Error err;
+  };
+
+  // indexes[r] lives on devices[r]; devices all distinct (one shard per GPU) or all the same (shards share a GPU)
+  static std::pair<std::unique_ptr<GpuFanout>, Error> New(const std::vector<sdb_index *> &indexes,
+                                                          const std::vector<int> &devices, unsigned workers = 2) {
+    std::unique_ptr<GpuFanout> f(new GpuFanout());
+    const int n = (int)indexes.size();
+    if (n < 1 || devices.size() != indexes.size()) return {nullptr, Error("one device per shard index")};
+    f->indexes_ = indexes;
+    f->ranks_.assign((size_t)n, nullptr);
+    if (int rc = sdb_cluster_create_local(n, devices.data(), f->ranks_.data()))
+      return {nullptr, Error::wrap("could not create the shard exchange", rc)};
+    uint64_t next = 1;
+    sdb_cluster_next_ticket(f->ranks_[0], &next);
+    f->ticket_ = next - 1;
+    f->queues_.resize((size_t)n);
+    for (int r = 0; r < n; r++) f->queues_[(size_t)r].reset(new Queue());
+    for (int r = 0; r < n; r++)
+      for (unsigned w = 0; w < (workers ? workers : 1); w++) f->threads_.emplace_back([p = f.get(), r] { p->loop(r); });
+    return {std::move(f), Error()};
+  }
+  ~GpuFanout() {
+    for (auto &q : queues_) {
+      std::lock_guard<std::mutex> g(q->mu);
+      q->stop = true;
+      q->cv.notify_all();
+    }
+    for (auto &t : threads_)
+      if (t.joinable()) t.join();
+    for (auto *r : ranks_) sdb_cluster_destroy(r);
+  }
+  GpuFanout(const GpuFanout &) = delete;
+  GpuFanout &operator=(const GpuFanout &) = delete;
+  int shards() const { return (int)ranks_.size(); }
+  // replace a shard's index (a shard that was rebuilt from its bucket); no request may be in flight
+  void setIndex(int r, sdb_index *ix) { indexes_[(size_t)r] = ix; }
+
+  // nq queries (row-major, dim floats each) over all local shards; `limit` is the request's original limit, the
+  // per-shard limit of actions.go:291-299 is applied inside.  Thread-safe.
+  Result SearchPoints(const float *queries, size_t nq, int limit, int searchSize) {
+    Result out;
+    const int n = (int)ranks_.size();
+    Request req;
+    req.queries = queries, req.nq = nq, req.limit = limit, req.search_size = searchSize;
+    req.parts.resize((size_t)n);
+    for (auto &p : req.parts) {
+      p.ids.resize(nq * (size_t)limit), p.shards.resize(nq * (size_t)limit);
+      p.dists.resize(nq * (size_t)limit), p.counts.resize(nq);
+    }
+    req.left = n;
+    {
+      // ticket and hand-over in one critical section: every rank's queue receives the requests in ticket order
+      // (not needed for correctness -- the library orders by ticket -- but a worker then never waits on a ticket
+      // whose request sits BEHIND its own in the same queue, which with one worker per rank would be a deadlock)
+      std::lock_guard<std::mutex> g(mu_);
+      req.ticket = ++ticket_;
+      for (int r = 0; r < n; r++) {
+        std::lock_guard<std::mutex> qg(queues_[(size_t)r]->mu);
+        queues_[(size_t)r]->items.push_back(&req);
+        queues_[(size_t)r]->cv.notify_one();
+      }
+    }
+    {
+      std::unique_lock<std::mutex> lk(req.mu);
+      req.cv.wait(lk, [&] { return req.left == 0; });
+    }
+    // a shard that failed has said so inside the exchange: every rank reports an error for this request, and the
+    // next request is served (actions.go:339-353 "could not search points")
+    for (int r = 0; r < n; r++)
+      if (req.parts[(size_t)r].rc != SDB_OK) {
+        out.err = Error("shard " + std::to_string(r) + " could not search points: " + req.parts[(size_t)r].msg);
+        return out;
+      }
+    Part &p0 = req.parts[0];  // every rank holds the same merged answer
+    out.ids.swap(p0.ids), out.shards.swap(p0.shards), out.dists.swap(p0.dists), out.counts.swap(p0.counts);
+    return out;
+  }
+
+ private:
+  GpuFanout() = default;
+  struct Part {
+    std::vector<uint64_t> ids;
+    std::vector<uint32_t> shards, counts;
+    std::vector<float> dists;
+    int rc = SDB_OK;
+    std::string msg;
+  };
+  struct Request {
+    const float *queries = nullptr;
+    size_t nq = 0;
+    int limit = 0, search_size = 0;
+    uint64_t ticket = 0;
+    std::vector<Part> parts;
+    std::mutex mu;
+    std::condition_variable cv;
+    int left = 0;
+  };
+  struct Queue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Request *> items;
+    bool stop = false;
+  };
+  void loop(int r) {
+    Queue &q = *queues_[(size_t)r];
+    for (;;) {
+      Request *req = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(q.mu);
+        q.cv.wait(lk, [&] { return q.stop || !q.items.empty(); });
+        if (q.items.empty()) return;
+        req = q.items.front();
+        q.items.pop_front();
+      }
+      Part &p = req->parts[(size_t)r];
+      p.rc = sdb_cluster_search_batch(ranks_[(size_t)r], indexes_[(size_t)r], req->ticket, req->nq, req->queries,
+                                      (uint32_t)req->limit, (uint32_t)req->search_size, p.ids.data(), p.dists.data(),
+                                      p.shards.data(), p.counts.data(), SDB_MEM_HOST, nullptr);
+      if (p.rc != SDB_OK) p.msg = sdb_last_error();
+      std::lock_guard<std::mutex> g(req->mu);  // notified under the lock: `req` lives on its caller's stack
+      if (--req->left == 0) req->cv.notify_all();
+    }
+  }
+  std::vector<sdb_cluster *> ranks_;
+  std::vector<sdb_index *> indexes_;
+  std::vector<std::unique_ptr<Queue>> queues_;
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  uint64_t ticket_ = 0;
+};
+}  // namespace cluster
 }  // namespace semadb

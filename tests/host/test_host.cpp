@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <tuple>
 
 #include "../../semadb_amd/host/semadb_host.hpp"
 
@@ -357,6 +358,129 @@ static void test_flat_index() {
   CHECK((bool)ix->Search(q).err);
 }
 
+// ClusterNode.SearchPoints inside one server (cluster/actions.go:316-376) through cluster::GpuFanout, the compiled
+// twin of integration/go/cluster/fanout_mi355x.go: two shards that share the GPU, requests from racing threads (one
+// ticket each), every answer equal to the reference's rule applied on the host to the shards' own answers -- per-shard
+// limit (:291-299), concatenate, sort by distance (HybridScore descending), truncate (:357-376).  Then a shard that
+// cannot search: the request fails on every rank, nobody hangs, the next request is served.
+static void test_cluster_fanout() {
+  const int kShards = 2, kPer = 400, kReq = 24;
+  std::vector<std::unique_ptr<vamana::IndexVamana>> shards;
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> u(0, 100);
+  for (int s = 0; s < kShards; s++) {
+    auto [inv, err] = vamana::NewIndexVamana("shard", vamanaParams(), nullptr);
+    CHECK(!err);
+    std::vector<vamana::IndexVectorChange> pts;
+    for (int i = 0; i < kPer; i++) pts.push_back({(uint64_t)(i + 2), {u(rng), u(rng)}});
+    CHECK(!inv->InsertUpdateDelete(pts));
+    shards.push_back(std::move(inv));
+  }
+  std::vector<sdb_index *> hs;
+  for (auto &s : shards) hs.push_back(s->handle());
+  auto [fan, ferr] = cluster::GpuFanout::New(hs, std::vector<int>(kShards, 0), 2);
+  CHECK(!ferr);
+  if (ferr) {
+    std::printf("fanout: %s\n", ferr.msg.c_str());
+    return;
+  }
+  CHECK(cluster::PerShardLimit(10, 8) == 10 && cluster::PerShardLimit(100, 5) == 38);  // actions.go:291-299
+  const int nq = 8, limit = 10, L = 75;
+  std::vector<std::vector<float>> batches(kReq, std::vector<float>((size_t)nq * 2));
+  for (auto &b : batches)
+    for (auto &x : b) x = u(rng);
+  // what the reference's merge makes of the shards' own answers
+  auto expect = [&](const std::vector<float> &q, std::vector<uint64_t> *ids, std::vector<uint32_t> *sh) {
+    const int per = cluster::PerShardLimit(limit, kShards);
+    for (int i = 0; i < nq; i++) {
+      std::vector<std::tuple<float, uint32_t, uint64_t>> all;
+      for (int s = 0; s < kShards; s++) {
+        models::SearchVectorVamanaOptions o;
+        o.Vector = {q[(size_t)2 * i], q[(size_t)2 * i + 1]}, o.SearchSize = L, o.Limit = per;
+        auto r = shards[(size_t)s]->Search(o);
+        CHECK(!r.err);
+        for (auto &x : r.results) all.emplace_back(x.Distance, (uint32_t)s, x.NodeId);
+      }
+      std::sort(all.begin(), all.end());
+      for (int k = 0; k < limit && k < (int)all.size(); k++) ids->push_back(std::get<2>(all[(size_t)k])), sh->push_back(std::get<1>(all[(size_t)k]));
+    }
+  };
+  std::vector<std::vector<uint64_t>> want_ids(kReq);
+  std::vector<std::vector<uint32_t>> want_sh(kReq);
+  for (int b = 0; b < kReq; b++) expect(batches[(size_t)b], &want_ids[(size_t)b], &want_sh[(size_t)b]);
+  std::atomic<int> bad{0}, done{0};
+  std::vector<std::thread> clients;
+  for (int t = 0; t < 6; t++)
+    clients.emplace_back([&, t] {
+      for (int b = t; b < kReq; b += 6) {
+        auto r = fan->SearchPoints(batches[(size_t)b].data(), nq, limit, L);
+        if (r.err) {
+          bad++;
+          continue;
+        }
+        for (int i = 0; i < nq; i++) {
+          if (r.counts[(size_t)i] != (uint32_t)limit) bad++;
+          for (int k = 0; k < limit; k++)
+            if (r.ids[(size_t)i * limit + k] != want_ids[(size_t)b][(size_t)i * limit + k] ||
+                r.shards[(size_t)i * limit + k] != want_sh[(size_t)b][(size_t)i * limit + k])
+              bad++;
+        }
+        done++;
+      }
+    });
+  for (auto &c : clients) c.join();
+  CHECK(bad == 0 && done == kReq);
+  // a shard without a start node cannot search (search.go:57-60): the request fails, the fan-out lives on
+  sdb_index_params p{};
+  p.dim = 2, p.metric = SDB_METRIC_EUCLIDEAN, p.search_size = 75, p.degree_bound = 64, p.alpha = 1.2f, p.device = 0;
+  sdb_index *broken = nullptr;
+  CHECK(sdb_index_create(&p, &broken) == SDB_OK);
+  fan->setIndex(1, broken);
+  auto r = fan->SearchPoints(batches[0].data(), nq, limit, L);
+  CHECK((bool)r.err);
+  fan->setIndex(1, hs[1]);
+  r = fan->SearchPoints(batches[0].data(), nq, limit, L);
+  CHECK(!r.err && r.ids == want_ids[0] && r.shards == want_sh[0]);
+  fan.reset();
+  sdb_index_destroy(broken);
+}
+
+// a write that cannot go through must not wedge the index (sdb_index_abort_write): a bad point after good ones, then
+// the same index takes the next write
+static void test_failed_write_leaves_the_index_writable() {
+  auto [inv, err] = vamana::NewIndexVamana("test", vamanaParams(), nullptr);
+  CHECK(!err);
+  CHECK(!inv->InsertUpdateDelete(detPoints(50)));
+  std::vector<vamana::IndexVectorChange> bad = detPoints(60);
+  bad.erase(bad.begin(), bad.begin() + 50);  // ids 52..61: new
+  bad.push_back({70, {1.0f, 2.0f, 3.0f}});   // wrong length (models/index.go:182-184)
+  CHECK((bool)inv->InsertUpdateDelete(bad));
+  CHECK(!inv->Exists(52));
+  bad.pop_back();
+  CHECK(!inv->InsertUpdateDelete(bad));  // the index was left as it was and takes the write
+  CHECK(inv->Exists(52) && inv->Exists(61));
+  // the C ABI itself: an explicit transaction abandoned before its first change
+  sdb_index *h = inv->handle();
+  CHECK(sdb_index_begin_write(h) == SDB_OK);
+  CHECK(sdb_index_begin_write(h) != SDB_OK);  // already open
+  CHECK(sdb_index_abort_write(h) == SDB_OK);
+  CHECK(sdb_index_begin_write(h) == SDB_OK);
+  CHECK(sdb_index_commit(h, nullptr) == SDB_OK);
+  CHECK(sdb_index_abort_write(h) == SDB_OK);  // nothing open: fine
+  // ... and after its first change: no rollback, the handle says it is unusable
+  flat::IndexFlat::SearchReturn unused;
+  (void)unused;
+  CHECK(sdb_index_begin_write(h) == SDB_OK);
+  uint64_t id = 500;
+  float v[2] = {5, 6};
+  CHECK(sdb_index_insert_batch(h, 1, &id, v, SDB_MEM_HOST, 0, nullptr) == SDB_OK);
+  CHECK(sdb_index_abort_write(h) == SDB_ERR_STATE);
+  CHECK(sdb_index_begin_write(h) == SDB_ERR_STATE);
+  models::SearchVectorVamanaOptions q;
+  q.Vector = {5, 6};
+  CHECK((bool)inv->Search(q).err);
+}
+
 int main() {
   int ndev = 0;
   if (sdb_device_count(&ndev) != SDB_OK) {
@@ -371,6 +495,8 @@ int main() {
   test_create_update_delete();
   test_quantized_index();
   test_flat_index();
+  test_failed_write_leaves_the_index_writable();
+  test_cluster_fanout();
   if (g_fail) {
     std::printf("%d HOST CHECKS FAILED\n", g_fail);
     return 1;
