@@ -95,6 +95,23 @@ __global__ __launch_bounds__(64) void k_index_distance(const float *__restrict__
 
 }  // namespace sdb
 
+namespace sdb {
+int launch_k1_tiles(int metric, uint32_t dim, const float *dq, uint64_t nq, const float *dc, uint64_t nc, float *dout,
+                    hipStream_t stream);
+
+// Stream-ordered scratch (hipMallocAsync) instead of a hipMalloc / hipFree pair per call: the device's default pool
+// is told to keep what it is given back, so that a serving process pays for staging memory once.
+void keep_pool_memory(int device) {
+  static std::atomic<uint64_t> done{0};
+  const uint64_t bit = 1ull << (device & 63);
+  if (done.fetch_or(bit) & bit) return;
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || !pool) return;
+  uint64_t keep = 1ull << 30;  // up to 1 GB of idle scratch stays with the process
+  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+}
+}  // namespace sdb
+
 using namespace sdb;
 
 extern "C" {
@@ -111,33 +128,48 @@ int sdb_distance_batch(int metric, uint32_t dim, const float *queries, uint64_t 
   if (device < 0 || device >= ndev) return fail(SDB_ERR_INVALID, "device %d out of range", device);
   DeviceGuard dg(device);
   hipStream_t stream = as_stream(stream_);
+  keep_pool_memory(device);
   const float *dq = queries, *dc = candidates;
   float *dout = out;
   float *buf = nullptr;
   if (mem == SDB_MEM_HOST) {
-    size_t bq = nq * dim * sizeof(float), bc = nc * dim * sizeof(float), bo = nq * nc * sizeof(float);
-    SDB_HIP(hipMalloc(&buf, bq + bc + bo));
-    float *pq = buf, *pc = buf + nq * dim, *po = pc + nc * dim;
-    hipError_t e = hipMemcpyAsync(pq, queries, bq, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(pc, candidates, bc, hipMemcpyHostToDevice, stream);
+    // staging from the stream-ordered pool (no hipMalloc / hipFree per call); the three parts start on 256-byte
+    // boundaries so that the tile kernels' 16-byte loads are aligned whatever the shapes
+    const size_t bq = (nq * dim * sizeof(float) + 255) & ~(size_t)255, bc = (nc * dim * sizeof(float) + 255) & ~(size_t)255;
+    const size_t bo = nq * nc * sizeof(float);
+    SDB_HIP(hipMallocAsync(reinterpret_cast<void **>(&buf), bq + bc + bo, stream));
+    float *pq = buf, *pc = reinterpret_cast<float *>(reinterpret_cast<char *>(buf) + bq);
+    float *po = reinterpret_cast<float *>(reinterpret_cast<char *>(buf) + bq + bc);
+    hipError_t e = hipMemcpyAsync(pq, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pc, candidates, nc * dim * sizeof(float), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {
-      (void)hipFree(buf);
+      (void)hipFreeAsync(buf, stream);
       return fail(SDB_ERR_DEVICE, "H2D copy failed: %s", hipGetErrorString(e));
     }
     dq = pq, dc = pc, dout = po;
   }
-  dim3 grid((unsigned)((nc + kK1CandPerBlock - 1) / kK1CandPerBlock), (unsigned)nq);
-  size_t lds = dim * sizeof(float);
-  if (metric == SDB_METRIC_EUCLIDEAN)
-    hipLaunchKernelGGL(k_distance_batch<true>, grid, dim3(256), lds, stream, dq, dc, dout, dim, nc, metric);
-  else
-    hipLaunchKernelGGL(k_distance_batch<false>, grid, dim3(256), lds, stream, dq, dc, dout, dim, nc, metric);
-  hipError_t e = hipGetLastError();
+  // row reuse (distance_tile.hip): a workgroup keeps 64 candidate rows and walks all queries over them; shapes it does
+  // not cover (a single query, rows shorter than a block or not whole float4s, unaligned callers) take the first kernel
+  hipError_t e = hipSuccess;
+  const int tiled = launch_k1_tiles(metric, dim, dq, nq, dc, nc, dout, stream);
+  if (tiled < 0) {
+    if (buf) (void)hipFreeAsync(buf, stream);
+    return -tiled;
+  }
+  if (tiled == 0) {
+    dim3 grid((unsigned)((nc + kK1CandPerBlock - 1) / kK1CandPerBlock), (unsigned)nq);
+    size_t lds = dim * sizeof(float);
+    if (metric == SDB_METRIC_EUCLIDEAN)
+      hipLaunchKernelGGL(k_distance_batch<true>, grid, dim3(256), lds, stream, dq, dc, dout, dim, nc, metric);
+    else
+      hipLaunchKernelGGL(k_distance_batch<false>, grid, dim3(256), lds, stream, dq, dc, dout, dim, nc, metric);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess && mem == SDB_MEM_HOST) {
     e = hipMemcpyAsync(out, dout, nq * nc * sizeof(float), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
-  if (buf) (void)hipFree(buf);
+  if (buf) (void)hipFreeAsync(buf, stream);
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "distance_batch failed: %s", hipGetErrorString(e));
   return SDB_OK;
 }
