@@ -13,13 +13,15 @@
 //                  register of dot.s:16-30, L % 8 its lane -- so a lane's eight operands per block are 32 contiguous
 //                  bytes of the row, and the reduce tree of dot.s:45-53 is plain adds inside the lane.  Query operands
 //                  arrive through LDS in operand order (k_k1_swizzle_queries, once per call), LDS-DMA, double buffered.
-//   euclidean      k_k1_tile_l2     (x - y) is rounded per pair before the multiply (euclidean.s:27), which is not an
-//                  outer product: 64 rows staged in LDS, lane r owns row r, query elements through the scalar cache,
+//   euclidean      k_k1_tile_pk     (x - y) is rounded per pair before the multiply (euclidean.s:27), which is not an
+//                  outer product: up to 64 rows staged in LDS, lane r owns row r, query elements through the scalar cache,
 //                  v_pk_fma_f32 on pairs of partial sums -- the exact scan's scheme (flat.hip k_flat_scan) on the
 //                  caller's layout with the full distance block as output.
 // Both write the [nq][nc] block with 64-byte (matrix) or 256-byte (packed) contiguous pieces per wave and query.
 #include "dist_core.h"
 #include "common.h"
+
+#include <algorithm>
 
 namespace sdb {
 
@@ -188,22 +190,25 @@ template <bool L2>
 __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__restrict__ cands,
                                                                 const float *__restrict__ queries,
                                                                 float *__restrict__ out, uint64_t nc, uint32_t nq,
-                                                                uint32_t dim, uint32_t nblk, int metric) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][kstride]
-  const uint32_t kstride = nblk * 32 + 4;
+                                                                uint32_t dim, uint32_t nblk, uint32_t tail,
+                                                                uint32_t tile_rows, int metric) {
+  // [tile_rows][kstride]: as many rows as fit LDS, at most one per lane (64 up to d = 608, 52 at 768, 39 at 1024)
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const uint32_t kstride = dim + 4;  // +16 B per row: lane r starts at bank 4r, the lanes' ds_read_b128 never collide
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint64_t row0 = (uint64_t)blockIdx.x * kK1Rows;
-  const uint32_t nrows = (uint32_t)min<uint64_t>(kK1Rows, nc - row0);
+  const uint64_t row0 = (uint64_t)blockIdx.x * tile_rows;
+  const uint32_t nrows = (uint32_t)min<uint64_t>(tile_rows, nc - row0);
   const uint32_t row_f4 = dim / 4;
-  for (uint32_t i = tid; i < kK1Rows * row_f4; i += kK1L2Waves * 64) {  // consecutive threads: consecutive 16 B of a row
+  for (uint32_t i = tid; i < tile_rows * row_f4; i += kK1L2Waves * 64) {  // consecutive threads: consecutive 16 B of a row
     const uint32_t r = i / row_f4, c = i % row_f4;
     const uint32_t rr = r < nrows ? r : nrows - 1;
     *reinterpret_cast<float4 *>(tile + (size_t)r * kstride + 4 * c) =
         reinterpret_cast<const float4 *>(cands + (size_t)(row0 + rr) * dim)[c];
   }
   __syncthreads();
-  const float4 *myrow = reinterpret_cast<const float4 *>(tile + (size_t)lane * kstride);
+  const float *myrow_f = tile + (size_t)((uint32_t)lane < tile_rows ? lane : 0) * kstride;  // idle lanes: row 0, dropped
+  const float4 *myrow = reinterpret_cast<const float4 *>(myrow_f);
   const uint32_t ngroups = (nq + 1) / 2;
   for (uint32_t grp = (uint32_t)wave; grp < ngroups; grp += kK1L2Waves) {
     const float *xq[2];
@@ -232,6 +237,13 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
         acc[1][2 * i + 1] = k1_chain_pk<L2>(acc[1][2 * i + 1], f2v{w.z, w.w}, f2v{y[i].z, y[i].w});
       }
     }
+    // the tail chain (dot.s:35-43 / euclidean.s:44-53): the n % 32 last elements, one after the other
+    float t[2] = {0.0f, 0.0f};
+    for (uint32_t m = 0; m < tail; m++) {
+      const float yv = myrow_f[nblk * 32 + m];
+      t[0] = chain1<L2>(t[0], xq[0][nblk * 32 + m], yv);
+      t[1] = chain1<L2>(t[1], xq[1][nblk * 32 + m], yv);
+    }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       auto A = [&](int L) { return acc[k][L >> 1][L & 1]; };
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
       for (int l = 0; l < 4; l++) {
         const float s0 = ((A(l) + A(8 + l)) + A(16 + l)) + A(24 + l);
         const float s1 = ((A(l + 4) + A(12 + l)) + A(20 + l)) + A(28 + l);
-        r4[l] = (s0 + s1) + 0.0f;
+        r4[l] = (s0 + s1) + (l == 0 ? t[k] : 0.0f);  // + {t, 0, 0, 0} (dot.s:51)
       }
       const float dist = metric_finish((r4[0] + r4[1]) + (r4[2] + r4[3]), metric);
       const uint32_t q = grp * 2 + k;
@@ -287,15 +299,18 @@ int launch_k1_tiles(int metric, uint32_t dim, const float *dq, uint64_t nq, cons
   if ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dc)) & 15) return 0;
   const dim3 grid((unsigned)((nc + kK1Rows - 1) / kK1Rows));
   if (metric == SDB_METRIC_EUCLIDEAN) {
-    if (tail || nblk > 19) return 0;  // the 64-row tile must fit LDS
-    const size_t lds = (size_t)kK1Rows * (nblk * 32 + 4) * sizeof(float);
+    // as many rows per workgroup as fit LDS, at most one per lane
+    const size_t row_bytes = (size_t)(dim + 4) * sizeof(float);
+    const uint32_t tile_rows = (uint32_t)std::min<size_t>(kK1Rows, (160 * 1024) / row_bytes);
+    if (tile_rows < 8) return 0;
+    const size_t lds = tile_rows * row_bytes;
     static std::atomic<uint64_t> attr{0};
     if (first_use_on_this_device(attr))
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_k1_tile_pk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024) != hipSuccess)
         return -fail(SDB_ERR_DEVICE, "hipFuncSetAttribute failed");
-    hipLaunchKernelGGL((k_k1_tile_pk<true>), grid, dim3(kK1L2Waves * 64), lds, stream, dc, dq, dout, nc, (uint32_t)nq, dim,
-                       nblk, metric);
+    hipLaunchKernelGGL((k_k1_tile_pk<true>), dim3((unsigned)((nc + tile_rows - 1) / tile_rows)), dim3(kK1L2Waves * 64), lds,
+                       stream, dc, dq, dout, nc, (uint32_t)nq, dim, nblk, tail, tile_rows, metric);
     if (hipGetLastError() != hipSuccess) return -fail(SDB_ERR_DEVICE, "k_k1_tile_pk launch failed");
     return 1;
   }

@@ -73,3 +73,51 @@ def test_device_memory_path(oracle):
     torch.cuda.synchronize()
     want = oracle.distance_matrix(q, c, "cosine", oracle.IMPL_ASM)
     assert np.array_equal(bits(got.cpu().numpy()), bits(want))
+
+
+# ---- the row-reuse kernels (csrc/distance_tile.hip): matrix cores for dot / cosine, packed FMAs for euclidean ----
+TILE_DIMS = [32, 36, 64, 96, 100, 128, 160, 300, 384, 416, 608, 640, 768, 1024, 1056, 1536, 4096]
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+@pytest.mark.parametrize("d", TILE_DIMS)
+def test_tiled_distance_bit_exact(oracle, metric, d):
+    """more queries than one operand group, candidate counts that leave ragged tiles, rows with and without a tail
+    chain (d % 32 = 4, 12), every register-block count of the matrix-core kernel, euclidean tiles of fewer than 64
+    rows (d > 608), and the shapes past the tile kernels' reach, which fall back to the first kernel -- all
+    bit-identical to the oracle"""
+    from semadb_amd import distance
+    rng = np.random.default_rng(d * 11 + len(metric))
+    for nq, nc in [(37, 1003), (16, 64), (2, 130)]:
+        q = (rng.standard_normal((nq, d)) * 2).astype(np.float32)
+        c = (rng.standard_normal((nc, d)) * 2).astype(np.float32)
+        got = distance.distance_batch(metric, q, c)
+        want = oracle.distance_matrix(q, c, metric, oracle.IMPL_ASM)
+        assert np.array_equal(bits(got), bits(want)), (nq, nc)
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+def test_tiled_distance_device_memory_and_special_values(oracle, metric):
+    import torch
+    from semadb_amd import distance
+    rng = np.random.default_rng(77)
+    d = 384
+    q = rng.standard_normal((64, d)).astype(np.float32)
+    c = rng.standard_normal((4096, d)).astype(np.float32)
+    q[0] *= np.float32(1e-38)
+    c[0] *= np.float32(1e-3)      # denormal products
+    q[1] *= np.float32(1e18)
+    c[1] *= np.float32(1e18)      # overflow
+    c[2] = q[2]
+    c[3] = -q[2]                  # cancellation
+    q[3, ::2] = 0.0
+    c[4, 1::2] = -0.0             # signed zeros
+    want = oracle.distance_matrix(q, c, metric, oracle.IMPL_ASM)
+    for nc in (4096, 4095):       # 16-byte stores, then the scalar store path (nc % 4 != 0)
+        got = distance.distance_batch(metric, torch.from_numpy(q).cuda(), torch.from_numpy(c[:nc].copy()).cuda())
+        torch.cuda.synchronize()
+        g = got.cpu().numpy()
+        w = want[:, :nc]
+        same = bits(g) == bits(w)
+        nan = np.isnan(g) & np.isnan(w)  # inf - inf: a NaN wherever the reference has one
+        assert (same | nan).all(), nc
