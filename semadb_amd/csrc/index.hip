@@ -168,7 +168,9 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // batch keeps them resident back to back (batch 16 384: 1.18 M QPS, 7.3 TB/s, against 0.88 M QPS on the
 // bitset variant at 16 waves per CU).
 bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
-  if (a.filt_off || a.prefer_bitset) return false;
+  // filtered searches too (round 3): their search set takes the same table, their result set a 4 KB one beside it
+  // (search_kernel.h kHashCapResult) -- no 2 x 128 MB bitset clear per batch, no HBM atomic per edge
+  if (a.prefer_bitset) return false;
   if (a.search_size > 96) return false;
   // quantized store: only with the small LUT of M*K <= 2048 entries next to the table (M = 32's 32 KB LUT leaves
   // room for three walks per CU beside the 16 KB table: 0.95 M QPS against 1.31 M on the bitset at five)
@@ -183,12 +185,15 @@ bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
 template <class Dist, uint32_t HCAP>
 static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, size_t lds) {
   const bool filt = a.filt_off != nullptr;
+  const size_t rwords = filt ? HashVisited<kHashCapResult>::kWords * sizeof(uint32_t) : 0;
   if constexpr (HCAP == kHash16) {
-    const size_t total = HashVisited16::kWords * sizeof(uint32_t) + lds;
-    hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, HCAP>), dim3(nq), dim3(64), total, stream, a);
+    const size_t total = HashVisited16::kWords * sizeof(uint32_t) + rwords + lds;
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true, HCAP>), dim3(nq), dim3(64), total, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, HCAP>), dim3(nq), dim3(64), total, stream, a);
   } else if constexpr (HCAP != 0) {
-    const size_t total = HashVisited<HCAP>::kWords * sizeof(uint32_t) + lds;
-    hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, HCAP>), dim3(nq), dim3(64), total, stream, a);
+    const size_t total = HashVisited<HCAP>::kWords * sizeof(uint32_t) + rwords + lds;
+    if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true, HCAP>), dim3(nq), dim3(64), total, stream, a);
+    else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, HCAP>), dim3(nq), dim3(64), total, stream, a);
   } else if (a.search_size <= 128) {
     if (filt) hipLaunchKernelGGL((k_greedy_search<Dist, 2, true, 0>), dim3(nq), dim3(64), lds, stream, a);
     else hipLaunchKernelGGL((k_greedy_search<Dist, 2, false, 0>), dim3(nq), dim3(64), lds, stream, a);

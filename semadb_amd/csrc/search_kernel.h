@@ -842,10 +842,19 @@ struct HashVisited16 {
   }
 };
 
-// greedySearch for one query by one wavefront.
-template <class Dist, int NREG, bool FILT, class Visited>
+// the unfiltered search has no result set of its own
+struct NoVisited {
+  __device__ __forceinline__ bool test_and_set(bool, uint32_t, int) { return false; }
+};
+// The filtered search's resultSet has a visited set of its own (search.go:37: NewDistSet(k, ...)): it sees the seeds
+// (<= searchSize ids) and the expanded nodes that pass the filter -- a few hundred ids at most, so a 1 024-entry table
+// (4 KB) next to the search set's; past 750 ids it spills to its HBM bitset like the big one does.
+constexpr uint32_t kHashCapResult = 1024;
+
+// greedySearch for one query by one wavefront.  RVis: the visited set of the filtered search's result set.
+template <class Dist, int NREG, bool FILT, class Visited, class RVis>
 __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist,
-                                            Visited &vis) {
+                                            Visited &vis, RVis &rvis) {
   uint32_t cid[NREG];
   float cd[NREG];
 #pragma unroll
@@ -860,13 +869,11 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
   float rd[FILT ? NREG : 1];
   int rlen = 0;
   const int rcap = (int)a.limit;
-  uint32_t *__restrict__ rbits = nullptr;
   const uint32_t *__restrict__ fsorted = nullptr;
   uint32_t nfilt = 0;
   if constexpr (FILT) {
 #pragma unroll
     for (int r = 0; r < NREG; r++) rid[r] = kNoSlot, rd[r] = 0.0f;
-    rbits = a.rbitsets + (size_t)q * a.words_per_query;
     fsorted = a.filt_slots + a.filt_off[q];
     nfilt = a.filt_off[q + 1] - a.filt_off[q];
     // seeds: the first <= searchSize filter ids in ascending id order that exist (:41-48)
@@ -891,11 +898,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         len++;
       }
       // resultSet.AddWithLimit(filterPoints...) (:50): its own CheckAndVisit, distances evaluated again
-      bool rnew = false;
-      if (has) {
-        const uint32_t bit = 1u << (slot & 31);
-        rnew = !(atomicOr(&rbits[slot >> 5], bit) & bit);
-      }
+      const bool rnew = rvis.test_and_set(has, slot, lane);
       const uint64_t rpend = __ballot(rnew);
       n_dist += (uint32_t)__popcll(rpend);
       add_with_limit_lanes(rid, rd, rlen, rcap, slot, mydist, rpend, lane);
@@ -1004,10 +1007,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     }
     if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
       if (filter_contains(fsorted, nfilt, pid, lane)) {
-        uint32_t old = 0;
-        if (lane == 0) old = atomicOr(&rbits[pid >> 5], 1u << (pid & 31));
-        old = rl(old, 0);
-        if (!(old & (1u << (pid & 31)))) {
+        const bool rnew = rvis.test_and_set(lane == 0, pid, lane);  // CheckAndVisit of the result set
+        if (__ballot(rnew)) {
           n_dist++;  // distFn is evaluated again by the reference; same inputs, same bits as pdist
           if (!(rlen == rcap && pdist > list_tail(rd, rcap))) list_insert(rid, rd, rlen, rcap, pid, pdist, lane);
         }
@@ -1079,20 +1080,44 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   Dist dist;
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
+  // dynamic LDS: [search set's hash table][filtered: result set's hash table][distance policy's tile / LUT / scratch]
+  constexpr uint32_t kRWords = FILT ? HashVisited<kHashCapResult>::kWords : 0;
   if constexpr (HCAP == kHash16) {
-    dist.init(a, q, lane, lds_f + HashVisited16::kWords);
+    dist.init(a, q, lane, lds_f + HashVisited16::kWords + kRWords);
     HashVisited16 hv;
     hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
-    search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
+    if constexpr (FILT) {
+      HashVisited<kHashCapResult> rv;
+      rv.init(reinterpret_cast<uint32_t *>(lds_f) + HashVisited16::kWords, a.rbitsets + (size_t)q * a.words_per_query,
+              a.words_per_query, lane, a.hash_limit);
+      search_body<Dist, NREG, FILT>(a, q, lane, dist, hv, rv);
+    } else {
+      NoVisited rv;
+      search_body<Dist, NREG, FILT>(a, q, lane, dist, hv, rv);
+    }
   } else if constexpr (HCAP != 0) {
-    dist.init(a, q, lane, lds_f + HashVisited<HCAP>::kWords);
+    dist.init(a, q, lane, lds_f + HashVisited<HCAP>::kWords + kRWords);
     HashVisited<HCAP> hv;
     hv.init(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
-    search_body<Dist, NREG, FILT>(a, q, lane, dist, hv);
+    if constexpr (FILT) {
+      HashVisited<kHashCapResult> rv;
+      rv.init(reinterpret_cast<uint32_t *>(lds_f) + HashVisited<HCAP>::kWords, a.rbitsets + (size_t)q * a.words_per_query,
+              a.words_per_query, lane, a.hash_limit);
+      search_body<Dist, NREG, FILT>(a, q, lane, dist, hv, rv);
+    } else {
+      NoVisited rv;
+      search_body<Dist, NREG, FILT>(a, q, lane, dist, hv, rv);
+    }
   } else {
     dist.init(a, q, lane, lds_f);
     BitVisited bv{bits};
-    search_body<Dist, NREG, FILT>(a, q, lane, dist, bv);
+    if constexpr (FILT) {
+      BitVisited rv{a.rbitsets + (size_t)q * a.words_per_query};
+      search_body<Dist, NREG, FILT>(a, q, lane, dist, bv, rv);
+    } else {
+      NoVisited rv;
+      search_body<Dist, NREG, FILT>(a, q, lane, dist, bv, rv);
+    }
   }
 }
 

@@ -331,7 +331,14 @@ class IndexVamana:
             raise SemaDBError(1, "query vector length must be %d" % self.parameters.VectorSize)
         nq = shape[0]
         f_off = f_ids = None
-        if filters is not None:
+        if isinstance(filters, tuple):  # (offsets [nq + 1], ascending ids) already in the ABI's form
+            f_off = np.ascontiguousarray(filters[0], dtype=np.uint64)
+            f_ids = np.ascontiguousarray(filters[1], dtype=np.uint64)
+            if f_off.size != nq + 1:
+                raise SemaDBError(1, "one filter per query expected")
+            if f_ids.size == 0:
+                f_ids = np.zeros(1, dtype=np.uint64)
+        elif filters is not None:
             if len(filters) != nq:
                 raise SemaDBError(1, "one filter per query expected")
             flat, off = [], [0]

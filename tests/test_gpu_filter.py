@@ -96,3 +96,33 @@ def test_filter_argument_errors(oracle):
                                            d.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), None, 0, None)
     assert rc != 0 and b"ascending" in _lib.lib().sdb_last_error()
     ix.close()
+
+
+def test_filtered_walk_is_the_same_under_every_visited_set(oracle):
+    """Round 3: filtered walks keep both visited sets (the search set's and the result set's, search.go:37) in LDS hash
+    tables.  Same answers, visit order and counters with the tables at their default size, with both forced to spill
+    to their HBM bitsets after a handful of ids, and on the bitsets from the start -- and all equal the oracle."""
+    rng = np.random.default_rng(2025)
+    d, n, L, k = 64, 2500, 60, 10
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ix = _gpu(o, d, "cosine", 32, 50)
+    nq = 16
+    q = unit_rows(rng, nq, d)
+    all_ids = np.arange(2, n + 2)
+    filters = [set(int(v) for v in rng.choice(all_ids, size=s, replace=False)) for s in
+               [3, 60, 61, 200, 1200, 2400, 10, 900] * 2]
+    runs = {}
+    for name, tune in [("hash", {}), ("spill", {"hash_limit": 24}), ("bitset", {"no_hash": 1})]:
+        for key, v in {"hash_limit": 0, "no_hash": 0, **tune}.items():
+            ix.set_tuning(key, v)
+        runs[name] = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+    for name, (g_ids, g_d, g_c, tr) in runs.items():
+        for i in range(nq):
+            o_ids, o_d, o_vis, o_tr = o.search(q[i], k, L, filter_ids=sorted(filters[i]))
+            assert int(g_c[i]) == len(o_ids), (name, i)
+            assert np.array_equal(g_ids[i, :len(o_ids)], o_ids), (name, i)
+            assert np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d)), (name, i)
+            assert int(tr.n_hop[i]) == o_tr.n_hop and int(tr.n_dist[i]) == o_tr.n_dist, (name, i)
+            assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), (name, i)
+    ix.close()

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Filtered search (search.go:33-51,93-95) at C2: 1M x 384 cosine, searchSize 75, batch 1024, filters of 10 / 1 000 /
+100 000 ids per query.  Reports the K2 kernel time (HIP events around the launch) and the whole call (which includes the
+host-side translation of the filter ids to slots -- filter arrays are host memory in the ABI, like the reference's
+roaring bitmap).  BENCH_TUNE=no_hash=1 gives the bitset variant of round 2 for comparison."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=1_000_000)
+ap.add_argument("--dim", type=int, default=384)
+ap.add_argument("--sizes", default="10,1000,100000")
+a0 = ap.parse_args()
+
+
+class A:
+    metric, search_size, degree_bound, alpha = "cosine", 75, 64, 1.2
+
+
+dev = "cuda:0"
+base = bench.gen_rows(a0.rows, a0.dim, 20250620, "latent:24", dev)
+queries = bench.gen_rows(4 * 1024, a0.dim, 20250621, "latent:24", dev).view(4, 1024, a0.dim)
+ix, build_s = bench.build_index(A, base, 0)
+out = {"rows": a0.rows, "dim": a0.dim, "build_s": round(build_s, 2), "tuning": os.environ.get("BENCH_TUNE", "")}
+rng = np.random.default_rng(3)
+ix.set_profiling(True)
+# unfiltered reference point
+for b in range(2):
+    ix.search_batch(queries[b], 10, 75)
+torch.cuda.synchronize()
+ix.profile_read()
+for b in range(4):
+    ix.search_batch(queries[b], 10, 75)
+torch.cuda.synchronize()
+out["unfiltered_kernel_ms"] = round(float(np.mean(ix.profile_read())), 4)
+for size in [int(x) for x in a0.sizes.split(",")]:
+    filt = [np.sort(rng.choice(a0.rows, size=size, replace=False).astype(np.uint64) + 2) for _ in range(1024)]
+    off = np.zeros(1025, dtype=np.uint64)
+    off[1:] = np.cumsum([len(f) for f in filt])
+    flat = np.concatenate(filt)
+    ix.search_batch(queries[0], 10, 75, filters=(off, flat))
+    torch.cuda.synchronize()
+    ix.profile_read()
+    t0 = time.perf_counter()
+    hits = 0
+    for b in range(1, 4):
+        ids, d, c, _ = ix.search_batch(queries[b], 10, 75, filters=(off, flat))
+        torch.cuda.synchronize()
+        hits += int(c.sum().item()) if hasattr(c, "sum") else 0
+    dt = (time.perf_counter() - t0) / 3
+    kms = float(np.mean(ix.profile_read()))
+    out["filter_%d" % size] = {"kernel_ms": round(kms, 4), "kernel_qps": round(1024 / kms * 1e3, 1),
+                               "call_ms": round(dt * 1e3, 2), "call_qps": round(1024 / dt, 1),
+                               "mean_results": round(hits / 3 / 1024, 2)}
+print(json.dumps(out, indent=1))
