@@ -7,15 +7,19 @@ One "step" = one batch of 1024 synthetic queries through the GPU-resident greedy
 (IndexVamana.Search semantics, searchSize 75, degreeBound 64, alpha 1.2, cosine, k = 10) with the
 index, the queries and the results in HBM.  Index = BASELINE configs[1] (C2).
 
-N > 1 (one rank per GPU, launched by torch.distributed.run), SURVEY 8e:
-  --mode shards   (default, the north-star mode) the SAME 1M rows split into N contiguous shards of 1M/N,
+N > 1 (one rank per GPU, launched by torch.distributed.run), SURVEY 8e.  The default (--mode all) measures the three
+modes below back to back and prints ONE line: value / ms_per_step / roofline are the primary mode's (shards, the
+north-star mode), the other two sit under config.modes with the same fields; config.exchange names the transport
+that carried the gather (RCCL inside libsemadb_amd.so, or the torch.distributed fallback) and config.ranks_seen the
+ranks whose blocks the merge saw.
+  --mode shards   (the north-star mode) the SAME 1M rows split into N contiguous shards of 1M/N,
                   one per GPU, each with its own graph; every shard answers every query; the per-shard
                   top-k blocks are exchanged with one RCCL all-gather issued by libsemadb_amd.so on its own
                   stream (sdb_cluster_search_batch) and merged with the reference's cluster rule
                   (cluster/actions.go:291-376).  value = merged, user-visible queries/s.  "strong".
   --mode replicas the full 1M index on every GPU, each batch split N ways, results gathered.  "strong".
-  --mode c5       C5's shape: a shard of --rows per GPU (the database grows with N), exchange as in
-                  `shards`.  value = merged queries/s.  "weak".
+  --mode c5       C5's shape: a shard of --c5-rows per GPU (12.5M: 100M over 8 GPUs; the database grows with N),
+                  exchange as in `shards`.  value = merged queries/s.  "weak".
 
 The JSON line also carries:
   roofline        algorithmic HBM bytes of the K2 kernel (n_dist*d*4 + n_edges*4 summed over the batch,
@@ -193,8 +197,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"])
-    ap.add_argument("--mode", default="shards", choices=["shards", "replicas", "c5"])
-    ap.add_argument("--rows", type=int, default=None, help="rows in the database (c5: per GPU)")
+    ap.add_argument("--mode", default="all", choices=["all", "shards", "replicas", "c5"])
+    ap.add_argument("--rows", type=int, default=None, help="rows in the database (--mode c5 alone: per GPU)")
+    ap.add_argument("--c5-rows", type=int, default=12_500_000, help="rows per GPU of the c5 mode inside --mode all")
+    ap.add_argument("--c4-rows", type=int, default=1_000_000, help="rows of the quantized point in the default line (0: skip)")
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
@@ -272,23 +278,51 @@ def main():
 # C2: the headline
 # ------------------------------------------------------------------------------------------------------------
 def run_c2(a, ctx):
+    """One line for the whole SURVEY 8e record: N = 1 -> the headline; N > 1 and --mode all -> shards (primary: value,
+    ms_per_step, roofline), then replicas and c5 under config.modes."""
+    world = ctx["world"]
+    ctx["ex"] = Exchange(ctx["backend"], ctx["dev"], ctx["dev_index"]) if ctx["use_dist"] else None
+    try:
+        if world == 1 or a.mode != "all":
+            return measure_mode(a, ctx, "shards" if (world == 1 or a.mode == "all") else a.mode, a.rows, primary=True)
+        res = measure_mode(a, ctx, "shards", a.rows, primary=True)
+        modes = {}
+        for m, rows in (("replicas", a.rows), ("c5", a.c5_rows)):
+            r = measure_mode(a, ctx, m, rows, primary=False)
+            cfg = r["config"]
+            modes[m] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],
+                        "workload": cfg["workload"], "parallelism": cfg["parallelism"], "dataset": cfg["dataset"],
+                        "recall_at_10": cfg["recall_at_10"], "build_s": cfg["build_s"], "mean_n_dist": cfg["mean_n_dist"],
+                        "exchange": cfg.get("exchange"), "ranks_seen": cfg.get("ranks_seen"),
+                        "per_shard_walk_qps": cfg.get("per_shard_walk_qps"), "roofline": r["roofline"]}
+            if r.get("invalid"):
+                modes[m]["invalid"] = r["invalid"]
+        res["config"]["primary_mode"] = "shards"
+        res["config"]["modes"] = modes
+        return res
+    finally:
+        if ctx["ex"] is not None:
+            ctx["ex"].close()
+
+
+def measure_mode(a, ctx, mode, rows, primary):
     from semadb_amd import flat
     rank, world, dev, dev_index = ctx["rank"], ctx["world"], ctx["dev"], ctx["dev_index"]
     use_dist, dist, barrier = ctx["use_dist"], ctx["dist"], ctx["barrier"]
     d, nq, k, L = a.dim, a.batch, a.k, a.search_size
-    mode = a.mode if world > 1 else "shards"
+    a_rows = rows
 
     # ---- data.  shards / replicas: ONE database of --rows rows (seed 20250620), identical on every rank;
     # c5: shard `rank` = --rows rows of its own (seed 20250620 + rank, SURVEY 8d per-shard offset)
     t0 = time.time()
     if mode == "c5":
-        base = gen_rows(a.rows, d, 20250620 + rank, a.dist, dev)
-        n_total = a.rows * world
+        base = gen_rows(a_rows, d, 20250620 + rank, a.dist, dev)
+        n_total = a_rows * world
     else:
-        full = gen_rows(a.rows, d, 20250620, a.dist, dev)
-        n_total = a.rows
+        full = gen_rows(a_rows, d, 20250620, a.dist, dev)
+        n_total = a_rows
         if mode == "shards" and world > 1:  # contiguous ranges, like the reference fills shards in order
-            lo, hi = rank * a.rows // world, (rank + 1) * a.rows // world
+            lo, hi = rank * a_rows // world, (rank + 1) * a_rows // world
             base = full[lo:hi].contiguous()
             del full
         else:
@@ -303,7 +337,7 @@ def run_c2(a, ctx):
     log("rank %d: data %.1fs, build %.2fs (%.0f inserts/s), avg degree %.2f" %
         (rank, t1 - t0, build_s, n / build_s, n_edges / n_nodes))
 
-    ex = Exchange(ctx["backend"], dev, dev_index) if use_dist else None
+    ex = ctx["ex"]
     split = mode == "replicas" and world > 1
     q_lo, q_hi = (rank * nq // world, (rank + 1) * nq // world) if split else (0, nq)
 
@@ -329,6 +363,7 @@ def run_c2(a, ctx):
 
     # ---- recall@10 against exact ground truth over the whole database, on the recall batches
     hits = total = 0
+    ranks_seen = set()
     for b in range(nb_recall):
         m_ids, m_d, m_sh, m_c = step(b)
         if ex is not None and not split:
@@ -349,6 +384,7 @@ def run_c2(a, ctx):
             sel = cs.topk(k, dim=1).indices
             truth = ci.gather(1, sel)
             got = m_ids.to(torch.int64) + (m_sh.to(torch.int64) << 40)
+            ranks_seen.update(int(v) for v in torch.unique(m_sh).tolist())
         else:
             truth = exact_topk(queries[b], base, k)[1] + 2
             got = m_ids.to(torch.int64)
@@ -484,7 +520,11 @@ def run_c2(a, ctx):
         },
         "build_roofline": broof,
     }
-    if ex is not None and world > 1 and not split:
+    if split:
+        result["config"]["exchange"] = "torch.distributed all_gather of the answers (%s); no merge" % ctx["backend"]
+        result["config"]["ranks_seen"] = list(range(world))
+    if ex is not None and not split:
+        result["config"]["ranks_seen"] = sorted(ranks_seen)
         result["config"]["exchange"] = ("libsemadb_amd.so: sdb_cluster_search_batch (ncclAllGather on the library's stream)"
                                         if ex.native else "torch.distributed all_gather_into_tensor (%s) + sdb_cluster_merge_gathered (tag check + merge)%s" %
                                         (ctx["backend"], "; " + ex.note if ex.note else ""))
@@ -500,7 +540,7 @@ def run_c2(a, ctx):
         except Exception:
             pass
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and primary:
         cfg = result["config"]
         # not the metric (one batch at a time): the same batches with two of them in flight on two streams, the way a
         # serving process (the host batcher) runs -- a second batch fills the SIMDs the first one's finished walks left
@@ -524,6 +564,9 @@ def run_c2(a, ctx):
         if not a.no_host_rates:
             try:
                 cfg.update(host_rates(a, ix, queries[nb_recall:], k, L, last))
+                # SURVEY 8d's protocol figure ("including H2D of queries and D2H of results") beside the headline
+                result["value_host"] = cfg["host_qps"]
+                result["value_host_definition"] = cfg["host_qps_definition"]
             except Exception as e:
                 cfg["host_rates_error"] = repr(e)
         if not a.no_cpu_baseline:
@@ -531,17 +574,92 @@ def run_c2(a, ctx):
                 result["cpu_baseline"] = cpu_baseline(a, ix, queries[:nb_recall], k, L)
             except Exception as e:  # never lose the GPU line to a host-side problem
                 result["cpu_baseline"] = {"error": repr(e)}
-    if ex is not None:
-        ex.close()
     ix.close()
     del base
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not a.no_secondary:
+    if rank == 0 and world == 1 and primary and not a.no_secondary:
         try:
             result["config"]["secondary_datasets"] = secondary_points(a, dev, dev_index)
         except Exception as e:
             result["config"]["secondary_datasets"] = {"error": repr(e)}
+        if a.c4_rows:
+            try:
+                result["config"]["c4"] = c4_point(a, dev, dev_index)
+            except Exception as e:
+                result["config"]["c4"] = {"error": repr(e)}
     return result
+
+
+def c4_point(a, dev, dev_index):
+    """BASELINE configs[3] (vectorVamana + product quantizer, d = 768, K = 256) inside the default line, at --c4-rows
+    rows (1M by default so that the driver's run stays short; `--config c4` is the full 10M x 768 run).  Per M: whole-call
+    QPS (LUT build + walk), kernel QPS, recall@10 without re-ranking (like the reference), SURVEY 8d's K5 bytes
+    (n_dist * M code bytes + edge ids) over the kernel time."""
+    from semadb_amd import vectorstore as vs
+    d, n, nq, k, L = 768, a.c4_rows, a.batch, a.k, a.search_size
+    base = gen_rows(n, d, 20250620, a.dist, dev)
+    nbq = 6
+    queries = gen_rows(nbq * nq, d, 20250621, a.dist, dev).view(nbq, nq, d)
+
+    class P:
+        metric, search_size, degree_bound, alpha = a.metric, a.search_size, a.degree_bound, a.alpha
+    ix, build_s = build_index(P, base, dev_index, name="c4")
+    truth = torch.cat([exact_topk(queries[b], base, k)[1] + 2 for b in range(nbq)])
+    ix.set_profiling(True)
+
+    def measure():
+        for b in range(2):
+            ix.search_batch(queries[b], k, L)
+        torch.cuda.synchronize()
+        ix.profile_read()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(3):
+            for b in range(nbq):
+                ix.search_batch(queries[b], k, L)
+        e1.record()
+        torch.cuda.synchronize()
+        call_ms = e0.elapsed_time(e1) / (3 * nbq)
+        kms = float(np.mean(ix.profile_read()))
+        hits = nd = ne = 0
+        for b in range(nbq):
+            ids, _, _, tr = ix.search_batch(queries[b], k, L, trace=True)
+            hits += int((ids.to(torch.int64).unsqueeze(2) == truth[b * nq:(b + 1) * nq].unsqueeze(1)).any(2).sum().item())
+            nd += int(tr.n_dist.to(torch.int64).sum().item())
+            ne += int(tr.n_edges.to(torch.int64).sum().item())
+        return {"call_qps": round(nq / call_ms * 1e3, 1), "call_ms": round(call_ms, 4), "kernel_ms": round(kms, 4),
+                "kernel_qps": round(nq / kms * 1e3, 1), "recall_at_10": round(hits / (nbq * nq * k), 4),
+                "n_dist_per_batch": nd / nbq, "n_edges_per_batch": ne / nbq}
+
+    out = {"workload": "vectorVamana + product quantizer %dx%d %s, K=256, searchSize=%d degreeBound=%d, batch=%d" %
+                       (n, d, a.metric, L, a.degree_bound, nq), "build_s": round(build_s, 2),
+           "recall_note": "no re-ranking, like the reference (product.go:238-277): recall is the quantizer's"}
+    full = measure()
+    full["GB/s"] = round((full["n_dist_per_batch"] * d * 4 + full["n_edges_per_batch"] * 4) / full["kernel_ms"] / 1e6, 1)
+    out["full_precision"] = full
+    keep = []
+    for M in [int(x) for x in a.pq_m.split(",")]:
+        if d % M:
+            continue
+        train_n = min(10000, n)
+        train = base[:train_n].cpu().numpy().copy()
+        pq = vs.ProductQuantizer(a.metric, vs.ProductQuantizerParameters(256, M, train_n), d, device=dev_index)
+        pq.Fit(train, np.arange(M) * 7 % train_n, alias=True)
+        vs.attach(ix, pq)
+        m = measure()
+        alg = m["n_dist_per_batch"] * M + m["n_edges_per_batch"] * 4
+        m["roofline"] = {"bound": "hbm", "kernel": "k_greedy_search<PQDist>", "achieved": round(alg / m["kernel_ms"] / 1e6, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / m["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                         "traffic": None}
+        out["M=%d" % M] = m
+        log("c4 point M=%d: %s" % (M, json.dumps(m)))
+        keep.append(pq)
+    ix.close()
+    for pq in keep:
+        pq.close()
+    del base
+    torch.cuda.empty_cache()
+    return out
 
 
 def host_rates(a, ix, queries, k, L, last_device_result):
@@ -574,16 +692,20 @@ def host_rates(a, ix, queries, k, L, last_device_result):
     hb.sdb_hostbench_batcher.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
-                                         C.POINTER(C.c_uint64)]
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     flat_q = np.ascontiguousarray(q_np.reshape(nb * nq, d))
     first_ids = np.zeros((nb * nq, k), dtype=np.uint64)
     first_c = np.zeros(nb * nq, dtype=np.uint32)
     threads, depth, workers = 64, 48, 2
     qps, batches, served = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    p50, p99 = C.c_double(0), C.c_double(0)
     rc = hb.sdb_hostbench_batcher(ix._h, d, flat_q.ctypes.data, nb * nq, k, L, threads, depth, nq, 300, workers, 2.0,
                                   first_ids.ctypes.data, first_c.ctypes.data, C.byref(qps), C.byref(batches),
-                                  C.byref(served))
+                                  C.byref(served), C.byref(p50), C.byref(p99))
     out["batcher_qps"] = round(qps.value, 1)
+    out["batcher_vs_host"] = round(qps.value / out["host_qps"], 3)
+    out["batcher_latency_us"] = {"p50": round(p50.value, 1), "p99": round(p99.value, 1),
+                                 "note": "per request, submit -> answered, at %d requests outstanding" % (threads * depth)}
     out["batcher_definition"] = "%d submitting threads x %d single-query Search requests outstanding each (a Go server's " \
                                 "request goroutines), coalesced by semadb_host.hpp SearchBatcher into host-memory " \
                                 "batches of <= %d, %d batches in flight; mean device batch %.0f queries; rc %d" % (

@@ -63,6 +63,11 @@ const char *sdb_last_error(void);
 int sdb_abi_version(void);
 /* number of visible MI355X devices; SDB_ERR_DEVICE if the HIP runtime finds none */
 int sdb_device_count(int *count);
+/* Page-locked host memory for SDB_MEM_HOST buffers a host re-uses call after call (a batcher's query and result
+ * slabs): copies to and from it are single DMAs and truly asynchronous, where pageable memory (a Go slice) is staged
+ * through the driver.  Plain pageable buffers keep working everywhere; this is an optimisation, not a requirement. */
+int sdb_host_alloc(size_t bytes, void **out);
+int sdb_host_free(void *p);
 
 /* ---------------------------------------------------------------------------------------------
  * distance/  (K1)

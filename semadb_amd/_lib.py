@@ -37,6 +37,8 @@ SIGNATURES = {
     "sdb_last_error": (C.c_char_p, []),
     "sdb_abi_version": (C.c_int, []),
     "sdb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sdb_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "sdb_host_free": (C.c_int, [C.c_void_p]),
     "sdb_distance_batch": (C.c_int, [C.c_int, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sdb_index_create": (C.c_int, [C.POINTER(IndexParams), C.POINTER(C.c_void_p)]),

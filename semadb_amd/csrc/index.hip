@@ -527,6 +527,19 @@ int sdb_device_count(int *count) {
   return SDB_OK;
 }
 
+int sdb_host_alloc(size_t bytes, void **out) {
+  if (!out) return fail(SDB_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return SDB_OK;
+  SDB_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return SDB_OK;
+}
+
+int sdb_host_free(void *p) {
+  if (p) SDB_HIP(hipHostFree(p));
+  return SDB_OK;
+}
+
 int sdb_index_create(const sdb_index_params *p, sdb_index **out) {
   if (!p || !out) return fail(SDB_ERR_INVALID, "NULL argument");
   *out = nullptr;

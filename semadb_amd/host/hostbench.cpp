@@ -3,6 +3,7 @@
 // through the micro-batcher of semadb_host.hpp into sdb_index_search_batch with SDB_MEM_HOST buffers.  This is
 // the SURVEY 8d "wall time including H2D of queries and D2H of results" rate of the drop-in as a Go host would
 // drive it.  Built into libsemadb_hostbench.so; bench.py calls it on the index it has just built.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -18,13 +19,18 @@ extern "C" {
 int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint64_t n_queries, uint32_t limit,
                           uint32_t search_size, uint32_t threads, uint32_t depth, uint32_t max_batch,
                           uint32_t window_us, uint32_t workers, double seconds, uint64_t *first_ids,
-                          uint32_t *first_counts, double *qps, uint64_t *device_batches, uint64_t *served) {
+                          uint32_t *first_counts, double *qps, uint64_t *device_batches, uint64_t *served,
+                          double *lat_p50_us, double *lat_p99_us) {
   using namespace semadb;
   if (!h || !queries || !n_queries || !threads || !depth || !qps) return 1;
   SearchBatcher batcher(h, dim, max_batch, std::chrono::microseconds(window_us), workers);
   std::atomic<uint64_t> next{0}, completed{0}, errors{0};
   std::atomic<bool> stop{false};
+  std::mutex lat_mu;
+  std::vector<uint32_t> lat_all;  // per-request time inside the batcher (submit -> answered), microseconds
   auto worker = [&](unsigned) {
+    std::vector<uint32_t> lat;
+    lat.reserve(1 << 16);
     SearchBatcher::Client client;
     std::vector<SearchBatcher::Request> reqs(depth);
     std::vector<uint64_t> qidx(depth);
@@ -51,6 +57,7 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
         SearchBatcher::Request &r = reqs[s];
         if (r.client && r.done.load(std::memory_order_acquire)) {
           if (r.err) errors++;
+          if (lat.size() < (1u << 20)) lat.push_back((uint32_t)std::min<int64_t>((r.t_done_ns - r.t_submit_ns) / 1000, 0xFFFFFFFFll));
           if (qidx[s] < n_queries && first_ids) {  // first pass over the query set: keep the answer
             for (uint32_t i = 0; i < limit; i++) first_ids[qidx[s] * limit + i] = i < r.count ? r.ids[i] : 0;
             if (first_counts) first_counts[qidx[s]] = r.count;
@@ -66,6 +73,11 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
     // while its wake-up is still on its way.  The client (a stack object) may only go away once every wake-up has
     // been delivered, i.e. once the count under the lock has reached what was submitted.
     SearchBatcher::waitFor(&client, submitted);
+    {
+      std::lock_guard<std::mutex> g(client.mu);  // a worker may still be inside its notify
+    }
+    std::lock_guard<std::mutex> g(lat_mu);
+    lat_all.insert(lat_all.end(), lat.begin(), lat.end());
   };
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> pool;
@@ -82,6 +94,11 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
   stop = true;
   for (auto &t : pool) t.join();
   *qps = (double)done_at_stop / el;
+  if (!lat_all.empty()) {
+    std::sort(lat_all.begin(), lat_all.end());
+    if (lat_p50_us) *lat_p50_us = lat_all[lat_all.size() / 2];
+    if (lat_p99_us) *lat_p99_us = lat_all[(size_t)((double)lat_all.size() * 0.99)];
+  }
   if (device_batches) *device_batches = batcher.deviceBatches();
   if (served) *served = batcher.queriesServed();
   return errors.load() ? 2 : 0;

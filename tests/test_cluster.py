@@ -157,7 +157,7 @@ def test_topk_merge_with_repeated_items(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["shards", "replicas"])
+@pytest.mark.parametrize("mode", ["all", "shards", "replicas"])
 def test_bench_two_ranks_over_gloo(mode, tmp_path):
     """bench.py --gpus 2 end to end with two ranks sharing this GPU (BENCH_BACKEND=gloo; RCCL refuses two ranks on
     one device): the N > 1 modes of SURVEY 8e produce a valid line whose merged answers recall the exact top-k of
@@ -169,16 +169,24 @@ def test_bench_two_ranks_over_gloo(mode, tmp_path):
     env = dict(os.environ, BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--rows", "120000", "--mode", mode, "--recall-batches", "3", "--timed-batches", "4"]
+           "--warmup", "2", "--rows", "120000", "--mode", mode, "--recall-batches", "3", "--timed-batches", "4",
+           "--c5-rows", "60000"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["mode"] == mode
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["mode"] == ("shards" if mode == "all" else mode)
     assert j["config"]["recall_at_10"] >= 0.95 and "invalid" not in j
     assert abs(j["value"] - 1024 * j["steps"] / (j["ms_per_step"] * j["steps"] * 1e-3)) / j["value"] < 1e-3
-    if mode == "shards":
+    if mode != "replicas":
         assert j["config"]["per_shard_walk_qps"] == pytest.approx(2 * j["value"], rel=1e-3)
+        assert j["config"]["ranks_seen"] == [0, 1] and "tag check" in j["config"]["exchange"]
+    if mode == "all":  # the whole SURVEY 8e record in one line: shards (primary) + replicas + c5
+        assert j["config"]["primary_mode"] == "shards" and sorted(j["config"]["modes"]) == ["c5", "replicas"]
+        rep, c5 = j["config"]["modes"]["replicas"], j["config"]["modes"]["c5"]
+        assert rep["recall_at_10"] >= 0.95 and rep["value"] > 0 and rep["scaling"] == "strong"
+        assert c5["recall_at_10"] >= 0.95 and c5["value"] > 0 and c5["scaling"] == "weak" and c5["ranks_seen"] == [0, 1]
+        assert "120000 rows in all" in c5["workload"] and "2 shard(s) x 60000" in c5["workload"]
 
 
 def _gloo_exchange_worker(rank, world, port, q):

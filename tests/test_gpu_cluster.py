@@ -135,14 +135,15 @@ def test_host_batcher_answers_equal_direct_calls():
     hb.sdb_hostbench_batcher.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
-                                         C.POINTER(C.c_uint64)]
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     nq, d, k = q.shape[0], q.shape[1], 10
     first_ids = np.zeros((nq, k), dtype=np.uint64)
     first_c = np.zeros(nq, dtype=np.uint32)
     qps, nb, served = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    p50, p99 = C.c_double(0), C.c_double(0)
     rc = hb.sdb_hostbench_batcher(ix._h, d, q.ctypes.data, nq, k, 50, 16, 8, 64, 500, 2, 0.3, first_ids.ctypes.data,
-                                  first_c.ctypes.data, C.byref(qps), C.byref(nb), C.byref(served))
-    assert rc == 0 and qps.value > 0 and served.value >= nq
+                                  first_c.ctypes.data, C.byref(qps), C.byref(nb), C.byref(served), C.byref(p50), C.byref(p99))
+    assert rc == 0 and qps.value > 0 and served.value >= nq and 0 < p50.value <= p99.value
     assert served.value / nb.value > 4, "requests were not coalesced"
     want_ids, _, want_c, _ = ix.search_batch(q, k, 50)
     assert np.array_equal(first_c, want_c) and np.array_equal(first_ids, want_ids)
