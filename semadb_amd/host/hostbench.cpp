@@ -23,6 +23,19 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
                           double *lat_p50_us, double *lat_p99_us) {
   using namespace semadb;
   if (!h || !queries || !n_queries || !threads || !depth || !qps) return 1;
+  // a Go server runs GOMAXPROCS = cores OS threads however many request goroutines it has: the same number of
+  // outstanding requests on at most one submitting thread per core
+  {
+    unsigned cores = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // a container's quota, not the host's core count
+      long long quota = 0, period = 0;
+      if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+        cores = std::min<unsigned>(cores, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+      std::fclose(f);
+    }
+    const uint64_t outstanding = (uint64_t)threads * depth;
+    if (threads > cores) threads = cores, depth = (uint32_t)((outstanding + threads - 1) / threads);
+  }
   SearchBatcher batcher(h, dim, max_batch, std::chrono::microseconds(window_us), workers);
   std::atomic<uint64_t> next{0}, completed{0}, errors{0};
   std::atomic<bool> stop{false};
@@ -73,9 +86,6 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
     // while its wake-up is still on its way.  The client (a stack object) may only go away once every wake-up has
     // been delivered, i.e. once the count under the lock has reached what was submitted.
     SearchBatcher::waitFor(&client, submitted);
-    {
-      std::lock_guard<std::mutex> g(client.mu);  // a worker may still be inside its notify
-    }
     std::lock_guard<std::mutex> g(lat_mu);
     lat_all.insert(lat_all.end(), lat.begin(), lat.end());
   };

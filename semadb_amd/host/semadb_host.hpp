@@ -244,12 +244,13 @@ inline Error GetFloatDistanceFn(const std::string &name, FloatDistFunc *out, int
 // What a request costs on the host, in the order it happens (round 3; the first version took one mutex and one
 // condition variable per request, re-gathered the query vectors into a fresh pageable buffer per batch, and moved
 // between 0.65 and 1.19 M queries/s from box to box):
-//   submit    a spin-lock held for a few instructions reserves slot i of the batch that is filling; the query
-//             vector is then copied -- outside the lock, by the submitting thread, 64 of them at once -- straight into
-//             that batch's PINNED slab (sdb_host_alloc), from which the device call's H2D copy is one DMA.
-//   seal      the submit that takes the last slot hands the batch to the workers; a batch that does not fill within
-//             `window` is sealed by a worker's timed wait.  Unfiltered requests of one (limit, searchSize) share
-//             batches; filtered ones go through a queue of their own (they carry id sets, not just a vector).
+//   submit    ONE atomic add reserves slot i of the batch that is filling -- no lock; the query vector is then
+//             copied by the submitting thread, all of them at once, straight into that batch's PINNED slab
+//             (sdb_host_alloc), from which the device call's H2D copy is one DMA.
+//   seal      the submit that takes the last slot hands the batch to the workers (the only lock of the fast path, once
+//             per batch); a batch that does not fill within `window` is sealed by a worker's timed wait.  Unfiltered
+//             requests with the prevailing (limit, searchSize) take this path; filtered ones (they carry id sets) and
+//             other parameters go through a queue that a worker groups.
 //   run       the worker waits until every reserved slot has been written, calls the device, scatters the answers
 //             from its pinned result slabs and adds to each submitting client's counter of finished requests.
 //   wake      a client polls its counter for a moment before it sleeps; only a client that is actually asleep costs
@@ -258,8 +259,8 @@ class SearchBatcher {
  public:
   using Filter = std::set<uint64_t>;  // roaring64.Bitmap: ascending iteration, Contains
   struct Client {
-    std::atomic<uint64_t> completed{0};  // requests of this client finished so far
-    std::atomic<bool> sleeping{false};
+    std::atomic<uint64_t> completed{0};  // requests of this client finished so far (written inside mu)
+    bool sleeping = false;               // inside mu
     std::mutex mu;
     std::condition_variable cv;
   };
@@ -282,7 +283,7 @@ class SearchBatcher {
       : h_(h), dim_(dim), max_batch_(max_batch ? max_batch : 1), window_(window) {
     workers = workers ? workers : 1;
     for (unsigned i = 0; i < workers + 2; i++) free_.push_back(newBatch());
-    cur_ = takeFree();
+    cur_.store(takeFree());
     for (unsigned i = 0; i < workers; i++) threads_.emplace_back([this] { loop(); });
   }
   ~SearchBatcher() {
@@ -301,12 +302,11 @@ class SearchBatcher {
   SearchBatcher(const SearchBatcher &) = delete;
   SearchBatcher &operator=(const SearchBatcher &) = delete;
 
+  // call before the first submit (the slabs were sized at construction; a smaller batch just uses less of them)
   void configure(size_t max_batch, std::chrono::microseconds window) {
     std::lock_guard<std::mutex> g(qmu_);
-    lockSpin();
-    if (max_batch && max_batch <= cap_) max_batch_ = max_batch;  // the slabs were sized at construction
+    if (max_batch && max_batch <= cap_) max_batch_ = max_batch;
     window_ = window;
-    unlockSpin();
   }
   uint64_t deviceBatches() const { return n_batches_.load(); }
   uint64_t queriesServed() const { return n_queries_.load(); }
@@ -314,65 +314,68 @@ class SearchBatcher {
   // enqueue; the request (and what it points to) must stay alive until r->done
   void submit(Request *r) {
     r->t_submit_ns = nowNs();
-    if (r->filter) {  // rare path: its own queue, batched by the worker
-      std::lock_guard<std::mutex> g(qmu_);
-      filtered_.push_back(r);
-      qcv_.notify_one();
-      return;
-    }
-    for (;;) {
-      lockSpin();
-      Batch *b = cur_;
-      if (b && (b->n == 0 || (b->limit == r->limit && b->search_size == r->search_size)) && b->n < max_batch_) {
-        const uint32_t i = b->n++;
-        if (i == 0) b->limit = r->limit, b->search_size = r->search_size, b->t_first_ns = r->t_submit_ns;
-        b->reqs[i] = r;
-        const bool full = b->n == max_batch_;
-        if (full) cur_ = nullptr;  // sealed: nobody else reserves in it
-        unlockSpin();
-        std::memcpy(b->queries + (size_t)i * dim_, r->vector, (size_t)dim_ * 4);  // into the pinned slab, unlocked
-        b->written.fetch_add(1, std::memory_order_release);
-        if (full || i == 0) {  // a worker takes the full batch / starts the window of a fresh one
-          std::lock_guard<std::mutex> g(qmu_);
-          if (full) sealed_.push_back(b);
-          qcv_.notify_one();
-        }
-        return;
-      }
-      // the filling batch is full, sealed or of another (limit, searchSize): rotate under the queue lock
-      unlockSpin();
-      std::unique_lock<std::mutex> lk(qmu_);
-      lockSpin();
-      if (cur_ && cur_->n && !(cur_->limit == r->limit && cur_->search_size == r->search_size) && cur_->n < max_batch_) {
-        sealed_.push_back(cur_);  // another group's partial batch goes out as it is
-        cur_ = nullptr;
-        qcv_.notify_one();
-      }
-      if (!cur_) {
-        unlockSpin();
-        fcv_.wait(lk, [&] { return !free_.empty() || stop_; });  // back-pressure: every slab is in use
+    const uint64_t key = ((uint64_t)r->limit << 32) | r->search_size;
+    while (!r->filter) {
+      Batch *b = cur_.load(std::memory_order_acquire);
+      if (!b) {  // every slab is in use (back-pressure) or a rotation is under way
+        std::unique_lock<std::mutex> lk(qmu_);
+        fcv_.wait(lk, [&] { return cur_.load(std::memory_order_acquire) != nullptr || stop_; });
         if (stop_) {
+          lk.unlock();
           r->err = Error("batcher stopped");
-          finish(r);
+          tell(finish(r), 1);
           return;
         }
-        lockSpin();
-        if (!cur_) cur_ = takeFree();
+        continue;
       }
-      unlockSpin();
+      if (b->key != key) break;  // other parameters than the filling batch's: the queue
+      // one atomic reserves slot i of the batch that is filling; no lock on this path
+      const uint32_t i = b->n.fetch_add(1, std::memory_order_acq_rel);
+      if (i >= max_batch_) {  // full or sealed: whoever filled / sealed it is installing the next one
+        while (cur_.load(std::memory_order_acquire) == b) std::this_thread::yield();
+        continue;
+      }
+      if (i == 0) b->t_first_ns.store(r->t_submit_ns, std::memory_order_relaxed);
+      b->reqs[i] = r;
+      std::memcpy(b->queries + (size_t)i * dim_, r->vector, (size_t)dim_ * 4);  // into the pinned slab
+      b->written.fetch_add(1, std::memory_order_release);
+      if (i + 1 == max_batch_) {  // the submit that takes the last slot hands the batch on
+        std::lock_guard<std::mutex> g(qmu_);
+        rotateLocked(b, (uint32_t)max_batch_);
+      } else if (i == 0) {
+        qcv_.notify_one();  // a worker starts this batch's window
+      }
+      return;
     }
+    // filtered requests (they carry id sets) and requests whose (limit, searchSize) differ from the filling batch's:
+    // a worker groups them.  When the unfiltered traffic has moved to other parameters the fast path follows it.
+    std::lock_guard<std::mutex> g(qmu_);
+    queued_.push_back(r);
+    if (!r->filter && (fast_key_ == 0 || ++other_streak_ > 4 * max_batch_)) {
+      fast_key_ = key, other_streak_ = 0;
+      Batch *b = cur_.load(std::memory_order_acquire);
+      if (b && b->key != key) {
+        const uint32_t got = b->n.fetch_add((uint32_t)max_batch_, std::memory_order_acq_rel);
+        if (got < max_batch_) rotateLocked(b, got);  // else: the submit that filled it is rotating
+      }
+    }
+    qcv_.notify_one();
   }
   // block the client until at least `target` of its requests have completed.  A Client must outlive its wake-ups:
   // before it is destroyed, wait for the count of everything it submitted (Request::done alone is raised earlier)
   static void waitFor(Client *c, uint64_t target) {
     for (int spin = 0; spin < 200; spin++) {  // ~a batch period of polling before paying for a futex sleep
-      if (c->completed.load(std::memory_order_acquire) >= target) return;
+      if (c->completed.load(std::memory_order_acquire) >= target) {
+        // the worker adds to the count inside c->mu: passing through it once means the worker has let go of `c`
+        std::lock_guard<std::mutex> g(c->mu);
+        return;
+      }
       std::this_thread::yield();
     }
     std::unique_lock<std::mutex> lk(c->mu);
-    c->sleeping.store(true, std::memory_order_seq_cst);
+    c->sleeping = true;
     c->cv.wait(lk, [&] { return c->completed.load(std::memory_order_acquire) >= target; });
-    c->sleeping.store(false, std::memory_order_relaxed);
+    c->sleeping = false;
   }
   // the synchronous form IndexVamana.Search uses
   void run(Request *r) {
@@ -380,30 +383,31 @@ class SearchBatcher {
     r->client = &c;
     submit(r);
     waitFor(&c, 1);
-    std::lock_guard<std::mutex> g(c.mu);  // the worker may still be inside its notify: leave only after it
   }
 
  private:
   struct Batch {
     float *queries = nullptr;  // pinned [cap][dim]
     std::vector<Request *> reqs;
-    uint32_t n = 0;                      // slots reserved (under the spin lock)
+    std::atomic<uint32_t> n{0};          // slots reserved; >= max_batch: full or sealed
     std::atomic<uint32_t> written{0};    // slots whose vector has been copied in
-    uint32_t limit = 0, search_size = 0;
-    int64_t t_first_ns = 0;
+    uint32_t count = 0;                  // slots that belong to the batch once it is sealed
+    uint64_t key = 0;                    // (limit << 32 | searchSize) of every request in it; set when installed
+    std::atomic<int64_t> t_first_ns{0};
   };
+  // `b` is full (count = max_batch) or was sealed (count = what had been reserved): queue it for the workers and
+  // install a fresh slab as the filling batch -- or none, if all are in use: submitters then wait.  qmu_ held.
+  void rotateLocked(Batch *b, uint32_t count) {
+    b->count = count;
+    if (count == max_batch_) other_streak_ = 0;  // the prevailing parameters are alive
+    if (count) sealed_.push_back(b);
+    else free_.push_back(b);
+    cur_.store(takeFree(), std::memory_order_release);
+    qcv_.notify_one();
+    fcv_.notify_all();
+  }
   static int64_t nowNs() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  }
-  void lockSpin() {
-    while (spin_.test_and_set(std::memory_order_acquire))
-      while (spin_flag_.load(std::memory_order_relaxed)) {
-      }
-    spin_flag_.store(true, std::memory_order_relaxed);
-  }
-  void unlockSpin() {
-    spin_flag_.store(false, std::memory_order_relaxed);
-    spin_.clear(std::memory_order_release);
   }
   Batch *newBatch() {
     Batch *b = new Batch();
@@ -419,21 +423,42 @@ class SearchBatcher {
     if (free_.empty()) return nullptr;
     Batch *b = free_.back();
     free_.pop_back();
-    b->n = 0;
     b->written.store(0, std::memory_order_relaxed);
+    b->t_first_ns.store(0, std::memory_order_relaxed);
+    b->count = 0;
+    b->key = fast_key_;
+    b->n.store(0, std::memory_order_release);
     return b;
   }
-  void finish(Request *r) {
+  // a request is answered: `r` may be gone as soon as its client has been told (tell()), so the client is returned
+  Client *finish(Request *r) {
     Client *c = r->client;
     r->t_done_ns = nowNs();
     r->done.store(true, std::memory_order_release);
-    if (!c) return;
-    c->completed.fetch_add(1, std::memory_order_release);
-    if (c->sleeping.load(std::memory_order_seq_cst)) {
-      std::lock_guard<std::mutex> g(c->mu);
-      c->cv.notify_all();
-    }
+    return c;
   }
+  // `k` more requests of client `c` are done: one short critical section per client and batch; the futex call only
+  // for a client that is asleep
+  static void tell(Client *c, uint64_t k) {
+    if (!c) return;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->completed.fetch_add(k, std::memory_order_release);
+    if (c->sleeping) c->cv.notify_all();
+  }
+  struct Told {  // (client, finished requests) pairs of one device batch
+    std::vector<std::pair<Client *, uint64_t>> v;
+    void add(Client *c) {
+      for (auto &w : v)
+        if (w.first == c) {
+          w.second++;
+          return;
+        }
+      v.emplace_back(c, 1);
+    }
+    ~Told() {
+      for (auto &w : v) tell(w.first, w.second);
+    }
+  };
 
   void loop() {
     // this worker's pinned result slabs, for the largest limit the API allows (models/search.go:287-297)
@@ -444,7 +469,7 @@ class SearchBatcher {
     sdb_host_alloc(cap_ * 4, &p_c);
     for (;;) {
       Batch *b = nullptr;
-      std::vector<Request *> filt;
+      std::vector<Request *> others;
       {
         std::unique_lock<std::mutex> lk(qmu_);
         for (;;) {
@@ -453,47 +478,44 @@ class SearchBatcher {
             sealed_.pop_front();
             break;
           }
-          if (!filtered_.empty()) {
-            filt.swap(filtered_);
+          if (!queued_.empty()) {
+            others.swap(queued_);
             break;
           }
-          // a partial batch whose first request has waited `window`: seal it
-          lockSpin();
-          Batch *c = cur_;
-          const bool some = c && c->n > 0;
-          const int64_t age = some ? nowNs() - c->t_first_ns : 0;
-          if (some && (age >= window_.count() * 1000 || stop_)) {
-            cur_ = takeFree();
-            unlockSpin();
-            b = c;
-            break;
+          // a partial batch whose first request has waited `window`: seal it.  Adding max_batch to its slot counter
+          // closes it (later reservations see a full batch); what the counter held before is what belongs to it.
+          Batch *c = cur_.load(std::memory_order_acquire);
+          const int64_t first = c ? c->t_first_ns.load(std::memory_order_relaxed) : 0;
+          const int64_t age = first ? nowNs() - first : 0;
+          if (c && first && (age >= window_.count() * 1000 || stop_)) {
+            const uint32_t got = c->n.fetch_add((uint32_t)max_batch_, std::memory_order_acq_rel);
+            if (got < max_batch_) rotateLocked(c, got);  // ours to seal (otherwise the submit that filled it is rotating)
+            else lk.unlock(), std::this_thread::yield(), lk.lock();
+            continue;
           }
-          unlockSpin();
           if (stop_) {
             lk.unlock();
             sdb_host_free(p_ids), sdb_host_free(p_d), sdb_host_free(p_c);
             return;
           }
-          if (some) qcv_.wait_for(lk, std::chrono::nanoseconds(window_.count() * 1000 - age));
-          else qcv_.wait(lk);
+          if (c && first) qcv_.wait_for(lk, std::chrono::nanoseconds(window_.count() * 1000 - age));
+          else qcv_.wait_for(lk, std::chrono::milliseconds(2));
         }
       }
       if (b) {
         runBatch(b, (uint64_t *)p_ids, (float *)p_d, (uint32_t *)p_c);
         std::lock_guard<std::mutex> g(qmu_);
         free_.push_back(b);
-        lockSpin();
-        if (!cur_) cur_ = takeFree();
-        unlockSpin();
+        if (!cur_.load(std::memory_order_acquire)) cur_.store(takeFree(), std::memory_order_release);
         fcv_.notify_all();
-      } else if (!filt.empty()) {
-        runFiltered(filt);
+      } else if (!others.empty()) {
+        runQueued(others);
       }
     }
   }
 
   void runBatch(Batch *b, uint64_t *ids, float *dists, uint32_t *counts) {
-    const uint32_t nq = b->n, limit = b->limit, L = b->search_size;
+    const uint32_t nq = b->count, limit = (uint32_t)(b->key >> 32), L = (uint32_t)b->key;
     while (b->written.load(std::memory_order_acquire) < nq) std::this_thread::yield();  // the last copies in flight
     int rc;
     if (limit > 128) rc = SDB_ERR_INVALID;
@@ -501,6 +523,7 @@ class SearchBatcher {
     n_batches_++;
     n_queries_ += nq;
     const Error err = rc ? Error(std::string(sdb_last_error())) : Error();
+    Told told;
     for (uint32_t i = 0; i < nq; i++) {
       Request *r = b->reqs[i];
       if (!rc) {
@@ -510,17 +533,23 @@ class SearchBatcher {
       } else {
         r->err = err;
       }
-      finish(r);  // `r` may be gone once its client has been told
+      told.add(finish(r));
     }
   }
 
-  // filtered requests: one device call per (limit, searchSize) group, filters flattened in ascending order like roaring
-  void runFiltered(std::vector<Request *> &all) {
+  // queued requests: one device call per (limit, searchSize, filtered) group, filters flattened in ascending order
+  // like roaring
+  void runQueued(std::vector<Request *> &all) {
     while (!all.empty()) {
       std::vector<Request *> reqs, rest;
       for (Request *r : all)
-        (reqs.size() < max_batch_ && r->limit == all[0]->limit && r->search_size == all[0]->search_size ? reqs : rest).push_back(r);
+        (reqs.size() < max_batch_ && r->limit == all[0]->limit && r->search_size == all[0]->search_size &&
+                 (r->filter != nullptr) == (all[0]->filter != nullptr)
+             ? reqs
+             : rest)
+            .push_back(r);
       all.swap(rest);
+      const bool filtered = reqs[0]->filter != nullptr;
       const size_t nq = reqs.size(), d = dim_;
       const uint32_t limit = reqs[0]->limit, L = reqs[0]->search_size;
       std::vector<float> queries(nq * d);
@@ -529,15 +558,17 @@ class SearchBatcher {
       std::vector<uint32_t> counts(nq);
       for (size_t i = 0; i < nq; i++) {
         std::memcpy(queries.data() + i * d, reqs[i]->vector, d * 4);
-        f_ids.insert(f_ids.end(), reqs[i]->filter->begin(), reqs[i]->filter->end());
+        if (filtered) f_ids.insert(f_ids.end(), reqs[i]->filter->begin(), reqs[i]->filter->end());
         f_off.push_back(f_ids.size());
       }
       if (f_ids.empty()) f_ids.push_back(0);
-      const int rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, f_off.data(), f_ids.data(), ids.data(),
-                                            dists.data(), counts.data(), nullptr, SDB_MEM_HOST, nullptr);
+      const int rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, filtered ? f_off.data() : nullptr,
+                                            filtered ? f_ids.data() : nullptr, ids.data(), dists.data(), counts.data(),
+                                            nullptr, SDB_MEM_HOST, nullptr);
       n_batches_++;
       n_queries_ += nq;
       const Error err = rc ? Error(std::string(sdb_last_error())) : Error();
+      Told told;
       for (size_t i = 0; i < nq; i++) {
         Request *r = reqs[i];
         if (!rc) {
@@ -547,7 +578,7 @@ class SearchBatcher {
         } else {
           r->err = err;
         }
-        finish(r);
+        told.add(finish(r));
       }
     }
   }
@@ -555,15 +586,15 @@ class SearchBatcher {
   sdb_index *h_;
   uint32_t dim_;
   std::vector<std::thread> threads_;
-  // the queue lock: sealed batches, the filtered queue, the free list, the workers' sleep.  The spin lock: the
-  // filling batch and its slot counter -- what every submit touches.  Order: qmu_ before the spin lock.
+  // the queue lock: sealed batches, queued requests, the free list, the workers' sleep -- taken once per BATCH on the
+  // fast path (by the submit that fills it), never per request
   std::mutex qmu_;
   std::condition_variable qcv_, fcv_;
-  std::atomic_flag spin_ = ATOMIC_FLAG_INIT;
-  std::atomic<bool> spin_flag_{false};
-  Batch *cur_ = nullptr;
+  std::atomic<Batch *> cur_{nullptr};  // the batch that is filling
+  uint64_t fast_key_ = 0;              // (limit << 32 | searchSize) the next installed batch is for (qmu_)
+  uint64_t other_streak_ = 0;          // unfiltered requests with other parameters since the last re-key (qmu_)
   std::deque<Batch *> sealed_;
-  std::vector<Request *> filtered_;
+  std::vector<Request *> queued_;
   std::vector<Batch *> free_, all_;
   bool stop_ = false;
   size_t max_batch_, cap_ = 0;
