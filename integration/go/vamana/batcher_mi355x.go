@@ -9,7 +9,9 @@ import "C"
 
 import (
 	"context"
+	"runtime"
 	"sync"
+	"sync/atomic"
 	"time"
 	"unsafe"
 
@@ -17,11 +19,16 @@ import (
 )
 
 // One REST request carries one query (httpapi/v2/handlers.go:435-489) and the reference answers it on its own
-// goroutine; a single walk leaves the GPU idle (it is ~80 dependent hops).  searchBatcher collects concurrent
-// submit calls that share (limit, searchSize, filtered?) for at most `window` or until `maxBatch` are waiting and
-// runs them as one sdb_index_search_batch with host buffers; `workers` goroutines keep that many device batches in
+// goroutine; a single walk leaves the GPU idle (it is ~80 dependent hops).  searchBatcher coalesces concurrent submit
+// calls into sdb_index_search_batch calls with host buffers; `workers` goroutines keep that many device batches in
 // flight (the library hands every call its own workspace).  semadb_host.hpp's SearchBatcher is the same logic in
-// compiled form.
+// compiled form, measured by bench.py (config.batcher_qps).
+//
+// What a request costs on the host: ONE atomic add reserves slot i of the batch that is filling (no lock); the caller's
+// goroutine copies its vector straight into that batch's pinned slab (sdb_host_alloc: the H2D copy of the device call is
+// then a single DMA); the submit that takes the last slot hands the batch to the workers; a batch that does not fill
+// within `window` is sealed by a worker.  Requests with the prevailing (limit, searchSize) and no filter take this
+// path; filtered ones (they carry a bitmap) and other parameters go through a queue that a worker groups.
 type searchResp struct {
 	ids   []uint64
 	dists []float32
@@ -36,14 +43,32 @@ type searchReq struct {
 	done       chan searchResp // buffered: a caller that gave up (context) never blocks the batcher
 }
 
+type fillBatch struct {
+	mem     unsafe.Pointer // pinned [maxBatch][dim] float32
+	queries []float32      // the same memory as a slice
+	reqs    []*searchReq
+	n       atomic.Uint32 // slots reserved; >= maxBatch: full or sealed
+	written atomic.Uint32 // slots whose vector has been copied in
+	count   uint32        // slots that belong to the batch once it is sealed
+	key     uint64        // limit<<32 | searchSize of every request in it
+	tFirst  atomic.Int64  // UnixNano of its first request
+}
+
 type searchBatcher struct {
 	ix       *IndexVamana
 	dim      int
 	maxBatch int
 	window   time.Duration
-	mu       sync.Mutex
-	cond     *sync.Cond
-	queue    []*searchReq
+	cur      atomic.Pointer[fillBatch] // the batch that is filling
+	mu       sync.Mutex                // sealed, queued, free, fastKey: once per BATCH on the fast path
+	cond     *sync.Cond                // workers sleep here
+	freeCond *sync.Cond                // submitters wait here when every slab is in use
+	sealed   []*fillBatch
+	queued   []*searchReq
+	free     []*fillBatch
+	all      []*fillBatch
+	fastKey  uint64
+	streak   int
 	stopped  bool
 	wg       sync.WaitGroup
 }
@@ -51,6 +76,18 @@ type searchBatcher struct {
 func newSearchBatcher(ix *IndexVamana, maxBatch int, window time.Duration, workers int) *searchBatcher {
 	b := &searchBatcher{ix: ix, dim: int(ix.parameters.VectorSize), maxBatch: maxBatch, window: window}
 	b.cond = sync.NewCond(&b.mu)
+	b.freeCond = sync.NewCond(&b.mu)
+	for i := 0; i < workers+2; i++ {
+		fb := &fillBatch{reqs: make([]*searchReq, maxBatch)}
+		if rc := C.sdb_host_alloc(C.size_t(maxBatch*b.dim*4), &fb.mem); rc == C.SDB_OK && fb.mem != nil {
+			fb.queries = unsafe.Slice((*float32)(fb.mem), maxBatch*b.dim)
+		} else {
+			fb.mem, fb.queries = nil, make([]float32, maxBatch*b.dim) // pageable memory works too, only slower
+		}
+		b.all = append(b.all, fb)
+		b.free = append(b.free, fb)
+	}
+	b.cur.Store(b.takeFree())
 	for i := 0; i < workers; i++ {
 		b.wg.Add(1)
 		go b.loop()
@@ -63,22 +100,109 @@ func (b *searchBatcher) stop() {
 	b.stopped = true
 	b.mu.Unlock()
 	b.cond.Broadcast()
+	b.freeCond.Broadcast()
 	b.wg.Wait()
+	for _, fb := range b.all {
+		if fb.mem != nil {
+			C.sdb_host_free(fb.mem)
+		}
+	}
+}
+
+// takeFree: b.mu held (or construction)
+func (b *searchBatcher) takeFree() *fillBatch {
+	if len(b.free) == 0 {
+		return nil
+	}
+	fb := b.free[len(b.free)-1]
+	b.free = b.free[:len(b.free)-1]
+	fb.written.Store(0)
+	fb.tFirst.Store(0)
+	fb.count, fb.key = 0, b.fastKey
+	fb.n.Store(0)
+	return fb
+}
+
+// rotateLocked: fb is full or was sealed with `count` reserved slots; b.mu held
+func (b *searchBatcher) rotateLocked(fb *fillBatch, count uint32) {
+	fb.count = count
+	if count == uint32(b.maxBatch) {
+		b.streak = 0
+	}
+	if count > 0 {
+		b.sealed = append(b.sealed, fb)
+	} else {
+		b.free = append(b.free, fb)
+	}
+	b.cur.Store(b.takeFree())
+	b.cond.Signal()
+	b.freeCond.Broadcast()
 }
 
 // submit enqueues one query and waits for its answer or for the context.  A cancelled request is still
 // answered by the device batch it is in; nobody reads the answer.
 func (b *searchBatcher) submit(ctx context.Context, vector []float32, limit, searchSize int, filter *roaring64.Bitmap) ([]uint64, []float32, error) {
 	r := &searchReq{vector: vector, limit: limit, searchSize: searchSize, filter: filter, done: make(chan searchResp, 1)}
-	b.mu.Lock()
-	if b.stopped {
-		b.mu.Unlock()
-		return nil, nil, context.Canceled
+	key := uint64(limit)<<32 | uint64(searchSize)
+	placed := false
+	for filter == nil && !placed {
+		fb := b.cur.Load()
+		if fb == nil { // every slab is in use (back-pressure) or a rotation is under way
+			b.mu.Lock()
+			for b.cur.Load() == nil && !b.stopped {
+				b.freeCond.Wait()
+			}
+			stopped := b.stopped
+			b.mu.Unlock()
+			if stopped {
+				return nil, nil, context.Canceled
+			}
+			continue
+		}
+		if fb.key != key {
+			break // other parameters than the filling batch's: the queue
+		}
+		i := fb.n.Add(1) - 1 // one atomic reserves slot i; no lock on this path
+		if i >= uint32(b.maxBatch) {
+			for b.cur.Load() == fb { // full or sealed: its last submitter / a worker is installing the next one
+				runtime.Gosched()
+			}
+			continue
+		}
+		if i == 0 {
+			fb.tFirst.Store(time.Now().UnixNano())
+		}
+		fb.reqs[i] = r
+		copy(fb.queries[int(i)*b.dim:(int(i)+1)*b.dim], vector) // into the pinned slab
+		fb.written.Add(1)
+		if int(i)+1 == b.maxBatch { // the submit that takes the last slot hands the batch on
+			b.mu.Lock()
+			b.rotateLocked(fb, uint32(b.maxBatch))
+			b.mu.Unlock()
+		} else if i == 0 {
+			b.cond.Signal() // a worker starts this batch's window
+		}
+		placed = true
 	}
-	b.queue = append(b.queue, r)
-	wake := len(b.queue) == 1 || len(b.queue) >= b.maxBatch
-	b.mu.Unlock()
-	if wake {
+	if !placed {
+		b.mu.Lock()
+		if b.stopped {
+			b.mu.Unlock()
+			return nil, nil, context.Canceled
+		}
+		b.queued = append(b.queued, r)
+		if filter == nil { // when the unfiltered traffic has moved to other parameters the fast path follows it
+			b.streak++
+			if b.fastKey == 0 || b.streak > 4*b.maxBatch {
+				b.fastKey, b.streak = key, 0
+				if fb := b.cur.Load(); fb != nil && fb.key != key {
+					if got := fb.n.Add(uint32(b.maxBatch)) - uint32(b.maxBatch); got < uint32(b.maxBatch) {
+						b.rotateLocked(fb, got)
+					}
+				}
+			}
+		}
+		b.mu.Unlock()
 		b.cond.Signal()
 	}
 	select {
@@ -92,40 +216,98 @@ func (b *searchBatcher) submit(ctx context.Context, vector []float32, limit, sea
 func (b *searchBatcher) loop() {
 	defer b.wg.Done()
 	for {
+		var fb *fillBatch
+		var others []*searchReq
 		b.mu.Lock()
-		for len(b.queue) == 0 && !b.stopped {
-			b.cond.Wait()
-		}
-		if b.stopped && len(b.queue) == 0 {
-			b.mu.Unlock()
-			return
-		}
-		if len(b.queue) < b.maxBatch { // a short window for more callers
-			b.mu.Unlock()
-			time.Sleep(b.window)
-			b.mu.Lock()
-		}
-		if len(b.queue) == 0 { // another worker took them
-			b.mu.Unlock()
-			continue
-		}
-		// one device call per (limit, searchSize, filtered) group, oldest group first
-		head := b.queue[0]
-		var batch, rest []*searchReq
-		for _, r := range b.queue {
-			if len(batch) < b.maxBatch && r.limit == head.limit && r.searchSize == head.searchSize && (r.filter != nil) == (head.filter != nil) {
-				batch = append(batch, r)
+		for {
+			if len(b.sealed) > 0 {
+				fb, b.sealed = b.sealed[0], b.sealed[1:]
+				break
+			}
+			if len(b.queued) > 0 {
+				others, b.queued = b.queued, nil
+				break
+			}
+			// a partial batch whose first request has waited `window`: seal it.  Adding maxBatch to its slot
+			// counter closes it; what the counter held before is what belongs to it.
+			c := b.cur.Load()
+			var age time.Duration
+			first := int64(0)
+			if c != nil {
+				first = c.tFirst.Load()
+			}
+			if first != 0 {
+				age = time.Duration(time.Now().UnixNano() - first)
+			}
+			if first != 0 && (age >= b.window || b.stopped) {
+				if got := c.n.Add(uint32(b.maxBatch)) - uint32(b.maxBatch); got < uint32(b.maxBatch) {
+					b.rotateLocked(c, got)
+				}
+				continue
+			}
+			if b.stopped {
+				b.mu.Unlock()
+				return
+			}
+			if first != 0 { // sync.Cond has no timed wait: a timer wakes this worker when the window is over
+				t := time.AfterFunc(b.window-age, b.cond.Signal)
+				b.cond.Wait()
+				t.Stop()
 			} else {
-				rest = append(rest, r)
+				b.cond.Wait()
 			}
 		}
-		b.queue = rest
-		more := len(rest) > 0
 		b.mu.Unlock()
-		if more {
-			b.cond.Signal()
+		if fb != nil {
+			b.flushSlab(fb)
+			b.mu.Lock()
+			b.free = append(b.free, fb)
+			if b.cur.Load() == nil {
+				b.cur.Store(b.takeFree())
+			}
+			b.mu.Unlock()
+			b.freeCond.Broadcast()
+		} else if len(others) > 0 {
+			for len(others) > 0 { // one device call per (limit, searchSize, filtered) group, oldest group first
+				head := others[0]
+				var batch, rest []*searchReq
+				for _, r := range others {
+					if len(batch) < b.maxBatch && r.limit == head.limit && r.searchSize == head.searchSize && (r.filter != nil) == (head.filter != nil) {
+						batch = append(batch, r)
+					} else {
+						rest = append(rest, r)
+					}
+				}
+				others = rest
+				b.flush(batch)
+			}
 		}
-		b.flush(batch)
+	}
+}
+
+// flushSlab runs a sealed batch straight from its pinned slab
+func (b *searchBatcher) flushSlab(fb *fillBatch) {
+	nq := int(fb.count)
+	for fb.written.Load() < fb.count { // the last copies in flight
+		runtime.Gosched()
+	}
+	limit, L := int(fb.key>>32), int(fb.key&0xFFFFFFFF)
+	ids := make([]uint64, nq*limit)
+	dists := make([]float32, nq*limit)
+	counts := make([]uint32, nq)
+	rc := C.sdb_index_search_batch(b.ix.h, C.uint64_t(nq), (*C.float)(unsafe.Pointer(&fb.queries[0])),
+		C.uint32_t(limit), C.uint32_t(L), nil, nil,
+		(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dists[0])),
+		(*C.uint32_t)(unsafe.Pointer(&counts[0])), nil, C.SDB_MEM_HOST, nil)
+	for i := 0; i < nq; i++ {
+		r := fb.reqs[i]
+		fb.reqs[i] = nil
+		if rc != C.SDB_OK {
+			r.done <- searchResp{err: lastErr("search_batch", rc)}
+			continue
+		}
+		n := int(counts[i])
+		r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
 	}
 }
 

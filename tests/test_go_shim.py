@@ -195,6 +195,9 @@ def test_helpers_are_defined_and_surface_is_complete():
         assert name in defined or name in builtin, "vamana package calls %s(), not defined in it" % name
     for name in set(re.findall(r"\b(?:v|b|ix)\.([a-z][A-Za-z0-9_]*)\(", vam)):
         assert name in defined or name in {"mu", "cond", "wg"}, "method %s() is not defined in the vamana package" % name
+    for helper in ["takeFree", "rotateLocked", "flushSlab"]:
+        assert helper in defined, "the batcher does not define %s" % helper
+    assert "C.sdb_host_alloc" in vam and "C.sdb_host_free" in vam  # pinned slabs
     # the exported surface of the reference package, with its signatures
     for sig in [r"const STARTID = 1",
                 r"type IndexVectorChange struct \{\s*Id\s+uint64\s*Vector \[\]float32\s*\}",
@@ -222,7 +225,8 @@ def test_helpers_are_defined_and_surface_is_complete():
 def test_imports_are_the_reference_modules():
     """import paths: the standard library or what the reference's go.mod (go 1.22; roaring v1.9.4) and its own tree
     provide -- a path from another major version would not resolve in the reference's module"""
-    allowed = {"context", "fmt", "hash/fnv", "math", "math/rand/v2", "sync", "time", "unsafe", "sort", "errors",
+    allowed = {"context", "fmt", "hash/fnv", "math", "math/rand/v2", "sync", "sync/atomic", "runtime", "time", "unsafe",
+               "sort", "errors",
                "github.com/RoaringBitmap/roaring/roaring64", "github.com/semafind/semadb/conversion",
                "github.com/semafind/semadb/diskstore", "github.com/semafind/semadb/models",
                "github.com/semafind/semadb/shard/index/vamana"}
