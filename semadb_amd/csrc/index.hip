@@ -167,6 +167,41 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // Any batch size: four resident waves per CU already saturate the memory system with this kernel, and a long
 // batch keeps them resident back to back (batch 16 384: 1.18 M QPS, 7.3 TB/s, against 0.88 M QPS on the
 // bitset variant at 16 waves per CU).
+// the multi-wave quantized walk (search_kernel.h PQWideDist): which instantiation serves (M, K), or -1
+static int pq_wide_shape(const SearchArgs &a) {
+  if (!a.pq_codes || a.pq_narrow || a.filt_off || a.prefer_bitset) return -1;
+  if (a.search_size > 96 || a.pq_K > 256 || a.pq_K % 32) return -1;
+  switch (a.pq_M) {
+    case 128: return 1;  // NL 32, RT 0
+    case 192: return 2;  // NL 32, RT 16
+    case 256: return 3;  // NL 32, RT 32
+    case 384: return 4;  // NL 32, RT 64
+    default: return -1;  // M <= 64: the table fits beside a one-wave walk
+  }
+}
+
+template <int NL, int RT>
+static int launch_pqw(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  const bool h16 = (uint64_t)a.words_per_query * 32 <= (1u << 24) && !a.wide_hash;
+  const size_t lut = (size_t)4 * NL * a.pq_K * sizeof(float);
+  static std::atomic<uint64_t> at16{0}, at32{0};
+  if (h16) {
+    const size_t lds = HashVisited16::kWords * 4 + sizeof(PQWideShared) + lut;
+    if (first_use_on_this_device(at16))
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHash16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHash16>), dim3(nq), dim3(256), lds, stream, a);
+  } else {
+    const size_t lds = HashVisited<kHashCapPQ>::kWords * 4 + sizeof(PQWideShared) + lut;
+    if (first_use_on_this_device(at32))
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHashCapPQ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHashCapPQ>), dim3(nq), dim3(256), lds, stream, a);
+  }
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
 bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
   // filtered searches too (round 3): their search set takes the same table, their result set a 4 KB one beside it
   // (search_kernel.h kHashCapResult) -- no 2 x 128 MB bitset clear per batch, no HBM atomic per edge
@@ -174,7 +209,7 @@ bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
   if (a.search_size > 96) return false;
   // quantized store: only with the small LUT of M*K <= 2048 entries next to the table (M = 32's 32 KB LUT leaves
   // room for three walks per CU beside the 16 KB table: 0.95 M QPS against 1.31 M on the bitset at five)
-  if (a.pq_codes) return a.pq_lut_in_lds && (size_t)a.pq_M * a.pq_K <= 2048;
+  if (a.pq_codes) return pq_wide_shape(a) >= 0 || (a.pq_lut_in_lds && (size_t)a.pq_M * a.pq_K <= 2048);
   switch (a.ng) {
     case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: return true;
     default: return false;
@@ -237,6 +272,13 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
   if (a.search_size == 0 || a.search_size > 512)
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
+    switch (pq_wide_shape(a)) {  // tables too large to sit beside a one-wave walk: one query per four waves
+      case 1: return launch_pqw<32, 0>(a, nq, stream);
+      case 2: return launch_pqw<32, 16>(a, nq, stream);
+      case 3: return launch_pqw<32, 32>(a, nq, stream);
+      case 4: return launch_pqw<32, 64>(a, nq, stream);
+      default: break;
+    }
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
     if (search_uses_hash(a, nq)) {
       // up to 2^24 rows: the 16-bit-cell set (16 KB, six walks per CU); beyond: 32-bit cells
@@ -922,6 +964,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
   a.hash_limit = ix->tune_hash_limit, a.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
   a.wide_hash = ix->tune_wide_hash ? 1u : 0u, a.hash16_probes = ix->tune_hash16_probes;
+  a.pq_narrow = ix->tune_pq_narrow ? 1u : 0u;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
@@ -1024,6 +1067,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       return SDB_OK;
     case SDB_TUNE_WIDE_HASH:
       ix->tune_wide_hash = value != 0;
+      return SDB_OK;
+    case SDB_TUNE_PQ_NARROW:
+      ix->tune_pq_narrow = value != 0;
       return SDB_OK;
     case SDB_TUNE_HASH16_PROBES:
       if (value > 15) return fail(SDB_ERR_INVALID, "at most 15 probes");

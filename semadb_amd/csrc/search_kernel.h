@@ -54,6 +54,7 @@ struct SearchArgs {
   const uint8_t *pq_codes;
   uint32_t pq_M, pq_K;
   uint32_t pq_lut_in_lds;  // != 0: the kernel copies its LUT into LDS first
+  uint32_t pq_narrow;      // != 0: never the multi-wave walk (k_greedy_search_pqw): A/B measurement and tests
   // filtered search (search.go:33-51,93-95): per query CSR of seeds (<= searchSize slots, ascending id
   // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
   const uint32_t *seed_off, *seeds, *filt_off, *filt_slots;
@@ -250,6 +251,9 @@ struct PlainDist {
   }
 
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
+  // hooks of the multi-wave quantized walk (PQWideDist); nothing to do for a one-wave policy
+  __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
+  __device__ __forceinline__ void skip(int) {}
 
   // The hop with the per-row instruction count cut to the arithmetic: the pending slots are compacted into LDS by rank (mbcnt), each
   // half-wave takes a contiguous run of them (so a lane fetches its 16 slots with plain ds_reads, no bit
@@ -412,6 +416,8 @@ struct PQDist {
     return dist;
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
+  __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
+  __device__ __forceinline__ void skip(int) {}
   // M == 8 (the documented configuration): the 8 code bytes of every neighbour are fetched as one 8-byte
   // load BEFORE the visited-set test, so the code gather and the test-and-set round trip overlap; codes of
   // neighbours that turn out to be already visited are simply not used (8 bytes each).
@@ -434,6 +440,156 @@ struct PQDist {
     dist += lut[6 * K + ((pre.y >> 16) & 0xFF)];
     dist += lut[7 * K + (pre.y >> 24)];
     return dist;
+  }
+};
+
+// Fitted product quantizer whose per-query table does not fit beside a one-wave walk (M x K x 4 bytes > 64 KB:
+// M = 192 at d = 768 is 192 KB).  Round 2 left that table in global memory and every lookup was a 4-byte gather from
+// a 200 MB working set: 125 k QPS at 10M x 768 against 450 k for the full-precision walk.  Here ONE query owns a
+// workgroup of four waves, one per SIMD, and with it a CU's LDS and register file:
+//   * the table of sub-quantizer i (K floats) lives in LDS, or in the registers of one of the four waves (four
+//     registers per table: lane l holds entries l, 64 + l, 128 + l, 192 + l; a lookup is four ds_bpermute and a
+//     select -- the register file as a second, larger LDS);
+//   * wave w owns the contiguous index range [w M/4, (w + 1) M/4): its first NL tables in LDS, its last RT in its
+//     registers (M = 4 (NL + RT)).  Wave 0 is the walker: it runs search_body exactly as the one-wave kernels do
+//     (candidate array, visited set, AddWithLimit).  Per adjacency chunk it publishes the row pointer, every wave
+//     reads the row (lane j = edge j) and fetches its range of the neighbours' code bytes while the walker runs the
+//     visited-set test; then all four look their table entries up in parallel;
+//   * the sum is the reference's: dist = 0; dist += lut[i][code_i] for i = 0 .. M-1, plain fp32 adds in index order
+//     (product.go:271-275).  The waves take turns -- wave 0 adds its M/4 values to 0 and hands the partial sums on
+//     through LDS, wave 1 adds its own, ... -- so the adds happen in exactly the sequential order.
+// Barriers per chunk (all four waves): B0 row published, B1 pending mask published, then one per wave's turn.
+struct PQWideShared {
+  unsigned long long rowp;  // mode 1: the adjacency chunk to expand
+  uint32_t mode;            // 0: the walk is over, 1: expand rowp, 2: the single point `slot` (start node)
+  uint32_t slot;
+  unsigned long long pend;  // lanes whose neighbour passed CheckAndVisit
+  uint32_t pad[2];
+  float psum[64];           // partial sums on their way from wave to wave, by lane
+};
+constexpr uint32_t kPqwSharedWords = sizeof(PQWideShared) / 4;
+
+template <int NL, int RT>  // tables per wave in LDS (multiple of 16) / in registers (multiple of 16, or 0)
+struct PQWideDist {
+  static constexpr bool kHasStamps = false;
+  static constexpr bool kPointDistances = false;
+  static constexpr int MS = NL + RT;  // sub-quantizers per wave; M = 4 MS
+  static constexpr int RTR = RT > 0 ? RT : 1;
+  PQWideShared *sh;
+  const float *lds_lut;  // this wave's LDS-resident tables, [NL][K]
+  uint32_t K, lo;
+  int wave;
+  float T[RTR][4];    // register-resident tables
+  uint4 cw[MS / 16];  // the wave's range of the lane's neighbour's code bytes
+
+  // all four waves: tables in, from the query's [M][K] block in global memory
+  __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lut_lds, PQWideShared *shared) {
+    sh = shared, wave = w, K = a.pq_K, lo = (uint32_t)w * MS;
+    float *dst = lut_lds + (size_t)w * NL * K;
+    lds_lut = dst;
+    const float *g = a.pq_lut + ((size_t)q * a.pq_M + lo) * K;
+    for (uint32_t i = lane; i < NL * K; i += 64) dst[i] = g[i];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint32_t e = c * 64 + lane;
+        T[t][c] = e < K ? g[(size_t)(NL + t) * K + e] : 0.0f;
+      }
+  }
+  __device__ __forceinline__ void load_codes(const SearchArgs &a, uint32_t nb) {
+    const uint32_t s = nb == kNoSlot ? 0u : nb;  // lanes without a neighbour read row 0 and are never looked at
+    const uint4 *cp = reinterpret_cast<const uint4 *>(a.pq_codes + (size_t)s * a.pq_M + lo);
+#pragma unroll
+    for (int j = 0; j < MS / 16; j++) cw[j] = cp[j];
+  }
+  template <int I>
+  __device__ __forceinline__ uint32_t code_at() const {  // code byte I of the wave's range
+    const uint4 v = cw[I / 16];
+    constexpr int wsel = (I / 4) % 4;
+    const uint32_t word = wsel == 0 ? v.x : wsel == 1 ? v.y : wsel == 2 ? v.z : v.w;
+    return (word >> (8 * (I % 4))) & 0xFFu;
+  }
+  template <int I>
+  __device__ __forceinline__ float lookup() const {
+    const uint32_t e = code_at<I>();
+    if constexpr (I < NL) {
+      return lds_lut[(size_t)I * K + e];
+    } else {
+      constexpr int t = I - NL;
+      const int addr = (int)((e & 63u) << 2);
+      const float v0 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(T[t][0])));
+      const float v1 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(T[t][1])));
+      const float v2 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(T[t][2])));
+      const float v3 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(T[t][3])));
+      const uint32_t c = e >> 6;
+      return c == 0 ? v0 : c == 1 ? v1 : c == 2 ? v2 : v3;
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ void lookups(float (&val)[MS]) const {
+    if constexpr (I < MS) {
+      val[I] = lookup<I>();
+      lookups<I + 1>(val);
+    }
+  }
+  // One chunk from B1 on, for every wave alike: look the wave's MS entries up (all waves at once), then the turns.
+  // Returns the finished sums (valid after the last turn) by lane.
+  __device__ __forceinline__ float finish_chunk() const {
+    float val[MS];
+    lookups<0>(val);
+#pragma unroll
+    for (int stage = 0; stage < 4; stage++) {
+      if (stage == wave) {
+        float acc = stage == 0 ? 0.0f : sh->psum[threadIdx.x & 63];
+#pragma unroll
+        for (int i = 0; i < MS; i++) acc += val[i];  // product.go:271-275: dist += dists[i*K + code[i]]
+        sh->psum[threadIdx.x & 63] = acc;
+      }
+      __syncthreads();  // B2 + stage
+    }
+    return sh->psum[threadIdx.x & 63];
+  }
+
+  // ---- the walker's side (wave 0): the policy interface search_body calls
+  __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *rowp, int lane) {
+    if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u;
+    __syncthreads();  // B0
+  }
+  __device__ __forceinline__ void prefetch(const SearchArgs &a, uint32_t nb, bool) { load_codes(a, nb); }
+  __device__ __forceinline__ void skip(int lane) {
+    if (lane == 0) sh->pend = 0ull;
+    __syncthreads();  // B1: nobody passed CheckAndVisit, the chunk ends here for every wave
+  }
+  __device__ __forceinline__ float hop(const SearchArgs &, uint32_t, uint64_t pend, int lane) {
+    if (lane == 0) sh->pend = pend;
+    __syncthreads();  // B1
+    return finish_chunk();
+  }
+  __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) {
+    if (lane == 0) sh->slot = s, sh->mode = 2u;
+    __syncthreads();  // B0
+    load_codes(a, lane == 0 ? s : kNoSlot);
+    return rlf(hop(a, s, 1ull, lane), 0);
+  }
+  __device__ __forceinline__ void finish(int lane) {
+    if (lane == 0) sh->mode = 0u;
+    __syncthreads();  // B0: the helpers leave
+  }
+  // ---- waves 1..3
+  __device__ __forceinline__ void serve(const SearchArgs &a, int lane) {
+    for (;;) {
+      __syncthreads();  // B0
+      const uint32_t mode = sh->mode;
+      if (mode == 0u) return;
+      uint32_t nb;
+      if (mode == 1u) nb = reinterpret_cast<const uint32_t *>(sh->rowp)[lane];
+      else nb = lane == 0 ? sh->slot : kNoSlot;
+      load_codes(a, nb);
+      __syncthreads();  // B1
+      if (sh->pend == 0ull) continue;
+      (void)finish_chunk();
+    }
   }
 };
 
@@ -663,12 +819,15 @@ struct HashVisited {
   uint32_t *bits;
   uint32_t words, count, limit;
   bool spilled;
-  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
+  __device__ __forceinline__ void init_nosync(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
     tab = lds, bits = bitset, words = nwords;
     count = 0, spilled = false;
     limit = (uint32_t)(((uint64_t)lim * CAP) >> 13);
     uint4 *t4 = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
+  }
+  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim) {
+    init_nosync(lds, bitset, nwords, lane, lim);
     __syncthreads();
   }
   __device__ __forceinline__ void spill(int lane) {
@@ -761,13 +920,16 @@ struct HashVisited16 {
   uint32_t *bits;
   uint32_t words, count, limit, maxp;
   bool spilled;
-  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim, uint32_t probes = 0) {
+  __device__ __forceinline__ void init_nosync(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim, uint32_t probes = 0) {
     tab = lds, bits = bitset, words = nwords;
     count = 0, spilled = false;
     maxp = (probes >= 1 && probes <= kMaxProbe) ? probes - 1 : kMaxProbe;  // last probe number a key may use
     limit = (uint32_t)(((uint64_t)lim * kCells) >> 13);  // 6 000 of 8 192 cells by default
     uint4 *t4 = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = lane; i < kWords / 4; i += 64) t4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+  }
+  __device__ __forceinline__ void init(uint32_t *lds, uint32_t *bitset, uint32_t nwords, int lane, uint32_t lim, uint32_t probes = 0) {
+    init_nosync(lds, bitset, nwords, lane, lim, probes);
     __syncthreads();
   }
   __device__ __forceinline__ void spill(int lane) {
@@ -968,6 +1130,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     const uint32_t *__restrict__ rowp = a.adj + (size_t)pid * kAdjStride;
     uint32_t ext_left = pid == a.start_slot ? a.start_ext_n : 0u, ext_done = 0;
     while (true) {
+      dist.begin_row(a, rowp, lane);
       const uint32_t nb = rowp[lane];
       const bool valid = nb != kNoSlot;
       n_edges += (uint32_t)__popcll(__ballot(valid));
@@ -999,6 +1162,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
 #endif
         SDB_STAMP(st_ins)
+      } else {
+        dist.skip(lane);
       }
       if (__builtin_expect(ext_left == 0, 1)) break;
       rowp = a.start_ext + ext_done;
@@ -1119,6 +1284,38 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
       search_body<Dist, NREG, FILT>(a, q, lane, dist, bv, rv);
     }
   }
+}
+
+// The multi-wave quantized walk: one query per workgroup of four waves (PQWideDist above).  Dynamic LDS: the visited
+// set's table, the command area, the LDS-resident tables [4][NL][K].
+template <int NL, int RT, uint32_t HCAP>
+__global__ __launch_bounds__(256) void k_greedy_search_pqw(const SearchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t q = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  constexpr uint32_t kVisWords = HCAP == kHash16 ? HashVisited16::kWords : HashVisited<HCAP == kHash16 ? 4u : HCAP>::kWords;
+  PQWideShared *sh = reinterpret_cast<PQWideShared *>(lds_f + kVisWords);
+  float *lut_lds = lds_f + kVisWords + kPqwSharedWords;
+  PQWideDist<NL, RT> dist;
+  dist.init_wave(a, q, lane, wave, lut_lds, sh);
+  uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
+  if constexpr (HCAP == kHash16) {
+    HashVisited16 hv;
+    if (wave == 0) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
+    __syncthreads();  // tables and visited set in place
+    if (wave != 0) return dist.serve(a, lane);
+    NoVisited rv;
+    search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
+  } else {
+    HashVisited<HCAP == kHash16 ? 4u : HCAP> hv;
+    if (wave == 0) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    __syncthreads();
+    if (wave != 0) return dist.serve(a, lane);
+    NoVisited rv;
+    search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
+  }
+  dist.finish(lane);
 }
 
 // host-side launcher: picks the instantiation for (ng, metric, search_size)

@@ -368,3 +368,49 @@ def test_quantized_walk_is_the_same_under_every_visited_set(oracle):
         assert int(ref[3].n_dist[k]) == o_tr.n_dist
     ix.close()
     gpq.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+@pytest.mark.parametrize("d,M,K", [(128, 128, 64), (192, 192, 256), (256, 256, 32), (384, 384, 256), (768, 192, 256)])
+def test_multi_wave_quantized_walk_parity(oracle, metric, d, M, K):
+    """Round 3: a quantizer whose per-query table does not fit beside a one-wave walk (M = 128 .. 384) is searched by
+    four waves per query -- tables in LDS and in registers, the waves adding their index ranges in turn
+    (search_kernel.h PQWideDist).  Ids, LUT-distance bits, visit order and counters equal the oracle's, equal the one-wave
+    kernel's (table in global memory, SDB_TUNE_PQ_NARROW), and stay equal when the visited set spills or is a bitset."""
+    from semadb_amd import vamana, vectorstore as vs
+    rng = np.random.default_rng(d + M + K)
+    n = 2500
+    lat = rng.standard_normal((12, d)).astype(np.float32)
+    base = rng.standard_normal((n, 12)).astype(np.float32) @ lat + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    o = build_oracle_index(oracle, base, metric, R=32, L=50)
+    ids, vecs, off, edges = o.export()
+    train = vecs[1:901].copy()
+    first = rng.integers(0, 900, M)
+    opq = oracle.PQ(d, metric, M, K)
+    opq.fit(train.copy(), first, alias=True)
+    codes = np.stack([opq.encode(v) for v in vecs])
+    assert o.attach_pq(opq, codes) == 0
+    ix = vamana.NewIndexVamana("pqw", vamana.IndexVectorVamanaParameters(d, metric, 50, 32, 1.2), strict=False)
+    ix.load(ids, vecs, off, edges)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(train.copy(), first, alias=True)
+    vs.attach(ix, gpq)
+    q = unit_rows(rng, 48, d)
+    g_ids, g_d, g_c, tr = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
+    for k in range(48):
+        o_ids, o_d, o_vis, o_tr = o.search(q[k], 10, 50)
+        assert int(g_c[k]) == len(o_ids)
+        assert np.array_equal(g_ids[k, :len(o_ids)], o_ids), k
+        assert np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d)), k
+        assert int(tr.n_hop[k]) == o_tr.n_hop and int(tr.n_dist[k]) == o_tr.n_dist, k
+        assert np.array_equal(tr.visit_ids[k, :o_tr.n_hop], o_vis), k
+    for key, value in [("pq_narrow", 1), ("hash_limit", 30), ("wide_hash", 1), ("no_hash", 1)]:
+        for kk in ("pq_narrow", "hash_limit", "wide_hash", "no_hash"):
+            ix.set_tuning(kk, 0)
+        ix.set_tuning(key, value)
+        got = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
+        assert np.array_equal(got[0], g_ids) and np.array_equal(bits(got[1]), bits(g_d)), key
+        assert np.array_equal(got[3].n_dist, tr.n_dist) and np.array_equal(got[3].visit_ids, tr.visit_ids), key
+    ix.close()
+    gpq.close()
