@@ -216,9 +216,10 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        euclidean uses) instead of the matrix cores
  *   SDB_TUNE_WIDE_HASH   != 0: searches over a quantized store keep their visited ids in 32-bit LDS cells (four
  *                        walks per CU) instead of the 16-bit cells used for stores of up to 2^24 rows (six)
- *   SDB_TUNE_PQ_NARROW   != 0: searches over a quantized store whose per-query table exceeds 64 KB (M = 128 .. 384 at
+ *   SDB_TUNE_PQ_NARROW   1: searches over a quantized store whose per-query table exceeds 64 KB (M = 128 .. 384 at
  *                        K = 256) stay on the one-wave kernel with the table in global memory (round 2) instead of the
- *                        four-wave walk that keeps it in LDS and registers
+ *                        four-wave walk that keeps it in LDS and registers; 2: M = 192 takes the four-wave variant with
+ *                        one query per CU instead of two
  *   SDB_TUNE_HASH16_PROBES  buckets a key of the 16-bit-cell set may try before the walk spills to the HBM bitset
  *                        (0 = all 15; 1..15).  With 15 that spill is a one-in-ten-million event; a test sets 1 or 2
  *                        to walk through it */

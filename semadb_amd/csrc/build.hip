@@ -1327,7 +1327,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.vis_slots = vis_slots, sa.vis_dists = vis_dists, sa.vis_count = vis_count, sa.vis_cap = vis_cap;
     sa.hash_limit = ix->tune_hash_limit, sa.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
     sa.wide_hash = ix->tune_wide_hash ? 1u : 0u, sa.hash16_probes = ix->tune_hash16_probes;
-    sa.pq_narrow = ix->tune_pq_narrow ? 1u : 0u;
+    sa.pq_narrow = ix->tune_pq_narrow;
     sa.totals = reinterpret_cast<unsigned long long *>(ix->d_bstats);  // [0] n_dist, [1] n_edges
     if (dcache) {
       SDB_W_HIP(hipMemsetAsync(dcache, 0xFF, ((size_t)rs << kDcacheBits) * sizeof(uint2), stream));  // no slot is ~0

@@ -169,7 +169,7 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // bitset variant at 16 waves per CU).
 // the multi-wave quantized walk (search_kernel.h PQWideDist): which instantiation serves (M, K), or -1
 static int pq_wide_shape(const SearchArgs &a) {
-  if (!a.pq_codes || a.pq_narrow || a.filt_off || a.prefer_bitset) return -1;
+  if (!a.pq_codes || a.pq_narrow == 1 || a.filt_off || a.prefer_bitset) return -1;
   if (a.search_size > 96 || a.pq_K > 256 || a.pq_K % 32) return -1;
   switch (a.pq_M) {
     case 128: return 1;  // NL 32, RT 0
@@ -274,7 +274,10 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
     switch (pq_wide_shape(a)) {  // tables too large to sit beside a one-wave walk: one query per four waves
       case 1: return launch_pqw<32, 0>(a, nq, stream);
-      case 2: return launch_pqw<32, 16>(a, nq, stream);
+      // M = 192: 15 tables per wave in LDS and 33 in registers leave room for TWO queries per CU (643 k against
+      // 570 k QPS at 10M x 768 with 32 + 16, one query per CU: profiles/r03_c4_10Mx768_pq.log); SDB_TUNE_PQ_NARROW = 2
+      // selects the latter for comparison
+      case 2: return a.pq_narrow == 2 ? launch_pqw<32, 16>(a, nq, stream) : launch_pqw<15, 33>(a, nq, stream);
       case 3: return launch_pqw<32, 32>(a, nq, stream);
       case 4: return launch_pqw<32, 64>(a, nq, stream);
       default: break;
@@ -964,7 +967,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   a.search_size = search_size, a.limit = limit, a.metric = (int)ix->P.metric;
   a.hash_limit = ix->tune_hash_limit, a.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
   a.wide_hash = ix->tune_wide_hash ? 1u : 0u, a.hash16_probes = ix->tune_hash16_probes;
-  a.pq_narrow = ix->tune_pq_narrow ? 1u : 0u;
+  a.pq_narrow = ix->tune_pq_narrow;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
@@ -1069,7 +1072,7 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       ix->tune_wide_hash = value != 0;
       return SDB_OK;
     case SDB_TUNE_PQ_NARROW:
-      ix->tune_pq_narrow = value != 0;
+      ix->tune_pq_narrow = (uint32_t)value;
       return SDB_OK;
     case SDB_TUNE_HASH16_PROBES:
       if (value > 15) return fail(SDB_ERR_INVALID, "at most 15 probes");

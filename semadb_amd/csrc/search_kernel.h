@@ -1288,8 +1288,9 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
 
 // The multi-wave quantized walk: one query per workgroup of four waves (PQWideDist above).  Dynamic LDS: the visited
 // set's table, the command area, the LDS-resident tables [4][NL][K].
+// NL < 16: the variant meant to run two queries per CU (half the LDS each) -- its registers are capped accordingly
 template <int NL, int RT, uint32_t HCAP>
-__global__ __launch_bounds__(256) void k_greedy_search_pqw(const SearchArgs a) {
+__global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(const SearchArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t q = blockIdx.x;

@@ -75,6 +75,10 @@ for M in [int(x) for x in a0.pq_m.split(",")]:
     vs.attach(ix, pq)
     ix.set_tuning("pq_narrow", 0)
     rec = {"multi_wave": measure()}
+    if M == 192:  # the variant with 32 tables per wave in LDS, 16 in registers: one query per CU (the default has two)
+        ix.set_tuning("pq_narrow", 2)
+        rec["multi_wave_one_per_cu"] = measure()
+        ix.set_tuning("pq_narrow", 0)
     if a0.narrow:
         ix.set_tuning("pq_narrow", 1)
         rec["one_wave_global_table"] = measure()
@@ -83,3 +87,5 @@ for M in [int(x) for x in a0.pq_m.split(",")]:
     print("[c4] M=%d: %s" % (M, json.dumps(rec)), file=sys.stderr, flush=True)
     keep.append(pq)
 print(json.dumps(out, indent=1))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/bench_c4_%d.json" % n, "w"), indent=1)
