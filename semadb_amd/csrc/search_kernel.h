@@ -533,11 +533,9 @@ struct PQWideDist {
       lookups<I + 1>(val);
     }
   }
-  // One chunk from B1 on, for every wave alike: look the wave's MS entries up (all waves at once), then the turns.
-  // Returns the finished sums (valid after the last turn) by lane.
-  __device__ __forceinline__ float finish_chunk() const {
-    float val[MS];
-    lookups<0>(val);
+  // The turns: wave w adds its MS values, in index order, on top of what the waves before it left.  Returns the
+  // finished sums (valid after the last turn) by lane.
+  __device__ __forceinline__ float turns(const float (&val)[MS]) const {
 #pragma unroll
     for (int stage = 0; stage < 4; stage++) {
       if (stage == wave) {
@@ -564,7 +562,9 @@ struct PQWideDist {
   __device__ __forceinline__ float hop(const SearchArgs &, uint32_t, uint64_t pend, int lane) {
     if (lane == 0) sh->pend = pend;
     __syncthreads();  // B1
-    return finish_chunk();
+    float val[MS];
+    lookups<0>(val);  // the helpers did theirs while this wave ran the visited-set test
+    return turns(val);
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) {
     if (lane == 0) sh->slot = s, sh->mode = 2u;
@@ -586,9 +586,15 @@ struct PQWideDist {
       if (mode == 1u) nb = reinterpret_cast<const uint32_t *>(sh->rowp)[lane];
       else nb = lane == 0 ? sh->slot : kNoSlot;
       load_codes(a, nb);
+      float val[MS];
+      // one query per CU (512 registers per wave): the lookups run now, for every lane, pending or not, under the
+      // walker's CheckAndVisit (1.59 -> 1.47 ms per batch at 1M x 768).  The two-per-CU variant has no registers to
+      // keep 48 values across the barrier -- there it cost 1.38 -> 1.89 ms in spills -- and looks up after it.
+      if constexpr (NL >= 16) lookups<0>(val);
       __syncthreads();  // B1
       if (sh->pend == 0ull) continue;
-      (void)finish_chunk();
+      if constexpr (NL < 16) lookups<0>(val);
+      (void)turns(val);
     }
   }
 };
