@@ -172,8 +172,8 @@ static int pq_wide_shape(const SearchArgs &a) {
   if (!a.pq_codes || a.pq_narrow == 1 || a.filt_off || a.prefer_bitset) return -1;
   if (a.search_size > 96 || a.pq_K > 256 || a.pq_K % 32) return -1;
   switch (a.pq_M) {
-    case 128: return 1;  // NL 32, RT 0
-    case 192: return 2;  // NL 32, RT 16
+    case 128: return 1;  // NL 15, RT 17 (two queries per CU)
+    case 192: return 2;  // NL 15, RT 33 (two queries per CU)
     case 256: return 3;  // NL 32, RT 32
     case 384: return 4;  // NL 32, RT 64
     default: return -1;  // M <= 64: the table fits beside a one-wave walk
@@ -273,7 +273,7 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
     return fail(SDB_ERR_INVALID, "searchSize %u not supported on device (1..512)", a.search_size);
   if (a.pq_codes) {  // fitted product quantizer attached (product.go:250-277)
     switch (pq_wide_shape(a)) {  // tables too large to sit beside a one-wave walk: one query per four waves
-      case 1: return launch_pqw<32, 0>(a, nq, stream);
+      case 1: return a.pq_narrow == 2 ? launch_pqw<32, 0>(a, nq, stream) : launch_pqw<15, 17>(a, nq, stream);  // two per CU
       // M = 192: 15 tables per wave in LDS and 33 in registers leave room for TWO queries per CU (643 k against
       // 570 k QPS at 10M x 768 with 32 + 16, one query per CU: profiles/r03_c4_10Mx768_pq.log); SDB_TUNE_PQ_NARROW = 2
       // selects the latter for comparison

@@ -54,7 +54,8 @@ struct SearchArgs {
   const uint8_t *pq_codes;
   uint32_t pq_M, pq_K;
   uint32_t pq_lut_in_lds;  // != 0: the kernel copies its LUT into LDS first
-  uint32_t pq_narrow;      // != 0: never the multi-wave walk (k_greedy_search_pqw): A/B measurement and tests
+  uint32_t pq_narrow;      // 1: never the multi-wave walk (k_greedy_search_pqw); 2: its one-query-per-CU variant for M = 192
+
   // filtered search (search.go:33-51,93-95): per query CSR of seeds (<= searchSize slots, ascending id
   // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
   const uint32_t *seed_off, *seeds, *filt_off, *filt_slots;
@@ -482,7 +483,10 @@ struct PQWideDist {
   float T[RTR][4];    // register-resident tables
   uint4 cw[MS / 16];  // the wave's range of the lane's neighbour's code bytes
 
-  // all four waves: tables in, from the query's [M][K] block in global memory
+  // All four waves: tables in, from the query's [M][K] block that pq_build_lut left in global memory.  (Computing the
+  // entries here instead -- no 200 MB block written and read back per batch -- was built and measured: the loads and
+  // chains of the build share the walk's register budget, and the two-per-CU variant went from 1.04 to 1.23 ms per
+  // batch with a loop per entry, to 1.89 ms with the loads batched; removed.  The block costs 0.12 ms per batch.)
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lut_lds, PQWideShared *shared) {
     sh = shared, wave = w, K = a.pq_K, lo = (uint32_t)w * MS;
     float *dst = lut_lds + (size_t)w * NL * K;
@@ -536,17 +540,18 @@ struct PQWideDist {
   // The turns: wave w adds its MS values, in index order, on top of what the waves before it left.  Returns the
   // finished sums (valid after the last turn) by lane.
   __device__ __forceinline__ float turns(const float (&val)[MS]) const {
+    const int lane_ = threadIdx.x & 63;
 #pragma unroll
     for (int stage = 0; stage < 4; stage++) {
       if (stage == wave) {
-        float acc = stage == 0 ? 0.0f : sh->psum[threadIdx.x & 63];
+        float acc = stage == 0 ? 0.0f : sh->psum[lane_];
 #pragma unroll
         for (int i = 0; i < MS; i++) acc += val[i];  // product.go:271-275: dist += dists[i*K + code[i]]
-        sh->psum[threadIdx.x & 63] = acc;
+        sh->psum[lane_] = acc;
       }
       __syncthreads();  // B2 + stage
     }
-    return sh->psum[threadIdx.x & 63];
+    return sh->psum[lane_];
   }
 
   // ---- the walker's side (wave 0): the policy interface search_body calls
@@ -1300,6 +1305,12 @@ __global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(cons
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t q = blockIdx.x;
+  // Which wave walks.  Every wave owns its index range whatever its role; the walker additionally runs search_body
+  // (visited set, candidate array), about twice a helper's instruction count, on ITS SIMD.  Two queries share a CU in
+  // the NL < 16 variant, and the k-th wave of a workgroup lands on the k-th SIMD: with wave 0 walking in both, one
+  // SIMD carried both walkers.  Workgroups that share a CU are 256 (or a multiple) apart in the grid, so the role
+  // rotates with blockIdx / 256.  Any choice is correct; this one balances.
+  const int walker = (NL < 16) ? (int)((blockIdx.x >> 8) & 3u) : 0;
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   constexpr uint32_t kVisWords = HCAP == kHash16 ? HashVisited16::kWords : HashVisited<HCAP == kHash16 ? 4u : HCAP>::kWords;
   PQWideShared *sh = reinterpret_cast<PQWideShared *>(lds_f + kVisWords);
@@ -1309,16 +1320,16 @@ __global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(cons
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
   if constexpr (HCAP == kHash16) {
     HashVisited16 hv;
-    if (wave == 0) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
+    if (wave == walker) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
     __syncthreads();  // tables and visited set in place
-    if (wave != 0) return dist.serve(a, lane);
+    if (wave != walker) return dist.serve(a, lane);
     NoVisited rv;
     search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
   } else {
     HashVisited<HCAP == kHash16 ? 4u : HCAP> hv;
-    if (wave == 0) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    if (wave == walker) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
     __syncthreads();
-    if (wave != 0) return dist.serve(a, lane);
+    if (wave != walker) return dist.serve(a, lane);
     NoVisited rv;
     search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
   }
@@ -1327,6 +1338,7 @@ __global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(cons
 
 // host-side launcher: picks the instantiation for (ng, metric, search_size)
 int launch_greedy_search(const SearchArgs &a, uint32_t nq, hipStream_t stream);
+
 // true when launch_greedy_search will use the LDS hash visited set (then the bitsets need no clearing)
 bool search_uses_hash(const SearchArgs &a, uint32_t nq);
 
