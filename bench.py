@@ -648,7 +648,8 @@ def c4_point(a, dev, dev_index):
         vs.attach(ix, pq)
         m = measure()
         alg = m["n_dist_per_batch"] * M + m["n_edges_per_batch"] * 4
-        m["roofline"] = {"bound": "hbm", "kernel": "k_greedy_search<PQDist>", "achieved": round(alg / m["kernel_ms"] / 1e6, 1),
+        m["roofline"] = {"bound": "hbm", "kernel": "k_greedy_search<PQDist>" if M * 256 * 4 <= 65536 else "k_greedy_search_pqw",
+                         "achieved": round(alg / m["kernel_ms"] / 1e6, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / m["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4),
                          "traffic": None}
         out["M=%d" % M] = m

@@ -851,8 +851,11 @@ constexpr uint32_t kBackCap = 256;
 // amdgpu_waves_per_eu(3): the kernel came out at 169 VGPRs, one over the limit for three waves per SIMD; held to 168 it
 // runs 12 waves per CU instead of 8 and 5 - 13 % faster (it lives on rows in flight); four waves (128 VGPRs) spill: 1.3 x slower.
 
+#ifndef SDB_BACK_WAVES
+#define SDB_BACK_WAVES 3
+#endif
 template <int NG, bool L2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_backedges(const BuildArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   PruneLds l(lds_raw, kBackCap, NG >= 0);
   const int lane = threadIdx.x, L = lane & 31;
@@ -862,7 +865,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
   if (key == kNoKey) return;
   const uint32_t b = (uint32_t)(key >> 32);
   if (pos > 0 && (uint32_t)(a.keys_sorted[pos - 1] >> 32) == b) return;  // not the head of B's segment
+#ifdef SDB_BACK_U
+  constexpr int U = NG == 3 ? SDB_BACK_U : (NG >= 0 ? ChunkPairs<NG, false>::value : 4);
+#else
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
+#endif
   // segment length m: requests for B, already in insert order
   size_t m = 1;
   while (pos + m < total) {
