@@ -185,7 +185,15 @@ __device__ __forceinline__ f2v k1_chain_pk(f2v acc, f2v x, f2v y) {
     return __builtin_elementwise_fma(x, y, acc);
   }
 }
-constexpr int kK1L2Waves = 16;
+// waves per workgroup x queries per pass, measured on 1 024 x 1M x 384 / 64 x 1M x 384 (ms): 16 x 2 (the exact scan's
+// shape: LDS reads and packed FMAs both near saturation) 31.0 / 1.81; 12 x 3: 37.7 / 2.27; 12 x 4 (168 VGPRs, 12 B of
+// scratch) 33.7 / 2.49; 8 x 4 (169 VGPRs, two waves per SIMD, each row block read once per four queries) 23.4 / 1.77
+#ifndef SDB_K1_WAVES
+#define SDB_K1_WAVES 8
+#define SDB_K1_QPP 4
+#endif
+constexpr int kK1L2Waves = SDB_K1_WAVES;
+constexpr int kK1Qpp = SDB_K1_QPP;
 template <bool L2>
 __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__restrict__ cands,
                                                                 const float *__restrict__ queries,
@@ -209,17 +217,17 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
   __syncthreads();
   const float *myrow_f = tile + (size_t)((uint32_t)lane < tile_rows ? lane : 0) * kstride;  // idle lanes: row 0, dropped
   const float4 *myrow = reinterpret_cast<const float4 *>(myrow_f);
-  const uint32_t ngroups = (nq + 1) / 2;
+  const uint32_t ngroups = (nq + kK1Qpp - 1) / kK1Qpp;
   for (uint32_t grp = (uint32_t)wave; grp < ngroups; grp += kK1L2Waves) {
-    const float *xq[2];
+    const float *xq[kK1Qpp];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const uint32_t q = grp * 2 + k;
+    for (int k = 0; k < kK1Qpp; k++) {
+      const uint32_t q = grp * kK1Qpp + k;
       xq[k] = queries + (size_t)(q < nq ? q : nq - 1) * dim;  // past the end: the last query again, dropped
     }
-    f2v acc[2][16];
+    f2v acc[kK1Qpp][16];
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < kK1Qpp; k++)
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[k][j] = f2v{0.0f, 0.0f};
 #pragma unroll 1
@@ -229,23 +237,25 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
       for (int i = 0; i < 8; i++) y[i] = myrow[b * 8 + i];
 #pragma unroll
       for (int i = 0; i < 8; i++) {  // float4 i of the block: partial sums 4i .. 4i + 3
-        const float4 u = reinterpret_cast<const float4 *>(xq[0] + b * 32)[i];  // wave-uniform: scalar loads
-        const float4 w = reinterpret_cast<const float4 *>(xq[1] + b * 32)[i];
-        acc[0][2 * i] = k1_chain_pk<L2>(acc[0][2 * i], f2v{u.x, u.y}, f2v{y[i].x, y[i].y});
-        acc[0][2 * i + 1] = k1_chain_pk<L2>(acc[0][2 * i + 1], f2v{u.z, u.w}, f2v{y[i].z, y[i].w});
-        acc[1][2 * i] = k1_chain_pk<L2>(acc[1][2 * i], f2v{w.x, w.y}, f2v{y[i].x, y[i].y});
-        acc[1][2 * i + 1] = k1_chain_pk<L2>(acc[1][2 * i + 1], f2v{w.z, w.w}, f2v{y[i].z, y[i].w});
+#pragma unroll
+        for (int k = 0; k < kK1Qpp; k++) {
+          const float4 u = reinterpret_cast<const float4 *>(xq[k] + b * 32)[i];  // wave-uniform: scalar loads
+          acc[k][2 * i] = k1_chain_pk<L2>(acc[k][2 * i], f2v{u.x, u.y}, f2v{y[i].x, y[i].y});
+          acc[k][2 * i + 1] = k1_chain_pk<L2>(acc[k][2 * i + 1], f2v{u.z, u.w}, f2v{y[i].z, y[i].w});
+        }
       }
     }
     // the tail chain (dot.s:35-43 / euclidean.s:44-53): the n % 32 last elements, one after the other
-    float t[2] = {0.0f, 0.0f};
+    float t[kK1Qpp];
+#pragma unroll
+    for (int k = 0; k < kK1Qpp; k++) t[k] = 0.0f;
     for (uint32_t m = 0; m < tail; m++) {
       const float yv = myrow_f[nblk * 32 + m];
-      t[0] = chain1<L2>(t[0], xq[0][nblk * 32 + m], yv);
-      t[1] = chain1<L2>(t[1], xq[1][nblk * 32 + m], yv);
+#pragma unroll
+      for (int k = 0; k < kK1Qpp; k++) t[k] = chain1<L2>(t[k], xq[k][nblk * 32 + m], yv);
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kK1Qpp; k++) {
       auto A = [&](int L) { return acc[k][L >> 1][L & 1]; };
       float r4[4];
 #pragma unroll
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
         r4[l] = (s0 + s1) + (l == 0 ? t[k] : 0.0f);  // + {t, 0, 0, 0} (dot.s:51)
       }
       const float dist = metric_finish((r4[0] + r4[1]) + (r4[2] + r4[3]), metric);
-      const uint32_t q = grp * 2 + k;
+      const uint32_t q = grp * kK1Qpp + k;
       if (q < nq && (uint32_t)lane < nrows) out[(size_t)q * nc + row0 + lane] = dist;  // 256 contiguous bytes per wave
     }
   }
