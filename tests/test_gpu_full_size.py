@@ -253,6 +253,27 @@ def test_c5_two_shards_merge(c2, oracle):
     want = np.take_along_axis(ti, sel, 1)
     got = m_ids + (m_s.astype(np.uint64) << np.uint64(40))
     assert (got[:, :, None] == want[:, None, :]).any(2).mean() >= 0.95
+    # the same through the library's exchange -- ClusterNode.SearchPoints for the two shards as two ranks that share
+    # this GPU (device copies in place of ncclAllGather, everything else the code an 8-GPU node runs): tickets, tagged
+    # blocks, tag check + merge, device-memory calls with four batches in flight, then a host-memory fan-out
+    ranks = cluster.Cluster.create_local([0, 0])
+    outs = []
+    for b in range(4):
+        qb = c2.queries[b * 1024:(b + 1) * 1024]
+        outs.append([ranks[r].search_batch(ix, qb, K, L, ticket=b + 1) for r, ix in enumerate((c2.ix, ix1))])
+    for r in ranks:
+        r.synchronize()
+    e_ids, e_d, e_s, e_c = (t.cpu().numpy() for t in outs[0][0])
+    assert np.array_equal(e_ids.view(np.uint64), m_ids) and np.array_equal(bits(e_d), bits(m_d))
+    assert np.array_equal(e_s.view(np.uint32), m_s.astype(np.uint32)) and (e_c.view(np.uint32) == K).all()
+    for b in range(4):  # both ranks hold the same merged answer
+        for j in range(4):
+            assert torch.equal(outs[b][0][j], outs[b][1][j])
+    fan = cluster.Fanout(ranks, [c2.ix, ix1])
+    h = fan.search_points(q.cpu().numpy(), K, L)
+    assert np.array_equal(h[0], m_ids) and np.array_equal(bits(h[1]), bits(m_d)) and np.array_equal(h[2], m_s.astype(np.uint32))
+    for r in ranks:
+        r.close()
     ix1.close()
 
 
