@@ -927,7 +927,9 @@ def run_c4(a, ctx):
     head_m = "M=192" if "M=192" in points else ("M=8" if "M=8" in points else next(iter(points)))
     head = points[head_m]["batch_%d" % nq]
     return {
-        "metric": "QPS, vectorVamana + product quantizer 10Mx768 (K=256, %s), PQ-LUT distance kernel, batch=1024" % head_m,
+        "metric": "QPS, vectorVamana + product quantizer %dMx%d (K=256, %s), PQ-LUT distance kernel, batch=1024" %
+                  (n // 1000000, d, head_m) if n >= 1000000 else
+                  "QPS, vectorVamana + product quantizer %dx%d (K=256, %s), PQ-LUT distance kernel, batch=1024" % (n, d, head_m),
         "value": head["call_qps"], "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": head["call_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
