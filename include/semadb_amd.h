@@ -146,17 +146,20 @@ int sdb_index_delete_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, void 
  * a write changes in place exists twice in HBM, a write changes the writer's copy only, and commit publishes it
  * (the searches launched before drain on the old copy; nobody blocks).  Between sdb_index_begin_write and
  * sdb_index_commit all insert / delete calls belong to one transaction; without begin_write every such call is a
- * transaction of its own.  One writer at a time (the shard's write lock).  There is no rollback: a write that fails
- * half-way leaves the handle unusable (SDB_ERR_STATE), the host reloads from the bucket -- the reference scraps its
- * cache after any error inside a transaction the same way (manager.go:231-240). */
+ * transaction of its own.  One writer at a time (the shard's write lock).  sdb_index_abort_write rolls an open
+ * transaction back.  A write that a DEVICE failure interrupts half-way leaves the handle unusable (SDB_ERR_STATE), the
+ * host reloads from the bucket -- the reference scraps its cache after any error inside a transaction the same way
+ * (manager.go:231-240). */
 int sdb_index_begin_write(sdb_index *ix);
 int sdb_index_commit(sdb_index *ix, void *stream);
 /* Leave a transaction without committing it -- the error path of a host's InsertUpdateDelete (a bad point found
- * after begin_write, a failed insert call).  If the transaction has not changed anything yet it just closes and the
- * index is what it was at begin_write (SDB_OK).  If it has, there is no rollback: the handle becomes unusable and
- * SDB_ERR_STATE says so; the host reloads from the bucket, as the reference's cache manager scraps a shard after any
- * error inside a transaction (shard/cache/manager.go:231-240).  Without an open transaction: SDB_OK.  Insert / delete
- * calls that fail before their first change close the transaction they opened for themselves the same way. */
+ * after begin_write, a failed call, a cancelled request).  The index goes back to what it was at begin_write: the
+ * rows the transaction wrote take back the committed copy that the searches have been walking all along, the rows it
+ * appended are dropped, the id tables follow (SDB_OK; milliseconds per million rows).  The reference has no rollback
+ * -- after an error inside a transaction its cache manager scraps the shard's cache and rebuilds it from the bucket
+ * (shard/cache/manager.go:231-240).  SDB_ERR_STATE only for a handle that a device failure had already left unusable.
+ * Without an open transaction: SDB_OK.  Insert / delete calls that fail before their first change close the
+ * transaction they opened for themselves. */
 int sdb_index_abort_write(sdb_index *ix);
 /* test support: rows on which the committed and the writer's copy of the graph differ (0 outside a transaction) */
 int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows);

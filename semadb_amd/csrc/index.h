@@ -122,6 +122,9 @@ struct sdb_index {
   bool in_tx = false, tx_explicit = false;
   bool tx_dirty = false;  // the open transaction has changed the writer's copy or the host tables (sdb_index_abort_write)
   uint32_t tx_n0 = 0;  // rows at the start of the open transaction
+  uint32_t tx_dead0 = 0;        // tombstones, largest node id and id-table form at the start of it (rollback)
+  uint64_t tx_max_id0 = 0;
+  int rollback();               // sdb_index_abort_write: the writer's copy and the host tables back to the committed state
   std::unordered_map<uint64_t, uint32_t> tx_deleted;  // ids the open transaction has removed -> their slots
   int begin_write();
   int commit(hipStream_t stream);   // publish the writer's state; `stream` carries the write

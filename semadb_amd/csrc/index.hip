@@ -401,6 +401,27 @@ __global__ void k_sync_rows(const uint32_t *__restrict__ src_adj, uint32_t *__re
   dst_adj[(size_t)row * kAdjStride + lane] = src_adj[(size_t)row * kAdjStride + lane];
   if (lane == 0) dst_ids[row] = src_ids[row], dirty[row] = 0;
 }
+// sdb_index_abort_write: the rows the transaction wrote take the committed copy back, the rows it appended become
+// empty again.  What only the write path keeps per row -- degree, clean prefix, cached edge distances -- is rebuilt
+// conservatively: the degree from the row, no clean prefix, no cached distances (both only ever save work: a prune
+// that finds none evaluates everything and arrives at the same row, build.hip).
+__global__ void k_restore_rows(const uint32_t *__restrict__ c_adj, uint32_t *__restrict__ w_adj,
+                               const uint64_t *__restrict__ c_ids, uint64_t *__restrict__ w_ids, uint32_t *__restrict__ deg,
+                               uint32_t *__restrict__ clean, uint32_t *__restrict__ dcount, uint8_t *__restrict__ dirty,
+                               uint32_t n_now, uint32_t n_committed) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_now) return;
+  const bool appended = row >= n_committed;
+  if (!appended && !dirty[row]) return;
+  const uint32_t e = appended ? kNoSlot : c_adj[(size_t)row * kAdjStride + lane];
+  w_adj[(size_t)row * kAdjStride + lane] = e;
+  const uint32_t d = (uint32_t)__popcll(__ballot(e != kNoSlot));
+  if (lane == 0) {
+    w_ids[row] = appended ? 0ull : c_ids[row];
+    deg[row] = d, clean[row] = 0, dcount[row] = 0, dirty[row] = 0;
+  }
+}
 // test support: rows on which the two copies differ
 __global__ void k_count_version_diff(const uint32_t *a_adj, const uint32_t *b_adj, const uint64_t *a_ids,
                                      const uint64_t *b_ids, uint32_t n, unsigned long long *out) {
@@ -414,7 +435,7 @@ __global__ void k_count_version_diff(const uint32_t *a_adj, const uint32_t *b_ad
 }  // namespace sdb
 
 int sdb_index::begin_write() {
-  if (!in_tx) in_tx = true, tx_n0 = n, tx_dirty = false;
+  if (!in_tx) in_tx = true, tx_n0 = n, tx_dead0 = n_dead, tx_max_id0 = max_node_id, tx_dirty = false;
   return SDB_OK;
 }
 
@@ -464,6 +485,47 @@ int sdb_index::commit(hipStream_t stream) {
     }
     SDB_HIP(hipMemcpyAsync(d_start_ext, r_start_ext, (size_t)need * 4, hipMemcpyDeviceToDevice, stream));
   }
+  return SDB_OK;
+}
+
+int sdb_index::rollback() {
+  std::unique_lock<sdb::ViewMutex> wl(view_mu);  // searches translate filter ids with the tables changed below
+  SDB_HIP(hipDeviceSynchronize());               // the transaction's kernels are done
+  if (n)
+    hipLaunchKernelGGL(sdb::k_restore_rows, dim3((n + 3) / 4), dim3(256), 0, nullptr, r_adj, d_adj, r_ids, d_ids, d_deg,
+                       d_clean, d_dcount, d_dirty, n, tx_n0);
+  SDB_HIP(hipGetLastError());
+  // the start node's overflow list as committed
+  const uint32_t ext_n = view.start_ext_n, need = (ext_n + 63) / 64 * 64;
+  h_start_ext.assign(ext_n, 0);
+  if (ext_n) {
+    SDB_HIP(hipMemcpy(h_start_ext.data(), r_start_ext, (size_t)ext_n * 4, hipMemcpyDeviceToHost));
+    if (need > start_ext_cap) {
+      if (d_start_ext) (void)hipFree(d_start_ext);
+      d_start_ext = nullptr, start_ext_cap = 0;
+      SDB_HIP(hipMalloc(&d_start_ext, (size_t)need * 2 * 4));
+      start_ext_cap = need * 2;
+    }
+    SDB_HIP(hipMemcpy(d_start_ext, r_start_ext, (size_t)need * 4, hipMemcpyDeviceToDevice));
+  }
+  SDB_HIP(hipDeviceSynchronize());
+  // host tables: appended rows go, rows the transaction tombstoned get their ids back
+  h_ids.resize(tx_n0);
+  for (auto &kv : tx_deleted)
+    if (kv.second < tx_n0) h_ids[kv.second] = kv.first;
+  n = tx_n0, n_dead = tx_dead0, max_node_id = tx_max_id0;
+  bool dense = n > 0;
+  for (uint32_t i = 1; i < n && dense; i++) dense = h_ids[i] == h_ids[0] + i;
+  if (n && h_ids[0] == 0) dense = false;
+  dense_ids = n == 0 ? true : dense;
+  id2slot.clear();
+  if (!dense_ids) {
+    id2slot.reserve((size_t)n * 2);
+    for (uint32_t sl = 0; sl < n; sl++)
+      if (h_ids[sl] != 0) id2slot.emplace(h_ids[sl], sl);
+  }
+  tx_deleted.clear();
+  in_tx = false, tx_explicit = false, tx_dirty = false;
   return SDB_OK;
 }
 
@@ -798,22 +860,27 @@ int sdb_index_commit(sdb_index *ix, void *stream_) {
   return SDB_OK;
 }
 
-// The way out of a transaction that will not be committed (a host that found a bad point after begin_write, an
-// insert call that failed).  Nothing changed yet: the transaction simply closes and the index is what it was at
-// begin_write.  Something changed: there is no rollback (the header says so), the handle is marked unusable like
-// after any failed write and the host reloads from the bucket -- what the reference's cache manager does with a
-// shard after an error inside a transaction (shard/cache/manager.go:231-240).
+// The way out of a transaction that will not be committed (a host that found a bad point after begin_write, a failed
+// call, a cancelled request).  Searches never saw the transaction: they walk the committed copy of the graph (index.h
+// graph versions), which is exactly what a rollback needs -- the rows the transaction wrote take the committed copy
+// back, the rows it appended are dropped, the host's id tables follow.  The reference has no such thing: after an
+// error inside a transaction its cache manager scraps the shard's cache and rebuilds it from the bucket
+// (shard/cache/manager.go:231-240); here the index is what it was at begin_write, in milliseconds.  Only a handle that
+// a device failure left half-written (index.h `broken`) cannot be brought back.
 int sdb_index_abort_write(sdb_index *ix) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
+  if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (!ix->in_tx) return SDB_OK;
-  if (ix->tx_dirty || ix->broken) {
-    ix->broken = true;
-    return fail(SDB_ERR_STATE, "the aborted transaction had already changed the graph: the index is unusable, reload it from the bucket");
+  if (!ix->tx_dirty) {  // nothing to undo
+    std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+    ix->tx_deleted.clear();
+    ix->in_tx = false, ix->tx_explicit = false;
+    return SDB_OK;
   }
-  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
-  ix->tx_deleted.clear();
-  ix->in_tx = false, ix->tx_explicit = false;
-  return SDB_OK;
+  DeviceGuard dg(ix->P.device);
+  const int rc = ix->rollback();
+  if (rc != SDB_OK) ix->broken = true;  // a device error half-way through the restore
+  return rc;
 }
 
 // test support: the number of rows on which the two graph copies differ (0 whenever no transaction is open)

@@ -125,8 +125,7 @@ class IndexFlat:
         check(lib().sdb_index_commit(self._h, None))
 
     def abort_write(self):
-        """leave an open transaction without committing; True if the index is unchanged, False if it had already
-        been changed and is now unusable (reload it from the bucket)"""
+        """leave an open transaction without committing: rolled back, the store is what it was at begin_write"""
         return lib().sdb_index_abort_write(self._h) == 0
 
     def row_usage(self):

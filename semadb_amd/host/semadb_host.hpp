@@ -750,9 +750,9 @@ class IndexVamana {
     // (every point was validated above: nothing below fails on the caller's input)
     if (any)
       if (int rc = sdb_index_begin_write(h_)) return Error::wrap("could not start the write", rc);
-    // an error inside the transaction: leave it (sdb_index_abort_write) so that the next write is not met by "a
-    // transaction is already open"; if the graph had already changed the handle is unusable from here on and the
-    // owner rebuilds this object from the bucket, like the reference's cache manager (manager.go:231-240)
+    // an error inside the transaction: roll it back (sdb_index_abort_write) -- the index is what it was before the
+    // call and takes the next write; the id set and the bucket are only touched after the commit.  (The reference's
+    // cache manager scraps the shard's cache after an error inside a transaction and rebuilds it, manager.go:231-240.)
     auto failed = [&](const std::string &what, int rc) {
       Error e = Error::wrap(what, rc);
       if (sdb_index_abort_write(h_) != SDB_OK) e.msg += "; the index must be reloaded from the bucket";
@@ -761,27 +761,26 @@ class IndexVamana {
     if (!ins_ids.empty())
       if (int rc = sdb_index_insert_batch(h_, ins_ids.size(), ins_ids.data(), ins_vecs.data(), SDB_MEM_HOST, round_size, nullptr))
         return failed("could not distribute or insert points", rc);
-    for (uint64_t id : ins_ids) live_.insert(id);
     std::vector<uint64_t> gone(del_ids);
     gone.insert(gone.end(), upd_ids.begin(), upd_ids.end());
-    if (!gone.empty()) {
+    if (!gone.empty())
       if (int rc = sdb_index_delete_batch(h_, gone.size(), gone.data(), nullptr))
         return failed("could not remove inbound edges", rc);
-      for (uint64_t id : del_ids) {  // DeleteFrom (plain.go:143-148, node.go:129-134)
-        live_.erase(id);
-        if (bucket_) {
-          bucket_->Delete(conversion::NodeKey(id, 'v'));
-          bucket_->Delete(conversion::NodeKey(id, 'q'));  // product.go:375-383
-          bucket_->Delete(conversion::NodeKey(id, 'e'));
-        }
-      }
-    }
     const size_t d = parameters_.VectorSize;
     for (size_t i = 0; i < upd_ids.size(); i++)  // :247-251
       if (int rc = sdb_index_insert_batch(h_, 1, &upd_ids[i], upd_vecs.data() + i * d, SDB_MEM_HOST, 1, nullptr))
         return failed("could not re-insert updated point", rc);
     if (any)
       if (int rc = sdb_index_commit(h_, nullptr)) return failed("could not commit the write", rc);
+    for (uint64_t id : ins_ids) live_.insert(id);
+    for (uint64_t id : del_ids) {  // DeleteFrom (plain.go:143-148, node.go:129-134)
+      live_.erase(id);
+      if (bucket_) {
+        bucket_->Delete(conversion::NodeKey(id, 'v'));
+        bucket_->Delete(conversion::NodeKey(id, 'q'));  // product.go:375-383
+        bucket_->Delete(conversion::NodeKey(id, 'e'));
+      }
+    }
     if (Error e = fit()) return Error("could not fit vector store: " + e.msg);  // vamana.go:257-260
     if (Error e = flush()) return e;
     // the reference frees deleted nodes at flush (node.go:129-134); here their rows stay behind as tombstones
@@ -1043,13 +1042,13 @@ class IndexFlat {
       const int rc = del ? sdb_index_remove_vectors(h_, ids.size(), ids.data())
                          : sdb_index_set_vectors(h_, ids.size(), ids.data(), vecs.data(), SDB_MEM_HOST);
       if (rc) return failed(rc);
-      if (bucket_)  // vecStore.Flush: plainPoint.WriteTo / DeleteFrom (plain.go:112-123,143-148)
-        for (size_t k = 0; k < ids.size(); k++) {
-          if (del) bucket_->Delete(conversion::NodeKey(ids[k], 'v'));
-          else bucket_->Put(conversion::NodeKey(ids[k], 'v'), conversion::Float32ToBytes(vecs.data() + k * d, d));
-        }
     }
     if (int rc = sdb_index_commit(h_, nullptr)) return failed(rc);
+    if (bucket_)  // vecStore.Flush, once the device has committed: plainPoint.WriteTo / DeleteFrom (plain.go:112-123,143-148)
+      for (const auto &p : points) {
+        if (p.Vector.empty()) bucket_->Delete(conversion::NodeKey(p.Id, 'v'));
+        else bucket_->Put(conversion::NodeKey(p.Id, 'v'), conversion::Float32ToBytes(p.Vector.data(), d));
+      }
     uint64_t rows = 0, dead = 0;
     if (sdb_index_row_usage(h_, &rows, &dead) == SDB_OK && dead * 4 > rows)
       if (int rc = sdb_index_compact(h_)) return Error::wrap("could not compact the store", rc);

@@ -276,9 +276,9 @@ class IndexVamana:
         check(lib().sdb_index_commit(self._h, None))
 
     def abort_write(self):
-        """leave an open transaction without committing (the error path of InsertUpdateDelete); True if the index is
-        what it was at begin_write, False if the transaction had already changed it -- the handle is then unusable
-        and is rebuilt from the bucket, as the reference scraps a shard's cache (manager.go:231-240)"""
+        """leave an open transaction without committing (the error path of InsertUpdateDelete): the transaction is
+        rolled back and the index is what it was at begin_write (True); False only for a handle a device failure had
+        already left unusable"""
         return lib().sdb_index_abort_write(self._h) == 0
 
     def version_diff(self):

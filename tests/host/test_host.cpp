@@ -467,18 +467,27 @@ static void test_failed_write_leaves_the_index_writable() {
   CHECK(sdb_index_begin_write(h) == SDB_OK);
   CHECK(sdb_index_commit(h, nullptr) == SDB_OK);
   CHECK(sdb_index_abort_write(h) == SDB_OK);  // nothing open: fine
-  // ... and after its first change: no rollback, the handle says it is unusable
-  flat::IndexFlat::SearchReturn unused;
-  (void)unused;
+  // ... and after its first change: rolled back -- the point is gone, the index answers and takes the next write
+  models::SearchVectorVamanaOptions q;
+  q.Vector = {5, 6}, q.Limit = 3;
+  auto before = inv->Search(q);
+  CHECK(!before.err);
   CHECK(sdb_index_begin_write(h) == SDB_OK);
   uint64_t id = 500;
   float v[2] = {5, 6};
   CHECK(sdb_index_insert_batch(h, 1, &id, v, SDB_MEM_HOST, 0, nullptr) == SDB_OK);
-  CHECK(sdb_index_abort_write(h) == SDB_ERR_STATE);
-  CHECK(sdb_index_begin_write(h) == SDB_ERR_STATE);
-  models::SearchVectorVamanaOptions q;
-  q.Vector = {5, 6};
-  CHECK((bool)inv->Search(q).err);
+  uint8_t there = 0;
+  CHECK(sdb_index_exists_batch(h, 1, &id, &there) == SDB_OK && there == 1);
+  CHECK(sdb_index_abort_write(h) == SDB_OK);
+  CHECK(sdb_index_exists_batch(h, 1, &id, &there) == SDB_OK && there == 0);
+  uint64_t diff = 1;
+  CHECK(sdb_index_version_diff(h, &diff) == SDB_OK && diff == 0);
+  auto after = inv->Search(q);
+  CHECK(!after.err && after.results.size() == before.results.size());
+  for (size_t i = 0; i < after.results.size() && i < before.results.size(); i++)
+    CHECK(after.results[i].NodeId == before.results[i].NodeId && after.results[i].Distance == before.results[i].Distance);
+  CHECK(!inv->InsertUpdateDelete({{500, {5.0f, 6.0f}}}));
+  CHECK(inv->Exists(500));
 }
 
 int main() {

@@ -275,3 +275,83 @@ def test_random_writes_under_concurrent_readers(oracle):
     assert ix.version_diff() == 0
     assert_same_graph(ix, o)
     ix.close()
+
+
+def test_abort_write_rolls_the_transaction_back(oracle):
+    """sdb_index_abort_write: inserts, deletes and updates of an open transaction are undone -- the exported graph, the
+    id tables and every answer are what they were at begin_write -- and the writer's state is restored well enough that
+    the SAME writes, applied again and committed, build exactly the oracle's graph (the restored rows have no clean
+    prefix and no cached edge distances: both only ever save work)."""
+    from semadb_amd import flat, vamana
+    rng = np.random.default_rng(77)
+    d, n0, R, L, k = 32, 6000, 32, 50, 10
+    lat = rng.standard_normal((8, d)).astype(np.float32)
+    base0, extra, q = _rows(rng, n0, d, lat), _rows(rng, 900, d, lat), _rows(rng, 48, d, lat)
+    sv = start_vector(np.random.default_rng(5), d)
+    impl = oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM
+    ids0 = np.arange(2, n0 + 2, dtype=np.uint64)
+    o = oracle.Index(d, "cosine", R, L, 1.2, impl=impl)
+    o.set_start(sv)
+    assert o.insert_rounds(ids0, base0, round_size=0) == 0
+    ix = vamana.NewIndexVamana("rb", vamana.IndexVectorVamanaParameters(d, "cosine", L, R, 1.2), strict=False)
+    ix.set_start(sv)
+    ix.insert_batch(ids0, base0)
+    snap = ix.export()
+    stats0, usage0 = ix.stats(), ix.row_usage()
+    pre = ix.search_batch(q, k, L, trace=True, visit_cap=512)
+    assert _same(pre, _oracle_answers(o, q, k, L))
+    new_ids = np.arange(n0 + 2, n0 + 2 + 600, dtype=np.uint64)
+    gone = rng.choice(ids0, 150, replace=False).astype(np.uint64)
+    upd = rng.choice(np.setdiff1d(ids0, gone), 40, replace=False).astype(np.uint64)
+
+    def writes(target, commit):
+        target.begin_write()
+        target.insert_batch(new_ids, extra[:600])
+        target.delete_batch(np.concatenate([gone, new_ids[:50]]))
+        target.delete_batch(upd)
+        target.insert_batch(upd, extra[600:640], round_size=1)
+        if commit:
+            target.commit()
+
+    for attempt in range(2):  # twice: an aborted transaction leaves nothing behind that a second one trips over
+        writes(ix, commit=False)
+        assert ix.version_diff() > 0 and ix.exists(int(new_ids[100])) and not ix.exists(int(gone[0]))
+        assert _same(ix.search_batch(q, k, L), _oracle_answers(o, q, k, L))  # invisible while open
+        assert ix.abort_write() is True
+        assert ix.version_diff() == 0
+        assert ix.stats() == stats0 and ix.row_usage() == usage0
+        assert not ix.exists(int(new_ids[100])) and ix.exists(int(gone[0])) and ix.exists(int(upd[0]))
+        again = ix.export()
+        for a, b in zip(snap, again):
+            assert np.array_equal(a, b)
+        got = ix.search_batch(q, k, L, trace=True, visit_cap=512)
+        assert np.array_equal(got[0], pre[0]) and np.array_equal(bits(got[1]), bits(pre[1]))
+        assert np.array_equal(got[3].visit_ids, pre[3].visit_ids) and np.array_equal(got[3].n_dist, pre[3].n_dist)
+        f = [set(int(v) for v in new_ids[:30]) | set(int(v) for v in gone[:10]) for _ in range(48)]
+        assert _same(ix.search_batch(q, 5, L, filters=f), _oracle_answers(o, q, 5, L, f))
+    assert ix.abort_write() is True  # nothing open: fine
+    # the same writes, for real, on both sides
+    writes(ix, commit=True)
+    assert o.insert_rounds(new_ids, extra[:600], round_size=0) == 0
+    assert o.delete(np.concatenate([gone, new_ids[:50]])) == 0
+    assert o.delete(upd) == 0
+    for i in range(len(upd)):
+        assert o.insert(int(upd[i]), extra[600 + i]) == 0
+    from tests.helpers import assert_same_graph
+    assert_same_graph(ix, o)
+    assert _same(ix.search_batch(q, k, L), _oracle_answers(o, q, k, L))
+    ix.close()
+    # a flat index: Set (insert and replace) and Delete rolled back the same way
+    fx = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, "euclidean"))
+    fx.set_vectors(ids0[:500], base0[:500])
+    want = flat.flat_search_batch(fx._h, d, q, 5)
+    fx.begin_write()
+    fx.set_vectors(np.concatenate([ids0[:20], new_ids[:20]]), extra[:40])  # 20 replaced, 20 new
+    fx.remove_vectors(ids0[100:140])
+    assert fx.abort_write() is True
+    assert fx.row_usage() == (500, 0)
+    got = flat.flat_search_batch(fx._h, d, q, 5)
+    assert np.array_equal(np.asarray(got[0]), np.asarray(want[0])) and np.array_equal(bits(np.asarray(got[1])), bits(np.asarray(want[1])))
+    fx.set_vectors(new_ids[:5], extra[:5])  # and it takes the next write
+    assert fx.row_usage() == (505, 0)
+    fx.close()
