@@ -271,10 +271,10 @@ func (v *IndexVamana) insertUpdateDelete(ctx context.Context, points <-chan Inde
 	}
 	committed := false
 	defer func() {
-		// An error inside the transaction: leave it, so that the next write is not refused with "a transaction is
-		// already open".  If the graph had been changed already the handle is unusable from here on (abort_write
-		// says so) and the cache manager, which scraps a shard after any error inside a write (manager.go:231-240),
-		// rebuilds this index from the bucket.
+		// An error inside the transaction: roll it back.  The device keeps the committed copy of the graph that the
+		// searches walk; abort_write restores the writer's copy from it, so the index is what it was before this call
+		// and takes the next write.  (The cache manager scraps a shard after any error inside a write anyway,
+		// manager.go:231-240; with the rollback it may just as well keep this one.)
 		if !committed {
 			C.sdb_index_abort_write(v.h)
 		}
