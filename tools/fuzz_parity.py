@@ -250,6 +250,21 @@ def trial(rng, t):
                         now = snapshot()
                         for x, y in zip(pre, now):
                             assert np.array_equal(x, y), ("a search inside the transaction saw it", tag)
+                if rng.integers(0, 3) == 0:
+                    # a rehearsal that is called off: the same inserts, deletes and updates inside a transaction that is
+                    # ABORTED (sdb_index_abort_write) -- the graph must be the oracle's untouched one again, and the real
+                    # write below must still build what the oracle builds
+                    CURRENT["stage"] += " [after an aborted rehearsal]"
+                    g.begin_write()
+                    if new_ids:
+                        g.insert_batch(np.array(new_ids, dtype=np.uint64), new_vecs[:len(new_ids)], round_size=wr)
+                    if dels or upds:
+                        g.delete_batch(np.array(dels + upds, dtype=np.uint64))
+                    for k, i in enumerate(upds):
+                        g.insert_batch(np.array([i], dtype=np.uint64), upd_vecs[k:k + 1], round_size=1)
+                    assert g.abort_write() is True
+                    assert g.version_diff() == 0
+                    check_graph(g, o)
                 g.InsertUpdateDelete(ch, round_size=wr, _between=between)
                 if wr == 1:
                     for k, i in enumerate(new_ids):
