@@ -81,4 +81,23 @@ inline bool first_use_on_this_device(std::atomic<uint64_t> &seen) {
   return !(seen.fetch_or(bit) & bit);
 }
 
+#ifdef __HIPCC__
+// Read-only kernel inputs that a wave reads at wave-uniform addresses (the queries of the scans): through the constant
+// address space such a load is a scalar load whatever else the kernel stores; as a global load the compiler makes it
+// one only when it can prove that no store in the kernel may have written the location first
+typedef const __attribute__((address_space(4))) float uniform_float;
+typedef float uniform_f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) uniform_f4v uniform_float4;
+__device__ __forceinline__ uniform_float *as_uniform(const float *p) { return (uniform_float *)p; }
+
+// A workgroup's waves take turns at a work counter in LDS: one ds_add_rtn by lane 0, the answer broadcast
+__device__ __forceinline__ uint32_t next_query_group(void *lds_counter, int lane) {
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const uint32_t addr = (uint32_t)(uintptr_t)(lds_u32 *)lds_counter;
+  uint32_t got = 0;
+  if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(addr), "v"(1u));
+  return __builtin_amdgcn_readfirstlane(got);
+}
+#endif
+
 }  // namespace sdb

@@ -9,9 +9,13 @@
 // phase 2 folds it into the per-query top list, one wavefront per query.
 #include <cfloat>
 
-// streaming scan shape: waves per workgroup x query pairs per pass.  16 x 1 (four waves per SIMD hide the scalar
-// loads and LDS reads of one another) measured 18.9 ms for 1 024 x 1M x 384; 8 x 2 (half the LDS reads per FMA, two
-// waves per SIMD) 20.8 ms
+// streaming scan shape: waves per workgroup x query pairs per pass, 1 024 x 1M x 384 euclidean.  Query groups handed
+// out from a counter (SDB_SCAN_DYN): 16 x 1 (four waves per SIMD) 16.2 - 17.3 ms depending on the box, 12 x 1 17.4,
+// 8 x 2 (half the LDS reads per FMA, two waves per SIMD) 22.5, 8 x 1 23.0; with a fixed share per wave 16 x 1 took
+// 18.9 - 19.5 ms (3.1 of 4 wave slots occupied on average: the SIMD favours its oldest wave, the youngest finishes alone)
+#ifndef SDB_SCAN_DYN
+#define SDB_SCAN_DYN 1
+#endif
 #ifndef SDB_SCAN_WAVES
 #define SDB_SCAN_WAVES 16
 #define SDB_SCAN_PAIRS 1
@@ -223,8 +227,11 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_flat_scan(const float *__re
                                                                const FlatScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][kstride]
   const uint32_t nblk = a.nblk, kstride = nblk * 32 + 4;
+  float *next_group = tile + (size_t)kScanRows * kstride;  // the waves' work counter, behind the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform, and the compiler may know it
+  if (tid == 0) *reinterpret_cast<uint32_t *>(next_group) = 0;
+  (void)wave;
   const uint32_t row0 = a.first + blockIdx.x * kScanRows;
   const uint32_t nrows = min(kScanRows, a.first + a.rows - row0);
   // ---- stage the tile: consecutive threads read consecutive 16 B of a slab row; float4 c = 32 g + L of it holds
@@ -247,12 +254,21 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_flat_scan(const float *__re
   const float4 *myrow = reinterpret_cast<const float4 *>(tile + (size_t)lane * kstride);
   // kScanPairs query pairs per pass: the lane's row block is read from LDS once and used for 2 * kScanPairs queries
   const uint32_t ngroups = (a.nq + 2 * kScanPairs - 1) / (2 * kScanPairs);
+  // The query groups are handed out as the waves come for them: the SIMD favours its oldest wave, so with a fixed
+  // share per wave the four waves of a SIMD finish one after another and the last runs alone with its loads exposed
+  // (3.1 of 4 wave slots occupied on average, SQ_WAVE_CYCLES); taken from a counter, all waves finish within one group
+#if SDB_SCAN_DYN
+  for (;;) {
+    const uint32_t grp = next_query_group(next_group, lane);
+    if (grp >= ngroups) break;
+#else
   for (uint32_t grp = (uint32_t)wave; grp < ngroups; grp += kScanWaves) {
-    const float *xq[2 * kScanPairs];
+#endif
+    uniform_float *xq[2 * kScanPairs];
 #pragma unroll
     for (int k = 0; k < 2 * kScanPairs; k++) {
       const uint32_t q = grp * 2 * kScanPairs + k;
-      xq[k] = queries + (size_t)(q < a.nq ? q : a.nq - 1) * a.dim;  // past the end: the last query again, dropped
+      xq[k] = as_uniform(queries) + (size_t)(q < a.nq ? q : a.nq - 1) * a.dim;  // past the end: the last query again, dropped
     }
     f2v acc[2 * kScanPairs][16];
 #pragma unroll
@@ -268,8 +284,8 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_flat_scan(const float *__re
       for (int pp = 0; pp < kScanPairs; pp++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {  // float4 i of the block: pairs j = 2i, 2i + 1
-          const float4 u = reinterpret_cast<const float4 *>(xq[2 * pp] + b * 32)[i];  // wave-uniform: scalar loads
-          const float4 w = reinterpret_cast<const float4 *>(xq[2 * pp + 1] + b * 32)[i];
+          const uniform_f4v u = reinterpret_cast<uniform_float4 *>(xq[2 * pp] + b * 32)[i];  // wave-uniform: scalar loads
+          const uniform_f4v w = reinterpret_cast<uniform_float4 *>(xq[2 * pp + 1] + b * 32)[i];
           acc[2 * pp][2 * i] = chain1_pk<L2>(acc[2 * pp][2 * i], f2v{u.x, u.y}, f2v{y[i].x, y[i].y});
           acc[2 * pp][2 * i + 1] = chain1_pk<L2>(acc[2 * pp][2 * i + 1], f2v{u.z, u.w}, f2v{y[i].z, y[i].w});
           acc[2 * pp + 1][2 * i] = chain1_pk<L2>(acc[2 * pp + 1][2 * i], f2v{w.x, w.y}, f2v{y[i].x, y[i].y});
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_flat_merge(const uint32_t *__
 template <bool L2>
 static int launch_flat_scan(const FlatScanArgs &a, hipStream_t stream) {
   const dim3 grid((a.rows + kScanRows - 1) / kScanRows);
-  const size_t lds = (size_t)kScanRows * (a.nblk * 32 + 4) * sizeof(float);
+  const size_t lds = (size_t)kScanRows * (a.nblk * 32 + 4) * sizeof(float) + 16;  // the tile and the group counter
   static std::atomic<uint64_t> attr{0};
   if (first_use_on_this_device(attr))
     SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flat_scan<L2>), hipFuncAttributeMaxDynamicSharedMemorySize,
