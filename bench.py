@@ -569,6 +569,11 @@ def measure_mode(a, ctx, mode, rows, primary):
                 result["value_host_definition"] = cfg["host_qps_definition"]
             except Exception as e:
                 cfg["host_rates_error"] = repr(e)
+        if not a.no_secondary:
+            try:
+                cfg["side_kernels"] = side_points(a, ix, base, queries, dev)
+            except Exception as e:
+                cfg["side_kernels"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(a, ix, queries[:nb_recall], k, L)
@@ -588,6 +593,68 @@ def measure_mode(a, ctx, mode, rows, primary):
             except Exception as e:
                 result["config"]["c4"] = {"error": repr(e)}
     return result
+
+
+def side_points(a, ix, base, queries, dev):
+    """The path's other kernels on the headline's data, so that they are in the driver's record and not only in
+    builder-run logs: K1 (sdb_distance_batch: 64 queries x all rows, row reuse on chip), the euclidean exact scan
+    (IndexFlat.Search, packed-FMA kernel; the cosine scan is `flat_scan_ms` above), the filtered walk
+    (search.go:33-51,93-95) with 10 / 1 000 filter ids per query (kernel time from HIP events inside the library; the
+    whole call adds the host-side translation of the filter ids)."""
+    from semadb_amd import distance, flat
+    n, d = base.shape
+    out = {}
+    q64 = queries[0][:64].contiguous()
+    for metric in ("cosine", "euclidean"):
+        distance.distance_batch(metric, q64, base)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r = distance.distance_batch(metric, q64, base)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        del r
+        out["k1_64x%dx%d_%s" % (n, d, metric)] = {"ms": round(dt * 1e3, 3), "G_pairs_per_s": round(64 * n / dt / 1e9, 1)}
+    fx = flat.NewIndexFlat(flat.IndexVectorFlatParameters(d, "euclidean"), capacity=n + 1)
+    try:
+        fx.set_vectors(None, base)
+        qb = queries[0].contiguous()
+        for _ in range(2):
+            flat.flat_search_batch(fx._h, d, qb, a.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            flat.flat_search_batch(fx._h, d, qb, a.k)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out["exact_scan_euclidean_%dx%dx%d" % (qb.shape[0], n, d)] = {
+            "ms": round(dt * 1e3, 2), "G_pairs_per_s": round(qb.shape[0] * n / dt / 1e9, 1)}
+    finally:
+        fx.close()
+    rng = np.random.default_rng(3)
+    nq = queries.shape[1]
+    ix.set_profiling(True)
+    try:
+        for size in (10, 1000):
+            filt = [np.sort(rng.choice(n, size=size, replace=False).astype(np.uint64) + 2) for _ in range(nq)]
+            off = np.zeros(nq + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(f) for f in filt])
+            ids = np.concatenate(filt)
+            for _ in range(3):  # the first filtered calls size their workspaces
+                ix.search_batch(queries[0], a.k, a.search_size, filters=(off, ids))
+                torch.cuda.synchronize()
+            ix.profile_read()
+            t0 = time.perf_counter()
+            for b in range(1, 4):
+                ix.search_batch(queries[b % queries.shape[0]], a.k, a.search_size, filters=(off, ids))
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            kms = float(np.mean(ix.profile_read()))
+            out["filtered_walk_%d_ids" % size] = {"kernel_ms": round(kms, 4), "kernel_qps": round(nq / kms * 1e3, 1),
+                                                  "call_ms": round(dt * 1e3, 2), "call_qps": round(nq / dt, 1)}
+    finally:
+        ix.set_profiling(False)
+    return out
 
 
 def c4_point(a, dev, dev_index):
