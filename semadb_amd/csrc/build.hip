@@ -861,6 +861,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SDB_BACK_WAV
   const int lane = threadIdx.x, L = lane & 31;
   const size_t pos = blockIdx.x;
   const size_t total = (size_t)a.nnew * 64;
+#ifdef SDB_BACK_PROFILE
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   const uint64_t key = a.keys_sorted[pos];
   if (key == kNoKey) return;
   const uint32_t b = (uint32_t)(key >> 32);
@@ -1005,6 +1008,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SDB_BACK_WAV
       if (a.dirty) a.dirty[b] = 1;
     }
   }
+#ifdef SDB_BACK_PROFILE  // measurement builds (tools/backprof.py): the wave's cycles by requests per target, spare stat slots
+  {
+    const unsigned long long cyc = __builtin_readcyclecounter() - t_begin;
+    stat_add(a, m == 1 ? 11 : (m <= 4 ? 12 : (m <= 16 ? 13 : 14)), cyc, lane);
+    stat_add(a, 15, cyc > 200000ull ? cyc : 0ull, lane);
+  }
+#endif
   stat_add(a, kStBackPairs, st_eval, lane);
   stat_add(a, kStBackCached, st_cached, lane);
   stat_add(a, kStRequests, m, lane);

@@ -1152,7 +1152,11 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
 
 int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) {
   if (!ix || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+#ifdef SDB_BACK_PROFILE  // measurement builds: the five spare slots carry k_backedges' cycle counters (tools/backprof.py)
+  const uint32_t n = cap < sdb_index::kStatStride ? cap : sdb_index::kStatStride;
+#else
   const uint32_t n = cap < SDB_BUILD_STATS ? cap : SDB_BUILD_STATS;
+#endif
   for (uint32_t i = 0; i < n; i++) out[i] = 0;
   if (!ix->d_bstats || n == 0) return SDB_OK;
   DeviceGuard dg(ix->P.device);
