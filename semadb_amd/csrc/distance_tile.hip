@@ -51,14 +51,16 @@ __global__ void k_k1_swizzle_queries(const float *__restrict__ q, float *__restr
   out[i] = qi < nq ? q[(size_t)qi * dim + e] : 0.0f;
 }
 
-// NG4: the wave's row operands are held for up to 4 NG4 blocks (32 NG4 registers); blocks past nblk are skipped.
-template <int NG4, bool TAIL>
-__global__ __launch_bounds__(256, (NG4 <= 3 && !TAIL) ? 2 : 1) void k_k1_tile_mfma(
+// NBLK: the row's whole blocks, exactly -- with a run-time count in the multiply loop the compiler copies the 128
+// accumulators around its branches (300 moves per group of queries)
+template <int NBLK, bool TAIL>
+__global__ __launch_bounds__(256, (NBLK <= 12 && !TAIL) ? 2 : 1) void k_k1_tile_mfma(
     const float *__restrict__ cands, const float *__restrict__ qsw, float *__restrict__ out, uint64_t nc, uint32_t nq,
-    uint32_t dim, uint32_t nblk, uint32_t tail, int metric, int vec_store) {
-  constexpr int NB = 4 * NG4;
-  const uint32_t grp_f4 = nblk * 128 + (TAIL ? kK1TailImgFloats / 4 : 0);  // float4 per query group image
-  const int pieces = (int)(grp_f4 / 64);                                   // 1 KB pieces of it
+    uint32_t dim, uint32_t tail, int metric, int vec_store) {
+  constexpr int NB = NBLK;
+  constexpr uint32_t nblk = NBLK;
+  constexpr uint32_t grp_f4 = nblk * 128 + (TAIL ? kK1TailImgFloats / 4 : 0);  // float4 per query group image
+  constexpr int pieces = (int)(grp_f4 / 64);                                   // 1 KB pieces of it
   extern __shared__ __attribute__((aligned(16))) float bs[];  // [2][group image], then [64][kK1TailPitch] row tails
   float *rowtail = bs + 2 * (size_t)grp_f4 * 4;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -71,12 +73,8 @@ __global__ __launch_bounds__(256, (NG4 <= 3 && !TAIL) ? 2 : 1) void k_k1_tile_mf
     const float *src = cands + (size_t)(r < nc ? r : nc - 1) * dim + 8 * (lane >> 4);
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      if ((uint32_t)b < nblk) {
-        A[b][0] = *reinterpret_cast<const f4v *>(src + 32 * b);
-        A[b][1] = *reinterpret_cast<const f4v *>(src + 32 * b + 4);
-      } else {
-        A[b][0] = f4v{0, 0, 0, 0}, A[b][1] = f4v{0, 0, 0, 0};
-      }
+      A[b][0] = *reinterpret_cast<const f4v *>(src + 32 * b);
+      A[b][1] = *reinterpret_cast<const f4v *>(src + 32 * b + 4);
     }
   }
   const uint32_t ngroups = (nq + 15) / 16;
@@ -105,21 +103,20 @@ __global__ __launch_bounds__(256, (NG4 <= 3 && !TAIL) ? 2 : 1) void k_k1_tile_mf
             T = __builtin_amdgcn_mfma_f32_16x16x1f32(low ? x4[c] : 0.0f, low ? y4[c] : 0.0f, T, 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
     f4v b0 = bq[0], b1 = bq[64];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      if ((uint32_t)b < nblk) {
-        f4v n0 = b0, n1 = b1;
-        if ((uint32_t)(b + 1) < nblk) n0 = bq[(b + 1) * 128], n1 = bq[(b + 1) * 128 + 64];
+      f4v n0 = b0, n1 = b1;
+      if (b + 1 < NB) n0 = bq[(b + 1) * 128], n1 = bq[(b + 1) * 128 + 64];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-          acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(A[b][k >> 2][k & 3], k < 4 ? b0[k & 3] : b1[k & 3], acc[k], 0, 0, 0);
-        b0 = n0, b1 = n1;
+      for (int k = 0; k < 8; k++) {
+        f16v c = acc[k];
+        if (b == 0)
+#pragma unroll
+          for (int r = 0; r < 16; r++) c[r] = 0.0f;
+        acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(A[b][k >> 2][k & 3], k < 4 ? b0[k & 3] : b1[k & 3], c, 0, 0, 0);
       }
+      b0 = n0, b1 = n1;
     }
   };
   // dot.s:45-53 in the lane: s[k] = ((P[0][k] + P[1][k]) + P[2][k]) + P[3][k]; r[l] = s[l] + s[l + 4]; r[0] += t;
@@ -165,14 +162,124 @@ __global__ __launch_bounds__(256, (NG4 <= 3 && !TAIL) ? 2 : 1) void k_k1_tile_mf
   }
   __syncthreads();  // waits for this wave's DMAs (vmcnt) and for everybody else's
   f16v acc[8], T;
-  float dist[4];
+  float dist[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // a group's distances are stored at the start of the next group's multiply (see k_k1_stream_mfma)
   for (uint32_t G = 0; G < ngroups; G++) {
     dma(G + 1);
+    if (G) emit(dist, G - 1);
     multiply(acc, T, G);
     reduce(acc, T, dist);
-    emit(dist, G);
     __syncthreads();
   }
+  emit(dist, ngroups - 1);
+}
+
+// ---- few queries (up to a few hundred): the roles turned around ------------------------------------------------------
+// k_k1_tile_mfma keeps 64 candidate rows in registers and streams the query groups: with 64 queries that is four groups
+// per workgroup, and a workgroup's life is mostly the load of its rows (77 G pairs/s at 64 x 1M x 384, 0.38 of the
+// matrix pipe).  Here a wave keeps 16 QUERIES in registers for the whole launch and the candidates stream through LDS,
+// 16 rows per group, double buffered: LDS-DMA takes the operand layout straight from the caller's row-major rows -- the
+// destination of a wave's piece is lane-linear, the source is per lane, and lane l's 16 bytes of piece (b, h) are
+// elements 32 b + 8 (l / 16) + 4 h .. + 3 of candidate 16 G + l % 16, exactly the [b][h][l][c] image k_k1_swizzle_queries
+// writes for the other kernel.  Same instruction, same chains, same reduce tree: the same bits.  A workgroup (four
+// waves = 64 queries; blockIdx.y counts query blocks) walks `span` candidates.
+template <int NBLK>
+__global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_k1_stream_mfma(const float *__restrict__ queries,
+                                                                          const float *__restrict__ cands,
+                                                                          float *__restrict__ out, uint64_t nc, uint32_t nq,
+                                                                          uint32_t dim, uint32_t span, int metric) {
+  constexpr int NB = NBLK;  // the row's blocks, exactly: a run-time block count in the multiply loop makes the compiler
+                            // copy the 128 accumulators around its branches (300 moves per group)
+  constexpr uint32_t nblk = NBLK;
+  constexpr uint32_t grp_f4 = nblk * 128;  // float4 per candidate group image
+  extern __shared__ __attribute__((aligned(16))) float bs[];  // [2][group image]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t q0 = 64 * blockIdx.y + 16 * wave;
+  // ---- the wave's 16 queries: lane 16 blk + i holds elements 32 b + 8 blk + (0..7) of query i for every block b
+  f4v A[NB][2];
+  {
+    const uint32_t r = q0 + (lane & 15);
+    const float *src = queries + (size_t)(r < nq ? r : nq - 1) * dim + 8 * (lane >> 4);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      A[b][0] = *reinterpret_cast<const f4v *>(src + 32 * b);
+      A[b][1] = *reinterpret_cast<const f4v *>(src + 32 * b + 4);
+    }
+  }
+  const uint64_t c0 = (uint64_t)blockIdx.x * span;
+  const uint64_t c_end = c0 + span < nc ? c0 + span : nc;
+  const uint32_t ngroups = (uint32_t)((c_end - c0 + 15) / 16);
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr int pieces = 2 * NBLK;
+  // wave w takes pieces w, w + 4, ..: piece (b, h) = 2 b + h starts 128 b + 16 h bytes into the lane's 8 floats per block,
+  // so the wave's pieces are 256 bytes apart from a start of its own -- immediates, one address register pair
+  const uint32_t wave_off = 32u * (uint32_t)(wave >> 1) + 4u * (uint32_t)(wave & 1);  // floats
+  auto dma = [&](uint32_t G) __attribute__((always_inline)) {
+    const uint64_t row = c0 + 16 * (uint64_t)min(G, ngroups - 1) + (uint32_t)(lane & 15);
+    const float *src = cands + (size_t)(row < nc ? row : nc - 1) * dim + 8 * (lane >> 4) + wave_off;
+    char *dst = reinterpret_cast<char *>(bs) + (size_t)(G & 1) * ((size_t)grp_f4 * 16) + (size_t)wave * 1024;
+#pragma unroll
+    for (int i = 0; 4 * i < pieces; i++)
+      if (4 * i + 3 < pieces || wave + 4 * i < pieces)
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + 64 * i), (lds_void *)(dst + (size_t)i * 4096), 16, 0, 0);
+  };
+  auto multiply = [&](f16v (&acc)[8], uint32_t G) __attribute__((always_inline)) {
+    const f4v *bq = reinterpret_cast<const f4v *>(bs) + (size_t)(G & 1) * grp_f4 + lane;
+    f4v b0 = bq[0], b1 = bq[64];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      f4v n0 = b0, n1 = b1;
+      if (b + 1 < NB) n0 = bq[(b + 1) * 128], n1 = bq[(b + 1) * 128 + 64];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        f16v c = acc[k];
+        if (b == 0)
+#pragma unroll
+          for (int r = 0; r < 16; r++) c[r] = 0.0f;
+        acc[k] = __builtin_amdgcn_mfma_f32_16x16x1f32(A[b][k >> 2][k & 3], k < 4 ? b0[k & 3] : b1[k & 3], c, 0, 0, 0);
+      }
+      b0 = n0, b1 = n1;
+    }
+  };
+  // dot.s:45-53 in the lane (see k_k1_tile_mfma): P[blk][k] = register 4 blk + i4 of accumulator set k
+  auto reduce = [&](const f16v (&acc)[8], float (&dist)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++) {
+      float s[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = ((acc[k][i4] + acc[k][4 + i4]) + acc[k][8 + i4]) + acc[k][12 + i4];
+      float r0 = s[0] + s[4], r1 = s[1] + s[5], r2 = s[2] + s[6], r3 = s[3] + s[7];
+      r0 = r0 + 0.0f, r1 = r1 + 0.0f, r2 = r2 + 0.0f, r3 = r3 + 0.0f;  // VADDPS with the {t, 0, 0, 0} vector (dot.s:51)
+      dist[i4] = (r0 + r1) + (r2 + r3);
+    }
+  };
+  const bool cosine = metric == SDB_METRIC_COSINE;
+  const uint32_t q_lane = q0 + 4 * (lane >> 4);  // the lane emits queries q_lane .. q_lane + 3 (the A side of the tile)
+  auto emit = [&](const float (&dist)[4], uint32_t G) __attribute__((always_inline)) {
+    const uint64_t c = c0 + 16 * (uint64_t)G + (uint32_t)(lane & 15);  // 16 lanes: 64 contiguous bytes of a query's row
+    if (c >= c_end) return;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++)
+      if (q_lane + i4 < nq) out[(size_t)(q_lane + i4) * nc + c] = cosine ? 1.0f - dist[i4] : -dist[i4];  // distance.go:19-25
+  };
+  dma(0);
+  __syncthreads();  // waits for this wave's DMAs (vmcnt) and for everybody else's
+  f16v acc[8];
+  float dist[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // a group's distances are stored at the start of the NEXT group's multiply: the barrier's vmcnt(0) -- it has to wait for
+  // the LDS-DMA -- would otherwise also wait for stores issued a moment before it, every group.  (A ring of three
+  // buffers with two groups' DMAs in flight behind counted vmcnt waits and bare barriers measured the same: 0.69 ms at
+  // 64 x 1M x 384 either way; what is left is the two waves of a SIMD not overlapping, matrix pipe 64 % busy at 1.75 GHz.)
+  for (uint32_t G = 0; G < ngroups; G++) {
+    dma(G + 1);
+    if (G) emit(dist, G - 1);
+    multiply(acc, G);
+    reduce(acc, dist);
+    __syncthreads();
+  }
+  emit(dist, ngroups - 1);
 }
 
 // ---- euclidean: packed FMAs over an LDS tile of 64 rows (original element order, padded by 16 B per row) --------
@@ -271,7 +378,7 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
   }
 }
 
-static int k1_mfma_launch(int ng4, bool tail_k, dim3 grid, size_t lds, hipStream_t stream, const float *dc, const float *qsw,
+static int k1_mfma_launch(bool tail_k, dim3 grid, size_t lds, hipStream_t stream, const float *dc, const float *qsw,
                           float *dout, uint64_t nc, uint32_t nq, uint32_t dim, uint32_t nblk, uint32_t tail, int metric,
                           int vec_store) {
 #define SDB_K1_CASE(N)                                                                                              \
@@ -281,19 +388,23 @@ static int k1_mfma_launch(int ng4, bool tail_k, dim3 grid, size_t lds, hipStream
       if (first_use_on_this_device(at1))                                                                            \
         SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_k1_tile_mfma<N, true>),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
-      hipLaunchKernelGGL((k_k1_tile_mfma<N, true>), grid, dim3(256), lds, stream, dc, qsw, dout, nc, nq, dim, nblk, \
-                         tail, metric, vec_store);                                                                  \
+      hipLaunchKernelGGL((k_k1_tile_mfma<N, true>), grid, dim3(256), lds, stream, dc, qsw, dout, nc, nq, dim, tail, \
+                         metric, vec_store);                                                                        \
     } else {                                                                                                        \
       if (first_use_on_this_device(at0))                                                                            \
         SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_k1_tile_mfma<N, false>),                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
       hipLaunchKernelGGL((k_k1_tile_mfma<N, false>), grid, dim3(256), lds, stream, dc, qsw, dout, nc, nq, dim,      \
-                         nblk, tail, metric, vec_store);                                                            \
+                         tail, metric, vec_store);                                                                  \
     }                                                                                                               \
     break;                                                                                                          \
   }
-  switch (ng4) {
+  switch (nblk) {
     SDB_K1_CASE(1) SDB_K1_CASE(2) SDB_K1_CASE(3) SDB_K1_CASE(4) SDB_K1_CASE(5) SDB_K1_CASE(6) SDB_K1_CASE(7) SDB_K1_CASE(8)
+    SDB_K1_CASE(9) SDB_K1_CASE(10) SDB_K1_CASE(11) SDB_K1_CASE(12) SDB_K1_CASE(13) SDB_K1_CASE(14) SDB_K1_CASE(15)
+    SDB_K1_CASE(16) SDB_K1_CASE(17) SDB_K1_CASE(18) SDB_K1_CASE(19) SDB_K1_CASE(20) SDB_K1_CASE(21) SDB_K1_CASE(22)
+    SDB_K1_CASE(23) SDB_K1_CASE(24) SDB_K1_CASE(25) SDB_K1_CASE(26) SDB_K1_CASE(27) SDB_K1_CASE(28) SDB_K1_CASE(29)
+    SDB_K1_CASE(30) SDB_K1_CASE(31) SDB_K1_CASE(32)
     default: return fail(SDB_ERR_INVALID, "row too long for the matrix-core tile");
   }
 #undef SDB_K1_CASE
@@ -325,6 +436,36 @@ int launch_k1_tiles(int metric, uint32_t dim, const float *dq, uint64_t nq, cons
     return 1;
   }
   if (nblk > 32) return 0;
+#ifndef SDB_K1_STREAM_MAX_NQ
+#define SDB_K1_STREAM_MAX_NQ 256
+#endif
+  if (tail == 0 && nblk <= 32 && nq <= SDB_K1_STREAM_MAX_NQ) {  // few queries: they stay in registers, the candidates stream
+    const uint32_t span = 512;
+    const dim3 sgrid((unsigned)((nc + span - 1) / span), (unsigned)((nq + 63) / 64));
+    const size_t slds = (size_t)2 * nblk * 2048;
+#define SDB_K1_STREAM(N)                                                                                               \
+  case N: {                                                                                                            \
+    static std::atomic<uint64_t> at{0};                                                                                \
+    if (first_use_on_this_device(at) &&                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_k1_stream_mfma<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            160 * 1024) != hipSuccess)                                                                 \
+      return -fail(SDB_ERR_DEVICE, "hipFuncSetAttribute failed");                                                      \
+    hipLaunchKernelGGL((k_k1_stream_mfma<N>), sgrid, dim3(256), slds, stream, dq, dc, dout, nc, (uint32_t)nq, dim, span, \
+                       metric);                                                                                        \
+    break;                                                                                                             \
+  }
+    switch (nblk) {
+      SDB_K1_STREAM(1) SDB_K1_STREAM(2) SDB_K1_STREAM(3) SDB_K1_STREAM(4) SDB_K1_STREAM(5) SDB_K1_STREAM(6) SDB_K1_STREAM(7)
+      SDB_K1_STREAM(8) SDB_K1_STREAM(9) SDB_K1_STREAM(10) SDB_K1_STREAM(11) SDB_K1_STREAM(12) SDB_K1_STREAM(13)
+      SDB_K1_STREAM(14) SDB_K1_STREAM(15) SDB_K1_STREAM(16) SDB_K1_STREAM(17) SDB_K1_STREAM(18) SDB_K1_STREAM(19)
+      SDB_K1_STREAM(20) SDB_K1_STREAM(21) SDB_K1_STREAM(22) SDB_K1_STREAM(23) SDB_K1_STREAM(24) SDB_K1_STREAM(25)
+      SDB_K1_STREAM(26) SDB_K1_STREAM(27) SDB_K1_STREAM(28) SDB_K1_STREAM(29) SDB_K1_STREAM(30) SDB_K1_STREAM(31)
+      SDB_K1_STREAM(32)
+    }
+#undef SDB_K1_STREAM
+    if (hipGetLastError() != hipSuccess) return -fail(SDB_ERR_DEVICE, "k_k1_stream_mfma launch failed");
+    return 1;
+  }
   const uint32_t ngroups = (uint32_t)((nq + 15) / 16);
   const uint32_t grp_floats = nblk * 512 + (tail ? kK1TailImgFloats : 0);
   const size_t lds = (size_t)2 * grp_floats * 4 + (tail ? (size_t)kK1Rows * kK1TailPitch * 4 : 0);
@@ -338,7 +479,7 @@ int launch_k1_tiles(int metric, uint32_t dim, const float *dq, uint64_t nq, cons
   hipLaunchKernelGGL(k_k1_swizzle_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dq, qsw,
                      (uint32_t)nq, dim, nblk, tail, (uint32_t)total);
   const int vec_store = ((nc & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0) ? 1 : 0;
-  int rc = k1_mfma_launch((int)((nblk + 3) / 4), tail != 0, grid, lds, stream, dc, qsw, dout, nc, (uint32_t)nq, dim, nblk,
+  int rc = k1_mfma_launch(tail != 0, grid, lds, stream, dc, qsw, dout, nc, (uint32_t)nq, dim, nblk,
                           tail, metric, vec_store);
   (void)hipFreeAsync(qsw, stream);
   return rc == SDB_OK ? 1 : -rc;

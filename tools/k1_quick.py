@@ -1,0 +1,11 @@
+import sys, os, time, json
+sys.path.insert(0, "/root/repo")
+import torch, bench
+from semadb_amd import distance
+d, nq, nc = 384, int(os.environ.get("NQ", 64)), 1000000
+q = bench.gen_rows(nq, d, 1, "gaussian", "cuda:0"); c = bench.gen_rows(nc, d, 2, "gaussian", "cuda:0")
+for _ in range(2): distance.distance_batch("cosine", q, c)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): r = distance.distance_batch("cosine", q, c)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print(os.path.basename(os.environ.get("SEMADB_AMD_LIB", "default")), nq, "ms %.3f" % (dt * 1e3), "Gpairs/s %.1f" % (nq * nc / dt / 1e9))
