@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, (NBLK <= 12 && !TAIL) ? 2 : 1) void k_k1_tile_
 // destination of a wave's piece is lane-linear, the source is per lane, and lane l's 16 bytes of piece (b, h) are
 // elements 32 b + 8 (l / 16) + 4 h .. + 3 of candidate 16 G + l % 16, exactly the [b][h][l][c] image k_k1_swizzle_queries
 // writes for the other kernel.  Same instruction, same chains, same reduce tree: the same bits.  A workgroup (four
-// waves = 64 queries; blockIdx.y counts query blocks) walks `span` candidates.
+// waves = 64 queries; blockIdx.x counts query blocks, blockIdx.y spans) walks `span` candidates.
 template <int NBLK>
 __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_k1_stream_mfma(const float *__restrict__ queries,
                                                                           const float *__restrict__ cands,
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_k1_stream_mfma(cons
   extern __shared__ __attribute__((aligned(16))) float bs[];  // [2][group image]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t q0 = 64 * blockIdx.y + 16 * wave;
+  const uint32_t q0 = 64 * blockIdx.x + 16 * wave;  // the query blocks of a span follow each other: its rows come from HBM once
   // ---- the wave's 16 queries: lane 16 blk + i holds elements 32 b + 8 blk + (0..7) of query i for every block b
   f4v A[NB][2];
   {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, NBLK <= 12 ? 2 : 1) void k_k1_stream_mfma(cons
       A[b][1] = *reinterpret_cast<const f4v *>(src + 32 * b + 4);
     }
   }
-  const uint64_t c0 = (uint64_t)blockIdx.x * span;
+  const uint64_t c0 = (uint64_t)blockIdx.y * span;
   const uint64_t c_end = c0 + span < nc ? c0 + span : nc;
   const uint32_t ngroups = (uint32_t)((c_end - c0 + 15) / 16);
   typedef __attribute__((address_space(3))) void lds_void;
@@ -440,8 +440,9 @@ int launch_k1_tiles(int metric, uint32_t dim, const float *dq, uint64_t nq, cons
 #define SDB_K1_STREAM_MAX_NQ 256
 #endif
   if (tail == 0 && nblk <= 32 && nq <= SDB_K1_STREAM_MAX_NQ) {  // few queries: they stay in registers, the candidates stream
-    const uint32_t span = 512;
-    const dim3 sgrid((unsigned)((nc + span - 1) / span), (unsigned)((nq + 63) / 64));
+    uint32_t span = 512;
+    while ((nc + span - 1) / span > 65535) span *= 2;  // grid.y
+    const dim3 sgrid((unsigned)((nq + 63) / 64), (unsigned)((nc + span - 1) / span));
     const size_t slds = (size_t)2 * nblk * 2048;
 #define SDB_K1_STREAM(N)                                                                                               \
   case N: {                                                                                                            \
