@@ -96,6 +96,23 @@ def test_tiled_distance_bit_exact(oracle, metric, d):
         assert np.array_equal(bits(got), bits(want)), (nq, nc)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("d", [64, 384, 416, 1024])
+def test_tiled_distance_query_blocks(oracle, metric, d):
+    """the two matrix-core kernels meet at 256 queries: up to there the queries stay in registers, 64 per workgroup
+    (one, two, four query blocks, a ragged last one) and the candidates stream in spans of 512 (one span, a ragged
+    second and third); above, the candidate rows stay in registers and the query groups stream.  d = 416 has a tail
+    (always the second kernel), d = 1 024 is the longest row of the first"""
+    from semadb_amd import distance
+    rng = np.random.default_rng(d * 13 + len(metric))
+    for nq, nc in [(64, 512), (65, 600), (130, 1100), (256, 513), (257, 520), (300, 1030)]:
+        q = (rng.standard_normal((nq, d)) * 2).astype(np.float32)
+        c = (rng.standard_normal((nc, d)) * 2).astype(np.float32)
+        got = distance.distance_batch(metric, q, c)
+        want = oracle.distance_matrix(q, c, metric, oracle.IMPL_ASM)
+        assert np.array_equal(bits(got), bits(want)), (nq, nc)
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
 def test_tiled_distance_device_memory_and_special_values(oracle, metric):
     import torch
