@@ -1,3 +1,4 @@
+"""K1 (sdb_distance_batch) at NQ x 1M x 384 cosine, one line: A/B runs of variant builds (SEMADB_AMD_LIB)."""
 import sys, os, time, json
 sys.path.insert(0, "/root/repo")
 import torch, bench
