@@ -26,6 +26,8 @@
 
 namespace sdb {
 
+void keep_pool_memory(int device);  // distance.hip
+
 // ---- phase 1: distances of `rows` slab rows (first_row ..) or of listed slots to every query -------------
 // grid (ceil(rows / 64), nq), block 256 = 8 half-waves, 8 candidates each
 template <bool L2>
@@ -694,14 +696,17 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
     hipStream_t s;
     ~WsHold() { ix->release_ws(ws, s, false); }
   } hold{ix, ix->acquire_ws(stream, false), stream};
+  // stream-ordered scratch from the device's pool (it keeps what it is given back: distance.hip), not a hipMalloc /
+  // hipFree pair of ~85 MB per call
   char *buf = nullptr;
-  SDB_HIP(hipMalloc(&buf, off));
+  keep_pool_memory(ix->P.device);
+  SDB_HIP(hipMallocAsync(reinterpret_cast<void **>(&buf), off, stream));
   struct Free {
     char *p;
     hipStream_t s;
     ~Free() {
+      (void)hipFreeAsync(p, s);
       (void)hipStreamSynchronize(s);
-      (void)hipFree(p);
     }
   } fr{buf, stream};
   const float *dq = queries;
