@@ -56,6 +56,16 @@ int Workspace::ensure_filter(size_t bytes) {
   return SDB_OK;
 }
 
+int Workspace::ensure_filter_host(size_t bytes) {
+  if (bytes <= filter_host_bytes) return SDB_OK;
+  if (filter_host) SDB_HIP(hipHostFree(filter_host));
+  filter_host = nullptr, filter_host_bytes = 0;
+  bytes += bytes / 4;  // grows in steps: pinning is the expensive part
+  SDB_HIP(hipHostMalloc(&filter_host, bytes, hipHostMallocDefault));
+  filter_host_bytes = bytes;
+  return SDB_OK;
+}
+
 int Workspace::ensure_lut(size_t bytes) {
   if (bytes <= lut_bytes) return SDB_OK;
   if (lut) SDB_HIP(hipFree(lut));
@@ -68,6 +78,8 @@ int Workspace::ensure_lut(size_t bytes) {
 void Workspace::release() {
   if (filter) (void)hipFree(filter);
   filter = nullptr;
+  if (filter_host) (void)hipHostFree(filter_host);
+  filter_host = nullptr, filter_host_bytes = 0;
   if (lut) (void)hipFree(lut);
   lut = nullptr;
   if (bitsets) (void)hipFree(bitsets);
@@ -958,12 +970,12 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   if (filtered) {
     // search.go:41-48: seeds = the first <= searchSize filter ids (ascending) that exist; Contains (:93) is
     // answered from the whole filter as ascending slots.  Filter arrays are host memory (header).
-    std::vector<uint32_t> off_seed(nq + 1, 0), off_filt(nq + 1, 0), seeds, fslots;
+    std::vector<uint32_t> off_seed(nq + 1, 0), off_filt(nq + 1, 0);
     // ids -> slots is a hash lookup per id; a batch of 1 024 queries with 1 000-id filters carries a million of them
     // (5 ms on one core), so big batches are split over a few host threads.  Pass 1 validates and counts, pass 2
     // fills the two CSR arrays in place.
     const uint64_t total_ids = filter_offsets[nq] - filter_offsets[0];
-    const unsigned nthr = total_ids < (1u << 16) ? 1u : std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned nthr = total_ids < (1u << 16) ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<uint32_t> n_seed(nq, 0), n_filt(nq, 0);
     std::atomic<int> bad{0};  // 1: offsets decrease, 2: ids not ascending
     std::atomic<uint64_t> bad_q{0};
@@ -1000,20 +1012,29 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     if (bad == 1) return fail(SDB_ERR_INVALID, "filter_offsets must be non-decreasing");
     if (bad == 2) return fail(SDB_ERR_INVALID, "filter ids of query %llu are not strictly ascending", (unsigned long long)bad_q.load());
     for (uint64_t q = 0; q < nq; q++) off_seed[q + 1] = off_seed[q] + n_seed[q], off_filt[q + 1] = off_filt[q] + n_filt[q];
-    seeds.resize(off_seed[nq]);
-    fslots.resize(off_filt[nq]);
+    // the two lists are written where the DMA engine can take them from (pinned, kept with the workspace): a pageable
+    // vector of 10^8 slots costs its zero-fill and a staged copy on top of the translation
+    const size_t n_seeds = off_seed[nq], n_fslots = off_filt[nq];
+    const size_t h_seeds = (n_seeds * 4 + 255) & ~(size_t)255;
+    SDB_TRY(ws->ensure_filter_host(h_seeds + n_fslots * 4 + 256));
+    uint32_t *seeds_h = static_cast<uint32_t *>(ws->filter_host);
+    uint32_t *fslots_h = reinterpret_cast<uint32_t *>(static_cast<char *>(ws->filter_host) + h_seeds);
     for_queries([&](uint64_t q) {
       const uint64_t b = filter_offsets[q], e = filter_offsets[q + 1];
-      uint32_t *sp = seeds.data() + off_seed[q], *fp = fslots.data() + off_filt[q];
+      uint32_t *sp = seeds_h + off_seed[q], *fp = fslots_h + off_filt[q];
+      bool ascending = true;  // rows stored in id order (the usual case) translate to ascending slots: nothing to sort
+      int64_t last = -1;
       for (uint64_t i = b; i < e; i++) {
         const int64_t s = ix->slot_of_committed(filter_ids[i], vw.n);
         if (s < 0) continue;
         if (i - b < search_size) *sp++ = (uint32_t)s;  // search.go:41-48: the first <= searchSize filter ids that exist
         *fp++ = (uint32_t)s;
+        ascending &= s > last;
+        last = s;
       }
-      std::sort(fslots.data() + off_filt[q], fp);  // Contains (:93) is answered from ascending slots
+      if (!ascending) std::sort(fslots_h + off_filt[q], fp);  // Contains (:93) is answered from ascending slots
     });
-    const size_t b_off = (nq + 1) * 4, b_seeds = seeds.size() * 4, b_f = fslots.size() * 4;
+    const size_t b_off = (nq + 1) * 4, b_seeds = n_seeds * 4, b_f = n_fslots * 4;
     SDB_TRY(ws->ensure_filter(2 * ((b_off + 255) & ~(size_t)255) + ((b_seeds + 255) & ~(size_t)255) + b_f + 256));
     char *fb = static_cast<char *>(ws->filter);
     uint32_t *d_so = (uint32_t *)fb;
@@ -1022,8 +1043,8 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     uint32_t *d_f = (uint32_t *)((char *)d_seeds + ((b_seeds + 255) & ~(size_t)255));
     SDB_HIP(hipMemcpyAsync(d_so, off_seed.data(), b_off, hipMemcpyHostToDevice, stream));
     SDB_HIP(hipMemcpyAsync(d_fo, off_filt.data(), b_off, hipMemcpyHostToDevice, stream));
-    if (b_seeds) SDB_HIP(hipMemcpyAsync(d_seeds, seeds.data(), b_seeds, hipMemcpyHostToDevice, stream));
-    if (b_f) SDB_HIP(hipMemcpyAsync(d_f, fslots.data(), b_f, hipMemcpyHostToDevice, stream));
+    if (b_seeds) SDB_HIP(hipMemcpyAsync(d_seeds, seeds_h, b_seeds, hipMemcpyHostToDevice, stream));
+    if (b_f) SDB_HIP(hipMemcpyAsync(d_f, fslots_h, b_f, hipMemcpyHostToDevice, stream));
     SDB_HIP(hipStreamSynchronize(stream));  // the staging vectors die with this scope
     a.seed_off = d_so, a.filt_off = d_fo, a.seeds = d_seeds, a.filt_slots = d_f;
     a.rbitsets = ws->bitsets + (size_t)nq * words;
