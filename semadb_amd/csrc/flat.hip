@@ -650,7 +650,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
         const int64_t s = ix->slot_of_committed(filter_ids[i], vw.n);
         if (s >= 0 && s != ix->start_slot) f_slots.push_back((uint32_t)s);
       }
-      std::sort(f_slots.begin() + f0, f_slots.end());
+      if (!std::is_sorted(f_slots.begin() + f0, f_slots.end())) std::sort(f_slots.begin() + f0, f_slots.end());
       f_off[q + 1] = (uint32_t)f_slots.size();
       max_f = std::max<uint32_t>(max_f, (uint32_t)(f_slots.size() - f0));
     }
