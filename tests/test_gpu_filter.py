@@ -80,6 +80,37 @@ def test_filtered_batch_parity(oracle, metric, d, n, L, k):
     ix.close()
 
 
+def test_filter_on_rows_stored_out_of_id_order(oracle):
+    """the filter ids of a query translate to slots that are NOT ascending when the rows are not stored in id order
+    (the translation sorts them only then): the exported graph is loaded with its rows shuffled (the start node stays
+    first), and filtered searches must still answer like the oracle"""
+    from semadb_amd import vamana
+    d, n, L, k = 64, 800, 40, 10
+    rng = np.random.default_rng(2024)
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ids, vecs, off, edges = o.export()
+    perm = np.concatenate([[0], 1 + rng.permutation(len(ids) - 1)])
+    deg = np.diff(off)
+    p_off = np.zeros_like(off)
+    p_off[1:] = np.cumsum(deg[perm])
+    p_edges = np.concatenate([edges[off[i]:off[i + 1]] for i in perm]) if len(edges) else edges
+    ix = vamana.NewIndexVamana("f", vamana.IndexVectorVamanaParameters(d, "cosine", L, 32, 1.2), strict=False)
+    ix.load(ids[perm], vecs[perm], p_off, p_edges)
+    nq = 12
+    q = unit_rows(rng, nq, d)
+    all_ids = np.arange(2, n + 2)
+    filters = [set(int(v) for v in rng.choice(all_ids, size=s, replace=False)) for s in (3, L, 200, n // 2) * 3]
+    g_ids, g_d, g_c, tr = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+    for i in range(nq):
+        o_ids, o_d, o_vis, o_tr = o.search(q[i], k, L, filter_ids=sorted(filters[i]))
+        assert int(g_c[i]) == len(o_ids), (i, g_c[i], len(o_ids))
+        assert np.array_equal(g_ids[i, :len(o_ids)], o_ids), i
+        assert np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d)), i
+        assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), i
+    ix.close()
+
+
 def test_filter_argument_errors(oracle):
     from semadb_amd import vamana, SemaDBError, _lib
     import ctypes as C
