@@ -20,7 +20,7 @@ factor = exp["calibration"]["bytes"] / (cal * 1024)
 res = {"shape": "%d x %d x %d" % (exp["nq"], exp["nc"], exp["dim"]), "fetch_correction_factor": round(factor, 3),
        "unique_bytes_(nq+nc)*d*4": exp["unique_bytes"], "pairs_bytes_nq*nc*d*4": exp["pairs_bytes"]}
 for k, v in per.items():
-    if k.startswith("k_k1_tile") or k.startswith("k_distance_batch"):
+    if k.startswith("k_k1_") or k.startswith("k_distance_batch"):
         hbm = sum(v[-3:]) / 3 * 1024 * factor
         res[k] = {"hbm_read_bytes_per_launch": round(hbm), "over_unique_bytes": round(hbm / exp["unique_bytes"], 3),
                   "of_pairs_bytes": round(hbm / exp["pairs_bytes"], 5)}
