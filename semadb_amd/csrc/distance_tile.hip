@@ -292,12 +292,18 @@ __device__ __forceinline__ f2v k1_chain_pk(f2v acc, f2v x, f2v y) {
     return __builtin_elementwise_fma(x, y, acc);
   }
 }
-// waves per workgroup x queries per pass, measured on 1 024 x 1M x 384 / 64 x 1M x 384 (ms): 16 x 2 (the exact scan's
-// shape: LDS reads and packed FMAs both near saturation) 31.0 / 1.81; 12 x 3: 37.7 / 2.27; 12 x 4 (168 VGPRs, 12 B of
-// scratch) 33.7 / 2.49; 8 x 4 (169 VGPRs, two waves per SIMD, each row block read once per four queries) 23.4 / 1.77
+// waves per workgroup x queries per pass, measured on 1 024 x 1M x 384 / 64 x 1M x 384 (ms).  With a fixed share of the
+// query groups per wave: 16 x 2 31.0 / 1.81; 12 x 3 37.7 / 2.27; 12 x 4 (168 VGPRs, 12 B of scratch) 33.7 / 2.49; 8 x 4
+// (169 VGPRs, two waves per SIMD, each row block read once per four queries) 23.3 / 1.81.  With the groups handed out from
+// a counter in LDS (SDB_K1_DYN, as in the exact scan): 16 x 1 **17.9 / 1.48** (shipped), 8 x 4 21.4 / 1.73, 16 x 2
+// 28.2 / 1.73 -- with two queries per pass the compiler reuses one set of scalar registers for the queries' loads and
+// waits for each (seven s_waitcnt per block instead of one)
+#ifndef SDB_K1_DYN
+#define SDB_K1_DYN 1
+#endif
 #ifndef SDB_K1_WAVES
-#define SDB_K1_WAVES 8
-#define SDB_K1_QPP 4
+#define SDB_K1_WAVES 16
+#define SDB_K1_QPP 1
 #endif
 constexpr int kK1L2Waves = SDB_K1_WAVES;
 constexpr int kK1Qpp = SDB_K1_QPP;
@@ -315,6 +321,9 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
   const uint64_t row0 = (uint64_t)blockIdx.x * tile_rows;
   const uint32_t nrows = (uint32_t)min<uint64_t>(tile_rows, nc - row0);
   const uint32_t row_f4 = dim / 4;
+#if SDB_K1_DYN
+  if (tid == 0) *reinterpret_cast<uint32_t *>(tile + (size_t)tile_rows * kstride) = 0;
+#endif
   for (uint32_t i = tid; i < tile_rows * row_f4; i += kK1L2Waves * 64) {  // consecutive threads: consecutive 16 B of a row
     const uint32_t r = i / row_f4, c = i % row_f4;
     const uint32_t rr = r < nrows ? r : nrows - 1;
@@ -325,12 +334,23 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
   const float *myrow_f = tile + (size_t)((uint32_t)lane < tile_rows ? lane : 0) * kstride;  // idle lanes: row 0, dropped
   const float4 *myrow = reinterpret_cast<const float4 *>(myrow_f);
   const uint32_t ngroups = (nq + kK1Qpp - 1) / kK1Qpp;
+#if SDB_K1_DYN
+  float *next_group = tile + (size_t)tile_rows * kstride;  // the waves' work counter, behind the tile (flat.hip k_flat_scan)
+  (void)wave;
+  uint32_t dim_u = dim;  // cut off from the phi that the staging loop's divergent exit makes of zext(dim): scalar loads stay scalar
+  asm volatile("" : "+s"(dim_u));
+  for (;;) {
+    const uint32_t grp = next_query_group(next_group, lane);
+    if (grp >= ngroups) break;
+#else
+  const uint32_t dim_u = dim;
   for (uint32_t grp = (uint32_t)wave; grp < ngroups; grp += kK1L2Waves) {
-    const float *xq[kK1Qpp];
+#endif
+    uniform_float *xq[kK1Qpp];
 #pragma unroll
     for (int k = 0; k < kK1Qpp; k++) {
       const uint32_t q = grp * kK1Qpp + k;
-      xq[k] = queries + (size_t)(q < nq ? q : nq - 1) * dim;  // past the end: the last query again, dropped
+      xq[k] = as_uniform(queries) + (size_t)(q < nq ? q : nq - 1) * dim_u;  // past the end: the last query again, dropped
     }
     f2v acc[kK1Qpp][16];
 #pragma unroll
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(kK1L2Waves * 64) void k_k1_tile_pk(const float *__r
       for (int i = 0; i < 8; i++) {  // float4 i of the block: partial sums 4i .. 4i + 3
 #pragma unroll
         for (int k = 0; k < kK1Qpp; k++) {
-          const float4 u = reinterpret_cast<const float4 *>(xq[k] + b * 32)[i];  // wave-uniform: scalar loads
+          const uniform_f4v u = reinterpret_cast<uniform_float4 *>(xq[k] + b * 32)[i];  // wave-uniform: scalar loads
           acc[k][2 * i] = k1_chain_pk<L2>(acc[k][2 * i], f2v{u.x, u.y}, f2v{y[i].x, y[i].y});
           acc[k][2 * i + 1] = k1_chain_pk<L2>(acc[k][2 * i + 1], f2v{u.z, u.w}, f2v{y[i].z, y[i].w});
         }
@@ -422,9 +442,9 @@ int launch_k1_tiles(int metric, uint32_t dim, const float *dq, uint64_t nq, cons
   if (metric == SDB_METRIC_EUCLIDEAN) {
     // as many rows per workgroup as fit LDS, at most one per lane
     const size_t row_bytes = (size_t)(dim + 4) * sizeof(float);
-    const uint32_t tile_rows = (uint32_t)std::min<size_t>(kK1Rows, (160 * 1024) / row_bytes);
+    const uint32_t tile_rows = (uint32_t)std::min<size_t>(kK1Rows, (160 * 1024 - 16) / row_bytes);
     if (tile_rows < 8) return 0;
-    const size_t lds = tile_rows * row_bytes;
+    const size_t lds = tile_rows * row_bytes + 16;  // the tile and the group counter
     static std::atomic<uint64_t> attr{0};
     if (first_use_on_this_device(attr))
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_k1_tile_pk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
