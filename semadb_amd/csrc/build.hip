@@ -63,6 +63,7 @@ struct BuildArgs {
   uint32_t start_ext_n;
   uint32_t no_tile;           // != 0: new nodes are pruned by k_prune_new (rows from global memory), a test knob
   uint32_t *prune_done;       // [nnew] 0: left to k_prune_new, 2: pair table ready for k_prune_select, 1: pruned; NULL: k_prune_new takes all
+  const uint32_t *self_list;  // k_prune_new_tiled for nodes that are not this round's new ones (delete.inc): the node of list q, or NULL
   float *pair_tab;            // [nnew][kTileMaxCand^2] the tiled kernel's pair table of a node (row stride = its list length)
   uint32_t *pair_slots;       // [nnew][kTileMaxCand] its sorted visit list
   float *pair_dists;
@@ -529,9 +530,9 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
   float *D = reinterpret_cast<float *>(lds_raw + kTileFixedBytes);  // [nc][nc], upper triangle used
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = lane & 31, half = lane >> 5;
   const uint32_t q = blockIdx.x;
-  const uint32_t self = a.first_slot + q;
+  const uint32_t self = a.self_list ? a.self_list[q] : a.first_slot + q;
   const uint32_t nc_raw = a.vis_count[q];
-  if (nc_raw > (uint32_t)kTileMaxCand) {  // a long list: the one-wave kernel prunes it
+  if (nc_raw > (uint32_t)kTileMaxCand || nc_raw == 0) {  // a long list: the one-wave kernel prunes it (an empty one: it has)
     if (tid == 0) a.prune_done[q] = 0u;
     return;
   }
@@ -762,8 +763,9 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
     a.prune_done[q] = 1u;
     if (a.dirty) a.dirty[self] = 1;
   }
-  a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
-      (lane < cnt) ? ((uint64_t)my_out << 32) | ((uint64_t)q << 6) | (uint64_t)lane : kNoKey;
+  if (a.keys_in)
+    a.keys_in[(size_t)q * 64 + lane] =  // back-edge requests (insert.go:36)
+        (lane < cnt) ? ((uint64_t)my_out << 32) | ((uint64_t)q << 6) | (uint64_t)lane : kNoKey;
   stat_add(a, kStPrunePairs, n_eval, lane);
   stat_add(a, kStStagedRows, (unsigned long long)nt, lane);
 }
