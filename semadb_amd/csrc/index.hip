@@ -975,7 +975,9 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     // (5 ms on one core), so big batches are split over a few host threads.  Pass 1 validates and counts, pass 2
     // fills the two CSR arrays in place.
     const uint64_t total_ids = filter_offsets[nq] - filter_offsets[0];
-    const unsigned nthr = total_ids < (1u << 16) ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    // one thread per 128 k ids, at most 16 (and what the machine has): a million ids take 5 ms on one core, a thread ~50 us to start
+    const unsigned nthr = (unsigned)std::min<uint64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                       std::max<uint64_t>(1, total_ids >> 17));
     std::vector<uint32_t> n_seed(nq, 0), n_filt(nq, 0);
     std::atomic<int> bad{0};  // 1: offsets decrease, 2: ids not ascending
     std::atomic<uint64_t> bad_q{0};
