@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
+#include <new>
 
 #include "pq.h"
 #include "search_kernel.h"
@@ -1018,9 +1020,18 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     // vector of 10^8 slots costs its zero-fill and a staged copy on top of the translation
     const size_t n_seeds = off_seed[nq], n_fslots = off_filt[nq];
     const size_t h_seeds = (n_seeds * 4 + 255) & ~(size_t)255;
-    SDB_TRY(ws->ensure_filter_host(h_seeds + n_fslots * 4 + 256));
-    uint32_t *seeds_h = static_cast<uint32_t *>(ws->filter_host);
-    uint32_t *fslots_h = reinterpret_cast<uint32_t *>(static_cast<char *>(ws->filter_host) + h_seeds);
+    std::unique_ptr<char[]> pageable;  // when the pinned buffer cannot be had (the limit on locked memory): an ordinary one
+    char *hbase = nullptr;
+    if (ws->ensure_filter_host(h_seeds + n_fslots * 4 + 256) == SDB_OK) {
+      hbase = static_cast<char *>(ws->filter_host);
+    } else {
+      (void)hipGetLastError();
+      pageable.reset(new (std::nothrow) char[h_seeds + n_fslots * 4 + 256]);
+      if (!pageable) return fail(SDB_ERR_DEVICE, "out of host memory for the filter lists");
+      hbase = pageable.get();
+    }
+    uint32_t *seeds_h = reinterpret_cast<uint32_t *>(hbase);
+    uint32_t *fslots_h = reinterpret_cast<uint32_t *>(hbase + h_seeds);
     for_queries([&](uint64_t q) {
       const uint64_t b = filter_offsets[q], e = filter_offsets[q + 1];
       uint32_t *sp = seeds_h + off_seed[q], *fp = fslots_h + off_filt[q];
