@@ -191,6 +191,31 @@ class Exchange:
             self.cl.close()
 
 
+def torchrun_command(gpus, argv, port=None):
+    """The command line the driver itself uses for N > 1 (one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def relaunch_under_torchrun(gpus, argv):
+    import subprocess
+    cmd = torchrun_command(gpus, argv)
+    log("no WORLD_SIZE in the environment and --gpus %d: starting the ranks:" % gpus, " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:            # rank 0 prints the one JSON line; anything else on stdout passes through too
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,10 +250,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python3 bench.py --gpus N` without a launcher: start the ranks ourselves (the reference's counterpart simply
+        # fans out, cluster/actions.go:316-351).  A CHILD process, started before anything here has touched the GPU
+        # (never an exec from a process that has); its stdout -- rank 0's one JSON line -- is relayed, its rc returned.
+        sys.exit(relaunch_under_torchrun(a.gpus, sys.argv[1:]))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (a.gpus, a.gpus))
         a.gpus = world
     # BENCH_BACKEND=gloo + more ranks than GPUs is a functional test of the N > 1 path on a 1-GPU box
     # (ranks share the device; RCCL itself refuses two ranks on one GPU).  The driver never sets it.
@@ -293,7 +320,8 @@ def run_c2(a, ctx):
             modes[m] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],
                         "workload": cfg["workload"], "parallelism": cfg["parallelism"], "dataset": cfg["dataset"],
                         "recall_at_10": cfg["recall_at_10"], "build_s": cfg["build_s"], "mean_n_dist": cfg["mean_n_dist"],
-                        "exchange": cfg.get("exchange"), "ranks_seen": cfg.get("ranks_seen"),
+                        "exchange": cfg.get("exchange"), "exchange_transport": cfg.get("exchange_transport"),
+                        "ranks_seen": cfg.get("ranks_seen"),
                         "per_shard_walk_qps": cfg.get("per_shard_walk_qps"), "roofline": r["roofline"]}
             if r.get("invalid"):
                 modes[m]["invalid"] = r["invalid"]
@@ -496,6 +524,7 @@ def measure_mode(a, ctx, mode, rows, primary):
                                 "shard merge); index, queries and results resident in HBM",
             "timed_batches": "%d distinct batches never walked before the timed loop; trace counters off" % nb_timed,
             "per_shard_walk_qps": round(world * nq * a.steps / elapsed, 1) if (world > 1 and not split) else None,
+            "per_shard_limit": (min(k, 75, int(k * (1.0 / world) * 1.42 + 10)) if not split else k),  # actions.go:291-299
             "build_s": round(build_s, 2),
             "build_inserts_per_s": round(n / build_s, 1),
             "avg_degree": round(n_edges / n_nodes, 2),
@@ -525,6 +554,8 @@ def measure_mode(a, ctx, mode, rows, primary):
         result["config"]["ranks_seen"] = list(range(world))
     if ex is not None and not split:
         result["config"]["ranks_seen"] = sorted(ranks_seen)
+        if ex.native:  # the library's own words: RCCL version, the librccl this process loaded, communicator size, rank
+            result["config"]["exchange_transport"] = ex.cl.transport()
         result["config"]["exchange"] = ("libsemadb_amd.so: sdb_cluster_search_batch (ncclAllGather on the library's stream)"
                                         if ex.native else "torch.distributed all_gather_into_tensor (%s) + sdb_cluster_merge_gathered (tag check + merge)%s" %
                                         (ctx["backend"], "; " + ex.note if ex.note else ""))

@@ -415,7 +415,9 @@ int sdb_cluster_allgather_merge(sdb_cluster *c, uint64_t ticket, uint64_t nq, ui
  * to SDB_CLUSTER_RING batches may be in flight before the caller waits (sdb_cluster_wait / _synchronize).
  * SDB_MEM_HOST calls block until their own answer is there, and up to SDB_CLUSTER_RING of them may be in flight
  * on one rank from different threads (each has its own staging; the exchange of one runs under the walk of the
- * next). */
+ * next).  Every rank ends up with the same merged answer: a single-process fan-out that needs it once passes NULL
+ * for all four out_* (SDB_MEM_HOST only) on the other ranks, which then take part in the exchange -- and return its
+ * verdict -- without copying their copy of the answer back. */
 #define SDB_CLUSTER_RING 8
 int sdb_cluster_search_batch(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries,
                              uint32_t limit, uint32_t search_size, uint64_t *out_ids,
@@ -428,6 +430,31 @@ int sdb_cluster_wait(sdb_cluster *c, void *stream);
 int sdb_cluster_synchronize(sdb_cluster *c);
 /* the next ticket this rank will let into the exchange (tickets below it have entered) */
 int sdb_cluster_next_ticket(const sdb_cluster *c, uint64_t *ticket);
+
+/* A way out of the turnstile.  The reference fails ONE request and serves the next (cluster/actions.go:339-353);
+ * a ticket that is drawn and never presented to some rank (the fan-out's goroutine panicked, the client went away
+ * between two ranks' calls) must not wedge every later request of that rank.
+ *
+ * sdb_cluster_set_deadline: the longest a call waits (a) at the turnstile for its predecessors' tickets, (b) for the
+ * other ranks to join its exchange.  Default 30 000 ms; 0 = for ever.  (a) expiring fails the call with
+ * SDB_ERR_STATE having done NOTHING on this rank: the same call (same ticket) may be presented again, or its ticket
+ * skipped.  (b) expiring fails it with SDB_ERR_STATE; on the shared-device transport the request is withdrawn and the
+ * handle stays in step when it was this rank's latest, otherwise -- and always on RCCL, where the all-gather already
+ * sits on the stream -- the handle is out of step for good (every later call SDB_ERR_STATE) and must be recreated;
+ * sdb_cluster_destroy then aborts the communicator instead of draining it.
+ *
+ * sdb_cluster_skip_ticket: the fan-out declares that `ticket` will never be presented to this rank.
+ *   nq == 0: no rank has entered the request's exchange or will (the request died before any call): the turnstile
+ *            passes over the ticket, now or when its turn comes.  Nothing is exchanged; call it on every rank.
+ *   nq  > 0: other ranks may already be inside the request's exchange: this rank enters it with an empty answer and
+ *            SDB_ERR_STATE in its tag (guard 3), so those ranks fail THAT request and serve the next.  nq / limit (and
+ *            per_shard for an sdb_cluster_allgather_merge request; 0 = the search_batch rule) must be the request's.
+ *            Blocks until the exchange has run on this rank (at most the deadline). */
+int sdb_cluster_set_deadline(sdb_cluster *c, uint32_t milliseconds);
+int sdb_cluster_skip_ticket(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32_t per_shard, uint32_t limit);
+/* one line for logs and measurement records: the transport that carries this rank's gathers -- for RCCL the library
+ * version, the path of the librccl the process has loaded, the communicator's size and this rank in it */
+int sdb_cluster_transport(const sdb_cluster *c, char *buf, size_t cap);
 
 /* The tag check + merge on a gathered buffer [world][bytes] that some other transport delivered (the tests' gloo
  * path; a host that moves the blocks over its own RPC): sdb_cluster_stamp_block writes this rank's tag into its

@@ -47,7 +47,7 @@ type fillBatch struct {
 	mem     unsafe.Pointer // pinned [maxBatch][dim] float32
 	queries []float32      // the same memory as a slice
 	reqs    []*searchReq
-	n       atomic.Uint32 // slots reserved; >= maxBatch: full or sealed
+	st      atomic.Uint64 // tagOf(key)<<32 | slots reserved; slots >= maxBatch: full or sealed
 	written atomic.Uint32 // slots whose vector has been copied in
 	count   uint32        // slots that belong to the batch once it is sealed
 	key     uint64        // limit<<32 | searchSize of every request in it
@@ -70,6 +70,7 @@ type searchBatcher struct {
 	fastKey  uint64
 	streak   int
 	stopped  bool
+	stopping atomic.Bool // the same, readable without b.mu on the fast path
 	wg       sync.WaitGroup
 }
 
@@ -98,6 +99,7 @@ func newSearchBatcher(ix *IndexVamana, maxBatch int, window time.Duration, worke
 func (b *searchBatcher) stop() {
 	b.mu.Lock()
 	b.stopped = true
+	b.stopping.Store(true)
 	b.mu.Unlock()
 	b.cond.Broadcast()
 	b.freeCond.Broadcast()
@@ -119,8 +121,39 @@ func (b *searchBatcher) takeFree() *fillBatch {
 	fb.written.Store(0)
 	fb.tFirst.Store(0)
 	fb.count, fb.key = 0, b.fastKey
-	fb.n.Store(0)
+	tag, ok := tagOf(b.fastKey)
+	if !ok {
+		tag = 0xFFFFFFFF // no request's tag: parameters that do not fit one fill no batch
+	}
+	fb.st.Store(uint64(tag) << 32)
 	return fb
+}
+
+// tagOf: the 32-bit form of (limit<<32 | searchSize) that shares the slot atomic.  The batch's parameters and its
+// slot counter live in ONE atomic and a slot is reserved by compare-and-swap on both, so that a slab which was sealed,
+// run, recycled for other parameters and installed again between a submitter's look at the parameters and its
+// reservation fails the swap instead of handing the request a slot of a batch with another (limit, searchSize).
+// Parameters beyond 16 bits (the API's maxima are 75 and 75, models/search.go:287-297) take the queue.
+func tagOf(key uint64) (uint32, bool) {
+	limit, L := key>>32, key&0xFFFFFFFF
+	if limit > 0xFFFF || L > 0xFFFF {
+		return 0, false
+	}
+	return uint32(limit<<16 | L), true
+}
+
+// seal closes a batch to further reservations: what its counter held before is what belongs to it (>= maxBatch: it
+// was full or sealed already and whoever did that is rotating it).  At most one seal per life adds to the counter.
+func (b *searchBatcher) seal(fb *fillBatch) uint32 {
+	for {
+		st := fb.st.Load()
+		if uint32(st) >= uint32(b.maxBatch) {
+			return uint32(st)
+		}
+		if fb.st.CompareAndSwap(st, st+uint64(b.maxBatch)) {
+			return uint32(st)
+		}
+	}
 }
 
 // rotateLocked: fb is full or was sealed with `count` reserved slots; b.mu held
@@ -145,7 +178,12 @@ func (b *searchBatcher) submit(ctx context.Context, vector []float32, limit, sea
 	r := &searchReq{vector: vector, limit: limit, searchSize: searchSize, filter: filter, done: make(chan searchResp, 1)}
 	key := uint64(limit)<<32 | uint64(searchSize)
 	placed := false
-	for filter == nil && !placed {
+	tag, fast := tagOf(key)
+	fast = fast && filter == nil
+	for fast && !placed {
+		if b.stopping.Load() { // the workers are leaving: a slot reserved now might never be run
+			return nil, nil, context.Canceled
+		}
 		fb := b.cur.Load()
 		if fb == nil { // every slab is in use (back-pressure) or a rotation is under way
 			b.mu.Lock()
@@ -159,14 +197,19 @@ func (b *searchBatcher) submit(ctx context.Context, vector []float32, limit, sea
 			}
 			continue
 		}
-		if fb.key != key {
+		st := fb.st.Load()
+		if uint32(st>>32) != tag {
 			break // other parameters than the filling batch's: the queue
 		}
-		i := fb.n.Add(1) - 1 // one atomic reserves slot i; no lock on this path
+		i := uint32(st)
 		if i >= uint32(b.maxBatch) {
-			for b.cur.Load() == fb { // full or sealed: its last submitter / a worker is installing the next one
+			// full or sealed: its last submitter / a worker is installing the next one
+			for b.cur.Load() == fb && uint32(fb.st.Load()) >= uint32(b.maxBatch) {
 				runtime.Gosched()
 			}
+			continue
+		}
+		if !fb.st.CompareAndSwap(st, st+1) { // slot i of THIS life of the slab, with THESE parameters, or nothing
 			continue
 		}
 		if i == 0 {
@@ -191,12 +234,12 @@ func (b *searchBatcher) submit(ctx context.Context, vector []float32, limit, sea
 			return nil, nil, context.Canceled
 		}
 		b.queued = append(b.queued, r)
-		if filter == nil { // when the unfiltered traffic has moved to other parameters the fast path follows it
+		if fast { // when the unfiltered traffic has moved to other parameters the fast path follows it
 			b.streak++
 			if b.fastKey == 0 || b.streak > 4*b.maxBatch {
 				b.fastKey, b.streak = key, 0
 				if fb := b.cur.Load(); fb != nil && fb.key != key {
-					if got := fb.n.Add(uint32(b.maxBatch)) - uint32(b.maxBatch); got < uint32(b.maxBatch) {
+					if got := b.seal(fb); got < uint32(b.maxBatch) {
 						b.rotateLocked(fb, got)
 					}
 				}
@@ -240,8 +283,13 @@ func (b *searchBatcher) loop() {
 				age = time.Duration(time.Now().UnixNano() - first)
 			}
 			if first != 0 && (age >= b.window || b.stopped) {
-				if got := c.n.Add(uint32(b.maxBatch)) - uint32(b.maxBatch); got < uint32(b.maxBatch) {
-					b.rotateLocked(c, got)
+				if got := b.seal(c); got < uint32(b.maxBatch) {
+					b.rotateLocked(c, got) // ours to seal
+				} else {
+					// the submit that took its last slot is rotating it and needs b.mu for that: let it have it
+					b.mu.Unlock()
+					runtime.Gosched()
+					b.mu.Lock()
 				}
 				continue
 			}

@@ -93,6 +93,9 @@ SIGNATURES = {
     "sdb_cluster_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sdb_cluster_synchronize": (C.c_int, [C.c_void_p]),
     "sdb_cluster_next_ticket": (C.c_int, [C.c_void_p, u64p]),
+    "sdb_cluster_set_deadline": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "sdb_cluster_skip_ticket": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "sdb_cluster_transport": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "sdb_cluster_stamp_block": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "sdb_cluster_merge_gathered": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,

@@ -241,11 +241,16 @@ class Cluster:
                                                 _buf.current_stream(MEM_DEVICE)))
         return outs
 
-    def search_batch(self, ix, queries, limit, search_size, ticket=0):
+    def search_batch(self, ix, queries, limit, search_size, ticket=0, want=True):
         """ClusterNode.SearchPoints for this rank's shard: search -> all-gather -> merge.  numpy queries ->
         numpy results (synchronous); torch CUDA queries -> device results, valid after wait()/synchronize()
-        (synchronize raises if the exchange failed its tag check)."""
+        (synchronize raises if the exchange failed its tag check).  want=False (host memory only): take part in the
+        exchange and return its verdict, but do not copy this rank's copy of the merged answer back (-> None)."""
         k, qp, mem, shape = _buf.as_f32(queries)
+        if not want and mem != MEM_DEVICE:
+            check(lib().sdb_cluster_search_batch(self._h, ix._h, ticket, shape[0], qp, limit, search_size, None, None,
+                                                 None, None, mem, _buf.current_stream(mem)))
+            return None
         outs, ptrs = self._outs(shape[0], limit, mem)
         check(lib().sdb_cluster_search_batch(self._h, ix._h, ticket, shape[0], qp, limit, search_size, ptrs[0], ptrs[1],
                                              ptrs[2], ptrs[3], mem, _buf.current_stream(mem)))
@@ -255,6 +260,21 @@ class Cluster:
         t = C.c_uint64(0)
         check(lib().sdb_cluster_next_ticket(self._h, C.byref(t)))
         return t.value
+
+    def set_deadline(self, milliseconds):
+        """longest wait at the turnstile / for the peers (0: for ever), sdb_cluster_set_deadline"""
+        check(lib().sdb_cluster_set_deadline(self._h, int(milliseconds)))
+
+    def skip_ticket(self, ticket, nq=0, limit=0, per_shard=0):
+        """the fan-out gives `ticket` up for this rank: nq == 0 -> the turnstile passes over it; nq > 0 -> this rank
+        enters the request's exchange with an empty answer under an error flag so that its peers fail that request and
+        serve the next (sdb_cluster_skip_ticket)"""
+        check(lib().sdb_cluster_skip_ticket(self._h, ticket, nq, per_shard, limit))
+
+    def transport(self):
+        buf = C.create_string_buffer(512)
+        check(lib().sdb_cluster_transport(self._h, buf, 512))
+        return buf.value.decode()
 
     def wait(self):
         """the current torch stream waits (on the device) for every exchange enqueued so far"""
@@ -284,21 +304,38 @@ class Fanout:
             return t
 
     def search_points(self, queries, limit, search_size):
-        """numpy queries [nq, dim] -> merged (ids, dists, shards, counts) as numpy; raises the first rank's error"""
+        """numpy queries [nq, dim] -> merged (ids, dists, shards, counts) as numpy; raises the first rank's error.
+        Every rank's GPU holds the same merged answer after the exchange; only rank 0 copies it to the host (the other
+        ranks' calls run with device outputs that are dropped).  A rank whose call could not even be made has the
+        ticket skipped for it, so that neither its peers (inside the exchange) nor its later requests (at the
+        turnstile) wait for it: the reference fails one request and serves the next (actions.go:339-353)."""
         ticket = self._ticket()
-        outs, errs = [None] * len(self.ranks), [None] * len(self.ranks)
+        n = len(self.ranks)
+        outs, errs, called = [None] * n, [None] * n, [False] * n
+        nq = int(np.asarray(queries).shape[0]) if hasattr(queries, "shape") else len(queries)
 
         def run(r):
             try:
-                outs[r] = self.ranks[r].search_batch(self.indexes[r], queries, limit, search_size, ticket=ticket)
+                called[r] = True
+                outs[r] = self.ranks[r].search_batch(self.indexes[r], queries, limit, search_size, ticket=ticket,
+                                                     want=(r == 0))
             except SemaDBError as e:  # every rank sees the failure of any rank
                 errs[r] = e
+            except BaseException as e:  # the binding itself failed before the library saw the ticket
+                called[r] = False
+                errs[r] = e
 
-        ts = [threading.Thread(target=run, args=(r,)) for r in range(len(self.ranks))]
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(n)]
         for t in ts:
             t.start()
         for t in ts:
             t.join()
+        for r in range(n):
+            if not called[r]:
+                try:
+                    self.ranks[r].skip_ticket(ticket, nq, limit)
+                except SemaDBError:
+                    pass
         for e in errs:
             if e is not None:
                 raise e

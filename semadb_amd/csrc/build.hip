@@ -129,13 +129,10 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
   uint32_t ev = 0, ca = 0;  // pair distances evaluated / taken from the searches' tables (sdb_index_build_stats)
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
+  const bool any_nan = wave_any_nan(in_dist, nc, lane);
   for (int i = lane; i < nc; i += 64) {
     const float d = in_dist[i];
-    int rank = 0;
-    for (int j = 0; j < nc; j++) {
-      const float dj = in_dist[j];
-      rank += (dj < d || (dj == d && j < i)) ? 1 : 0;
-    }
+    const int rank = dist_sort_rank(in_dist, nc, i, any_nan);
     s_slot[rank] = in_slot[i];
     s_dist[rank] = d;
     s_rem[rank] = i < n_clean ? 2u : 0u;  // bit 0: pruneRemoved (distset.go:124), bit 1: clean
@@ -543,13 +540,10 @@ __global__ __launch_bounds__(NW * 64) void k_prune_new_tiled(const BuildArgs a) 
     in_dist[tid] = a.vis_dists[(size_t)q * a.vis_cap + tid];
   }
   __syncthreads();
+  const bool any_nan = wave_any_nan(in_dist, nc, lane);  // every wave looks at the whole list: no LDS word to share
   if (tid < nc) {
     const float d = in_dist[tid];
-    uint32_t rank = 0;
-    for (int j = 0; j < nc; j++) {
-      const float dj = in_dist[j];
-      rank += (dj < d || (dj == d && j < tid)) ? 1u : 0u;
-    }
+    const int rank = dist_sort_rank(in_dist, nc, tid, any_nan);
     s_slot[rank] = in_slot[tid], s_dist[rank] = d;
   }
   __syncthreads();

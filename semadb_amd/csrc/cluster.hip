@@ -17,11 +17,14 @@
 // Order and failure (include/semadb_amd.h "Collective calls, order and failure"): calls enter the exchange in ticket
 // order; every block carries a tag that the merge compares across ranks; a rank whose shard search failed enters
 // anyway with its status in the tag.
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <map>
+#include <set>
 
 #include "exchange.h"
 #include "index.h"
@@ -137,6 +140,8 @@ struct sdb_cluster {
   uint64_t seq = 0;          // collectives this rank has entered
   uint64_t next_ticket = 1;  // the ticket the turnstile lets in next
   bool desync = false;       // a call left between taking its sequence number and entering the exchange
+  std::set<uint64_t> skipped;  // tickets the fan-out has declared lost on this rank (sdb_cluster_skip_ticket)
+  uint32_t deadline_ms = 30000;  // longest wait at the turnstile / for the peers (0: for ever)
   // verdicts of the exchanges in flight (pinned host memory, written by the merge kernels)
   static constexpr int kVerdicts = 64;
   sdb::ExchangeVerdict *verdicts = nullptr;
@@ -166,13 +171,16 @@ struct Arrival {
   float *o_d = nullptr;
   uint32_t *o_s = nullptr, *o_c = nullptr;
   bool host = false;
+  bool copy_back = false;  // a host caller that wants this rank's copy of the merged answer
   int vi = 0;
+  uint64_t seq = 0, ticket = 0;
 };
 
 struct Group {
   std::mutex mu;
   std::condition_variable cv;
   int world = 0, device = 0, alive = 0;
+  int gone = -1;  // a rank of the group that has been destroyed: no exchange can complete any more
   std::map<uint64_t, std::vector<Arrival>> rv;  // sequence number -> arrivals so far
 };
 
@@ -218,7 +226,7 @@ static int enqueue_merge(sdb_cluster *c, const Arrival &a, const BlockLayout &bl
                             c->gathered + bl.off_c, bl.bytes, a.limit, a.o_ids, a.o_d, a.o_s, a.o_c, c->xs,
                             c->gathered + bl.off_t, bl.bytes, v));
   SDB_HIP(hipEventRecord(c->vdone[a.vi], c->xs));
-  if (a.host) {
+  if (a.copy_back) {
     const OutLayout ol(a.nq, a.limit);
     SDB_HIP(hipMemcpyAsync(a.slot->hstage, a.slot->stage, ol.bytes, hipMemcpyDeviceToHost, c->xs));
   }
@@ -236,6 +244,30 @@ static int exchange_rccl(sdb_cluster *c, const Arrival &a) {
   return enqueue_merge(c, a, bl);
 }
 
+// An exchange that cannot run (shapes differ; a rank of the group is gone): the verdict is written from the host,
+// behind whatever this rank's block was waiting for, and the outputs say "no answer".  Group mutex held.
+static int fail_arrival(const Arrival &a, uint32_t state, uint32_t fields, uint32_t status, uint32_t status_rank) {
+  sdb_cluster *c = a.c;
+  ExchangeVerdict *v = &c->verdicts[a.vi];
+  int rc = SDB_OK;
+  auto chk = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && rc == SDB_OK) rc = fail(SDB_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(e));
+  };
+  chk(hipStreamWaitEvent(c->xs, a.produced, 0), "stream wait");
+  chk(hipMemsetAsync(a.o_c, 0, a.nq * 4, c->xs), "clearing the counts");
+  // the stream has nothing of this exchange on it that writes the verdict: a plain host store, ordered before the
+  // event the reader waits for
+  v->bad_rank = 0, v->fields = fields, v->status = status, v->status_rank = status_rank;
+  v->seq = a.seq, v->ticket = a.ticket;
+  v->state = state;
+  chk(hipEventRecord(c->vdone[a.vi], c->xs), "event record");
+  if (a.copy_back) chk(hipMemcpyAsync(a.slot->hstage, a.slot->stage, OutLayout(a.nq, a.limit).bytes, hipMemcpyDeviceToHost, c->xs), "copy back");
+  chk(hipEventRecord(a.slot->done, c->xs), "event record");
+  chk(hipEventRecord(c->finished, c->xs), "event record");
+  c->any = true;
+  return rc;
+}
+
 // shared-device transport: called by the last rank to arrive for a sequence number, group mutex held
 static int exchange_shared(std::vector<Arrival> &arr) {
   bool same = true;
@@ -245,15 +277,7 @@ static int exchange_shared(std::vector<Arrival> &arr) {
     // ranks that disagree on the shape cannot even be gathered: the verdict is written here, no answer for anybody
     for (auto &a : arr) {
       sdb_cluster *c = a.c;
-      (void)hipStreamWaitEvent(c->xs, a.produced, 0);
-      (void)hipMemsetAsync(a.o_c, 0, a.nq * 4, c->xs);
-      ExchangeVerdict *v = &c->verdicts[a.vi];
-      v->bad_rank = 0, v->fields = kTagNq | kTagPerShard, v->status = 0, v->status_rank = 0;
-      v->state = kVerdictMismatch;
-      (void)hipEventRecord(c->vdone[a.vi], c->xs);
-      if (a.host) (void)hipMemcpyAsync(a.slot->hstage, a.slot->stage, OutLayout(a.nq, a.limit).bytes, hipMemcpyDeviceToHost, c->xs);
-      (void)hipEventRecord(a.slot->done, c->xs);
-      (void)hipEventRecord(c->finished, c->xs);
+      if (fail_arrival(a, kVerdictMismatch, kTagNq | kTagPerShard, 0, 0) != SDB_OK) rc = SDB_ERR_DEVICE;
       c->any = true;
     }
   } else {
@@ -279,27 +303,70 @@ static int exchange_shared(std::vector<Arrival> &arr) {
 }
 
 // the ticket turnstile: a call enters in ticket order and ALWAYS gives the turn on when it leaves the locked section,
-// whatever happened in between -- otherwise its successors would wait forever
+// whatever happened in between -- otherwise its successors would wait forever.  A ticket that is never presented on
+// this rank (the fan-out's thread died, the request was cancelled before this rank was called) would wedge them all
+// the same: the wait has a deadline (sdb_cluster_set_deadline) after which the call fails having done NOTHING -- it
+// may be presented again --, and sdb_cluster_skip_ticket lets the fan-out declare a ticket lost.  The reference fails
+// one request and serves the next (cluster/actions.go:339-353).
 struct Turn {
   sdb_cluster *c;
   uint64_t ticket;
   bool mine = false;
+  static void advance(sdb_cluster *c, uint64_t to) {  // lock held
+    c->next_ticket = to;
+    for (auto it = c->skipped.find(c->next_ticket); it != c->skipped.end(); it = c->skipped.find(c->next_ticket)) {
+      c->skipped.erase(it);
+      c->next_ticket++;
+    }
+    c->cv->notify_all();
+  }
   int enter(std::unique_lock<std::mutex> &lk) {
     if (!ticket) return SDB_OK;
     if (ticket < c->next_ticket)
       return fail(SDB_ERR_INVALID, "ticket %llu has already entered the exchange on rank %d (next is %llu)",
                   (unsigned long long)ticket, c->rank, (unsigned long long)c->next_ticket);
-    c->cv->wait(lk, [&] { return c->next_ticket == ticket; });
+    if (c->skipped.count(ticket))
+      return fail(SDB_ERR_INVALID, "ticket %llu was skipped on rank %d (sdb_cluster_skip_ticket)", (unsigned long long)ticket, c->rank);
+    auto ready = [&] { return c->next_ticket == ticket; };
+    if (c->deadline_ms == 0) {
+      c->cv->wait(lk, ready);
+    } else if (!c->cv->wait_for(lk, std::chrono::milliseconds(c->deadline_ms), ready)) {
+      return fail(SDB_ERR_STATE, "ticket %llu waited %u ms on rank %d for ticket %llu, which has not been presented to this rank; "
+                  "the call did nothing (present it again once the missing ticket has been presented or skipped: sdb_cluster_skip_ticket)",
+                  (unsigned long long)ticket, c->deadline_ms, c->rank, (unsigned long long)c->next_ticket);
+    }
     mine = true;
     return SDB_OK;
   }
   ~Turn() {  // runs with the lock held (declared after the lock)
-    if (mine) {
-      c->next_ticket = ticket + 1;
-      c->cv->notify_all();
-    }
+    if (mine) advance(c, ticket + 1);
   }
 };
+
+// hipEventSynchronize with the handle's deadline: 0 = the event has fired, 1 = deadline passed, -1 = the device failed
+static int wait_event(sdb_cluster *c, hipEvent_t ev) {
+  if (c->deadline_ms == 0) return hipEventSynchronize(ev) == hipSuccess ? 0 : -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return -1;
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (waited > std::chrono::milliseconds(c->deadline_ms)) return 1;
+    // an exchange takes a millisecond or two: yield through that, then stop burning the core
+    if (waited < std::chrono::milliseconds(4)) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+}
+
+static int wait_event_or_fail(sdb_cluster *c, hipEvent_t ev, const char *what) {
+  const int w = wait_event(c, ev);
+  if (w == 0) return SDB_OK;
+  if (w < 0) return fail(SDB_ERR_DEVICE, "waiting for %s failed", what);
+  c->desync = true;  // something this rank enqueued never ran: a peer did not join its collective
+  return fail(SDB_ERR_STATE, "rank %d waited %u ms for %s: a peer never joined that exchange; the cluster handle is out of "
+              "step with its peers, recreate it", c->rank, c->deadline_ms, what);
+}
 
 // a free ring slot (may wait for one); lock held
 static sdb_cluster::Slot *take_slot(sdb_cluster *c, std::unique_lock<std::mutex> &lk) {
@@ -319,7 +386,7 @@ static sdb_cluster::Slot *take_slot(sdb_cluster *c, std::unique_lock<std::mutex>
 static int verdict_slot(sdb_cluster *c, uint64_t seq, int *vi) {
   const int i = (int)(seq % sdb_cluster::kVerdicts);
   if (c->vused[i]) {
-    SDB_HIP(hipEventSynchronize(c->vdone[i]));  // only when kVerdicts exchanges are in flight
+    SDB_TRY(wait_event_or_fail(c, c->vdone[i], "an earlier exchange"));  // only when kVerdicts exchanges are in flight
     if (c->verdicts[i].state >= kVerdictMismatch && c->sticky.empty()) c->sticky = describe(c->verdicts[i], c->world);
   }
   c->verdicts[i].state = kVerdictNone;
@@ -332,18 +399,20 @@ static int verdict_slot(sdb_cluster *c, uint64_t seq, int *vi) {
 // Common body of the two collective calls.  ix == nullptr: the caller's own block (allgather_merge).
 static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries, uint32_t per_shard,
                       void *user_block, uint32_t limit, uint32_t search_size, uint64_t *out_ids, float *out_dists,
-                      uint32_t *out_shards, uint32_t *out_counts, int mem, hipStream_t user_stream) {
+                      uint32_t *out_shards, uint32_t *out_counts, int mem, hipStream_t user_stream, bool skip = false) {
   const bool host = mem == SDB_MEM_HOST;
   std::unique_lock<std::mutex> lk(*c->mu);
   Turn turn{c, ticket};
   SDB_TRY(turn.enter(lk));
   // ---- what every rank decides alike (same arguments everywhere): no sequence number is spent on these
   if (nq == 0) return SDB_OK;
+  if (c->group && c->group->gone >= 0)
+    return fail(SDB_ERR_STATE, "rank %d of this shard group has been destroyed: no exchange can complete, recreate the group", c->group->gone);
   if (c->desync) return fail(SDB_ERR_STATE, "this rank left an earlier exchange half-way: the cluster handle is out of step with its peers, recreate it");
   if (limit < 1) return fail(SDB_ERR_INVALID, "invalid limit %u", limit);
   if (ix && search_size < limit)  // search.go:23-25, checked against the query's own limit
     return fail(SDB_ERR_INVALID, "searchSize (%u) must be greater than k (%u)", search_size, limit);
-  if (ix) SDB_TRY(sdb_shard_limit(limit, (uint32_t)c->world, 75, &per_shard));  // actions.go:291-299, MaxSearchLimit 75
+  if (ix || (skip && per_shard == 0)) SDB_TRY(sdb_shard_limit(limit, (uint32_t)c->world, 75, &per_shard));  // actions.go:291-299, MaxSearchLimit 75
   SDB_TRY(check_merge_shape((uint32_t)c->world, per_shard, limit));
   DeviceGuard dg(c->device);
   const BlockLayout bl(nq, per_shard);
@@ -351,12 +420,12 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
   // ---- buffers first: an allocation that fails here leaves this rank outside the exchange (its peers' only cure is
   // their own timeout), so nothing that can fail for another reason comes before the rank is sure to get in
   sdb_cluster::Slot *slot = take_slot(c, lk);
-  if (slot->used) SDB_HIP(hipEventSynchronize(slot->done));  // its previous exchange is over (staging, events)
+  if (slot->used) SDB_TRY(wait_event_or_fail(c, slot->done, "this ring slot's previous exchange"));  // staging, events
   int vi = 0;
   SDB_TRY(verdict_slot(c, c->seq, &vi));
   SDB_TRY(ensure_dev(&c->gathered, &c->gathered_bytes, bl.bytes * (size_t)c->world, c->xs));
   char *block = static_cast<char *>(user_block);
-  if (ix) {
+  if (ix || skip) {
     if (slot->bytes < bl.bytes) {
       SDB_TRY(ensure_dev(&slot->block, &slot->bytes, bl.bytes, nullptr));
       SDB_HIP(hipMemset(slot->block, 0, bl.bytes));  // the padding travels too
@@ -376,7 +445,9 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
       slot->hstage_bytes = ol.bytes;
     }
     if (!slot->hs) SDB_HIP(hipStreamCreateWithFlags(&slot->hs, hipStreamNonBlocking));
-    stream = slot->hs;
+    // a search of the library's own runs on the slot's stream; the caller's own block (allgather_merge) was written
+    // by work on the CALLER's stream, and the tag / the `produced` event must be ordered behind that work
+    if (ix || skip) stream = slot->hs;
   }
   // ---- from here on this rank WILL enter the exchange; a failure of its own goes into the tag
   const uint64_t seq = c->seq++;
@@ -386,6 +457,11 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
     if (rc != SDB_OK && local_rc == SDB_OK) local_rc = rc, local_msg = last_error_ref();
   };
   const float *dq = queries;
+  if (skip) {  // the fan-out gave this request up for this rank: an empty answer under an error flag, so that the
+               // peers that did enter are not left inside the all-gather (guard 3)
+    note(fail(SDB_ERR_STATE, "ticket %llu was skipped on rank %d", (unsigned long long)ticket, c->rank));
+    (void)hipMemsetAsync(block + bl.off_c, 0, nq * 4, stream);
+  }
   if (ix) {
     if (ix->P.device != c->device) note(fail(SDB_ERR_INVALID, "index lives on device %d, cluster rank on %d", ix->P.device, c->device));
     if (host && local_rc == SDB_OK) {
@@ -409,7 +485,8 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
   if (entered && hipEventRecord(slot->produced, stream) != hipSuccess) entered = false;
   Arrival a;
   a.c = c, a.slot = slot, a.block = block, a.produced = slot->produced, a.nq = nq, a.per_shard = per_shard, a.limit = limit;
-  a.host = host, a.vi = vi;
+  a.host = host, a.vi = vi, a.seq = seq, a.ticket = ticket;
+  a.copy_back = host && out_ids != nullptr;
   if (host) {
     a.o_ids = (uint64_t *)slot->stage, a.o_d = (float *)(slot->stage + ol.b_i);
     a.o_s = (uint32_t *)(slot->stage + ol.b_i + ol.b_d), a.o_c = (uint32_t *)(slot->stage + ol.b_i + 2 * ol.b_d);
@@ -451,14 +528,56 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
   slot->busy = true;
   c->vhost[vi] = true;
   if (turn.mine) {
-    c->next_ticket = ticket + 1;
     turn.mine = false;
-    c->cv->notify_all();
+    Turn::advance(c, ticket + 1);
   }
-  c->cv->wait(lk, [&] { return !slot->pending; });  // shared transport: until the last rank has enqueued it
+  // shared transport: until the last rank has enqueued it
+  auto enqueued = [&] { return !slot->pending; };
+  if (c->deadline_ms == 0) {
+    c->cv->wait(lk, enqueued);
+  } else if (!c->cv->wait_for(lk, std::chrono::milliseconds(c->deadline_ms), enqueued)) {
+    // the peers never presented this request: take the arrival back.  Nothing of it is on any stream yet, so if it was
+    // this rank's latest sequence number the handle is exactly where it was before the call
+    auto it = c->group->rv.find(seq);
+    if (it != c->group->rv.end()) {
+      auto &arr = it->second;
+      arr.erase(std::remove_if(arr.begin(), arr.end(), [&](const Arrival &x) { return x.c == c; }), arr.end());
+      if (arr.empty()) c->group->rv.erase(it);
+    }
+    slot->pending = false, slot->busy = false;
+    c->vhost[vi] = false, c->verdicts[vi].state = kVerdictNone;
+    if (c->seq == seq + 1) c->seq = seq;
+    else c->desync = true;
+    c->cv->notify_all();
+    if (out_counts) memset(out_counts, 0, nq * 4);
+    return fail(SDB_ERR_STATE, "shard exchange %llu (ticket %llu): the other ranks did not join within %u ms; the request was "
+                "withdrawn on rank %d%s", (unsigned long long)seq, (unsigned long long)ticket, c->deadline_ms, c->rank,
+                c->desync ? " and the handle is out of step with its peers, recreate it" : "");
+  }
   lk.unlock();
   int rc = SDB_OK;
-  if (hipEventSynchronize(slot->done) != hipSuccess) rc = fail(SDB_ERR_DEVICE, "waiting for the exchange failed");
+  {
+    const int w = wait_event(c, slot->done);
+    if (w < 0) rc = fail(SDB_ERR_DEVICE, "waiting for the exchange failed");
+    if (w > 0) {
+      lk.lock();
+      c->desync = true;
+      lk.unlock();
+      rc = fail(SDB_ERR_STATE, "shard exchange %llu (ticket %llu): rank %d waited %u ms inside the all-gather, a peer never "
+                "joined; the cluster handle is out of step, recreate it", (unsigned long long)seq, (unsigned long long)ticket,
+                c->rank, c->deadline_ms);
+    }
+  }
+  if (skip) {  // nothing to deliver: the peers have been told
+    if (rc == SDB_OK && c->verdicts[vi].state < kVerdictMismatch)
+      rc = fail(SDB_ERR_DEVICE, "the merge of the skipped exchange %llu left no failure verdict", (unsigned long long)seq);
+    lk.lock();
+    c->verdicts[vi].state = kVerdictNone;
+    c->vhost[vi] = false;
+    slot->busy = false;
+    c->cv->notify_all();
+    return rc;
+  }
   if (rc == SDB_OK) {
     const ExchangeVerdict v = c->verdicts[vi];
     if (v.state >= kVerdictMismatch) {
@@ -468,12 +587,12 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
       rc = fail(SDB_ERR_DEVICE, "the merge of exchange %llu left no verdict", (unsigned long long)seq);
     }
   }
-  if (rc == SDB_OK) {
+  if (rc == SDB_OK && out_ids) {
     memcpy(out_ids, slot->hstage, ol.b_i);
     memcpy(out_dists, slot->hstage + ol.b_i, ol.b_d);
     if (out_shards) memcpy(out_shards, slot->hstage + ol.b_i + ol.b_d, ol.b_d);
     memcpy(out_counts, slot->hstage + ol.b_i + 2 * ol.b_d, nq * 4);
-  } else {
+  } else if (out_counts) {
     memset(out_counts, 0, nq * 4);
   }
   lk.lock();
@@ -573,13 +692,23 @@ int sdb_cluster_destroy(sdb_cluster *c) {
   DeviceGuard dg(c->device);
   {
     std::unique_lock<std::mutex> lk(*c->mu);
-    // a registered exchange that the peers never joined is abandoned with the handle
-    if (c->group)
-      for (auto it = c->group->rv.begin(); it != c->group->rv.end();) {
-        auto &arr = it->second;
-        arr.erase(std::remove_if(arr.begin(), arr.end(), [&](const Arrival &a) { return a.c == c; }), arr.end());
-        it = arr.empty() ? c->group->rv.erase(it) : std::next(it);
-      }
+    // Exchanges registered with the group that have not run yet can never run without this rank: its own arrivals go
+    // with the handle, the peers' are failed (verdict "shard failed", no answer) instead of leaving their callers
+    // waiting for a last rank that will not come; later calls on the peers are refused (group->gone).
+    if (c->group) {
+      c->group->gone = c->rank;
+      for (auto &kv : c->group->rv)
+        for (auto &a : kv.second) {
+          if (a.c != c) (void)fail_arrival(a, kVerdictShardFailed, 0, (uint32_t)SDB_ERR_STATE, (uint32_t)c->rank);
+          a.slot->pending = false;
+        }
+      c->group->rv.clear();
+      c->cv->notify_all();
+    }
+  }
+  if (c->comm && c->desync) {
+    (void)ncclCommAbort(c->comm);  // an all-gather the peers never joined sits on the exchange stream: abort, don't drain
+    c->comm = nullptr;
   }
   if (c->xs) (void)hipStreamSynchronize(c->xs);
   for (auto &s : c->ring)
@@ -618,6 +747,48 @@ int sdb_cluster_info(const sdb_cluster *c, int *rank, int *world, int *device) {
   if (world) *world = c->world;
   if (device) *device = c->device;
   return SDB_OK;
+}
+
+int sdb_cluster_set_deadline(sdb_cluster *c, uint32_t milliseconds) {
+  if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
+  std::lock_guard<std::mutex> g(*c->mu);
+  c->deadline_ms = milliseconds;
+  c->cv->notify_all();
+  return SDB_OK;
+}
+
+int sdb_cluster_transport(const sdb_cluster *c, char *buf, size_t cap) {
+  if (!c || !buf || cap == 0) return fail(SDB_ERR_INVALID, "NULL argument");
+  if (c->group) {
+    snprintf(buf, cap, "shared-device: %d ranks on GPU %d, device-to-device copies behind a host rendezvous", c->world, c->device);
+    return SDB_OK;
+  }
+  int ver = 0, count = 0, urank = -1;
+  (void)ncclGetVersion(&ver);
+  (void)ncclCommCount(c->comm, &count);
+  (void)ncclCommUserRank(c->comm, &urank);
+  Dl_info di{};
+  const char *path = dladdr(reinterpret_cast<const void *>(&ncclAllGather), &di) && di.dli_fname ? di.dli_fname : "?";
+  snprintf(buf, cap, "rccl %d.%d.%d (%s): ncclAllGather, communicator of %d ranks, this is rank %d on GPU %d", ver / 10000,
+           (ver / 100) % 100, ver % 100, path, count, urank, c->device);
+  return SDB_OK;
+}
+
+int sdb_cluster_skip_ticket(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32_t per_shard, uint32_t limit) {
+  if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
+  if (!ticket) return fail(SDB_ERR_INVALID, "ticket 0 is not a ticket");
+  if (nq == 0) {  // no rank has entered or will enter for this ticket: the turn passes over it
+    std::lock_guard<std::mutex> g(*c->mu);
+    if (ticket < c->next_ticket)
+      return fail(SDB_ERR_INVALID, "ticket %llu has already entered the exchange on rank %d (next is %llu)",
+                  (unsigned long long)ticket, c->rank, (unsigned long long)c->next_ticket);
+    if (ticket == c->next_ticket) Turn::advance(c, ticket + 1);
+    else c->skipped.insert(ticket);
+    return SDB_OK;
+  }
+  // other ranks may be inside this request's exchange: stand in for it with an empty answer under an error flag
+  return collective(c, nullptr, ticket, nq, nullptr, per_shard, nullptr, limit, 0, nullptr, nullptr, nullptr, nullptr,
+                    SDB_MEM_HOST, nullptr, true);
 }
 
 int sdb_cluster_block_layout(uint64_t nq, uint32_t per_shard, size_t *off_dists, size_t *off_counts, size_t *off_tag,
@@ -663,7 +834,7 @@ int sdb_cluster_synchronize(sdb_cluster *c) {
   DeviceGuard dg(c->device);
   std::unique_lock<std::mutex> lk(*c->mu);
   wait_enqueued(c, lk);
-  SDB_HIP(hipStreamSynchronize(c->xs));
+  if (c->any) SDB_TRY(wait_event_or_fail(c, c->finished, "the exchanges in flight"));
   // verdicts of the device-memory exchanges since the last call (host-memory calls took theirs with them)
   std::string first = c->sticky;
   uint64_t first_seq = ~0ull;
@@ -692,7 +863,8 @@ int sdb_cluster_search_batch(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uin
                              uint32_t limit, uint32_t search_size, uint64_t *out_ids, float *out_dists,
                              uint32_t *out_shards, uint32_t *out_counts, int mem, void *stream_) {
   if (!c || !ix) return fail(SDB_ERR_INVALID, "NULL handle");
-  if (nq && (!queries || !out_ids || !out_dists || !out_counts)) return fail(SDB_ERR_INVALID, "NULL argument");
+  const bool no_out = mem == SDB_MEM_HOST && !out_ids && !out_dists && !out_shards && !out_counts;  // answer not wanted here
+  if (nq && (!queries || (!no_out && (!out_ids || !out_dists || !out_counts)))) return fail(SDB_ERR_INVALID, "NULL argument");
   return collective(c, ix, ticket, nq, queries, 0, nullptr, limit, search_size, out_ids, out_dists, out_shards, out_counts,
                     mem, as_stream(stream_));
 }

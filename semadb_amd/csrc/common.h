@@ -22,9 +22,11 @@ int fail(int code, const char *fmt, ...);
 #define SDB_HIP(expr)                                                                        \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess)                                                                    \
+    if (_e != hipSuccess) {                                                                  \
+      (void)hipGetLastError(); /* reported here: a later launch check must not find it again */ \
       return sdb::fail(SDB_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                        __FILE__, __LINE__);                                                  \
+    }                                                                                        \
   } while (0)
 
 #define SDB_TRY(expr)            \
@@ -89,6 +91,45 @@ typedef const __attribute__((address_space(4))) float uniform_float;
 typedef float uniform_f4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) uniform_f4v uniform_float4;
 __device__ __forceinline__ uniform_float *as_uniform(const float *p) { return (uniform_float *)p; }
+
+// Position of element i of d[0..n) after DistSet.Sort (distset.go:223-238): an insertion sort that moves an element left
+// while it is strictly `<` its left neighbour.  For ordinary and infinite distances that is a stable sort -- rank by
+// counting under (distance, arrival index).  A NaN compares false both ways: it is never moved and nothing moves past
+// it, so the NaNs stay where they are and cut the list into runs that are sorted each on its own.  (Counting without
+// that rule gives every NaN rank 0 and leaves other positions unwritten -- whatever lay in the scratch then went into
+// the graph as a slot number.)  `any_nan`: whether d[] holds a NaN at all, the same for every caller of one list.
+__device__ __forceinline__ int dist_sort_rank(const float *d, int n, int i, bool any_nan) {
+  const float di = d[i];
+  int rank = 0;
+  if (!any_nan) {
+    for (int j = 0; j < n; j++) {
+      const float dj = d[j];
+      rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+    }
+    return rank;
+  }
+  if (di != di) return i;
+  int lo = -1, hi = n;  // the NaNs next to i on either side
+  for (int j = 0; j < n; j++) {
+    const float dj = d[j];
+    if (dj != dj) {
+      if (j < i) lo = j;
+      else if (j < hi) hi = j;
+    }
+  }
+  rank = lo + 1;
+  for (int j = lo + 1; j < hi; j++) {
+    const float dj = d[j];
+    rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+  }
+  return rank;
+}
+// does d[0..n) hold a NaN?  One wave, every lane gets the answer.
+__device__ __forceinline__ bool wave_any_nan(const float *d, int n, int lane) {
+  bool f = false;
+  for (int j = lane; j < n; j += 64) f |= d[j] != d[j];
+  return __ballot(f) != 0;
+}
 
 // A workgroup's waves take turns at a work counter in LDS: one ds_add_rtn by lane 0, the answer broadcast
 __device__ __forceinline__ uint32_t next_query_group(void *lds_counter, int lane) {

@@ -144,7 +144,9 @@ __global__ __launch_bounds__(64) void k_flat_fold(const FlatFoldArgs a) {
     uint64_t pd = __ballot(has && slot != a.skip_slot && a.ids[slot] != 0);
     while (pd) {
       bool ok = true;
-      if (len == cap) ok = dist < list_tail(cd, cap);  // :104 `dist >= tail -> skip`
+      // :104 `dist >= tail -> skip`, literally: a NaN on either side compares false, so a NaN row REPLACES the tail of
+      // a full list and any row replaces a NaN tail -- the walk in storage order decides, and this loop is that walk
+      if (len == cap) ok = !(dist >= list_tail(cd, cap));
       const uint64_t am = __ballot(ok) & pd;
       if (!am) break;
       const int j = __ffsll((unsigned long long)am) - 1;
@@ -537,6 +539,13 @@ __global__ __launch_bounds__(kMergeThreads) void k_flat_merge(const uint32_t *__
     if (t == 0) atomicOr(overflow, 1u);
     c = cap;
   }
+  // A NaN distance in the list or among the candidates: the reference's loop is not a sort then (flat.go:104-123 with a
+  // NaN on either side of `>=` / `<`) and only the walk in storage order reproduces it -- the call starts over on the
+  // block path, like a list that overflowed
+  bool nan = false;
+  for (uint32_t i = t; i < len; i += kMergeThreads) nan |= top_dist[(size_t)q * 128 + i] != top_dist[(size_t)q * 128 + i];
+  for (uint32_t i = t; i < c; i += kMergeThreads) nan |= (cand[(size_t)q * cap + i].y & 0x7fffffffu) > 0x7f800000u;
+  if (nan) atomicOr(overflow, 1u);
   if (c == 0) {
     if (t == 0) thr[q] = len >= limit ? top_dist[(size_t)q * 128 + limit - 1] : __int_as_float(0x7f800000);
     return;

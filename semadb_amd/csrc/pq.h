@@ -18,9 +18,10 @@ namespace sdb {
 int pq_build_lut(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream);
 // codes[v][i] = argmin_j distFn(v_sub_i, centroid_ij) (product.go:136-159); device buffers
 int pq_encode_device(const sdb_pq *pq, const float *d_vecs, uint64_t n, uint8_t *d_codes, hipStream_t stream);
-int kmeans_device(float *dX, uint32_t n, uint32_t stride, uint32_t offset, uint32_t len, uint32_t K,
-                  uint32_t max_iter, uint32_t first_idx, int alias, float *d_centroids_out, uint8_t *d_labels,
-                  uint32_t *iters_out, hipStream_t stream);
+// KMeans.Fit (utils/kmeans.go:34-150) for M problems at once: problem m = columns [offset0 + m * len, + len) of dX's rows
+int kmeans_device(float *dX, uint32_t n, uint32_t stride, uint32_t offset0, uint32_t len, uint32_t M, uint32_t K,
+                  uint32_t max_iter, const uint32_t *h_first_idx, int alias, float *d_centroids_out, uint8_t *d_labels_out,
+                  uint32_t labels_stride, uint32_t *h_iters_out, hipStream_t stream);
 // original-layout copy of slab rows [first, first+n) into dst (device)
 int unpermute_rows_public(const sdb_index *ix, uint32_t first, uint32_t n, float *dst, hipStream_t stream);
 }  // namespace sdb

@@ -51,9 +51,8 @@ __device__ __forceinline__ float dist_serial_metric(const float *x, const float 
 // elements in memory (sub_len % 32 of them), chained sequentially as the asm does.
 constexpr int kRegBlocksMax = 8;  // sub-vectors of up to 8 * 32 + 31 floats take the register path
 typedef float pq_f2v __attribute__((ext_vector_type(2)));
-template <bool L2, int NB>
-__device__ __forceinline__ float dist_regs(const float *r, const float *__restrict__ u, const float *__restrict__ rt,
-                                           uint32_t tail) {
+template <bool L2, int NB, typename UP = const float *__restrict__>
+__device__ __forceinline__ float dist_regs(const float *r, UP u, const float *__restrict__ rt, uint32_t tail) {
   // partial sums 2p and 2p + 1 advance together: one v_pk_fma_f32 (and, for euclidean, one packed subtract, rounded per
   // element like VSUBPS) per pair of elements -- each half is the reference's own operation on its own chain
   pq_f2v acc2[16];
@@ -102,182 +101,411 @@ __device__ __forceinline__ float dist_regs(const float *r, const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// k-means.  Centroid j is a VIEW: row cent_row[j] of cent_base (stride cent_stride) at cent_off --
-// either into X itself (the reference's aliasing, kmeans.go:63,82,144) or into a private copy.
+// k-means, M problems at once.  The reference fits the M sub-quantizers of a product quantizer concurrently, one
+// goroutine each over its own columns of the same rows (product.go:202-232); here problem m is the sub-vector
+// [offset0 + m * len, offset0 + (m + 1) * len) of every row and every launch below carries all M problems in one
+// grid dimension.  A problem that has converged (no label changed, kmeans.go:116-118) idles through the remaining
+// launches on a device-side flag: no host round trip per iteration, none per problem (round 3 ran the problems one
+// after another with two launches per furthest-point step and a stream synchronise per Lloyd iteration: 10.45 s at
+// M = 192, K = 256, 10 000 rows).  KMeans.Fit itself (sdb_kmeans_fit) is the M = 1 case.
+//
+// Centroid (m, j) is a VIEW: row cent_row[m][j] of cent_base at the problem's columns -- either into X itself (the
+// reference's aliasing, kmeans.go:63,82,144) or into a private copy.
 // ---------------------------------------------------------------------------------------------
 struct KmArgs {
   float *X;
-  uint32_t n, stride, offset, len, K;
+  uint32_t n, stride, offset0, len, K, M;
+  // centroid (m, j) = cent_base + m * cent_m_stride + cent_row[m * K + j] * cent_stride + cent_off0 + m * cent_off_step
   float *cent_base;
-  uint32_t cent_stride, cent_off;
-  uint32_t *cent_row;  // [K]
-  float *min_dist;     // [n]
-  uint8_t *labels;     // [n]
-  uint32_t *change;    // [1]
-  float *sums;         // [K][len]
-  uint32_t *counts;    // [K]
-  uint32_t first_idx;
+  size_t cent_m_stride;
+  uint32_t cent_stride, cent_off0, cent_off_step;
+  uint32_t *cent_row;         // [M][K]
+  const float *Xt;            // [M * len][n] the problems' columns, transposed (furthest-point phase: coalesced)
+  float *min_dist;            // [M][n]
+  uint8_t *labels;            // [M][lab_stride]
+  uint32_t lab_stride;        // n rounded up to 16
+  uint32_t *change;           // [M] labels changed by the current assignment
+  uint32_t *done;             // [M] converged
+  uint32_t *iters;            // [M] assignment passes run (kmeans.go:96)
+  uint32_t *n_done;           // [1]
+  float *sums;                // [M][K][len]
+  uint32_t *counts;           // [M][K]
+  uint32_t *lbase;            // [M][K] first member of label l in order[]
+  uint32_t *order;            // [M][n] members by label, in data order within a label
+  const uint32_t *first_idx;  // [M]
 };
 
-__device__ __forceinline__ float *km_centroid(const KmArgs &a, uint32_t j) {
-  return a.cent_base + (size_t)a.cent_row[j] * a.cent_stride + a.cent_off;
+__device__ __forceinline__ float *km_centroid(const KmArgs &a, uint32_t m, uint32_t j) {
+  return a.cent_base + (size_t)m * a.cent_m_stride + (size_t)a.cent_row[(size_t)m * a.K + j] * a.cent_stride + a.cent_off0 +
+         m * a.cent_off_step;
 }
 
-// one furthest-point step (kmeans.go:65-78): distance to centroid i-1, running minimum per point
-__global__ void k_km_init_dist(const KmArgs a, uint32_t i) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.n || j == a.first_idx) return;  // alreadyCentroid only ever holds randId (:60-62,68)
-  const float d = dist_serial<true>(a.X + (size_t)j * a.stride + a.offset, km_centroid(a, i - 1), a.len);
-  if (d < a.min_dist[j]) a.min_dist[j] = d;
-}
-
-// furthestId (kmeans.go:66-80): strict '>' scanning ascending, so the lowest index among equal maxima
-// wins and index 0 is returned when nothing is > 0.
-__global__ __launch_bounds__(1024) void k_km_argmax(const KmArgs a, uint32_t i) {
-  __shared__ float s_v[1024];
-  __shared__ uint32_t s_i[1024];
-  float best = 0.0f;
-  uint32_t best_i = 0;
-  for (uint32_t j = threadIdx.x; j < a.n; j += blockDim.x) {
-    if (j == a.first_idx) continue;
-    const float v = a.min_dist[j];
-    if (v > best) best = v, best_i = j;
-  }
-  s_v[threadIdx.x] = best, s_i[threadIdx.x] = best_i;
+// Xt[c][j] = X[j][offset0 + c]: a 32 x 32 tile through LDS
+__global__ __launch_bounds__(256) void k_km_transpose(const float *__restrict__ X, uint32_t n, uint32_t stride, uint32_t offset0,
+                                                      uint32_t cols, float *__restrict__ Xt) {
+  __shared__ float tile[32][33];
+  const uint32_t j0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (uint32_t r = ty; r < 32; r += 8)
+    if (j0 + r < n && c0 + tx < cols) tile[r][tx] = X[(size_t)(j0 + r) * stride + offset0 + c0 + tx];
   __syncthreads();
-  for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float ov = s_v[threadIdx.x + s], mv = s_v[threadIdx.x];
-      const uint32_t oi = s_i[threadIdx.x + s], mi = s_i[threadIdx.x];
-      if (ov > mv || (ov == mv && ov > 0.0f && oi < mi)) s_v[threadIdx.x] = ov, s_i[threadIdx.x] = oi;
+  for (uint32_t r = ty; r < 32; r += 8)
+    if (c0 + r < cols && j0 + tx < n) Xt[(size_t)(c0 + r) * n + j0 + tx] = tile[tx][r];
+}
+
+// asm.SquaredEuclideanDistance (euclidean.s:7-65) of point j's sub-vector, read down a column of Xt (element e at
+// xt[e * n]), against a centroid whose elements arrive through the scalar cache -- dist_serial's arithmetic
+__device__ __forceinline__ float dist_column(const float *__restrict__ xt, size_t n, uniform_float *c, uint32_t len) {
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) acc[i] = 0.0f;
+  const uint32_t nblk = len / 32;
+  for (uint32_t b = 0; b < nblk; b++) {
+#pragma unroll
+    for (int L = 0; L < 32; L++) acc[L] = chain1<true>(acc[L], xt[(size_t)(32 * b + L) * n], c[32 * b + L]);
+  }
+  float t = 0.0f;
+  for (uint32_t i = nblk * 32; i < len; i++) t = chain1<true>(t, xt[(size_t)i * n], c[i]);
+  float r[4];
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    const float s0 = ((acc[l] + acc[8 + l]) + acc[16 + l]) + acc[24 + l];
+    const float s1 = ((acc[l + 4] + acc[12 + l]) + acc[20 + l]) + acc[28 + l];
+    r[l] = s0 + s1;
+  }
+  r[0] = r[0] + t;
+  r[1] = r[1] + 0.0f;
+  r[2] = r[2] + 0.0f;
+  r[3] = r[3] + 0.0f;
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+// furthestId's order (kmeans.go:66-80): strict '>' scanning ascending -- the lowest index among equal maxima wins and
+// index 0 is returned when nothing is > 0
+__device__ __forceinline__ void km_far_combine(float &v, uint32_t &i, float ov, uint32_t oi) {
+  if (ov > v || (ov == v && ov > 0.0f && oi < i)) v = ov, i = oi;
+}
+
+// The whole furthest-point initialisation (kmeans.go:56-83) of problem m by ONE workgroup: K - 1 steps of (distance of
+// every point to the centroid chosen last, running minimum per point, arg max), the chosen row handed from step to step
+// through LDS.  Nothing is written but min_dist and the row list, so the points are read from the transposed copy.
+__global__ __launch_bounds__(1024) void k_km_init(const KmArgs a) {
+  __shared__ float s_v[16];
+  __shared__ uint32_t s_i[16];
+  __shared__ uint32_t s_row;
+  const uint32_t m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t first = a.first_idx[m];
+  float *md = a.min_dist + (size_t)m * a.n;
+  const float *xt = a.Xt + (size_t)m * a.len * a.n;
+  uint32_t *rows = a.cent_row + (size_t)m * a.K;
+  for (uint32_t j = tid; j < a.n; j += 1024) md[j] = FLT_MAX;
+  if (tid == 0) rows[0] = first;
+  uint32_t prev = first;
+  for (uint32_t i = 1; i < a.K; i++) {
+    uniform_float *c = as_uniform(a.X + (size_t)prev * a.stride + a.offset0 + (size_t)m * a.len);
+    float best = 0.0f;
+    uint32_t best_i = 0;
+    for (uint32_t j = tid; j < a.n; j += 1024) {
+      if (j == first) continue;  // alreadyCentroid only ever holds randId (:60-62,68)
+      const float d = dist_column(xt + j, a.n, c, a.len);
+      float v = md[j];
+      if (d < v) v = d, md[j] = d;
+      if (v > best) best = v, best_i = j;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) km_far_combine(best, best_i, __shfl_down(best, o, 64), __shfl_down(best_i, o, 64));
+    if (lane == 0) s_v[wave] = best, s_i[wave] = best_i;
+    __syncthreads();
+    if (wave == 0) {
+      float v = lane < 16 ? s_v[lane] : 0.0f;
+      uint32_t vi = lane < 16 ? s_i[lane] : 0u;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) km_far_combine(v, vi, __shfl_down(v, o, 64), __shfl_down(vi, o, 64));
+      if (lane == 0) {
+        const uint32_t r = v > 0.0f ? vi : 0u;
+        s_row = r, rows[i] = r;
+      }
     }
     __syncthreads();
+    prev = s_row;
+    __syncthreads();  // s_v / s_i / s_row are rewritten by the next step
   }
-  if (threadIdx.x == 0) a.cent_row[i] = s_v[0] > 0.0f ? s_i[0] : 0u;
 }
 
-// assignment (kmeans.go:100-115): argmin over centroids, strict '<' starting from centroid 0
-__global__ void k_km_assign(const KmArgs a) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const float *sv = a.X + (size_t)i * a.stride + a.offset;
-  float best = dist_serial<true>(sv, km_centroid(a, 0), a.len);
+// assignment (kmeans.go:100-115): argmin over centroids, strict '<' starting from centroid 0.  Thread = point, its
+// sub-vector in registers, the centroids wave-uniform through the scalar cache (k_pq_encode_t's scheme).
+template <int NB>
+__global__ __launch_bounds__(256) void k_km_assign_t(const KmArgs a) {
+  const uint32_t m = blockIdx.y;
+  if (a.done[m]) return;
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  const float *sub = a.X + (size_t)(v < a.n ? v : a.n - 1) * a.stride + a.offset0 + (size_t)m * a.len;
+  float r[NB > 0 ? NB * 32 : 1];
+#pragma unroll
+  for (int e = 0; e < NB * 32; e++) r[e] = sub[e];
+  const uint32_t tail = a.len - NB * 32;
+  float rt[31];
+#pragma unroll
+  for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? sub[NB * 32 + e] : 0.0f;
+  float best = dist_regs<true, NB>(r, as_uniform(km_centroid(a, m, 0)), rt, tail);
   uint32_t best_id = 0;
   for (uint32_t j = 1; j < a.K; j++) {
-    const float d = dist_serial<true>(sv, km_centroid(a, j), a.len);
+    const float d = dist_regs<true, NB>(r, as_uniform(km_centroid(a, m, j)), rt, tail);
     if (d < best) best = d, best_id = j;
   }
-  if (a.labels[i] != (uint8_t)best_id) {
-    a.labels[i] = (uint8_t)best_id;
-    atomicAdd(a.change, 1u);
+  uint8_t *lab = a.labels + (size_t)m * a.lab_stride;
+  const bool ch = v < a.n && lab[v] != (uint8_t)best_id;
+  if (ch) lab[v] = (uint8_t)best_id;
+  const uint64_t b = __ballot(ch);
+  if (b && (threadIdx.x & 63) == 0) atomicAdd(a.change + m, (uint32_t)__popcll(b));
+}
+
+// the same for sub-vectors too long for the register file
+__global__ __launch_bounds__(64) void k_km_assign(const KmArgs a) {
+  const uint32_t m = blockIdx.y;
+  if (a.done[m]) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float *sv = a.X + (size_t)i * a.stride + a.offset0 + (size_t)m * a.len;
+  float best = dist_serial<true>(sv, km_centroid(a, m, 0), a.len);
+  uint32_t best_id = 0;
+  for (uint32_t j = 1; j < a.K; j++) {
+    const float d = dist_serial<true>(sv, km_centroid(a, m, j), a.len);
+    if (d < best) best = d, best_id = j;
+  }
+  uint8_t *lab = a.labels + (size_t)m * a.lab_stride;
+  if (lab[i] != (uint8_t)best_id) {
+    lab[i] = (uint8_t)best_id;
+    atomicAdd(a.change + m, 1u);
   }
 }
 
-// update sums (kmeans.go:125-137): per label, members added IN DATA ORDER (fp32 adds are not
-// associative).  Thread (label, component) walks the points in order.
-__global__ void k_km_sums(const KmArgs a) {
-  const uint32_t lb = blockIdx.x;
-  for (uint32_t j = threadIdx.x; j < a.len; j += blockDim.x) {
-    float s = 0.0f;
-    uint32_t c = 0;
-    for (uint32_t i = 0; i < a.n; i++)
-      if (a.labels[i] == lb) {
-        s += a.X[(size_t)i * a.stride + a.offset + j];
-        c++;
-      }
-    a.sums[(size_t)lb * a.len + j] = s;
-    if (j == 0) a.counts[lb] = c;
+// The members of every label in DATA ORDER (the sums below are fp32 additions in that order, kmeans.go:125-137, and
+// fp32 addition is not associative): thread (label l, segment s) counts, then lists, the points of segment s that
+// carry label l -- the segments are four contiguous quarters of the points, so (l, s = 0..3) in sequence is data order.
+// The labels are wave-uniform reads (a wave = 64 labels of one segment): scalar loads, 4 labels per word.
+__global__ __launch_bounds__(1024) void k_km_members(const KmArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (a.done[m] || a.change[m] == 0) return;  // converged before, or with this very assignment (:116-118)
+  __shared__ uint32_t s_cnt[4][256];
+  __shared__ uint32_t s_scan[256];
+  const uint32_t tid = threadIdx.x, l = tid & 255, s = tid >> 8;
+  typedef const __attribute__((address_space(4))) uint32_t uniform_u32;
+  uniform_u32 *lab = (uniform_u32 *)(a.labels + (size_t)m * a.lab_stride);
+  const uint32_t words = (a.n + 3) / 4, seg = (((words + 3) / 4) + 3) & ~3u;
+  const uint32_t w0 = min(words, s * seg), w1 = min(words, w0 + seg);
+  uint32_t cnt = 0;
+  for (uint32_t w = w0; w < w1; w++) {
+    const uint32_t x = lab[w];
+#pragma unroll
+    for (int b = 0; b < 4; b++) cnt += (4 * w + b < a.n && ((x >> (8 * b)) & 255u) == l) ? 1u : 0u;
   }
-}
-
-// means (kmeans.go:139-146) written through the centroid views in centroid order: with aliasing two
-// centroids can share a row and the later one wins, exactly as in the reference.
-__global__ void k_km_means(const KmArgs a) {
-  for (uint32_t i = 0; i < a.K; i++) {
-    const uint32_t c = a.counts[i];
-    if (c != 0) {
-      float *dst = km_centroid(a, i);
-      for (uint32_t j = threadIdx.x; j < a.len; j += blockDim.x) dst[j] = a.sums[(size_t)i * a.len + j] / (float)c;
-    }
+  s_cnt[s][l] = cnt;
+  __syncthreads();
+  uint32_t tot = 0;
+  if (tid < 256) {
+    tot = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
+    s_scan[tid] = tot;
+  }
+  __syncthreads();
+  for (uint32_t o = 1; o < 256; o <<= 1) {  // inclusive scan over the labels
+    uint32_t add = 0;
+    if (tid < 256 && tid >= o) add = s_scan[tid - o];
+    __syncthreads();
+    if (tid < 256) s_scan[tid] += add;
     __syncthreads();
   }
+  if (tid < 256 && tid < a.K) {
+    a.counts[(size_t)m * a.K + tid] = tot;
+    a.lbase[(size_t)m * a.K + tid] = s_scan[tid] - tot;
+  }
+  uint32_t pos = s_scan[l] - (s_cnt[0][l] + s_cnt[1][l] + s_cnt[2][l] + s_cnt[3][l]);
+  for (uint32_t k = 0; k < s; k++) pos += s_cnt[k][l];
+  uint32_t *ord = a.order + (size_t)m * a.n;
+  for (uint32_t w = w0; w < w1; w++) {
+    const uint32_t x = lab[w];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (4 * w + b < a.n && ((x >> (8 * b)) & 255u) == l) ord[pos++] = 4 * w + b;
+  }
 }
 
-__global__ void k_km_gather_centroids(const KmArgs a, float *out /* [K][len] */) {
-  const uint32_t j = blockIdx.x;
-  const float *c = km_centroid(a, j);
-  for (uint32_t t = threadIdx.x; t < a.len; t += blockDim.x) out[(size_t)j * a.len + t] = c[t];
+// update sums (kmeans.go:125-137): thread (label, component) adds its members' components in data order
+__global__ __launch_bounds__(256) void k_km_sums(const KmArgs a) {
+  const uint32_t m = blockIdx.y;
+  if (a.done[m] || a.change[m] == 0) return;
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.K * a.len) return;
+  const uint32_t l = t / a.len, j = t % a.len;
+  const uint32_t c = a.counts[(size_t)m * a.K + l];
+  if (c == 0) return;  // no member: the stale sum is never read (:140-142)
+  const uint32_t *ord = a.order + (size_t)m * a.n + a.lbase[(size_t)m * a.K + l];
+  const float *col = a.X + a.offset0 + (size_t)m * a.len + j;
+  float sum = 0.0f;
+  uint32_t k = 0;
+  for (; k + 4 <= c; k += 4) {  // the loads do not depend on the additions: four in flight
+    const float x0 = col[(size_t)ord[k] * a.stride], x1 = col[(size_t)ord[k + 1] * a.stride];
+    const float x2 = col[(size_t)ord[k + 2] * a.stride], x3 = col[(size_t)ord[k + 3] * a.stride];
+    sum += x0, sum += x1, sum += x2, sum += x3;
+  }
+  for (; k < c; k++) sum += col[(size_t)ord[k] * a.stride];
+  a.sums[((size_t)m * a.K + l) * a.len + j] = sum;
 }
 
-__global__ void k_fill_f32(float *p, float v, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+// means (kmeans.go:139-146) written through the centroid views.  The reference writes them in centroid order, so when
+// two centroids share a row (aliasing over duplicate points) the later one with members wins: a centroid shadowed by
+// such a successor does not write.  Then the iteration's bookkeeping of problem m.
+__global__ __launch_bounds__(256) void k_km_means(const KmArgs a) {
+  const uint32_t m = blockIdx.x, tid = threadIdx.x;
+  if (a.done[m]) return;
+  __shared__ uint8_t s_shadow[256];
+  const uint32_t change = a.change[m];
+  if (change != 0) {
+    const uint32_t *rows = a.cent_row + (size_t)m * a.K, *cnt = a.counts + (size_t)m * a.K;
+    if (tid < a.K) {
+      bool sh = false;
+      const uint32_t r = rows[tid];
+      for (uint32_t k = tid + 1; k < a.K; k++) sh |= rows[k] == r && cnt[k] != 0;
+      s_shadow[tid] = sh ? 1 : 0;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < a.K * a.len; t += 256) {
+      const uint32_t l = t / a.len, j = t % a.len, c = cnt[l];
+      if (c != 0 && !s_shadow[l]) km_centroid(a, m, l)[j] = a.sums[((size_t)m * a.K + l) * a.len + j] / (float)c;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.iters[m] += 1;
+    if (change == 0) {
+      a.done[m] = 1;
+      atomicAdd(a.n_done, 1u);
+    }
+    a.change[m] = 0;
+  }
 }
 
-__global__ void k_iota_u32(uint32_t *p, uint32_t n) {
+__global__ void k_km_gather_centroids(const KmArgs a, float *out /* [M][K][len] */) {
+  const uint32_t j = blockIdx.x, m = blockIdx.y;
+  const float *c = km_centroid(a, m, j);
+  for (uint32_t t = threadIdx.x; t < a.len; t += blockDim.x) out[((size_t)m * a.K + j) * a.len + t] = c[t];
+}
+
+__global__ void k_km_iota_rows(uint32_t *p, uint32_t K, uint32_t total) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
+  if (i < total) p[i] = i % K;
 }
 
-// KMeans.Fit on device buffers.  d_centroids_out [K][len], d_labels [n].
-int kmeans_device(float *dX, uint32_t n, uint32_t stride, uint32_t offset, uint32_t len, uint32_t K,
-                  uint32_t max_iter, uint32_t first_idx, int alias, float *d_centroids_out, uint8_t *d_labels,
-                  uint32_t *iters_out, hipStream_t stream) {
+// labels [M][lab_stride] -> out[j * out_stride + m]  (the codes of product.go:216-218; M = 1: the labels themselves)
+__global__ void k_km_scatter_labels(const uint8_t *__restrict__ labels, uint32_t lab_stride, uint8_t *__restrict__ out, uint32_t n,
+                                    uint32_t out_stride) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (j < n) out[(size_t)j * out_stride + m] = labels[(size_t)m * lab_stride + j];
+}
+
+template <int NB>
+static void launch_km_assign_t(const KmArgs &a, hipStream_t stream) {
+  hipLaunchKernelGGL((k_km_assign_t<NB>), dim3((a.n + 255) / 256, a.M), dim3(256), 0, stream, a);
+}
+
+// KMeans.Fit for M problems on device buffers: problem m = columns [offset0 + m * len, + len) of dX's rows, first
+// centroid = row h_first_idx[m].  d_centroids_out [M][K][len]; d_labels_out[j * labels_stride + m] (may be NULL);
+// h_iters_out [M] (may be NULL).  Returns after the stream has drained.
+int kmeans_device(float *dX, uint32_t n, uint32_t stride, uint32_t offset0, uint32_t len, uint32_t M, uint32_t K,
+                  uint32_t max_iter, const uint32_t *h_first_idx, int alias, float *d_centroids_out, uint8_t *d_labels_out,
+                  uint32_t labels_stride, uint32_t *h_iters_out, hipStream_t stream) {
   if (n == 0 || K == 0 || K > 256) return fail(SDB_ERR_INVALID, "kmeans: need n > 0 and 1 <= K <= 256");
-  if (first_idx >= n) return fail(SDB_ERR_INVALID, "kmeans: first_idx out of range");
-  if (len == 0 || offset + len > stride) return fail(SDB_ERR_INVALID, "kmeans: sub-vector out of range");
+  if (M == 0 || len == 0 || (uint64_t)offset0 + (uint64_t)M * len > stride) return fail(SDB_ERR_INVALID, "kmeans: sub-vector out of range");
+  for (uint32_t m = 0; m < M; m++)
+    if (h_first_idx[m] >= n) return fail(SDB_ERR_INVALID, "kmeans: first_idx out of range");
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const uint32_t lab_stride = (n + 15) & ~15u;
+  const size_t b_xt = up((size_t)M * len * n * 4), b_min = up((size_t)M * n * 4), b_lab = up((size_t)M * lab_stride);
+  const size_t b_rows = up((size_t)M * K * 4), b_sums = up((size_t)M * K * len * 4), b_ord = up((size_t)M * n * 4);
+  const size_t b_m = up((size_t)M * 4), b_priv = alias ? 0 : b_sums;
   char *buf = nullptr;
-  const size_t b_min = ((size_t)n * 4 + 255) & ~(size_t)255, b_rows = 1024, b_sums = ((size_t)K * len * 4 + 255) & ~(size_t)255;
-  const size_t b_priv = alias ? 0 : b_sums;
-  SDB_HIP(hipMalloc(&buf, b_min + 3 * b_rows + b_sums + 256 + b_priv));
+  uint32_t *h_done = nullptr;
+  SDB_HIP(hipMalloc(&buf, b_xt + b_min + b_lab + 4 * b_rows + b_sums + b_ord + 4 * b_m + 256 + b_priv));
   struct Free {
     char *p;
+    uint32_t **h;
     hipStream_t s;
     ~Free() {
       (void)hipStreamSynchronize(s);
       (void)hipFree(p);
+      if (*h) (void)hipHostFree(*h);
     }
-  } fr{buf, stream};
+  } fr{buf, &h_done, stream};
+  SDB_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_done), 64, hipHostMallocDefault));
   KmArgs a{};
-  a.X = dX, a.n = n, a.stride = stride, a.offset = offset, a.len = len, a.K = K, a.first_idx = first_idx;
-  a.min_dist = (float *)buf;
-  uint32_t *rows_x = (uint32_t *)(buf + b_min);
-  uint32_t *rows_id = (uint32_t *)(buf + b_min + b_rows);
-  a.counts = (uint32_t *)(buf + b_min + 2 * b_rows);
-  a.sums = (float *)(buf + b_min + 3 * b_rows);
-  a.change = (uint32_t *)(buf + b_min + 3 * b_rows + b_sums);
-  float *priv = alias ? nullptr : (float *)(buf + b_min + 3 * b_rows + b_sums + 256);
-  a.labels = d_labels;
+  a.X = dX, a.n = n, a.stride = stride, a.offset0 = offset0, a.len = len, a.K = K, a.M = M, a.lab_stride = lab_stride;
+  char *p = buf;
+  auto take = [&](size_t b) {
+    char *r = p;
+    p += b;
+    return r;
+  };
+  float *xt = (float *)take(b_xt);
+  a.Xt = xt;
+  a.min_dist = (float *)take(b_min);
+  a.labels = (uint8_t *)take(b_lab);
+  uint32_t *rows_x = (uint32_t *)take(b_rows), *rows_id = (uint32_t *)take(b_rows);
+  a.counts = (uint32_t *)take(b_rows), a.lbase = (uint32_t *)take(b_rows);
+  a.sums = (float *)take(b_sums);
+  a.order = (uint32_t *)take(b_ord);
+  uint32_t *d_first = (uint32_t *)take(b_m);
+  a.first_idx = d_first;
+  a.change = (uint32_t *)take(b_m), a.done = (uint32_t *)take(b_m), a.iters = (uint32_t *)take(b_m);
+  a.n_done = (uint32_t *)take(256);
+  float *priv = alias ? nullptr : (float *)take(b_priv);
+  SDB_HIP(hipMemcpyAsync(d_first, h_first_idx, (size_t)M * 4, hipMemcpyHostToDevice, stream));
+  SDB_HIP(hipMemsetAsync(a.change, 0, 3 * b_m + 256, stream));  // change, done, iters, n_done
+  SDB_HIP(hipMemsetAsync(a.labels, 0, b_lab, stream));           // Labels start at 0 (kmeans.go:87)
   // ---- furthest-point initialisation (kmeans.go:56-83): centroids are views into X
-  a.cent_base = dX, a.cent_stride = stride, a.cent_off = offset, a.cent_row = rows_x;
-  hipLaunchKernelGGL(k_fill_f32, dim3((n + 255) / 256), dim3(256), 0, stream, a.min_dist, FLT_MAX, (size_t)n);
-  SDB_HIP(hipMemcpyAsync(rows_x, &a.first_idx, 4, hipMemcpyHostToDevice, stream));
-  for (uint32_t i = 1; i < K; i++) {
-    hipLaunchKernelGGL(k_km_init_dist, dim3((n + 127) / 128), dim3(128), 0, stream, a, i);
-    hipLaunchKernelGGL(k_km_argmax, dim3(1), dim3(1024), 0, stream, a, i);
-  }
+  a.cent_base = dX, a.cent_m_stride = 0, a.cent_stride = stride, a.cent_off0 = offset0, a.cent_off_step = len, a.cent_row = rows_x;
+  hipLaunchKernelGGL(k_km_transpose, dim3((n + 31) / 32, (M * len + 31) / 32), dim3(256), 0, stream, dX, n, stride, offset0,
+                     M * len, xt);
+  hipLaunchKernelGGL(k_km_init, dim3(M), dim3(1024), 0, stream, a);
   SDB_HIP(hipGetLastError());
   if (!alias) {  // fenced mode: work on copies, X stays untouched
-    hipLaunchKernelGGL(k_km_gather_centroids, dim3(K), dim3(64), 0, stream, a, priv);
-    hipLaunchKernelGGL(k_iota_u32, dim3(1), dim3(256), 0, stream, rows_id, 256u);
-    a.cent_base = priv, a.cent_stride = len, a.cent_off = 0, a.cent_row = rows_id;
+    hipLaunchKernelGGL(k_km_gather_centroids, dim3(K, M), dim3(64), 0, stream, a, priv);
+    hipLaunchKernelGGL(k_km_iota_rows, dim3((M * K + 255) / 256), dim3(256), 0, stream, rows_id, K, M * K);
+    a.cent_base = priv, a.cent_m_stride = (size_t)K * len, a.cent_stride = len, a.cent_off0 = 0, a.cent_off_step = 0;
+    a.cent_row = rows_id;
   }
-  SDB_HIP(hipMemsetAsync(d_labels, 0, n, stream));  // Labels start at 0 (kmeans.go:87)
-  uint32_t iters = 0;
-  for (uint32_t it = 0; it < max_iter; it++) {  // kmeans.go:96
-    iters++;
-    SDB_HIP(hipMemsetAsync(a.change, 0, 4, stream));
-    hipLaunchKernelGGL(k_km_assign, dim3((n + 63) / 64), dim3(64), 0, stream, a);
-    uint32_t change = 0;
-    SDB_HIP(hipMemcpyAsync(&change, a.change, 4, hipMemcpyDeviceToHost, stream));
-    SDB_HIP(hipStreamSynchronize(stream));
-    if (change == 0) break;  // :116-118
-    hipLaunchKernelGGL(k_km_sums, dim3(K), dim3(128), 0, stream, a);
-    hipLaunchKernelGGL(k_km_means, dim3(1), dim3(256), 0, stream, a);
+  // ---- Lloyd iterations (kmeans.go:96-147); the host looks at the number of converged problems every 8th one
+  for (uint32_t it = 0; it < max_iter; it++) {
+    if (len < 32 * (kRegBlocksMax + 1)) {
+      switch (len / 32) {
+        case 0: launch_km_assign_t<0>(a, stream); break;
+        case 1: launch_km_assign_t<1>(a, stream); break;
+        case 2: launch_km_assign_t<2>(a, stream); break;
+        case 3: launch_km_assign_t<3>(a, stream); break;
+        case 4: launch_km_assign_t<4>(a, stream); break;
+        case 5: launch_km_assign_t<5>(a, stream); break;
+        case 6: launch_km_assign_t<6>(a, stream); break;
+        case 7: launch_km_assign_t<7>(a, stream); break;
+        default: launch_km_assign_t<8>(a, stream); break;
+      }
+    } else {
+      hipLaunchKernelGGL(k_km_assign, dim3((n + 63) / 64, M), dim3(64), 0, stream, a);
+    }
+    hipLaunchKernelGGL(k_km_members, dim3(M), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(k_km_sums, dim3((K * len + 255) / 256, M), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_km_means, dim3(M), dim3(256), 0, stream, a);
+    if ((it & 7) == 7 && it + 1 < max_iter) {
+      SDB_HIP(hipMemcpyAsync(h_done, a.n_done, 4, hipMemcpyDeviceToHost, stream));
+      SDB_HIP(hipStreamSynchronize(stream));
+      if (*h_done == M) break;
+    }
   }
-  hipLaunchKernelGGL(k_km_gather_centroids, dim3(K), dim3(64), 0, stream, a, d_centroids_out);
   SDB_HIP(hipGetLastError());
-  if (iters_out) *iters_out = iters;
+  hipLaunchKernelGGL(k_km_gather_centroids, dim3(K, M), dim3(64), 0, stream, a, d_centroids_out);
+  if (d_labels_out)
+    hipLaunchKernelGGL(k_km_scatter_labels, dim3((n + 255) / 256, M), dim3(256), 0, stream, a.labels, lab_stride, d_labels_out, n,
+                       labels_stride);
+  SDB_HIP(hipGetLastError());
+  if (h_iters_out) SDB_HIP(hipMemcpyAsync(h_iters_out, a.iters, (size_t)M * 4, hipMemcpyDeviceToHost, stream));
+  SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
 }
 
@@ -482,12 +710,6 @@ __global__ void k_pq_sym(const float *__restrict__ cdists, const uint8_t *__rest
   out[p] = dist;
 }
 
-__global__ void k_scatter_labels(const uint8_t *__restrict__ labels, uint8_t *__restrict__ codes, uint32_t n,
-                                 uint32_t M, uint32_t i) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) codes[(size_t)j * M + i] = labels[j];
-}
-
 int pq_build_lut(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
   if (nq == 0) return SDB_OK;
   if (pq->metric != SDB_METRIC_EUCLIDEAN && pq->sub_len % 32 == 0 && pq->sub_len >= 32 && pq->sub_len <= 32 * kRegBlocksMax &&
@@ -571,8 +793,8 @@ int sdb_kmeans_fit(float *X, uint32_t n, uint32_t stride, uint32_t offset, uint3
   SDB_TRY(stage_in(sx, X, (size_t)n * stride * 4, mem, stream));
   SDB_TRY(stage_in(sc, centroids_out, (size_t)K * len * 4, mem, stream, false));
   SDB_TRY(stage_in(sl, labels_out, n, mem, stream, false));
-  int rc = kmeans_device((float *)sx.dev, n, stride, offset, len, K, max_iter, first_idx, alias, (float *)sc.dev,
-                         (uint8_t *)sl.dev, iters_out, stream);
+  int rc = kmeans_device((float *)sx.dev, n, stride, offset, len, 1, K, max_iter, &first_idx, alias, (float *)sc.dev,
+                         (uint8_t *)sl.dev, 1, iters_out, stream);
   if (rc != SDB_OK) {
     (void)hipStreamSynchronize(stream);
     return rc;
@@ -634,21 +856,14 @@ int sdb_pq_fit(sdb_pq *pq, float *X, uint32_t n, const uint32_t *first_idx, int 
   Staged sx, sc;
   SDB_TRY(stage_in(sx, X, (size_t)n * pq->dim * 4, mem, stream));
   SDB_TRY(stage_in(sc, codes_out, codes_out ? (size_t)n * pq->M : 0, codes_out ? mem : SDB_MEM_HOST, stream, false));
-  uint8_t *labels = nullptr;
-  SDB_HIP(hipMalloc(&labels, n));
-  int rc = SDB_OK;
-  for (uint32_t i = 0; i < pq->M && rc == SDB_OK; i++) {  // one goroutine per sub-quantizer, product.go:202-232
-    rc = kmeans_device((float *)sx.dev, n, pq->dim, i * pq->sub_len, pq->sub_len, pq->K, 100, first_idx[i], alias,
-                       pq->d_centroids + (size_t)i * pq->K * pq->sub_len, labels, nullptr, stream);
-    if (rc == SDB_OK && codes_out)  // :216-218
-      hipLaunchKernelGGL(k_scatter_labels, dim3((n + 255) / 256), dim3(256), 0, stream, labels, (uint8_t *)sc.dev, n,
-                         pq->M, i);
-  }
+  // one KMeans.Fit per sub-quantizer, all of them at once (one goroutine each in the reference, product.go:202-232);
+  // the labels are the codes (:216-218)
+  int rc = kmeans_device((float *)sx.dev, n, pq->dim, 0, pq->sub_len, pq->M, pq->K, 100, first_idx, alias, pq->d_centroids,
+                         codes_out ? (uint8_t *)sc.dev : nullptr, pq->M, nullptr, stream);
   if (rc == SDB_OK) rc = pq_fill_cdists(pq, stream);
   if (rc == SDB_OK && codes_out) rc = stage_out(sc, stream);
   if (rc == SDB_OK && alias) rc = stage_out(sx, stream);
   (void)hipStreamSynchronize(stream);
-  (void)hipFree(labels);
   if (rc == SDB_OK) pq->fitted = true;
   return rc;
 }

@@ -22,12 +22,14 @@
 #include <cmath>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <optional>
 #include <set>
 #include <string>
@@ -295,7 +297,8 @@ class SearchBatcher {
     for (auto &t : threads_)
       if (t.joinable()) t.join();
     for (Batch *b : all_) {
-      sdb_host_free(b->queries);
+      if (b->pinned) sdb_host_free(b->queries);
+      else std::free(b->queries);
       delete b;
     }
   }
@@ -315,7 +318,9 @@ class SearchBatcher {
   void submit(Request *r) {
     r->t_submit_ns = nowNs();
     const uint64_t key = ((uint64_t)r->limit << 32) | r->search_size;
-    while (!r->filter) {
+    uint32_t tag = 0;
+    const bool fast = !r->filter && tagOf(key, &tag);
+    while (fast) {
       Batch *b = cur_.load(std::memory_order_acquire);
       if (!b) {  // every slab is in use (back-pressure) or a rotation is under way
         std::unique_lock<std::mutex> lk(qmu_);
@@ -328,13 +333,19 @@ class SearchBatcher {
         }
         continue;
       }
-      if (b->key != key) break;  // other parameters than the filling batch's: the queue
-      // one atomic reserves slot i of the batch that is filling; no lock on this path
-      const uint32_t i = b->n.fetch_add(1, std::memory_order_acq_rel);
+      // The batch's parameters and its slot counter live in ONE atomic (tag << 32 | slots reserved) and a slot is
+      // reserved by compare-and-swap on both: a slab that was sealed, run, recycled for other parameters and installed
+      // again between the look at its parameters and the reservation fails the swap instead of handing this request
+      // a slot of a batch with another (limit, searchSize), whose answers would not fit the caller's buffers.
+      uint64_t st = b->st.load(std::memory_order_acquire);
+      if ((uint32_t)(st >> 32) != tag) break;  // other parameters than the filling batch's: the queue
+      const uint32_t i = (uint32_t)st;
       if (i >= max_batch_) {  // full or sealed: whoever filled / sealed it is installing the next one
-        while (cur_.load(std::memory_order_acquire) == b) std::this_thread::yield();
+        while (cur_.load(std::memory_order_acquire) == b && (uint32_t)b->st.load(std::memory_order_acquire) >= max_batch_)
+          std::this_thread::yield();
         continue;
       }
+      if (!b->st.compare_exchange_weak(st, st + 1, std::memory_order_acq_rel)) continue;
       if (i == 0) b->t_first_ns.store(r->t_submit_ns, std::memory_order_relaxed);
       b->reqs[i] = r;
       std::memcpy(b->queries + (size_t)i * dim_, r->vector, (size_t)dim_ * 4);  // into the pinned slab
@@ -350,12 +361,17 @@ class SearchBatcher {
     // filtered requests (they carry id sets) and requests whose (limit, searchSize) differ from the filling batch's:
     // a worker groups them.  When the unfiltered traffic has moved to other parameters the fast path follows it.
     std::lock_guard<std::mutex> g(qmu_);
+    if (stop_) {  // nobody will run the queue any more
+      r->err = Error("batcher stopped");
+      tell(finish(r), 1);
+      return;
+    }
     queued_.push_back(r);
-    if (!r->filter && (fast_key_ == 0 || ++other_streak_ > 4 * max_batch_)) {
+    if (fast && (fast_key_ == 0 || ++other_streak_ > 4 * max_batch_)) {
       fast_key_ = key, other_streak_ = 0;
       Batch *b = cur_.load(std::memory_order_acquire);
       if (b && b->key != key) {
-        const uint32_t got = b->n.fetch_add((uint32_t)max_batch_, std::memory_order_acq_rel);
+        const uint32_t got = seal(b);
         if (got < max_batch_) rotateLocked(b, got);  // else: the submit that filled it is rotating
       }
     }
@@ -389,7 +405,8 @@ class SearchBatcher {
   struct Batch {
     float *queries = nullptr;  // pinned [cap][dim]
     std::vector<Request *> reqs;
-    std::atomic<uint32_t> n{0};          // slots reserved; >= max_batch: full or sealed
+    std::atomic<uint64_t> st{0};         // tagOf(key) << 32 | slots reserved; slots >= max_batch: full or sealed
+    bool pinned = false;                 // queries came from sdb_host_alloc (else malloc)
     std::atomic<uint32_t> written{0};    // slots whose vector has been copied in
     uint32_t count = 0;                  // slots that belong to the batch once it is sealed
     uint64_t key = 0;                    // (limit << 32 | searchSize) of every request in it; set when installed
@@ -406,6 +423,23 @@ class SearchBatcher {
     qcv_.notify_one();
     fcv_.notify_all();
   }
+  // the 32-bit form of (limit << 32 | searchSize) that shares the slot atomic; parameters beyond 16 bits (the API's
+  // maxima are 75 and 75, models/search.go:287-297) take the queue
+  static bool tagOf(uint64_t key, uint32_t *tag) {
+    const uint64_t limit = key >> 32, L = key & 0xFFFFFFFFull;
+    if (limit > 0xFFFF || L > 0xFFFF) return false;
+    *tag = (uint32_t)(limit << 16 | L);
+    return true;
+  }
+  // close a batch to further reservations: what its counter held before is what belongs to it (>= max_batch: it was
+  // full or sealed already and whoever did that is rotating it).  At most one seal per life adds to the counter.
+  uint32_t seal(Batch *b) {
+    uint64_t st = b->st.load(std::memory_order_acquire);
+    for (;;) {
+      if ((uint32_t)st >= max_batch_) return (uint32_t)st;
+      if (b->st.compare_exchange_weak(st, st + max_batch_, std::memory_order_acq_rel)) return (uint32_t)st;
+    }
+  }
   static int64_t nowNs() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
@@ -413,7 +447,9 @@ class SearchBatcher {
     Batch *b = new Batch();
     cap_ = max_batch_;
     void *p = nullptr;
-    if (sdb_host_alloc(cap_ * (size_t)dim_ * 4, &p) != SDB_OK) p = nullptr;
+    b->pinned = sdb_host_alloc(cap_ * (size_t)dim_ * 4, &p) == SDB_OK && p;
+    if (!b->pinned) p = std::malloc(cap_ * (size_t)dim_ * 4 + 4);  // pageable: the device call stages it, slower, same answers
+    if (!p) throw std::bad_alloc();
     b->queries = static_cast<float *>(p);
     b->reqs.resize(cap_);
     all_.push_back(b);
@@ -427,7 +463,9 @@ class SearchBatcher {
     b->t_first_ns.store(0, std::memory_order_relaxed);
     b->count = 0;
     b->key = fast_key_;
-    b->n.store(0, std::memory_order_release);
+    uint32_t tag = 0xFFFFFFFFu;  // no request's tag: parameters that do not fit one fill no batch
+    (void)tagOf(fast_key_, &tag);
+    b->st.store((uint64_t)tag << 32, std::memory_order_release);
     return b;
   }
   // a request is answered: `r` may be gone as soon as its client has been told (tell()), so the client is returned
@@ -488,7 +526,7 @@ class SearchBatcher {
           const int64_t first = c ? c->t_first_ns.load(std::memory_order_relaxed) : 0;
           const int64_t age = first ? nowNs() - first : 0;
           if (c && first && (age >= window_.count() * 1000 || stop_)) {
-            const uint32_t got = c->n.fetch_add((uint32_t)max_batch_, std::memory_order_acq_rel);
+            const uint32_t got = seal(c);
             if (got < max_batch_) rotateLocked(c, got);  // ours to seal (otherwise the submit that filled it is rotating)
             else lk.unlock(), std::this_thread::yield(), lk.lock();
             continue;
@@ -1168,7 +1206,8 @@ class GpuFanout {
     Request req;
     req.queries = queries, req.nq = nq, req.limit = limit, req.search_size = searchSize;
     req.parts.resize((size_t)n);
-    for (auto &p : req.parts) {
+    {  // every rank's GPU ends up with the same merged answer: only rank 0 copies it to the host
+      Part &p = req.parts[0];
       p.ids.resize(nq * (size_t)limit), p.shards.resize(nq * (size_t)limit);
       p.dists.resize(nq * (size_t)limit), p.counts.resize(nq);
     }
@@ -1238,9 +1277,11 @@ class GpuFanout {
         q.items.pop_front();
       }
       Part &p = req->parts[(size_t)r];
+      const bool want = !p.ids.empty();  // rank 0 (NULL outputs: take part, return the verdict, copy nothing back)
       p.rc = sdb_cluster_search_batch(ranks_[(size_t)r], indexes_[(size_t)r], req->ticket, req->nq, req->queries,
-                                      (uint32_t)req->limit, (uint32_t)req->search_size, p.ids.data(), p.dists.data(),
-                                      p.shards.data(), p.counts.data(), SDB_MEM_HOST, nullptr);
+                                      (uint32_t)req->limit, (uint32_t)req->search_size, want ? p.ids.data() : nullptr,
+                                      want ? p.dists.data() : nullptr, want ? p.shards.data() : nullptr,
+                                      want ? p.counts.data() : nullptr, SDB_MEM_HOST, nullptr);
       if (p.rc != SDB_OK) p.msg = sdb_last_error();
       std::lock_guard<std::mutex> g(req->mu);  // notified under the lock: `req` lives on its caller's stack
       if (--req->left == 0) req->cv.notify_all();

@@ -156,6 +156,78 @@ def test_topk_merge_with_repeated_items(oracle):
         assert np.array_equal(o_s[q].astype(np.int32), w_s)
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch, capsys):
+    """`python3 bench.py --gpus N` (the shape of the driver's single-GPU command, with N > 1): bench.py builds the
+    torch.distributed.run command line itself and runs it as a CHILD process before touching the GPU, relays the
+    child's stdout line and returns its exit code -- instead of a usage message and rc 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.torchrun_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "3"], port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+    # main() takes that path exactly when WORLD_SIZE is absent and --gpus > 1, and never imports a GPU call before it
+    seen = {}
+
+    class FakeProc:
+        stdout = iter(['{"metric": "relayed"}\n'])
+
+        def wait(self):
+            return 7
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return FakeProc()
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched before the relaunch")))
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    assert seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "4" and seen["cmd"][-6:] == sys.argv[1:]
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert '{"metric": "relayed"}' in capsys.readouterr().out
+    # under a launcher (WORLD_SIZE set) nothing is relaunched
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    seen.clear()
+    with pytest.raises(AssertionError, match="GPU touched"):
+        bench.main()
+    assert not seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_without_a_launcher_runs_all_its_ranks(world):
+    """`python3 bench.py --gpus N` with NO torchrun on the command line, N ranks sharing this GPU over gloo: the line
+    comes back through the self-started launcher, the merge saw every rank's block (ranks_seen == [0..N-1]) and at 8
+    shards the per-shard limit is the reference's int(10/8*1.42+10) -> 10 (cluster/actions.go:291-299)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    rows = 60000 * world
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+           "--rows", str(rows), "--mode", "shards", "--recall-batches", "2", "--timed-batches", "3"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == world and j["config"]["mode"] == "shards" and "invalid" not in j
+    assert j["config"]["ranks_seen"] == list(range(world)) and "tag check" in j["config"]["exchange"]
+    assert j["config"]["recall_at_10"] >= 0.95
+    assert j["config"]["per_shard_limit"] == min(10, int(10 / world * 1.42 + 10))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["all", "shards", "replicas"])
 def test_bench_two_ranks_over_gloo(mode, tmp_path):

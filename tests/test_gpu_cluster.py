@@ -192,7 +192,7 @@ def _check(got, want):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_shards_on_one_gpu_fanout_equals_reference_merge(oracle, world):
     """ClusterNode.SearchPoints over `world` shards that share the GPU: requests from racing threads, one ticket each,
     every rank's blocking host-memory call on a thread of its own -- every answer is the reference's merge of the
@@ -202,6 +202,8 @@ def test_shards_on_one_gpu_fanout_equals_reference_merge(oracle, world):
     ixs, bases, qs = _shards(rng, world)
     ranks = cluster.Cluster.create_local([0] * world)
     assert [(r.rank, r.world) for r in ranks] == [(i, world) for i in range(world)]
+    assert "shared-device: %d ranks" % world in ranks[0].transport()
+    assert cluster.shard_limit(10, world, 75) == min(10, int(10 / world * 1.42 + 10))  # actions.go:291-299: 10 at 8 shards
     fan = cluster.Fanout(ranks, ixs)
     want = [_expected(oracle, ixs, q, 10, 50) for q in qs]
     results, errors = {}, []
@@ -221,8 +223,11 @@ def test_shards_on_one_gpu_fanout_equals_reference_merge(oracle, world):
         t.join()
     assert not errors, errors
     assert len(results) == 18
+    seen = set()
     for b, got in results.values():
         _check(got, want[b])
+        seen.update(int(v) for i in range(got[0].shape[0]) for v in got[2][i, :int(got[3][i])])
+    assert sorted(seen) == list(range(world))  # every shard's block reached the merge
     assert ranks[0].next_ticket() == 19 and ranks[-1].next_ticket() == 19
     for r in ranks:
         r.close()
@@ -394,3 +399,150 @@ def test_mixed_device_lists_are_rejected():
             cluster.Cluster.create_local([0, 1])  # device 1 does not exist here
     with pytest.raises(SemaDBError):
         cluster.Cluster.create_local([0, 0, 1] if device_count() >= 2 else [0, 0, 7])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a way out of the turnstile (sdb_cluster_set_deadline / sdb_cluster_skip_ticket): the reference fails one request
+# and serves the next (cluster/actions.go:339-353)
+# ---------------------------------------------------------------------------------------------------------------
+def _call(rank, ix, q, ticket, out, key, want=True):
+    from semadb_amd._lib import SemaDBError
+    try:
+        out[key] = rank.search_batch(ix, q, 10, 50, ticket=ticket, want=want)
+    except SemaDBError as e:
+        out[key] = e
+
+
+@pytest.mark.gpu
+def test_a_ticket_that_is_never_presented_does_not_wedge_the_ranks(oracle):
+    """Ticket t is drawn and presented to NO rank (the request died in the host).  The next request waits at the
+    turnstile for the deadline, fails with SDB_ERR_STATE having done nothing, the fan-out skips the lost ticket, and
+    the SAME request (same ticket) is then answered -- as is the one after it."""
+    import time
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError
+    rng = np.random.default_rng(311)
+    ixs, bases, qs = _shards(rng, 2)
+    ranks = cluster.Cluster.create_local([0, 0])
+    for r in ranks:
+        r.set_deadline(300)
+    fan = cluster.Fanout(ranks, ixs)
+    _check(fan.search_points(qs[0], 10, 50), _expected(oracle, ixs, qs[0], 10, 50))  # ticket 1
+    lost = fan._ticket()  # ticket 2: never presented
+    nxt = fan._ticket()  # ticket 3
+    out = {}
+    t0 = time.time()
+    ths = [threading.Thread(target=_call, args=(ranks[r], ixs[r], qs[1], nxt, out, r)) for r in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert 0.25 < time.time() - t0 < 5
+    for r in range(2):
+        assert isinstance(out[r], SemaDBError) and out[r].code == 3, out[r]
+        assert "ticket %d" % lost in str(out[r]) and "did nothing" in str(out[r])
+        assert ranks[r].next_ticket() == lost  # nothing moved
+    for r in ranks:
+        r.skip_ticket(lost)
+        assert r.next_ticket() == nxt
+    with pytest.raises(SemaDBError):  # a skipped ticket cannot come back
+        ranks[0].search_batch(ixs[0], qs[1], 10, 50, ticket=lost)
+    ths = [threading.Thread(target=_call, args=(ranks[r], ixs[r], qs[1], nxt, out, r)) for r in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    want = _expected(oracle, ixs, qs[1], 10, 50)
+    for r in range(2):
+        _check(out[r], want)
+    # a ticket skipped BEFORE its turn: the turnstile passes over it when it gets there
+    a, b, c = fan._ticket(), fan._ticket(), fan._ticket()
+    for r in ranks:
+        r.skip_ticket(b)
+    for tk, q in ((a, qs[2]), (c, qs[3])):
+        ths = [threading.Thread(target=_call, args=(ranks[r], ixs[r], q, tk, out, r)) for r in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for r in range(2):
+            _check(out[r], _expected(oracle, ixs, q, 10, 50))
+    assert ranks[0].next_ticket() == c + 1 == ranks[1].next_ticket()
+    for r in ranks:
+        r.close()
+    for ix in ixs:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_a_ticket_dropped_on_one_rank_fails_that_request_and_the_next_is_served(oracle):
+    """The reference's failure model (actions.go:339-353): the request reaches shard 0 and never shard 1 (its goroutine
+    died).  (a) The fan-out notices and skips the ticket on rank 1 WITH the request's shape: rank 1 enters the exchange
+    with an empty answer under an error flag, rank 0's call fails naming shard 1, and the next request is served.
+    (b) Nobody notices: rank 0's call gives up after the deadline, the request is withdrawn, the handles stay in
+    step, and once rank 1's turnstile has been told (skip, nq = 0) the next request is served."""
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError
+    rng = np.random.default_rng(312)
+    ixs, bases, qs = _shards(rng, 2)
+    ranks = cluster.Cluster.create_local([0, 0])
+    for r in ranks:
+        r.set_deadline(400)
+    fan = cluster.Fanout(ranks, ixs)
+    # (a)
+    tk = fan._ticket()
+    out = {}
+    th = threading.Thread(target=_call, args=(ranks[0], ixs[0], qs[0], tk, out, 0))
+    th.start()
+    ranks[1].skip_ticket(tk, nq=qs[0].shape[0], limit=10)
+    th.join()
+    assert isinstance(out[0], SemaDBError) and out[0].code == 3
+    assert "shard 1" in str(out[0]) and "failed" in str(out[0])
+    _check(fan.search_points(qs[1], 10, 50), _expected(oracle, ixs, qs[1], 10, 50))
+    # (b)
+    tk = fan._ticket()
+    _call(ranks[0], ixs[0], qs[2], tk, out, 0)
+    assert isinstance(out[0], SemaDBError) and out[0].code == 3 and "did not join" in str(out[0])
+    assert "out of step" not in str(out[0])
+    ranks[1].skip_ticket(tk)
+    _check(fan.search_points(qs[3], 10, 50), _expected(oracle, ixs, qs[3], 10, 50))
+    _check(fan.search_points(qs[4], 10, 50), _expected(oracle, ixs, qs[4], 10, 50))
+    for r in ranks:
+        r.close()
+    for ix in ixs:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_destroying_a_rank_fails_its_peers_pending_exchanges(oracle):
+    """a rank of a shared-device group goes away while its peer waits for it inside an exchange: the peer's call fails
+    (no answer, SDB_ERR_STATE) instead of waiting for ever, and later calls on the peer are refused"""
+    import time
+    from semadb_amd import cluster
+    from semadb_amd._lib import SemaDBError
+    rng = np.random.default_rng(313)
+    ixs, bases, qs = _shards(rng, 2)
+    ranks = cluster.Cluster.create_local([0, 0])
+    out = {}
+    th = threading.Thread(target=_call, args=(ranks[0], ixs[0], qs[0], 1, out, 0))
+    th.start()
+    time.sleep(0.3)
+    ranks[1].close()
+    th.join(timeout=20)
+    assert not th.is_alive()
+    assert isinstance(out[0], SemaDBError) and out[0].code == 3 and "shard 1" in str(out[0])
+    with pytest.raises(SemaDBError) as ei:
+        ranks[0].search_batch(ixs[0], qs[0], 10, 50, ticket=2)
+    assert "destroyed" in str(ei.value)
+    ranks[0].close()
+    for ix in ixs:
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_rccl_transport_names_the_library_and_the_communicator():
+    from semadb_amd import cluster
+    cl = cluster.Cluster.create_local([0])[0]
+    t = cl.transport()
+    assert t.startswith("rccl ") and "librccl" in t and "communicator of 1 ranks" in t and "rank 0" in t
+    cl.close()
