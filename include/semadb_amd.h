@@ -223,6 +223,11 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        K = 256) stay on the one-wave kernel with the table in global memory (round 2) instead of the
  *                        four-wave walk that keeps it in LDS and registers; 2: M = 192 takes the four-wave variant with
  *                        one query per CU instead of two
+ *   SDB_TUNE_WIDE_WALK   the walk of calls with few queries (one REST request is one query, vamana.go:278-310): a
+ *                        workgroup of four waves per query -- one walks, all four split every hop's rows -- instead of
+ *                        one wave per query.  0 (default): calls of up to 256 queries on a full-precision store,
+ *                        unfiltered, vectors of 32 .. 1055 floats; 1: never; 2: always (any number of queries).
+ *                        Same ids, distance bits, visit order and counters either way.
  *   SDB_TUNE_HASH16_PROBES  buckets a key of the 16-bit-cell set may try before the walk spills to the HBM bitset
  *                        (0 = all 15; 1..15).  With 15 that spill is a one-in-ten-million event; a test sets 1 or 2
  *                        to walk through it */
@@ -234,6 +239,7 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
 #define SDB_TUNE_WIDE_HASH 6
 #define SDB_TUNE_HASH16_PROBES 7
 #define SDB_TUNE_PQ_NARROW 8
+#define SDB_TUNE_WIDE_WALK 9
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
 
 /* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts

@@ -254,8 +254,28 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
   return SDB_OK;
 }
 
+// The workgroup-per-query walk (search_kernel.h PlainWideDist) for calls with few queries: a 256-query call is one
+// workgroup per CU.  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
+// rounds of thousands).
+constexpr uint32_t kWideMaxQueries = 256;
+constexpr int kWideWaves = 4;
+static bool wide_walk(const SearchArgs &a, uint32_t nq) {
+  if (a.wide_mode == 1 || a.filt_off || a.vis_slots || a.dcache || a.pq_codes || !search_uses_hash(a, nq)) return false;
+  return a.wide_mode == 2 || nq <= kWideMaxQueries;
+}
+template <int NG, bool L2>
+static int launch_wide(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  using D = PlainWideDist<NG, L2, kWideWaves>;
+  const size_t lds = HashVisited<kHashCap>::kWords * sizeof(uint32_t) + D::kLdsBytes;
+  hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, kWideWaves>), dim3(nq), dim3(64 * kWideWaves), lds, stream, a);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
 template <int NG, bool L2>
 static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  if constexpr (NG >= 1 && NG <= 8)
+    if (wide_walk(a, nq)) return launch_wide<NG, L2>(a, nq, stream);
   if (search_uses_hash(a, nq))
     return launch_nreg<PlainDist<NG, L2, true>, kHashCap>(a, nq, stream, PlainDist<NG, L2, true>::kLdsBytes);
   return launch_nreg<PlainDist<NG, L2, false>, 0>(a, nq, stream, PlainDist<NG, L2, false>::kLdsBytes);
@@ -1069,6 +1089,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   a.hash_limit = ix->tune_hash_limit, a.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
   a.wide_hash = ix->tune_wide_hash ? 1u : 0u, a.hash16_probes = ix->tune_hash16_probes;
   a.pq_narrow = ix->tune_pq_narrow;
+  a.wide_mode = ix->tune_wide_walk;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
@@ -1174,6 +1195,10 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       return SDB_OK;
     case SDB_TUNE_PQ_NARROW:
       ix->tune_pq_narrow = (uint32_t)value;
+      return SDB_OK;
+    case SDB_TUNE_WIDE_WALK:
+      if (value > 2) return fail(SDB_ERR_INVALID, "wide walk: 0 = few queries, 1 = never, 2 = always");
+      ix->tune_wide_walk = (uint32_t)value;
       return SDB_OK;
     case SDB_TUNE_HASH16_PROBES:
       if (value > 15) return fail(SDB_ERR_INVALID, "at most 15 probes");

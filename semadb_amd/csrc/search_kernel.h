@@ -70,6 +70,7 @@ struct SearchArgs {
   uint32_t wide_hash;      // != 0: quantized store keeps the 32-bit-cell set (HashVisited) instead of HashVisited16
   uint32_t hash16_probes;  // test knob: buckets a key of HashVisited16 may try (0 = all 15); fewer make the `stuck` spill common
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
+  uint32_t wide_mode;      // the workgroup-per-query walk: 0 = calls of up to kWideMaxQueries queries, 1 = never, 2 = always
 };
 
 // pairs of candidate rows a wave keeps in flight per chunk.  DEEP (one wave per SIMD, the batch-search
@@ -266,23 +267,16 @@ struct PlainDist {
   // TAIL (dim % 32 != 0, e.g. 100, 784): the sequential scalar chain over the tail elements (dot.s:35-43)
   // runs in lane 0 of each half -- the query element comes from a readlane (once per element, shared by all
   // rows of the chunk), the row's elements walk down to lane 0 with one wave_shl DPP move per step.
+  // raw distances of the pending rows of ranks [first, first + count) of the list in s_slot (one spare entry behind its
+  // last rank), two rows per wave instruction, into s_res by rank.  `first` is even.
   template <bool TAIL>
-  __device__ __forceinline__ float hop_fast(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+  __device__ __forceinline__ void rows_range(const SearchArgs &a, const uint32_t *s_slot, float *s_res, int first, int count,
+                                             int lane) {
     const int L = lane & 31, half = lane >> 5;
-    const int cnt = __popcll(pend);
-    const bool mine = (pend >> lane) & 1ull;
-    const uint32_t rank =
-        __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
-    uint32_t *s_slot = hs;
-    float *s_res = reinterpret_cast<float *>(hs + kHopSlots);
-    if (mine) {
-      s_slot[rank] = nb;
-      if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
-    }
-    wave_lds_sync();
     const char *baseL = reinterpret_cast<const char *>(a.slab) + L * 16;
     const uint32_t row_bytes = a.ld * 4u;
-    for (int c0 = 0; c0 < cnt; c0 += 2 * U) {
+    const int cnt = first + count;
+    for (int c0 = first; c0 < cnt; c0 += 2 * U) {
       const int m = cnt - c0 < 2 * U ? cnt - c0 : 2 * U;
       const int h0 = (m + 1) >> 1;  // rows of half 0; half 1 takes the other m - h0 (+ the spare when m is odd)
       const int base = c0 + (half ? h0 : 0);
@@ -354,6 +348,22 @@ struct PlainDist {
       st[0] += t1 - t0, st[1] += t2 - t1, st[2] += t3 - t2;  // issue, wait, compute
 #endif
     }
+  }
+
+  template <bool TAIL>
+  __device__ __forceinline__ float hop_fast(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    const int cnt = __popcll(pend);
+    const bool mine = (pend >> lane) & 1ull;
+    const uint32_t rank =
+        __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+    uint32_t *s_slot = hs;
+    float *s_res = reinterpret_cast<float *>(hs + kHopSlots);
+    if (mine) {
+      s_slot[rank] = nb;
+      if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
+    }
+    wave_lds_sync();
+    rows_range<TAIL>(a, s_slot, s_res, 0, cnt, lane);
     wave_lds_sync();
     return mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
   }
@@ -391,6 +401,76 @@ struct PlainDist {
       }
     }
     return mydist;
+  }
+};
+
+// The same store walked by a WORKGROUP per query, for calls with few queries (a single REST request is one query,
+// vamana.go:278-310): one wave per query leaves most of the chip idle and a hop costs two dependent memory round trips
+// plus the issue time of ~50 rows' loads on one SIMD.  Here wave 0 is the walker -- search_body as it stands: candidate
+// array, visited set, AddWithLimit -- and a hop's pending rows are split over all W waves of the workgroup: the walker
+// publishes the rank-compacted slot list (the one hop_fast builds anyway), every wave takes a contiguous share of it,
+// two rows per instruction, and leaves the raw sums at the rows' ranks; the walker reads them back.  Same pairs, same
+// arithmetic, same bits, same visit order; two workgroup barriers per hop.
+struct WideShared {
+  uint32_t cnt;  // pending rows of the hop the walker has published; kWideDone: the walk is over
+  uint32_t pad[3];
+};
+constexpr uint32_t kWideDone = 0xFFFFFFFFu;
+
+template <int NG, bool L2, int W>
+struct PlainWideDist : PlainDist<NG, L2, true> {
+  using Base = PlainDist<NG, L2, true>;
+  static constexpr size_t kLdsBytes = Base::kLdsBytes + sizeof(WideShared);
+  WideShared *sh;
+  int wave;
+  __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lds) {
+    Base::init(a, q, lane, lds);  // every wave keeps the query in its registers
+    sh = reinterpret_cast<WideShared *>(reinterpret_cast<char *>(lds) + Base::kLdsBytes);
+    wave = w;
+  }
+  // this wave's share of `cnt` pending rows: contiguous ranks, an even number per wave so that only the list's last row
+  // can be the odd one out (its spare entry sits behind the list)
+  __device__ __forceinline__ void share(const SearchArgs &a, int cnt, int lane) {
+    const int per = (((cnt + W - 1) / W) + 1) & ~1;
+    const int first = wave * per;
+    const int count = cnt - first < per ? cnt - first : per;
+    if (count <= 0) return;
+    uint32_t *s_slot = this->hs;
+    float *s_res = reinterpret_cast<float *>(this->hs + Base::kHopSlots);
+    if (a.tail) this->template rows_range<true>(a, s_slot, s_res, first, count, lane);
+    else this->template rows_range<false>(a, s_slot, s_res, first, count, lane);
+  }
+  // ---- the walker (wave 0)
+  __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    const int cnt = __popcll(pend);
+    const bool mine = (pend >> lane) & 1ull;
+    const uint32_t rank =
+        __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+    uint32_t *s_slot = this->hs;
+    float *s_res = reinterpret_cast<float *>(this->hs + Base::kHopSlots);
+    if (mine) {
+      s_slot[rank] = nb;
+      if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
+    }
+    if (lane == 0) sh->cnt = (uint32_t)cnt;
+    __syncthreads();  // B1: the list is published
+    share(a, cnt, lane);
+    __syncthreads();  // B2: every share has been written
+    return mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
+  }
+  __device__ __forceinline__ void finish(int lane) {
+    if (lane == 0) sh->cnt = kWideDone;
+    __syncthreads();  // B1: the helpers leave
+  }
+  // ---- waves 1 .. W-1
+  __device__ __forceinline__ void serve(const SearchArgs &a, int lane) {
+    for (;;) {
+      __syncthreads();  // B1
+      const uint32_t cnt = sh->cnt;
+      if (cnt == kWideDone) return;
+      share(a, (int)cnt, lane);
+      __syncthreads();  // B2
+    }
   }
 };
 
@@ -1333,6 +1413,27 @@ __global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(cons
     NoVisited rv;
     search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
   }
+  dist.finish(lane);
+}
+
+// The workgroup-per-query walk of a plain store (PlainWideDist): W waves, wave 0 walks.  Dynamic LDS: the visited set's
+// table, then the policy's hop scratch and command word.
+template <int NG, bool L2, int W>
+__global__ __launch_bounds__(64 * W) void k_greedy_search_wide(const SearchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t q = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  PlainWideDist<NG, L2, W> dist;
+  dist.init_wave(a, q, lane, wave, lds_f + HashVisited<kHashCap>::kWords);
+  HashVisited<kHashCap> hv;
+  if (wave == 0)
+    hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), a.bitsets + (size_t)q * a.words_per_query, a.words_per_query, lane,
+                   a.hash_limit);
+  __syncthreads();
+  if (wave != 0) return dist.serve(a, lane);
+  NoVisited rv;
+  search_body<PlainWideDist<NG, L2, W>, 2, false>(a, q, lane, dist, hv, rv);
   dist.finish(lane);
 }
 

@@ -33,6 +33,14 @@ def _gpu_index(o, d, metric, R, L):
 
 
 def _check_walk(o, ix, queries, limit, L, visit_cap=2048):
+    for mode in (1, 2):  # one wave per query; the workgroup-per-query walk of small calls
+        ix.set_tuning("wide_walk", mode)
+        out = _check_walk_mode(o, ix, queries, limit, L, visit_cap)
+    ix.set_tuning("wide_walk", 0)
+    return out
+
+
+def _check_walk_mode(o, ix, queries, limit, L, visit_cap):
     g_ids, g_d, g_c, tr = ix.search_batch(queries, limit, L, trace=True, visit_cap=visit_cap)
     seen_nan = seen_inf = 0
     for q in range(queries.shape[0]):

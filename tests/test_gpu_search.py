@@ -17,6 +17,15 @@ def _gpu_index(o, d, metric, R, L, strict=False):
 
 
 def _check_batch(o, ix, queries, limit, L, visit_cap=1024):
+    """both forms of the walk: one wave per query (wide_walk = 1) and the workgroup-per-query walk of small calls
+    (wide_walk = 2: a hop's rows split over four waves; shapes it does not cover fall back to the one-wave kernel)"""
+    for mode in (1, 2):
+        ix.set_tuning("wide_walk", mode)
+        _check_batch_mode(o, ix, queries, limit, L, visit_cap)
+    ix.set_tuning("wide_walk", 0)
+
+
+def _check_batch_mode(o, ix, queries, limit, L, visit_cap):
     g_ids, g_d, g_c, tr = ix.search_batch(queries, limit, L, trace=True, visit_cap=visit_cap)
     for q in range(queries.shape[0]):
         o_ids, o_d, o_vis, o_tr = o.search(queries[q], limit, L)
