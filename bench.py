@@ -607,6 +607,10 @@ def measure_mode(a, ctx, mode, rows, primary):
                 cfg["side_kernels"] = side_points(a, ix, base, queries, dev)
             except Exception as e:
                 cfg["side_kernels"] = {"error": repr(e)}
+            try:
+                cfg["latency_ms"] = latency_points(a, ix, queries)
+            except Exception as e:
+                cfg["latency_ms"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(a, ix, queries[:nb_recall], k, L)
@@ -633,7 +637,8 @@ def side_points(a, ix, base, queries, dev):
     builder-run logs: K1 (sdb_distance_batch: 64 queries x all rows, row reuse on chip), the euclidean exact scan
     (IndexFlat.Search, packed-FMA kernel; the cosine scan is `flat_scan_ms` above), the filtered walk
     (search.go:33-51,93-95) with 10 / 1 000 filter ids per query (kernel time from HIP events inside the library; the
-    whole call adds the host-side translation of the filter ids)."""
+    whole call adds the upload of the filter ids and their translation to slots, on the device for a table with
+    consecutive ids)."""
     from semadb_amd import distance, flat
     n, d = base.shape
     out = {}
@@ -687,6 +692,37 @@ def side_points(a, ix, base, queries, dev):
                                                   "call_ms": round(dt * 1e3, 2), "call_qps": round(nq / dt, 1)}
     finally:
         ix.set_profiling(False)
+    return out
+
+
+def latency_points(a, ix, queries):
+    """A REST request is ONE query (IndexVamana.Search, vamana.go:278-310): whole sdb_index_search_batch calls of 1 .. 256
+    queries, device-resident in and out, median of 30.  `workgroup_per_query` is what the library does for calls of up to
+    256 queries (16 waves per query, wave 0 walks, all split every hop's rows; the next hop's adjacency row fetched ahead);
+    `one_wave_per_query` is the batch kernel forced onto the same calls (SDB_TUNE_WIDE_WALK = 1)."""
+    flat_q = queries.reshape(-1, queries.shape[-1])
+    out = {}
+    try:
+        for mode, name in ((0, "workgroup_per_query"), (1, "one_wave_per_query")):
+            ix.set_tuning("wide_walk", mode)
+            res = {}
+            for nq in (1, 16, 64, 256):
+                reps = 30
+                qs = [flat_q[(i * nq) % (flat_q.shape[0] - nq):(i * nq) % (flat_q.shape[0] - nq) + nq].contiguous()
+                      for i in range(reps + 3)]
+                for i in range(3):
+                    ix.search_batch(qs[i], a.k, a.search_size)
+                ts = []
+                for i in range(reps):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ix.search_batch(qs[3 + i], a.k, a.search_size)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                res[str(nq)] = round(float(np.median(ts)), 4)
+            out[name] = res
+    finally:
+        ix.set_tuning("wide_walk", 0)
     return out
 
 

@@ -850,8 +850,11 @@ constexpr uint32_t kBackCap = 256;
 #ifndef SDB_BACK_WAVES
 #define SDB_BACK_WAVES 3
 #endif
+// Rows of 1 536 floats and more (NG >= 12: the query row alone is 48+ registers, a pair of candidate rows as many again)
+// do not fit that cap: NG = 12 spilled 20 registers, NG = 24 more than 180 (404 bytes of scratch per lane).  They run two
+// waves per SIMD with 256 registers each.
 template <int NG, bool L2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   PruneLds l(lds_raw, kBackCap, NG >= 0);
   const int lane = threadIdx.x, L = lane & 31;

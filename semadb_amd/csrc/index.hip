@@ -169,6 +169,40 @@ __global__ __launch_bounds__(64) void k_compact_rows(const uint32_t *__restrict_
     for (uint32_t i = lane; i < M; i += 64) ncodes[(size_t)j * M + i] = codes[(size_t)s * M + i];
 }
 
+// The filter of a search is a set of node ids (a roaring bitmap in the reference, search.go:33-51,93); the walk wants
+// slots: per query the slots of the ids that exist, ascending (Contains, :93), and how many of the first searchSize ids
+// exist (the seeds, :41-48).  One wave per query resolves its ids in place -- the compacted slots at the start of the
+// query's own segment -- for a table whose ids are consecutive (id = base + slot: resolving is a subtraction, and
+// ascending ids are ascending slots).  Tables with holes or arbitrary ids keep the host's hash map (below).
+// flags[0]: != 0 when some query's ids are not strictly ascending; flags[1]: one such query.
+__global__ __launch_bounds__(64) void k_filter_resolve(const uint64_t *__restrict__ ids, const uint32_t *__restrict__ off,
+                                                       uint64_t base_id, uint32_t view_n, uint32_t search_size,
+                                                       uint32_t *__restrict__ slots, uint32_t *__restrict__ fcnt,
+                                                       uint32_t *__restrict__ scnt, uint32_t *__restrict__ flags) {
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t b = off[q], e = off[q + 1];
+  uint32_t pos = 0, ns = 0;
+  bool bad = false;
+  for (uint32_t base = b; base < e; base += 64) {
+    const uint32_t i = base + lane;
+    const bool has = i < e;
+    const uint64_t id = has ? ids[i] : 0;
+    if (has && i > b && id <= ids[i - 1]) bad = true;
+    const uint64_t s = id - base_id;
+    const bool ok = has && id >= base_id && s < (uint64_t)view_n;  // rows past the committed count do not exist yet
+    const uint64_t m = __ballot(ok);
+    if (ok) slots[b + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)s;
+    if (base - b < search_size) {  // GetMany(first searchSize ids) skips the unknown ones (itemcache.go:109-128)
+      const uint32_t left = search_size - (base - b);
+      ns += (uint32_t)__popcll(left >= 64 ? m : (m & ((1ull << left) - 1)));
+    }
+    pos += (uint32_t)__popcll(m);
+  }
+  if (__ballot(bad) && lane == 0) atomicOr(flags, 1u), flags[1] = q;
+  if (lane == 0) fcnt[q] = pos, scnt[q] = ns;
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -189,28 +223,28 @@ static int pq_wide_shape(const SearchArgs &a) {
     case 128: return 1;  // NL 15, RT 17 (two queries per CU)
     case 192: return 2;  // NL 15, RT 33 (two queries per CU)
     case 256: return 3;  // NL 32, RT 32
-    case 384: return 4;  // NL 32, RT 64
+    case 384: return 4;  // NL 15, RT 33, eight waves
     default: return -1;  // M <= 64: the table fits beside a one-wave walk
   }
 }
 
-template <int NL, int RT>
+template <int NL, int RT, int W = 4>
 static int launch_pqw(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   const bool h16 = (uint64_t)a.words_per_query * 32 <= (1u << 24) && !a.wide_hash;
-  const size_t lut = (size_t)4 * NL * a.pq_K * sizeof(float);
+  const size_t lut = (size_t)W * NL * a.pq_K * sizeof(float);
   static std::atomic<uint64_t> at16{0}, at32{0};
   if (h16) {
     const size_t lds = HashVisited16::kWords * 4 + sizeof(PQWideShared) + lut;
     if (first_use_on_this_device(at16))
-      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHash16>),
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHash16, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHash16>), dim3(nq), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHash16, W>), dim3(nq), dim3(64 * W), lds, stream, a);
   } else {
     const size_t lds = HashVisited<kHashCapPQ>::kWords * 4 + sizeof(PQWideShared) + lut;
     if (first_use_on_this_device(at32))
-      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHashCapPQ>),
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHashCapPQ, W>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHashCapPQ>), dim3(nq), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHashCapPQ, W>), dim3(nq), dim3(64 * W), lds, stream, a);
   }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
@@ -255,10 +289,21 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 }
 
 // The workgroup-per-query walk (search_kernel.h PlainWideDist) for calls with few queries: a 256-query call is one
-// workgroup per CU.  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
+// workgroup per CU.  Waves per workgroup, measured at 1M x 384 (tools/bench_latency.py, whole call of 1 / 256 queries;
+// one wave per query: 0.538 / 0.598 ms): 2 waves 0.78 / 0.86, 4 waves 0.536 / 0.607, 8 waves 0.410 / 0.469, 16 waves
+// 0.361 / 0.416 ms -- a hop's ~50 rows are 2 pairs per wave then, one short burst of loads each.  With the helpers
+// pulling the likely next hop's rows through L2 (PlainWideDist::pull_ahead): 0.336 / 0.419 ms; 0.371 at 128 queries
+// (0.408 without).  Past 256 queries the one-wave kernel wins (512: 0.66 against 0.80 ms).  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
 // rounds of thousands).
 constexpr uint32_t kWideMaxQueries = 256;
-constexpr int kWideWaves = 4;
+#ifndef SDB_WIDE_PULL
+#define SDB_WIDE_PULL 256
+#endif
+constexpr uint32_t kWidePullQueries = SDB_WIDE_PULL;
+#ifndef SDB_WIDE_WAVES
+#define SDB_WIDE_WAVES 16
+#endif
+constexpr int kWideWaves = SDB_WIDE_WAVES;
 static bool wide_walk(const SearchArgs &a, uint32_t nq) {
   if (a.wide_mode == 1 || a.filt_off || a.vis_slots || a.dcache || a.pq_codes || !search_uses_hash(a, nq)) return false;
   return a.wide_mode == 2 || nq <= kWideMaxQueries;
@@ -267,7 +312,10 @@ template <int NG, bool L2>
 static int launch_wide(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   using D = PlainWideDist<NG, L2, kWideWaves>;
   const size_t lds = HashVisited<kHashCap>::kWords * sizeof(uint32_t) + D::kLdsBytes;
-  hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, kWideWaves>), dim3(nq), dim3(64 * kWideWaves), lds, stream, a);
+  SearchArgs b = a;
+  // the pull-ahead doubles the call's traffic: for calls that leave most of the memory system idle
+  b.wide_pull = (nq <= kWidePullQueries && kWideWaves == 16 && a.wide_pull != 2) ? 1u : 0u;
+  hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, kWideWaves>), dim3(nq), dim3(64 * kWideWaves), lds, stream, b);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }
@@ -313,7 +361,7 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
       // selects the latter for comparison
       case 2: return a.pq_narrow == 2 ? launch_pqw<32, 16>(a, nq, stream) : launch_pqw<15, 33>(a, nq, stream);
       case 3: return launch_pqw<32, 32>(a, nq, stream);
-      case 4: return launch_pqw<32, 64>(a, nq, stream);
+      case 4: return launch_pqw<15, 33, 8>(a, nq, stream);  // M = 384: eight waves with M = 192's per-wave layout
       default: break;
     }
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
@@ -992,11 +1040,53 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   if (filtered) {
     // search.go:41-48: seeds = the first <= searchSize filter ids (ascending) that exist; Contains (:93) is
     // answered from the whole filter as ascending slots.  Filter arrays are host memory (header).
-    std::vector<uint32_t> off_seed(nq + 1, 0), off_filt(nq + 1, 0);
+    const uint64_t total_ids = filter_offsets[nq] - filter_offsets[0];
+    bool on_device = false;
+    {
+      // Consecutive ids (the bulk-loaded and append-only table: id = first id + slot, no holes): the ids go up as they
+      // are and one wave per query turns them into slots on the device.  What the host did for this -- a hash lookup per
+      // id on up to 16 threads, two passes, an upload of the slots -- cost 1.2 ms per batch at 1 000 ids per query next
+      // to a 1.5 ms walk, 26 ms at 100 000.  The ids of the open transaction's appended rows resolve to slots past the
+      // committed count and are dropped; deletes end the table's consecutiveness and with it this path.
+      // (the id tables only change under the view lock, which this call holds shared)
+      on_device = ix->dense_ids && ix->n > 0 && total_ids < (1ull << 32) && !ix->tune_host_filters;
+    }
+    if (on_device) {
+      for (uint64_t q = 0; q < nq; q++)
+        if (filter_offsets[q + 1] < filter_offsets[q]) return fail(SDB_ERR_INVALID, "filter_offsets must be non-decreasing");
+      const uint64_t base_id = ix->h_ids[0];
+      const size_t b_off = ((nq + 1) * 4 + 255) & ~(size_t)255, b_ids = (total_ids * 8 + 255) & ~(size_t)255;
+      const size_t b_sl = (total_ids * 4 + 255) & ~(size_t)255, b_cnt = (nq * 4 + 255) & ~(size_t)255;
+      SDB_TRY(ws->ensure_filter(b_off + b_ids + b_sl + 2 * b_cnt + 256));
+      SDB_TRY(ws->ensure_filter_host(b_off + 256));
+      char *fb = static_cast<char *>(ws->filter);
+      uint32_t *d_off = (uint32_t *)fb;
+      uint64_t *d_raw = (uint64_t *)(fb + b_off);
+      uint32_t *d_sl = (uint32_t *)(fb + b_off + b_ids);
+      uint32_t *d_fc = (uint32_t *)(fb + b_off + b_ids + b_sl), *d_sc = (uint32_t *)(fb + b_off + b_ids + b_sl + b_cnt);
+      uint32_t *d_flags = (uint32_t *)(fb + b_off + b_ids + b_sl + 2 * b_cnt);
+      uint32_t *h_off = static_cast<uint32_t *>(ws->filter_host);
+      uint32_t *h_flags = h_off + (nq + 1) + 2;
+      for (uint64_t q = 0; q <= nq; q++) h_off[q] = (uint32_t)(filter_offsets[q] - filter_offsets[0]);
+      SDB_HIP(hipMemcpyAsync(d_off, h_off, (nq + 1) * 4, hipMemcpyHostToDevice, stream));
+      // straight from the caller's array: one DMA when it is pinned (sdb_host_alloc), a staged copy otherwise
+      if (total_ids) SDB_HIP(hipMemcpyAsync(d_raw, filter_ids + filter_offsets[0], total_ids * 8, hipMemcpyHostToDevice, stream));
+      SDB_HIP(hipMemsetAsync(d_flags, 0, 8, stream));
+      hipLaunchKernelGGL(k_filter_resolve, dim3((unsigned)nq), dim3(64), 0, stream, d_raw, d_off, base_id, vw.n, search_size, d_sl, d_fc,
+                         d_sc, d_flags);
+      SDB_HIP(hipGetLastError());
+      SDB_HIP(hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, stream));
+      SDB_HIP(hipStreamSynchronize(stream));  // the caller's arrays are free again; an invalid filter is an error, not a search
+      if (h_flags[0])
+        return fail(SDB_ERR_INVALID, "filter ids of query %llu are not strictly ascending", (unsigned long long)h_flags[1]);
+      a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
+      a.rbitsets = ws->bitsets + (size_t)nq * words;
+    }
+    std::vector<uint32_t> off_seed(on_device ? 0 : nq + 1, 0), off_filt(on_device ? 0 : nq + 1, 0);
+    if (!on_device) {
     // ids -> slots is a hash lookup per id; a batch of 1 024 queries with 1 000-id filters carries a million of them
     // (5 ms on one core), so big batches are split over a few host threads.  Pass 1 validates and counts, pass 2
     // fills the two CSR arrays in place.
-    const uint64_t total_ids = filter_offsets[nq] - filter_offsets[0];
     // one thread per 128 k ids, at most 16 (and what the machine has): a million ids take 5 ms on one core, a thread ~50 us to start
     const unsigned nthr = (unsigned)std::min<uint64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())),
                                                        std::max<uint64_t>(1, total_ids >> 17));
@@ -1081,6 +1171,7 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
     SDB_HIP(hipStreamSynchronize(stream));  // the staging vectors die with this scope
     a.seed_off = d_so, a.filt_off = d_fo, a.seeds = d_seeds, a.filt_slots = d_f;
     a.rbitsets = ws->bitsets + (size_t)nq * words;
+    }
   }
   a.dim = l.dim, a.nblk = l.nblk, a.ng = l.ng, a.tail = l.tail, a.ld = l.ld;
   a.start_slot = (uint32_t)ix->start_slot;
@@ -1199,6 +1290,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
     case SDB_TUNE_WIDE_WALK:
       if (value > 2) return fail(SDB_ERR_INVALID, "wide walk: 0 = few queries, 1 = never, 2 = always");
       ix->tune_wide_walk = (uint32_t)value;
+      return SDB_OK;
+    case SDB_TUNE_HOST_FILTERS:
+      ix->tune_host_filters = value != 0;
       return SDB_OK;
     case SDB_TUNE_HASH16_PROBES:
       if (value > 15) return fail(SDB_ERR_INVALID, "at most 15 probes");

@@ -59,6 +59,9 @@ struct SearchArgs {
   // filtered search (search.go:33-51,93-95): per query CSR of seeds (<= searchSize slots, ascending id
   // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
   const uint32_t *seed_off, *seeds, *filt_off, *filt_slots;
+  // filter lists resolved on the device (index.hip k_filter_resolve): the counts are not offset differences then
+  // (segments keep the caller's offsets, unknown ids leave gaps at their ends); NULL: offset differences
+  const uint32_t *seed_cnt, *filt_cnt;
   uint32_t *rbitsets;
   // build path, full-precision store: every evaluated (slot, distance) also goes into the query's
   // direct-mapped table of 2^(32 - dcache_shift) entries (last writer wins); the back-edge prunes of the
@@ -71,6 +74,7 @@ struct SearchArgs {
   uint32_t hash16_probes;  // test knob: buckets a key of HashVisited16 may try (0 = all 15); fewer make the `stuck` spill common
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
   uint32_t wide_mode;      // the workgroup-per-query walk: 0 = calls of up to kWideMaxQueries queries, 1 = never, 2 = always
+  uint32_t wide_pull;      // that walk's helpers pull the next hop's rows through L2 ahead of time (calls of very few queries)
 };
 
 // pairs of candidate rows a wave keeps in flight per chunk.  DEEP (one wave per SIMD, the batch-search
@@ -191,12 +195,13 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
 
 // Full-precision store.  NG >= 0: compile-time group count, query in registers.  NG == -1: run-time
 // ng, query tile in LDS.
-template <int NG, bool L2, bool DEEP = false>
+template <int NG, bool L2, bool DEEP = false, int UPAIRS = 0>  // UPAIRS != 0: that many pairs of rows per chunk
 struct PlainDist {
   static constexpr bool kHasStamps = true;
   static constexpr bool kPointDistances = true;  // dist(query, row) is distFn between two stored vectors
+  static constexpr bool kSpeculate = false;      // search_body: no adjacency row is fetched ahead of its hop
   static constexpr int NGR = NG > 0 ? NG : 1;
-  static constexpr int U = NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4;
+  static constexpr int U = UPAIRS ? UPAIRS : (NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4);
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
   // [kHopSlots], raw distances by rank [kHopSlots], a U-word dump
   static constexpr uint32_t kHopSlots = 64 + U;  // ranks 0..63 and the overrun of the last half-wave run
@@ -253,6 +258,8 @@ struct PlainDist {
   }
 
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
+  __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
+  __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
   // hooks of the multi-wave quantized walk (PQWideDist); nothing to do for a one-wave policy
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
@@ -413,20 +420,49 @@ struct PlainDist {
 // arithmetic, same bits, same visit order; two workgroup barriers per hop.
 struct WideShared {
   uint32_t cnt;  // pending rows of the hop the walker has published; kWideDone: the walk is over
-  uint32_t pad[3];
+  uint32_t pad;
+  unsigned long long ahead;  // adjacency row of the candidate the walk will most likely expand next (0: none)
+  uint32_t dump[64];         // where the helpers retire the words they pulled through the cache
 };
 constexpr uint32_t kWideDone = 0xFFFFFFFFu;
 
 template <int NG, bool L2, int W>
-struct PlainWideDist : PlainDist<NG, L2, true> {
-  using Base = PlainDist<NG, L2, true>;
+struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
+  // a wave's share of a hop is at most 64 / W rows (rounded up to even): one chunk of 32 / W pairs holds it
+  using Base = PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)>;
+  // A call of few queries has bandwidth to spare and a dependent chain to shorten: with every hop the walker also fetches
+  // the adjacency row of the candidate that will be expanded next unless this hop's neighbours overtake it (search_body);
+  // when the guess holds the next hop starts with its row in a register.  256 bytes per hop, never used for a decision
+  // before the real pick has been made.
+  static constexpr bool kSpeculate = true;
   static constexpr size_t kLdsBytes = Base::kLdsBytes + sizeof(WideShared);
   WideShared *sh;
   int wave;
+  const uint32_t *pub_ahead;
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lds) {
     Base::init(a, q, lane, lds);  // every wave keeps the query in its registers
     sh = reinterpret_cast<WideShared *>(reinterpret_cast<char *>(lds) + Base::kLdsBytes);
     wave = w;
+    pub_ahead = nullptr;
+  }
+  __device__ __forceinline__ void speculation(bool, const uint32_t *spec_rowp) { pub_ahead = spec_rowp; }
+  // Calls of very few queries (SearchArgs::wide_pull) leave the memory system idle, and 70 % of the hops expand the
+  // candidate that was first in line one hop earlier: while the walker inserts this hop's points the helpers pull the
+  // vectors of THAT candidate's neighbours through the XCD's L2, one 4-byte read per 64-byte sector, so that the next
+  // hop's row loads -- the longest wait of a hop -- find them there.  Nothing is decided on these reads.
+  __device__ __forceinline__ void pull_ahead(const SearchArgs &a, const uint32_t *rowp, int lane, uint32_t (&got)[2]) {
+    const uint32_t sectors = a.ld / 16;  // 64-byte sectors of a slab row
+    got[0] = got[1] = 0u;
+    if (!rowp || wave == 0) return;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint32_t p = ((uint32_t)(wave - 1) * 2u + (uint32_t)r) * 64u + (uint32_t)lane;
+      const uint32_t i = p / sectors, j = p - i * sectors;
+      if (i < kAdjStride) {
+        const uint32_t nb = rowp[i];
+        if (nb != kNoSlot) got[r] = reinterpret_cast<const uint32_t *>(a.slab)[(size_t)nb * a.ld + j * 16u];
+      }
+    }
   }
   // this wave's share of `cnt` pending rows: contiguous ranks, an even number per wave so that only the list's last row
   // can be the odd one out (its spare entry sits behind the list)
@@ -452,7 +488,7 @@ struct PlainWideDist : PlainDist<NG, L2, true> {
       s_slot[rank] = nb;
       if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
     }
-    if (lane == 0) sh->cnt = (uint32_t)cnt;
+    if (lane == 0) sh->cnt = (uint32_t)cnt, sh->ahead = a.wide_pull ? reinterpret_cast<unsigned long long>(pub_ahead) : 0ull;
     __syncthreads();  // B1: the list is published
     share(a, cnt, lane);
     __syncthreads();  // B2: every share has been written
@@ -464,12 +500,16 @@ struct PlainWideDist : PlainDist<NG, L2, true> {
   }
   // ---- waves 1 .. W-1
   __device__ __forceinline__ void serve(const SearchArgs &a, int lane) {
+    uint32_t got[2] = {0u, 0u};
     for (;;) {
       __syncthreads();  // B1
       const uint32_t cnt = sh->cnt;
       if (cnt == kWideDone) return;
+      const uint32_t *ahead = reinterpret_cast<const uint32_t *>(sh->ahead);
+      if (a.wide_pull) sh->dump[lane] = got[0] ^ got[1];  // the last hop's pulls have long arrived: retire them
       share(a, (int)cnt, lane);
       __syncthreads();  // B2
+      if (a.wide_pull) pull_ahead(a, ahead, lane, got);
     }
   }
 };
@@ -477,6 +517,7 @@ struct PlainWideDist : PlainDist<NG, L2, true> {
 // Fitted product quantizer: dist = sum_i lut[i*K + code_i], plain fp32 adds in index order
 // (product.go:271-275).  One lane per neighbour: all new neighbours of a hop in one pass.
 struct PQDist {
+  static constexpr bool kSpeculate = false;
   static constexpr bool kHasStamps = false;
   static constexpr bool kPointDistances = false;  // LUT distance != the centroid-pair distance of the prunes
   const float *lut;  // this query's [M][K] table, in LDS or in global memory
@@ -497,6 +538,8 @@ struct PQDist {
     return dist;
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
+  __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
+  __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
   // M == 8 (the documented configuration): the 8 code bytes of every neighbour are fetched as one 8-byte
@@ -550,8 +593,16 @@ struct PQWideShared {
 };
 constexpr uint32_t kPqwSharedWords = sizeof(PQWideShared) / 4;
 
-template <int NL, int RT>  // tables per wave in LDS (multiple of 16) / in registers (multiple of 16, or 0)
+// NL / RT: tables per wave in LDS / in registers (NL + RT a multiple of 16); W: waves per query, M = W (NL + RT).
+// W = 8 (two waves per SIMD, 256 registers each) carries M = 384 with the per-wave layout of M = 192: round 3's
+// four-wave form of it kept 64 tables = 256 registers per wave and spilled 80 more.
+template <int NL, int RT, int W = 4>
 struct PQWideDist {
+  // Fetching ahead (search_body, Dist::kSpeculate) was built for this walk too -- every wave fetched the likely next
+  // row at the start of a hop and its neighbours' codes at the end of it, so that 70 % of the hops started with both in
+  // registers -- and measured no gain at two queries per CU (M = 192, 1M x 768: 1.089 ms per batch against 1.04 without,
+  // twice the code traffic): the other query's waves already fill the waits.  Removed.
+  static constexpr bool kSpeculate = false;
   static constexpr bool kHasStamps = false;
   static constexpr bool kPointDistances = false;
   static constexpr int MS = NL + RT;  // sub-quantizers per wave; M = 4 MS
@@ -561,7 +612,10 @@ struct PQWideDist {
   uint32_t K, lo;
   int wave;
   float T[RTR][4];    // register-resident tables
-  uint4 cw[MS / 16];  // the wave's range of the lane's neighbour's code bytes
+  // (a native vector type: copies of HIP's uint4 struct between members become 16-byte memcpys that keep the whole
+  // policy object -- register tables included -- in scratch memory)
+  typedef uint32_t code16 __attribute__((ext_vector_type(4)));
+  code16 cw[MS / 16];  // the wave's range of the lane's neighbour's code bytes
 
   // All four waves: tables in, from the query's [M][K] block that pq_build_lut left in global memory.  (Computing the
   // entries here instead -- no 200 MB block written and read back per batch -- was built and measured: the loads and
@@ -569,6 +623,7 @@ struct PQWideDist {
   // batch with a loop per entry, to 1.89 ms with the loads batched; removed.  The block costs 0.12 ms per batch.)
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lut_lds, PQWideShared *shared) {
     sh = shared, wave = w, K = a.pq_K, lo = (uint32_t)w * MS;
+
     float *dst = lut_lds + (size_t)w * NL * K;
     lds_lut = dst;
     const float *g = a.pq_lut + ((size_t)q * a.pq_M + lo) * K;
@@ -583,13 +638,13 @@ struct PQWideDist {
   }
   __device__ __forceinline__ void load_codes(const SearchArgs &a, uint32_t nb) {
     const uint32_t s = nb == kNoSlot ? 0u : nb;  // lanes without a neighbour read row 0 and are never looked at
-    const uint4 *cp = reinterpret_cast<const uint4 *>(a.pq_codes + (size_t)s * a.pq_M + lo);
+    const code16 *cp = reinterpret_cast<const code16 *>(a.pq_codes + (size_t)s * a.pq_M + lo);
 #pragma unroll
     for (int j = 0; j < MS / 16; j++) cw[j] = cp[j];
   }
   template <int I>
   __device__ __forceinline__ uint32_t code_at() const {  // code byte I of the wave's range
-    const uint4 v = cw[I / 16];
+    const code16 v = cw[I / 16];
     constexpr int wsel = (I / 4) % 4;
     const uint32_t word = wsel == 0 ? v.x : wsel == 1 ? v.y : wsel == 2 ? v.z : v.w;
     return (word >> (8 * (I % 4))) & 0xFFu;
@@ -622,7 +677,7 @@ struct PQWideDist {
   __device__ __forceinline__ float turns(const float (&val)[MS]) const {
     const int lane_ = threadIdx.x & 63;
 #pragma unroll
-    for (int stage = 0; stage < 4; stage++) {
+    for (int stage = 0; stage < W; stage++) {
       if (stage == wave) {
         float acc = stage == 0 ? 0.0f : sh->psum[lane_];
 #pragma unroll
@@ -635,6 +690,8 @@ struct PQWideDist {
   }
 
   // ---- the walker's side (wave 0): the policy interface search_body calls
+  __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
+  __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *rowp, int lane) {
     if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u;
     __syncthreads();  // B0
@@ -1128,9 +1185,9 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #pragma unroll
     for (int r = 0; r < NREG; r++) rid[r] = kNoSlot, rd[r] = 0.0f;
     fsorted = a.filt_slots + a.filt_off[q];
-    nfilt = a.filt_off[q + 1] - a.filt_off[q];
+    nfilt = a.filt_cnt ? a.filt_cnt[q] : a.filt_off[q + 1] - a.filt_off[q];
     // seeds: the first <= searchSize filter ids in ascending id order that exist (:41-48)
-    const uint32_t s0 = a.seed_off[q], ns = a.seed_off[q + 1] - s0;
+    const uint32_t s0 = a.seed_off[q], ns = a.seed_cnt ? a.seed_cnt[q] : a.seed_off[q + 1] - s0;
     for (uint32_t base = 0; base < ns; base += 64) {
       const uint32_t j = base + lane;
       const bool has = j < ns;
@@ -1182,6 +1239,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #else
 #define SDB_STAMP(acc)
 #endif
+  uint32_t spec_pid = kNoSlot, spec_nb = kNoSlot;  // Dist::kSpeculate: the row fetched ahead, and whose it is
+#ifdef SDB_SPEC_STATS
+  uint32_t n_spec_hit = 0;  // measurement builds: hops that found their row fetched ahead, reported in place of n_edges
+#endif
   // ---- main loop search.go:65-98
   while (true) {
 #ifdef SDB_STAMPS
@@ -1220,9 +1281,39 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     // is all AddWithLimit(neighbours...) depends on.
     const uint32_t *__restrict__ rowp = a.adj + (size_t)pid * kAdjStride;
     uint32_t ext_left = pid == a.start_slot ? a.start_ext_n : 0u, ext_done = 0;
+    // Dist::kSpeculate: is this hop's row the one fetched ahead, and which row to fetch ahead now -- the first
+    // unvisited entry as the array stands (this hop's own entry is marked already)
+    bool use_spec = false;
+    const uint32_t *spec_rowp = nullptr;
+    if constexpr (Dist::kSpeculate) {
+      use_spec = pid == spec_pid;
+      int sel2 = -1;
+#pragma unroll
+      for (int r = 0; r < NREG; r++) {
+        const uint64_t m2 = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
+        if (sel2 < 0 && m2) sel2 = r * 64 + __ffsll((unsigned long long)m2) - 1;
+      }
+      spec_pid = kNoSlot;
+#pragma unroll
+      for (int r = 0; r < NREG; r++)
+        if (sel2 >= 0 && (sel2 >> 6) == r) spec_pid = rl(cid[r], sel2 & 63) & ~kVisBit;
+      if (spec_pid != kNoSlot) spec_rowp = a.adj + (size_t)spec_pid * kAdjStride;
+      dist.speculation(use_spec, spec_rowp);
+    }
+    bool first_chunk = true;
     while (true) {
       dist.begin_row(a, rowp, lane);
-      const uint32_t nb = rowp[lane];
+      uint32_t nb;
+      if (Dist::kSpeculate && first_chunk && use_spec) {
+        nb = spec_nb;  // fetched during the hop before this one
+#ifdef SDB_SPEC_STATS
+        n_spec_hit++;
+#endif
+      } else {
+        nb = rowp[lane];
+      }
+      if constexpr (Dist::kSpeculate)
+        if (first_chunk && spec_rowp) spec_nb = spec_rowp[lane];
       const bool valid = nb != kNoSlot;
       n_edges += (uint32_t)__popcll(__ballot(valid));
 #ifdef SDB_STAMPS
@@ -1255,6 +1346,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         SDB_STAMP(st_ins)
       } else {
         dist.skip(lane);
+      }
+      if constexpr (Dist::kSpeculate) {
+        if (first_chunk && spec_rowp) dist.fetch_ahead(a, spec_nb);
+        first_chunk = false;
       }
       if (__builtin_expect(ext_left == 0, 1)) break;
       rowp = a.start_ext + ext_done;
@@ -1314,7 +1409,11 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
   if (lane == 0) {
     if (a.tr_ndist) a.tr_ndist[q] = n_dist;
     if (a.tr_nhop) a.tr_nhop[q] = n_hop;
+#ifdef SDB_SPEC_STATS
+    if (a.tr_nedges) a.tr_nedges[q] = Dist::kSpeculate ? n_spec_hit : n_edges;
+#else
     if (a.tr_nedges) a.tr_nedges[q] = n_edges;
+#endif
     if (a.vis_count) a.vis_count[q] = n_hop;
     if (a.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
       unsigned long long *t = a.totals + (q & 63u) * 16u;
@@ -1380,8 +1479,8 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
 // The multi-wave quantized walk: one query per workgroup of four waves (PQWideDist above).  Dynamic LDS: the visited
 // set's table, the command area, the LDS-resident tables [4][NL][K].
 // NL < 16: the variant meant to run two queries per CU (half the LDS each) -- its registers are capped accordingly
-template <int NL, int RT, uint32_t HCAP>
-__global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(const SearchArgs a) {
+template <int NL, int RT, uint32_t HCAP, int W = 4>
+__global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_search_pqw(const SearchArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t q = blockIdx.x;
@@ -1390,12 +1489,12 @@ __global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(cons
   // the NL < 16 variant, and the k-th wave of a workgroup lands on the k-th SIMD: with wave 0 walking in both, one
   // SIMD carried both walkers.  Workgroups that share a CU are 256 (or a multiple) apart in the grid, so the role
   // rotates with blockIdx / 256.  Any choice is correct; this one balances.
-  const int walker = (NL < 16) ? (int)((blockIdx.x >> 8) & 3u) : 0;
+  const int walker = (NL < 16 && W == 4) ? (int)((blockIdx.x >> 8) & 3u) : 0;
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   constexpr uint32_t kVisWords = HCAP == kHash16 ? HashVisited16::kWords : HashVisited<HCAP == kHash16 ? 4u : HCAP>::kWords;
   PQWideShared *sh = reinterpret_cast<PQWideShared *>(lds_f + kVisWords);
   float *lut_lds = lds_f + kVisWords + kPqwSharedWords;
-  PQWideDist<NL, RT> dist;
+  PQWideDist<NL, RT, W> dist;
   dist.init_wave(a, q, lane, wave, lut_lds, sh);
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
   if constexpr (HCAP == kHash16) {
@@ -1404,14 +1503,14 @@ __global__ __launch_bounds__(256, NL < 16 ? 2 : 1) void k_greedy_search_pqw(cons
     __syncthreads();  // tables and visited set in place
     if (wave != walker) return dist.serve(a, lane);
     NoVisited rv;
-    search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
+    search_body<PQWideDist<NL, RT, W>, 2, false>(a, q, lane, dist, hv, rv);
   } else {
     HashVisited<HCAP == kHash16 ? 4u : HCAP> hv;
     if (wave == walker) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
     __syncthreads();
     if (wave != walker) return dist.serve(a, lane);
     NoVisited rv;
-    search_body<PQWideDist<NL, RT>, 2, false>(a, q, lane, dist, hv, rv);
+    search_body<PQWideDist<NL, RT, W>, 2, false>(a, q, lane, dist, hv, rv);
   }
   dist.finish(lane);
 }

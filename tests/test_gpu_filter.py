@@ -77,6 +77,46 @@ def test_filtered_batch_parity(oracle, metric, d, n, L, k):
         assert int(tr.n_hop[i]) == o_tr.n_hop and int(tr.n_dist[i]) == o_tr.n_dist, i
         assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), i
         assert set(int(v) for v in o_ids) <= filters[i]
+    # the table's ids are consecutive, so the filter ids above were resolved to slots on the device (k_filter_resolve);
+    # the host's hash-map translation gives the same walk
+    ix.set_tuning("host_filters", 1)
+    h_ids, h_d, h_c, htr = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+    assert np.array_equal(h_ids, g_ids) and np.array_equal(bits(h_d), bits(g_d)) and np.array_equal(h_c, g_c)
+    assert np.array_equal(htr.visit_ids, tr.visit_ids) and np.array_equal(htr.n_dist, tr.n_dist)
+    ix.close()
+
+
+def test_filters_resolved_on_the_device_are_validated(oracle):
+    """the device-side resolution keeps the ABI's contract: ids of a query strictly ascending (an error otherwise, and
+    no search), offsets non-decreasing, unknown / out-of-range ids skipped, empty filters, ids of rows past the table"""
+    from semadb_amd import SemaDBError
+    rng = np.random.default_rng(77)
+    n, d = 500, 32
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ix = _gpu(o, d, "cosine", 32, 50)
+    q = unit_rows(rng, 3, d)
+    off = np.array([0, 3, 3, 7], dtype=np.uint64)
+    good = np.array([5, 9, 400, 2, 3, 10 ** 12, 2 ** 63], dtype=np.uint64)
+    g_ids, g_d, g_c, _ = ix.search_batch(q, 10, 50, filters=(off, good))
+    assert sorted(int(v) for v in g_ids[0, :int(g_c[0])]) == [5, 9, 400] and int(g_c[1]) == 0
+    assert sorted(int(v) for v in g_ids[2, :int(g_c[2])]) == [2, 3]
+    for i, f in enumerate([[5, 9, 400], [], [2, 3]]):
+        o_ids, o_d, _, _ = o.search(q[i], 10, 50, filter_ids=f)
+        assert np.array_equal(g_ids[i, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d))
+    bad = good.copy()
+    bad[1], bad[2] = 400, 9  # query 0: 5, 400, 9
+    with pytest.raises(SemaDBError) as ei:
+        ix.search_batch(q, 10, 50, filters=(off, bad))
+    assert "not strictly ascending" in str(ei.value) and "query 0" in str(ei.value)
+    dup = good.copy()
+    dup[4] = 2  # query 2: 2, 2, ...
+    with pytest.raises(SemaDBError):
+        ix.search_batch(q, 10, 50, filters=(off, dup))
+    with pytest.raises(SemaDBError):
+        ix.search_batch(q, 10, 50, filters=(np.array([0, 3, 2, 7], dtype=np.uint64), good))
+    g2 = ix.search_batch(q, 10, 50, filters=(off, good))  # and the next call is served
+    assert np.array_equal(g2[0], g_ids)
     ix.close()
 
 
