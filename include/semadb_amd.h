@@ -188,7 +188,8 @@ typedef struct {
  * concurrent Search calls).  limit = query.Limit, search_size =
  * query.SearchSize; search_size < limit is an error (search.go:23-25).
  * Optional filter (the roaring bitmap argument): filter_offsets[nq+1] into filter_ids, each
- * query's ids ascending; NULL = no filter.  Filter arrays are host memory.
+ * query's ids ascending; NULL = no filter.  Filter arrays are host memory (pinned -- sdb_host_alloc -- they go up
+ * in one DMA); for a table with consecutive ids they are resolved to slots on the device.
  * Outputs: out_ids[nq*limit], out_dists[nq*limit] (ascending distance, start node removed),
  * out_counts[nq].  HybridScore = -1 * dist * weight is left to the caller (vamana.go:303). */
 int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
@@ -196,6 +197,19 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
                            const uint64_t *filter_ids, uint64_t *out_ids, float *out_dists,
                            uint32_t *out_counts, const sdb_search_trace *trace, int mem,
                            void *stream);
+
+/* The same search with the filters handed over as BITMAPS: query q's filter is the set
+ * { filter_first_id[q] + i : bit i of its words is set }, its words being filter_words[filter_word_offsets[q] ..
+ * filter_word_offsets[q + 1]) -- bit i of the set is bit i % 64 of word i / 64.  The reference's filter IS a bitmap
+ * (roaring64, search.go:33-51,93): a dense roaring container is 1 024 such words, and a filter of 100 000 ids out of a
+ * million is an eighth of the bytes of its id list in this form -- what a large filter costs is its upload.  Unknown ids
+ * (bits outside the table) are skipped like GetMany does (itemcache.go:109-128); the seeds are the first searchSize set
+ * bits (:41-48).  Filter arrays are host memory; everything else as sdb_index_search_batch, same answers bit for bit.
+ * For a table with consecutive ids the bitmaps are expanded to slots on the device; otherwise on the host. */
+int sdb_index_search_batch_bitmap(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit, uint32_t search_size,
+                                  const uint64_t *filter_first_id, const uint64_t *filter_word_offsets,
+                                  const uint64_t *filter_words, uint64_t *out_ids, float *out_dists, uint32_t *out_counts,
+                                  const sdb_search_trace *trace, int mem, void *stream);
 
 /* plainStore.DistanceFromFloat (shard/vectorstore/plain.go:76-85) batched: distances from each
  * query to an explicit list of stored node ids (nc per query, cand_ids[nq*nc], host memory).

@@ -376,6 +376,47 @@ func packFilters(reqs []*searchReq) (offsets, ids []uint64) {
 	return offsets, ids
 }
 
+// bitmapsAreSmaller: would the batch's filters take fewer bytes as bitmaps over [Minimum, Maximum] than as id lists?
+// True for dense filters (an inverted-index hit list over a large share of the shard): 100 000 ids out of a million are
+// 800 KB as a list and 125 KB as a bitmap, and the upload is what a large filter costs.
+func bitmapsAreSmaller(reqs []*searchReq) bool {
+	var words, card uint64
+	for _, r := range reqs {
+		if r.filter.IsEmpty() {
+			continue
+		}
+		card += r.filter.GetCardinality()
+		words += (r.filter.Maximum()-(r.filter.Minimum()&^63))/64 + 1
+	}
+	return card > 4096 && words < card
+}
+
+// packFilterBitmaps lays the batch's roaring bitmaps out for sdb_index_search_batch_bitmap: query q's filter is
+// {first[q] + i : bit i of words[offsets[q]:offsets[q+1]]}.
+func packFilterBitmaps(reqs []*searchReq) (first, offsets, words []uint64) {
+	offsets = make([]uint64, 1, len(reqs)+1)
+	for _, r := range reqs {
+		if r.filter.IsEmpty() {
+			first = append(first, 0)
+			offsets = append(offsets, uint64(len(words)))
+			continue
+		}
+		f0 := r.filter.Minimum() &^ 63
+		base := len(words)
+		words = append(words, make([]uint64, (r.filter.Maximum()-f0)/64+1)...)
+		for it := r.filter.Iterator(); it.HasNext(); {
+			v := it.Next() - f0
+			words[base+int(v/64)] |= 1 << (v % 64)
+		}
+		first = append(first, f0)
+		offsets = append(offsets, uint64(len(words)))
+	}
+	if len(words) == 0 {
+		words = append(words, 0) // a valid pointer for cgo; no query reads it
+	}
+	return first, offsets, words
+}
+
 func (b *searchBatcher) flush(reqs []*searchReq) {
 	nq, d := len(reqs), b.dim
 	queries := make([]float32, nq*d)
@@ -386,15 +427,25 @@ func (b *searchBatcher) flush(reqs []*searchReq) {
 	ids := make([]uint64, nq*limit)
 	dists := make([]float32, nq*limit)
 	counts := make([]uint32, nq)
-	fOff, fIds := packFilters(reqs)
-	var fo, fi *C.uint64_t
-	if fOff != nil {
-		fo, fi = (*C.uint64_t)(unsafe.Pointer(&fOff[0])), (*C.uint64_t)(unsafe.Pointer(&fIds[0]))
+	var rc C.int
+	if reqs[0].filter != nil && bitmapsAreSmaller(reqs) {
+		first, wOff, words := packFilterBitmaps(reqs)
+		rc = C.sdb_index_search_batch_bitmap(b.ix.h, C.uint64_t(nq), (*C.float)(unsafe.Pointer(&queries[0])),
+			C.uint32_t(limit), C.uint32_t(L), (*C.uint64_t)(unsafe.Pointer(&first[0])), (*C.uint64_t)(unsafe.Pointer(&wOff[0])),
+			(*C.uint64_t)(unsafe.Pointer(&words[0])),
+			(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dists[0])),
+			(*C.uint32_t)(unsafe.Pointer(&counts[0])), nil, C.SDB_MEM_HOST, nil)
+	} else {
+		fOff, fIds := packFilters(reqs)
+		var fo, fi *C.uint64_t
+		if fOff != nil {
+			fo, fi = (*C.uint64_t)(unsafe.Pointer(&fOff[0])), (*C.uint64_t)(unsafe.Pointer(&fIds[0]))
+		}
+		rc = C.sdb_index_search_batch(b.ix.h, C.uint64_t(nq), (*C.float)(unsafe.Pointer(&queries[0])),
+			C.uint32_t(limit), C.uint32_t(L), fo, fi,
+			(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dists[0])),
+			(*C.uint32_t)(unsafe.Pointer(&counts[0])), nil, C.SDB_MEM_HOST, nil)
 	}
-	rc := C.sdb_index_search_batch(b.ix.h, C.uint64_t(nq), (*C.float)(unsafe.Pointer(&queries[0])),
-		C.uint32_t(limit), C.uint32_t(L), fo, fi,
-		(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dists[0])),
-		(*C.uint32_t)(unsafe.Pointer(&counts[0])), nil, C.SDB_MEM_HOST, nil)
 	for i, r := range reqs {
 		if rc != C.SDB_OK {
 			r.done <- searchResp{err: lastErr("search_batch", rc)}

@@ -57,6 +57,9 @@ SIGNATURES = {
     "sdb_index_search_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SearchTrace),
                                          C.c_int, C.c_void_p]),
+    "sdb_index_search_batch_bitmap": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.POINTER(SearchTrace), C.c_int, C.c_void_p]),
     "sdb_index_distance_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p]),
     "sdb_index_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),

@@ -24,6 +24,8 @@ struct Workspace {
   size_t lut_bytes = 0;
   void *filter = nullptr;  // seeds / filter slot lists of a filtered batch
   size_t filter_bytes = 0;
+  void *filter_aux = nullptr;  // a batch's filter bitmaps and their per-query counts (sdb_index_search_batch_bitmap)
+  size_t filter_aux_bytes = 0;
   void *filter_host = nullptr;  // the same lists as the host threads write them: pinned, so that the upload is one DMA
   size_t filter_host_bytes = 0;
   hipEvent_t launched = nullptr;   // recorded behind the last search kernels that were given a graph version
@@ -34,6 +36,7 @@ struct Workspace {
   hipEvent_t done = nullptr;
   int ensure_filter(size_t bytes);
   int ensure_filter_host(size_t bytes);
+  int ensure_filter_aux(size_t bytes);
   int ensure_lut(size_t bytes);
   int ensure_bitsets(size_t bytes);
   int ensure_scratch(size_t bytes);

@@ -58,6 +58,15 @@ int Workspace::ensure_filter(size_t bytes) {
   return SDB_OK;
 }
 
+int Workspace::ensure_filter_aux(size_t bytes) {
+  if (bytes <= filter_aux_bytes) return SDB_OK;
+  if (filter_aux) SDB_HIP(hipFree(filter_aux));
+  filter_aux = nullptr, filter_aux_bytes = 0;
+  SDB_HIP(hipMalloc(&filter_aux, bytes));
+  filter_aux_bytes = bytes;
+  return SDB_OK;
+}
+
 int Workspace::ensure_filter_host(size_t bytes) {
   if (bytes <= filter_host_bytes) return SDB_OK;
   if (filter_host) SDB_HIP(hipHostFree(filter_host));
@@ -82,6 +91,8 @@ void Workspace::release() {
   filter = nullptr;
   if (filter_host) (void)hipHostFree(filter_host);
   filter_host = nullptr, filter_host_bytes = 0;
+  if (filter_aux) (void)hipFree(filter_aux);
+  filter_aux = nullptr, filter_aux_bytes = 0;
   if (lut) (void)hipFree(lut);
   lut = nullptr;
   if (bitsets) (void)hipFree(bitsets);
@@ -201,6 +212,116 @@ __global__ __launch_bounds__(64) void k_filter_resolve(const uint64_t *__restric
   }
   if (__ballot(bad) && lane == 0) atomicOr(flags, 1u), flags[1] = q;
   if (lane == 0) fcnt[q] = pos, scnt[q] = ns;
+}
+
+// The same for a filter handed over as a BITMAP (sdb_index_search_batch_bitmap): bit i of query q's words is the id
+// first_id[q] + i.  A roaring bitmap keeps its dense chunks in exactly this form, and at 100 000 ids out of a million it is
+// an eighth of the bytes of the id list -- the upload is what a large filter costs.  Pass 1 (this kernel, one wave per
+// query, a lane per 64-bit word): how many of its bits name rows that exist (fcnt) and how many of its FIRST searchSize
+// bits do (scnt: the seeds are GetMany(first searchSize ids), unknown ids skipped, search.go:41-48).
+__device__ __forceinline__ uint64_t bitmap_valid_mask(uint64_t id0, uint64_t base_id, uint32_t view_n) {
+  // bits b of a word whose first id is id0 with base_id <= id0 + b < base_id + view_n  (ids wrap nowhere near 2^64 here)
+  uint64_t m = ~0ull;
+  if (id0 < base_id) {
+    const uint64_t skip = base_id - id0;
+    m = skip >= 64 ? 0ull : (m << skip);
+  }
+  const uint64_t end = base_id + view_n;  // first id past the table
+  if (id0 >= end) return 0ull;
+  const uint64_t room = end - id0;
+  if (room < 64) m &= (1ull << room) - 1;
+  return m;
+}
+__device__ __forceinline__ uint64_t lowest_set_bits(uint64_t w, uint32_t k) {  // the k lowest set bits of w (k < popc(w))
+  uint64_t out = 0;
+  for (uint32_t i = 0; i < k; i++) {
+    const uint64_t b = w & (0 - w);
+    out |= b, w ^= b;
+  }
+  return out;
+}
+__global__ __launch_bounds__(64) void k_filter_bitmap_count(const uint64_t *__restrict__ words, const uint32_t *__restrict__ woff,
+                                                            const uint64_t *__restrict__ first_id, uint64_t base_id,
+                                                            uint32_t view_n, uint32_t search_size, uint32_t *__restrict__ fcnt,
+                                                            uint32_t *__restrict__ scnt) {
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t b = woff[q], e = woff[q + 1];
+  const uint64_t f0 = first_id[q];
+  uint32_t total = 0, seeds = 0, seen = 0;  // seen: set bits before this round of 64 words
+  for (uint32_t base = b; base < e; base += 64) {
+    const uint32_t w = base + lane;
+    const uint64_t word = w < e ? words[w] : 0ull;
+    const uint64_t valid = word & bitmap_valid_mask(f0 + (uint64_t)(w - b) * 64u, base_id, view_n);
+    uint32_t pc = (uint32_t)__popcll(word), incl = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {  // inclusive scan of the words' populations over the lanes
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const uint32_t before = seen + incl - pc;  // set bits of the filter in front of this word
+    if (before < search_size) {
+      const uint32_t left = search_size - before;
+      seeds += (uint32_t)__popcll(left >= pc ? valid : (valid & lowest_set_bits(word, left)));
+    }
+    total += (uint32_t)__popcll(valid);
+    seen += __shfl(incl, 63, 64);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64), seeds += __shfl_down(seeds, o, 64);
+  if (lane == 0) fcnt[q] = total, scnt[q] = seeds;
+}
+// exclusive scan of the per-query counts -> where each query's slot list starts (one workgroup; nq is a batch size)
+__global__ __launch_bounds__(1024) void k_filter_offsets(const uint32_t *__restrict__ cnt, uint32_t nq, uint32_t *__restrict__ off,
+                                                          uint32_t *__restrict__ overflow) {
+  __shared__ uint64_t s_part[1024];
+  const uint32_t t = threadIdx.x, per = (nq + 1023) / 1024;
+  uint64_t sum = 0;
+  for (uint32_t i = t * per; i < min(nq, (t + 1) * per); i++) sum += cnt[i];
+  s_part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < 1024; i++) {
+      const uint64_t v = s_part[i];
+      s_part[i] = run, run += v;
+    }
+    off[nq] = (uint32_t)run;
+    if (run > 0xFFFFFFFFull) *overflow = 1u;
+  }
+  __syncthreads();
+  uint64_t run = s_part[t];
+  for (uint32_t i = t * per; i < min(nq, (t + 1) * per); i++) off[i] = (uint32_t)run, run += cnt[i];
+}
+// pass 2: the slots, ascending, at the query's place in the list
+__global__ __launch_bounds__(64) void k_filter_bitmap_expand(const uint64_t *__restrict__ words, const uint32_t *__restrict__ woff,
+                                                             const uint64_t *__restrict__ first_id, uint64_t base_id,
+                                                             uint32_t view_n, const uint32_t *__restrict__ off,
+                                                             uint32_t *__restrict__ slots) {
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t b = woff[q], e = woff[q + 1];
+  const uint64_t f0 = first_id[q];
+  uint32_t pos = off[q];
+  for (uint32_t base = b; base < e; base += 64) {
+    const uint32_t w = base + lane;
+    const uint64_t id0 = f0 + (uint64_t)(w - b) * 64u;
+    uint64_t valid = w < e ? (words[w] & bitmap_valid_mask(id0, base_id, view_n)) : 0ull;
+    const uint32_t pc = (uint32_t)__popcll(valid);
+    uint32_t incl = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    uint32_t at = pos + incl - pc;
+    while (valid) {
+      const int bit = __ffsll((unsigned long long)valid) - 1;
+      valid &= valid - 1;
+      slots[at++] = (uint32_t)(id0 + (uint64_t)bit - base_id);
+    }
+    pos += __shfl(incl, 63, 64);
+  }
 }
 
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
@@ -992,10 +1113,16 @@ int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows) {
   return SDB_OK;
 }
 
-int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
-                           uint32_t search_size, const uint64_t *filter_offsets,
-                           const uint64_t *filter_ids, uint64_t *out_ids, float *out_dists,
-                           uint32_t *out_counts, const sdb_search_trace *trace, int mem, void *stream_) {
+// a filter handed over as bitmaps (sdb_index_search_batch_bitmap)
+struct BitmapFilters {
+  const uint64_t *first_id, *word_offsets, *words;
+};
+constexpr int kBitmapNeedsIds = -7001;  // search_batch_impl: this table cannot take bitmaps on the device; the caller expands them
+
+static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
+                             uint32_t search_size, const uint64_t *filter_offsets,
+                             const uint64_t *filter_ids, const BitmapFilters *bm, uint64_t *out_ids, float *out_dists,
+                             uint32_t *out_counts, const sdb_search_trace *trace, int mem, void *stream_) {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (nq == 0) return SDB_OK;
   if (!queries || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -1007,8 +1134,8 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
                 search_size, limit);
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (ix->start_slot < 0) return fail(SDB_ERR_STATE, "failed to get start point");  // search.go:57-60
-  const bool filtered = filter_offsets != nullptr;
-  if (filtered && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
+  const bool filtered = filter_offsets != nullptr || bm != nullptr;
+  if (filter_offsets && filter_offsets[nq] && !filter_ids) return fail(SDB_ERR_INVALID, "filter_ids is NULL");
   if (nq > 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many queries");
   DeviceGuard dg(ix->P.device);
   hipStream_t stream = as_stream(stream_);
@@ -1037,7 +1164,48 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   SearchArgs a{};
   a.slab = ix->d_slab, a.adj = vw.adj, a.ids = vw.ids;
   a.bitsets = ws->bitsets, a.words_per_query = words;
-  if (filtered) {
+  if (bm) {
+    // bitmaps: two passes on the device (count, expand) turn them into the same ascending slot lists; only for a table
+    // with consecutive ids, where id -> slot is a subtraction
+    if (!(ix->dense_ids && ix->n > 0) || ix->tune_host_filters) return kBitmapNeedsIds;
+    for (uint64_t q = 0; q < nq; q++)
+      if (bm->word_offsets[q + 1] < bm->word_offsets[q]) return fail(SDB_ERR_INVALID, "filter_word_offsets must be non-decreasing");
+    const uint64_t total_words = bm->word_offsets[nq] - bm->word_offsets[0];
+    if (total_words >= (1ull << 32)) return fail(SDB_ERR_INVALID, "filter bitmaps of one batch are limited to 2^32 words");
+    const uint64_t base_id = ix->h_ids[0];
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_off = up((nq + 1) * 4), b_first = up(nq * 8), b_words = up(total_words * 8), b_cnt = up(nq * 4);
+    SDB_TRY(ws->ensure_filter_host(b_off + 256));
+    SDB_TRY(ws->ensure_filter_aux(2 * b_off + b_first + b_words + 2 * b_cnt + 256));
+    char *fb = static_cast<char *>(ws->filter_aux);
+    uint32_t *d_woff = (uint32_t *)fb, *d_off = (uint32_t *)(fb + b_off);
+    uint64_t *d_first = (uint64_t *)(fb + 2 * b_off), *d_words = (uint64_t *)(fb + 2 * b_off + b_first);
+    uint32_t *d_fc = (uint32_t *)(fb + 2 * b_off + b_first + b_words), *d_sc = (uint32_t *)((char *)d_fc + b_cnt);
+    uint32_t *d_flags = (uint32_t *)((char *)d_sc + b_cnt);
+    uint32_t *h_off = static_cast<uint32_t *>(ws->filter_host);
+    uint32_t *h_back = h_off + (nq + 1) + 2;  // [0] total slots, [1] overflow
+    for (uint64_t q = 0; q <= nq; q++) h_off[q] = (uint32_t)(bm->word_offsets[q] - bm->word_offsets[0]);
+    SDB_HIP(hipMemcpyAsync(d_woff, h_off, (nq + 1) * 4, hipMemcpyHostToDevice, stream));
+    SDB_HIP(hipMemcpyAsync(d_first, bm->first_id, nq * 8, hipMemcpyHostToDevice, stream));
+    if (total_words)
+      SDB_HIP(hipMemcpyAsync(d_words, bm->words + bm->word_offsets[0], total_words * 8, hipMemcpyHostToDevice, stream));
+    SDB_HIP(hipMemsetAsync(d_flags, 0, 8, stream));
+    hipLaunchKernelGGL(k_filter_bitmap_count, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
+                       search_size, d_fc, d_sc);
+    hipLaunchKernelGGL(k_filter_offsets, dim3(1), dim3(1024), 0, stream, d_fc, (uint32_t)nq, d_off, d_flags);
+    SDB_HIP(hipGetLastError());
+    SDB_HIP(hipMemcpyAsync(h_back, d_off + nq, 4, hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipMemcpyAsync(h_back + 1, d_flags, 4, hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipStreamSynchronize(stream));  // the slot list's size; the caller's arrays are free again
+    if (h_back[1]) return fail(SDB_ERR_INVALID, "the filters of one batch name more than 2^32 stored ids");
+    SDB_TRY(ws->ensure_filter((size_t)h_back[0] * 4 + 256));
+    uint32_t *d_sl = static_cast<uint32_t *>(ws->filter);
+    hipLaunchKernelGGL(k_filter_bitmap_expand, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n, d_off,
+                       d_sl);
+    SDB_HIP(hipGetLastError());
+    a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
+    a.rbitsets = ws->bitsets + (size_t)nq * words;
+  } else if (filtered) {
     // search.go:41-48: seeds = the first <= searchSize filter ids (ascending) that exist; Contains (:93) is
     // answered from the whole filter as ascending slots.  Filter arrays are host memory (header).
     const uint64_t total_ids = filter_offsets[nq] - filter_offsets[0];
@@ -1259,6 +1427,39 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
   }
   SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
+}
+
+int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
+                           uint32_t search_size, const uint64_t *filter_offsets,
+                           const uint64_t *filter_ids, uint64_t *out_ids, float *out_dists,
+                           uint32_t *out_counts, const sdb_search_trace *trace, int mem, void *stream_) {
+  return search_batch_impl(ix, nq, queries, limit, search_size, filter_offsets, filter_ids, nullptr, out_ids, out_dists, out_counts,
+                           trace, mem, stream_);
+}
+
+int sdb_index_search_batch_bitmap(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit, uint32_t search_size,
+                                  const uint64_t *filter_first_id, const uint64_t *filter_word_offsets,
+                                  const uint64_t *filter_words, uint64_t *out_ids, float *out_dists, uint32_t *out_counts,
+                                  const sdb_search_trace *trace, int mem, void *stream_) {
+  if (!filter_first_id || !filter_word_offsets) return fail(SDB_ERR_INVALID, "NULL filter argument");
+  if (nq && filter_word_offsets[nq] > filter_word_offsets[0] && !filter_words) return fail(SDB_ERR_INVALID, "filter_words is NULL");
+  const BitmapFilters bm{filter_first_id, filter_word_offsets, filter_words};
+  const int rc = search_batch_impl(ix, nq, queries, limit, search_size, nullptr, nullptr, &bm, out_ids, out_dists, out_counts, trace,
+                                   mem, stream_);
+  if (rc != kBitmapNeedsIds) return rc;
+  // a table whose ids are not consecutive (deletes, arbitrary ids): the host's hash map resolves ids, so the bitmaps
+  // become id lists here -- the reference iterates its roaring bitmap the same way (search.go:41-48)
+  std::vector<uint64_t> off(nq + 1, 0), ids;
+  for (uint64_t q = 0; q < nq; q++) {
+    if (filter_word_offsets[q + 1] < filter_word_offsets[q]) return fail(SDB_ERR_INVALID, "filter_word_offsets must be non-decreasing");
+    for (uint64_t w = filter_word_offsets[q]; w < filter_word_offsets[q + 1]; w++)
+      for (uint64_t word = filter_words[w]; word; word &= word - 1)
+        ids.push_back(filter_first_id[q] + (w - filter_word_offsets[q]) * 64 + (uint64_t)__builtin_ctzll(word));
+    off[q + 1] = ids.size();
+  }
+  if (ids.empty()) ids.push_back(0);
+  return search_batch_impl(ix, nq, queries, limit, search_size, off.data(), ids.data(), nullptr, out_ids, out_dists, out_counts, trace,
+                           mem, stream_);
 }
 
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {

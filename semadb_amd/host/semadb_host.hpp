@@ -600,9 +600,34 @@ class SearchBatcher {
         f_off.push_back(f_ids.size());
       }
       if (f_ids.empty()) f_ids.push_back(0);
-      const int rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, filtered ? f_off.data() : nullptr,
-                                            filtered ? f_ids.data() : nullptr, ids.data(), dists.data(), counts.data(),
-                                            nullptr, SDB_MEM_HOST, nullptr);
+      // dense filters go up as bitmaps over [min, max] when that is fewer bytes than the id lists (the Go twin's
+      // bitmapsAreSmaller / packFilterBitmaps): the upload is what a large filter costs
+      uint64_t words = 0, card = f_ids.size();
+      if (filtered)
+        for (size_t i = 0; i < nq; i++)
+          if (!reqs[i]->filter->empty()) words += (*reqs[i]->filter->rbegin() - (*reqs[i]->filter->begin() & ~63ull)) / 64 + 1;
+      int rc;
+      if (filtered && card > 4096 && words < card) {
+        std::vector<uint64_t> first(nq, 0), w_off{0}, w;
+        for (size_t i = 0; i < nq; i++) {
+          const Filter &f = *reqs[i]->filter;
+          if (!f.empty()) {
+            const uint64_t f0 = *f.begin() & ~63ull;
+            const size_t base = w.size();
+            w.resize(base + (*f.rbegin() - f0) / 64 + 1, 0);
+            for (uint64_t id : f) w[base + (id - f0) / 64] |= 1ull << ((id - f0) % 64);
+            first[i] = f0;
+          }
+          w_off.push_back(w.size());
+        }
+        if (w.empty()) w.push_back(0);
+        rc = sdb_index_search_batch_bitmap(h_, nq, queries.data(), limit, L, first.data(), w_off.data(), w.data(), ids.data(),
+                                           dists.data(), counts.data(), nullptr, SDB_MEM_HOST, nullptr);
+      } else {
+        rc = sdb_index_search_batch(h_, nq, queries.data(), limit, L, filtered ? f_off.data() : nullptr,
+                                    filtered ? f_ids.data() : nullptr, ids.data(), dists.data(), counts.data(),
+                                    nullptr, SDB_MEM_HOST, nullptr);
+      }
       n_batches_++;
       n_queries_ += nq;
       const Error err = rc ? Error(std::string(sdb_last_error())) : Error();

@@ -60,6 +60,38 @@ class BatchTrace:
     visit_ids: Optional[np.ndarray] = None
 
 
+class FilterBitmaps:
+    """The filters of a batch as bitmaps (sdb_index_search_batch_bitmap): query q's filter is {first_id[q] + i : bit i of
+    its words}; words[word_offsets[q]:word_offsets[q + 1]] are its 64-bit words.  from_sets() builds the form a roaring
+    bitmap's dense containers already have."""
+
+    def __init__(self, first_id, word_offsets, words):
+        self.first_id = np.ascontiguousarray(first_id, dtype=np.uint64)
+        self.word_offsets = np.ascontiguousarray(word_offsets, dtype=np.uint64)
+        self.words = np.ascontiguousarray(words if len(words) else [0], dtype=np.uint64)
+
+    @classmethod
+    def from_sets(cls, filters, align=64):
+        first, off, chunks = [], [0], []
+        for f in filters:
+            ids = np.unique(np.asarray(sorted(int(v) for v in f), dtype=np.uint64)) if not isinstance(f, np.ndarray) \
+                else np.unique(f.astype(np.uint64))
+            if ids.size == 0:
+                first.append(0)
+                off.append(off[-1])
+                continue
+            f0 = int(ids[0]) // align * align
+            rel = (ids - np.uint64(f0)).astype(np.int64)
+            nwords = int(rel[-1]) // 64 + 1
+            w = np.zeros(nwords, dtype=np.uint64)
+            np.bitwise_or.at(w, rel // 64, np.uint64(1) << (rel % 64).astype(np.uint64))
+            first.append(f0)
+            chunks.append(w)
+            off.append(off[-1] + nwords)
+        words = np.concatenate(chunks) if chunks else np.zeros(1, dtype=np.uint64)
+        return cls(np.array(first, dtype=np.uint64), np.array(off, dtype=np.uint64), words)
+
+
 class IndexVamana:
     """vamana.IndexVamana (vamana.go:36-52) with its state pinned in one MI355X's HBM."""
 
@@ -332,6 +364,11 @@ class IndexVamana:
             raise SemaDBError(1, "query vector length must be %d" % self.parameters.VectorSize)
         nq = shape[0]
         f_off = f_ids = None
+        bitmaps = None
+        if isinstance(filters, FilterBitmaps):  # sdb_index_search_batch_bitmap
+            bitmaps, filters = filters, None
+            if bitmaps.word_offsets.size != nq + 1 or bitmaps.first_id.size != nq:
+                raise SemaDBError(1, "one filter per query expected")
         if isinstance(filters, tuple):  # (offsets [nq + 1], ascending ids) already in the ABI's form
             f_off = np.ascontiguousarray(filters[0], dtype=np.uint64)
             f_ids = np.ascontiguousarray(filters[1], dtype=np.uint64)
@@ -368,6 +405,12 @@ class IndexVamana:
                 vis, visp = _buf.empty_like_mem(mem, (nq, visit_cap), "uint64", self.device, zero=True)
             tr_struct = SearchTrace(ndp, nhp, nep, visp, visit_cap)
             tr_out = BatchTrace(nd, nh, ne, vis)
+        if bitmaps is not None:
+            check(lib().sdb_index_search_batch_bitmap(self._h, nq, qp, limit, search_size, _buf.np_ptr(bitmaps.first_id),
+                                                      _buf.np_ptr(bitmaps.word_offsets), _buf.np_ptr(bitmaps.words), idp,
+                                                      dp, cp, C.byref(tr_struct) if tr_struct is not None else None, mem,
+                                                      _buf.current_stream(mem)))
+            return ids, dists, counts, tr_out
         check(lib().sdb_index_search_batch(self._h, nq, qp, limit, search_size, _buf.np_ptr(f_off),
                                            _buf.np_ptr(f_ids), idp, dp, cp,
                                            C.byref(tr_struct) if tr_struct is not None else None, mem,

@@ -197,3 +197,61 @@ def test_filtered_walk_is_the_same_under_every_visited_set(oracle):
             assert int(tr.n_hop[i]) == o_tr.n_hop and int(tr.n_dist[i]) == o_tr.n_dist, (name, i)
             assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), (name, i)
     ix.close()
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_filters_as_bitmaps_give_the_same_walk(oracle, dense):
+    """sdb_index_search_batch_bitmap: the filter as the bitmap it is in the reference (roaring64, search.go:33-51,93) --
+    {first_id + i : bit i} -- expanded to slots on the device for a table with consecutive ids, on the host otherwise
+    (dense = False: a delete leaves a hole).  Same answers as the id lists and as the oracle: ids, distance bits, visit
+    order, counters; unknown ids (bits outside the table, a window that starts below the first id), empty bitmaps,
+    windows that are not word-aligned with each other, bits of the start node."""
+    from semadb_amd import vamana
+    rng = np.random.default_rng(91 if dense else 92)
+    n, d, L, k = 1500, 32, 50, 10
+    base = unit_rows(rng, n, d)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ix = _gpu(o, d, "cosine", 32, 50)
+    if not dense:
+        gone = np.array([7, 8, 900], dtype=np.uint64)
+        ix.delete_batch(gone)
+        assert o.delete(gone) == 0
+    nq = 20
+    q = unit_rows(rng, nq, d)
+    all_ids = np.arange(2, n + 2)
+    filters = []
+    for i in range(nq):
+        kind = i % 7
+        if kind == 0:
+            f = rng.choice(all_ids, size=6, replace=False)
+        elif kind == 1:
+            f = rng.choice(all_ids, size=n // 3, replace=False)                     # dense: most words full-ish
+        elif kind == 2:
+            f = np.concatenate([rng.choice(all_ids, size=30, replace=False), [n + 500, n + 4000]])  # past the table
+        elif kind == 3:
+            f = np.concatenate([[1], rng.choice(all_ids, size=25, replace=False)])  # the start node's id
+        elif kind == 4:
+            f = np.array([], dtype=np.int64)
+        elif kind == 5:
+            f = np.arange(600 + i, 600 + i + 130)                                   # a run: unaligned window
+        else:
+            f = rng.choice(all_ids, size=L, replace=False)                          # exactly searchSize seeds
+        filters.append(set(int(v) for v in f))
+    bm = vamana.FilterBitmaps.from_sets(filters, align=1 if not dense else 64)
+    g_ids, g_d, g_c, tr = ix.search_batch(q, k, L, filters=bm, trace=True, visit_cap=1024)
+    l_ids, l_d, l_c, ltr = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+    assert np.array_equal(g_ids, l_ids) and np.array_equal(bits(g_d), bits(l_d)) and np.array_equal(g_c, l_c)
+    assert np.array_equal(tr.visit_ids, ltr.visit_ids) and np.array_equal(tr.n_dist, ltr.n_dist)
+    for i in range(nq):
+        o_ids, o_d, o_vis, o_tr = o.search(q[i], k, L, filter_ids=sorted(filters[i]))
+        assert int(g_c[i]) == len(o_ids), i
+        assert np.array_equal(g_ids[i, :len(o_ids)], o_ids) and np.array_equal(bits(g_d[i, :len(o_ids)]), bits(o_d)), i
+        assert int(tr.n_hop[i]) == o_tr.n_hop and int(tr.n_dist[i]) == o_tr.n_dist, i
+        assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), i
+    # a window that starts far below the table's first id, and one word per query
+    bm2 = vamana.FilterBitmaps(np.zeros(nq, dtype=np.uint64), np.arange(nq + 1, dtype=np.uint64),
+                               np.full(nq, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))  # ids 0 .. 63
+    b_ids, b_d, b_c, _ = ix.search_batch(q, k, L, filters=bm2)
+    w_ids, w_d, w_c, _ = ix.search_batch(q, k, L, filters=[set(range(0, 64))] * nq)
+    assert np.array_equal(b_ids, w_ids) and np.array_equal(b_c, w_c) and np.array_equal(bits(b_d), bits(w_d))
+    ix.close()

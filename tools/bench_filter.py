@@ -65,5 +65,23 @@ for size in [int(x) for x in a0.sizes.split(",")]:
     kms = float(np.mean(ix.profile_read()))
     out["filter_%d" % size] = {"kernel_ms": round(kms, 4), "kernel_qps": round(1024 / kms * 1e3, 1),
                                "call_ms": round(dt * 1e3, 2), "call_qps": round(1024 / dt, 1),
-                               "mean_results": round(hits / 3 / 1024, 2)}
+                               "mean_results": round(hits / 3 / 1024, 2), "upload_MB": round(flat.nbytes / 1e6, 1)}
+    # the same filters as bitmaps (sdb_index_search_batch_bitmap)
+    from semadb_amd import vamana
+    bm = vamana.FilterBitmaps.from_sets(filt)
+    for _ in range(2):
+        ix.search_batch(queries[0], 10, 75, filters=bm)
+        torch.cuda.synchronize()
+    ix.profile_read()
+    dt = 0.0
+    for b in range(1, 4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix.search_batch(queries[b], 10, 75, filters=bm)
+        torch.cuda.synchronize()
+        dt += time.perf_counter() - t0
+    dt /= 3
+    kms = float(np.mean(ix.profile_read()))
+    out["filter_%d" % size]["as_bitmaps"] = {"kernel_ms": round(kms, 4), "call_ms": round(dt * 1e3, 2),
+                                             "upload_MB": round(bm.words.nbytes / 1e6, 1)}
 print(json.dumps(out, indent=1))
