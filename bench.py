@@ -721,6 +721,20 @@ def latency_points(a, ix, queries):
                     ts.append((time.perf_counter() - t0) * 1e3)
                 res[str(nq)] = round(float(np.median(ts)), 4)
             out[name] = res
+        # the REST path end to end: query in host memory, answer in host memory, one blocking SDB_MEM_HOST call
+        ix.set_tuning("wide_walk", 0)
+        host_q = flat_q[:4096].cpu().numpy()
+        res = {}
+        for nq in (1, 16, 64, 256):
+            ts = []
+            for i in range(33):
+                qn = host_q[(i * nq) % (4096 - nq):(i * nq) % (4096 - nq) + nq]
+                t0 = time.perf_counter()
+                ix.search_batch(qn, a.k, a.search_size)
+                if i >= 3:
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            res[str(nq)] = round(float(np.median(ts)), 4)
+        out["host_memory_call"] = res
     finally:
         ix.set_tuning("wide_walk", 0)
     return out

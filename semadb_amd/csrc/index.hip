@@ -426,19 +426,30 @@ constexpr uint32_t kWidePullQueries = SDB_WIDE_PULL;
 #endif
 constexpr int kWideWaves = SDB_WIDE_WAVES;
 static bool wide_walk(const SearchArgs &a, uint32_t nq) {
-  if (a.wide_mode == 1 || a.filt_off || a.vis_slots || a.dcache || a.pq_codes || !search_uses_hash(a, nq)) return false;
-  return a.wide_mode == 2 || nq <= kWideMaxQueries;
+  if (a.wide_mode == 1 || a.vis_slots || a.dcache || a.pq_codes || !search_uses_hash(a, nq)) return false;
+  return a.wide_mode == 2 || nq <= 2 * kWideMaxQueries;
 }
-template <int NG, bool L2>
-static int launch_wide(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
-  using D = PlainWideDist<NG, L2, kWideWaves>;
+template <int NG, bool L2, int W>
+static int launch_wide_w(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  using D = PlainWideDist<NG, L2, W>;
   const size_t lds = HashVisited<kHashCap>::kWords * sizeof(uint32_t) + D::kLdsBytes;
   SearchArgs b = a;
   // the pull-ahead doubles the call's traffic: for calls that leave most of the memory system idle
-  b.wide_pull = (nq <= kWidePullQueries && kWideWaves == 16 && a.wide_pull != 2) ? 1u : 0u;
-  hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, kWideWaves>), dim3(nq), dim3(64 * kWideWaves), lds, stream, b);
+  b.wide_pull = (nq <= kWidePullQueries && W == 16) ? 1u : 0u;
+  if (a.filt_off)  // the filtered walk (search.go:33-51,93-95): a hybrid REST query is one query with a filter
+    hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, W, true>), dim3(nq), dim3(64 * W),
+                       lds + HashVisited<kHashCapResult>::kWords * sizeof(uint32_t), stream, b);
+  else
+    hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, W, false>), dim3(nq), dim3(64 * W), lds, stream, b);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
+}
+// up to 256 queries: 16 waves per query (one workgroup per CU); up to 512: 8 waves (two per CU: 0.56 ms per call against
+// 0.66 for one wave per query and 0.78 for 16 waves)
+template <int NG, bool L2>
+static int launch_wide(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  if (nq <= kWideMaxQueries || kWideWaves != 16) return launch_wide_w<NG, L2, kWideWaves>(a, nq, stream);
+  return launch_wide_w<NG, L2, 8>(a, nq, stream);
 }
 
 template <int NG, bool L2>

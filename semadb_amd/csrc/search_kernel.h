@@ -1517,22 +1517,33 @@ __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_
 
 // The workgroup-per-query walk of a plain store (PlainWideDist): W waves, wave 0 walks.  Dynamic LDS: the visited set's
 // table, then the policy's hop scratch and command word.
-template <int NG, bool L2, int W>
+template <int NG, bool L2, int W, bool FILT>
 __global__ __launch_bounds__(64 * W) void k_greedy_search_wide(const SearchArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t q = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  // dynamic LDS: [search set's hash table][filtered: the result set's][the policy's hop scratch and command words]
+  constexpr uint32_t kRWords = FILT ? HashVisited<kHashCapResult>::kWords : 0;
   PlainWideDist<NG, L2, W> dist;
-  dist.init_wave(a, q, lane, wave, lds_f + HashVisited<kHashCap>::kWords);
+  dist.init_wave(a, q, lane, wave, lds_f + HashVisited<kHashCap>::kWords + kRWords);
   HashVisited<kHashCap> hv;
-  if (wave == 0)
+  HashVisited<kHashCapResult> rv;
+  if (wave == 0) {
     hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), a.bitsets + (size_t)q * a.words_per_query, a.words_per_query, lane,
                    a.hash_limit);
+    if constexpr (FILT)
+      rv.init_nosync(reinterpret_cast<uint32_t *>(lds_f) + HashVisited<kHashCap>::kWords,
+                     a.rbitsets + (size_t)q * a.words_per_query, a.words_per_query, lane, a.hash_limit);
+  }
   __syncthreads();
   if (wave != 0) return dist.serve(a, lane);
-  NoVisited rv;
-  search_body<PlainWideDist<NG, L2, W>, 2, false>(a, q, lane, dist, hv, rv);
+  if constexpr (FILT) {
+    search_body<PlainWideDist<NG, L2, W>, 2, true>(a, q, lane, dist, hv, rv);
+  } else {
+    NoVisited nv;
+    search_body<PlainWideDist<NG, L2, W>, 2, false>(a, q, lane, dist, hv, nv);
+  }
   dist.finish(lane);
 }
 

@@ -77,6 +77,13 @@ def test_filtered_batch_parity(oracle, metric, d, n, L, k):
         assert int(tr.n_hop[i]) == o_tr.n_hop and int(tr.n_dist[i]) == o_tr.n_dist, i
         assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), i
         assert set(int(v) for v in o_ids) <= filters[i]
+    # a call of 24 queries takes the workgroup-per-query walk (k_greedy_search_wide, filtered form); one wave per query
+    # walks the same path
+    ix.set_tuning("wide_walk", 1)
+    w_ids, w_d, w_c, wtr = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+    assert np.array_equal(w_ids, g_ids) and np.array_equal(bits(w_d), bits(g_d)) and np.array_equal(w_c, g_c)
+    assert np.array_equal(wtr.visit_ids, tr.visit_ids) and np.array_equal(wtr.n_dist, tr.n_dist)
+    ix.set_tuning("wide_walk", 0)
     # the table's ids are consecutive, so the filter ids above were resolved to slots on the device (k_filter_resolve);
     # the host's hash-map translation gives the same walk
     ix.set_tuning("host_filters", 1)

@@ -92,6 +92,18 @@ def compare_searches(rng, g, o, d, kind, L, live, tag, metric=None):
             assert np.array_equal(ids_g[i, :len(o_ids)], o_ids), (tag, "filtered ids", i)
             assert np.array_equal(bits(d_g[i, :len(o_ids)]), bits(o_d)), (tag, "filtered dist bits", i)
             assert np.array_equal(tr.visit_ids[i, :o_tr.n_hop], o_vis), (tag, "filtered visit order", i)
+        # the same filters as bitmaps (sdb_index_search_batch_bitmap), and both walks forms for the id lists
+        bm = vamana.FilterBitmaps.from_sets([set(v for v in f if v < 2 ** 30) for f in filters], align=int(rng.choice([1, 64])))
+        trimmed = [set(v for v in f if v < 2 ** 30) for f in filters]
+        b_ids, b_d, b_c, btr = g.search_batch(q, k, sl, filters=bm, trace=True, visit_cap=2048)
+        l_ids, l_d, l_c, ltr = g.search_batch(q, k, sl, filters=trimmed, trace=True, visit_cap=2048)
+        assert np.array_equal(b_ids, l_ids) and np.array_equal(bits(b_d), bits(l_d)) and np.array_equal(b_c, l_c), (tag, "bitmap filters")
+        assert np.array_equal(btr.visit_ids, ltr.visit_ids) and np.array_equal(btr.n_dist, ltr.n_dist), (tag, "bitmap filters, visits")
+        g.set_tuning("wide_walk", 1)
+        w_ids, w_d, w_c, wtr = g.search_batch(q, k, sl, filters=filters, trace=True, visit_cap=2048)
+        g.set_tuning("wide_walk", 0)
+        assert np.array_equal(w_ids, ids_g) and np.array_equal(bits(w_d), bits(d_g)) and np.array_equal(w_c, c_g), (tag, "one wave per query, filtered")
+        assert np.array_equal(wtr.visit_ids, tr.visit_ids), (tag, "one wave per query, filtered visits")
 
 
 CURRENT = {}
