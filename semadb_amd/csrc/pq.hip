@@ -602,6 +602,51 @@ __global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ v
   if (v < n) codes[v * M + i] = (uint8_t)best_id;
 }
 
+// Sub-vectors shorter than 32 floats (M = 32, 192 at d = 768) are nothing but the sequential tail chain: 2 x sub_len
+// dependent operations per centroid and thread, which no packing inside ONE pair can shorten.  Two VECTORS per thread
+// can: the chains of vector 2t and 2t + 1 against the same centroid advance together in the halves of one packed
+// subtract and one packed FMA (the centroid element broadcast to both halves) -- each half is the reference's own
+// operation on its own chain.  Half the instructions per (vector, centroid).
+template <bool L2>
+__global__ __launch_bounds__(256) void k_pq_encode_pair(const float *__restrict__ vecs, uint64_t n, uint32_t dim,
+                                                        const float *__restrict__ cent, uint32_t M, uint32_t K,
+                                                        uint32_t sub_len, int metric, uint8_t *__restrict__ codes) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t va = 2 * t, vb = 2 * t + 1;
+  const uint32_t i = blockIdx.y;
+  const float *sa = vecs + (va < n ? va : n - 1) * dim + (size_t)i * sub_len;
+  const float *sb = vecs + (vb < n ? vb : n - 1) * dim + (size_t)i * sub_len;
+  pq_f2v x[31];
+#pragma unroll
+  for (int e = 0; e < 31; e++) x[e] = (uint32_t)e < sub_len ? pq_f2v{sa[e], sb[e]} : pq_f2v{0.0f, 0.0f};
+  float best_a = FLT_MAX, best_b = FLT_MAX;
+  uint32_t id_a = 0, id_b = 0;
+  for (uint32_t j = 0; j < K; j++) {
+    const float *__restrict__ u = cent + ((size_t)i * K + j) * sub_len;
+    pq_f2v tt = {0.0f, 0.0f};
+#pragma unroll
+    for (int e = 0; e < 31; e++)
+      if ((uint32_t)e < sub_len) {
+        const pq_f2v y = {u[e], u[e]};
+        if constexpr (L2) {
+          const pq_f2v d = x[e] - y;
+          tt = __builtin_elementwise_fma(d, d, tt);
+        } else {
+          tt = __builtin_elementwise_fma(x[e], y, tt);
+        }
+      }
+    // dist_regs with no whole block: ((0 + t) + 0) + (0 + 0)
+    pq_f2v r0 = pq_f2v{0.0f, 0.0f} + tt;
+    r0 = (r0 + pq_f2v{0.0f, 0.0f}) + pq_f2v{0.0f, 0.0f};
+    float da = r0[0], db = r0[1];
+    if constexpr (!L2) da = metric_finish(da, metric), db = metric_finish(db, metric);
+    if (da < best_a) best_a = da, id_a = j;
+    if (db < best_b) best_b = db, id_b = j;
+  }
+  if (va < n) codes[va * M + i] = (uint8_t)id_a;
+  if (vb < n) codes[vb * M + i] = (uint8_t)id_b;
+}
+
 template <int NB>
 static void launch_lut_t(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
   const dim3 grid((pq->K + 255) / 256, pq->M, (unsigned)((nq + kLutQT - 1) / kLutQT));
@@ -615,6 +660,16 @@ static void launch_lut_t(const sdb_pq *pq, const float *d_queries, uint64_t nq, 
 
 template <int NB>
 static void launch_encode_t(const sdb_pq *pq, const float *d_vecs, uint64_t n, uint8_t *d_codes, hipStream_t stream) {
+  if constexpr (NB == 0) {
+    const dim3 pgrid((unsigned)(((n + 1) / 2 + 255) / 256), pq->M);
+    if (pq->metric == SDB_METRIC_EUCLIDEAN)
+      hipLaunchKernelGGL((k_pq_encode_pair<true>), pgrid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M, pq->K,
+                         pq->sub_len, pq->metric, d_codes);
+    else
+      hipLaunchKernelGGL((k_pq_encode_pair<false>), pgrid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M, pq->K,
+                         pq->sub_len, pq->metric, d_codes);
+    return;
+  }
   const dim3 grid((unsigned)((n + 255) / 256), pq->M);
   if (pq->metric == SDB_METRIC_EUCLIDEAN)
     hipLaunchKernelGGL((k_pq_encode_t<true, NB>), grid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids,
