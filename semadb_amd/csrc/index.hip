@@ -414,13 +414,18 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 // one wave per query: 0.538 / 0.598 ms): 2 waves 0.78 / 0.86, 4 waves 0.536 / 0.607, 8 waves 0.410 / 0.469, 16 waves
 // 0.361 / 0.416 ms -- a hop's ~50 rows are 2 pairs per wave then, one short burst of loads each.  With the helpers
 // pulling the likely next hop's rows through L2 (PlainWideDist::pull_ahead): 0.336 / 0.419 ms; 0.371 at 128 queries
-// (0.408 without).  Past 256 queries the one-wave kernel wins (512: 0.66 against 0.80 ms).  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
+// (0.408 without); with the helpers COMPUTING that hop's distances ahead (compute_ahead): 0.316 / 0.405 ms, 0.362 at 128.
+// Past 256 queries eight waves per query (0.58 ms at 512 against 0.66 for one wave per query, 0.80 for sixteen).  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
 // rounds of thousands).
 constexpr uint32_t kWideMaxQueries = 256;
 #ifndef SDB_WIDE_PULL
 #define SDB_WIDE_PULL 256
 #endif
 constexpr uint32_t kWidePullQueries = SDB_WIDE_PULL;
+#ifndef SDB_WIDE_AHEAD
+#define SDB_WIDE_AHEAD 256
+#endif
+constexpr uint32_t kWideAheadQueries = SDB_WIDE_AHEAD;
 #ifndef SDB_WIDE_WAVES
 #define SDB_WIDE_WAVES 16
 #endif
@@ -435,7 +440,9 @@ static int launch_wide_w(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   const size_t lds = HashVisited<kHashCap>::kWords * sizeof(uint32_t) + D::kLdsBytes;
   SearchArgs b = a;
   // the pull-ahead doubles the call's traffic: for calls that leave most of the memory system idle
-  b.wide_pull = (nq <= kWidePullQueries && W == 16) ? 1u : 0u;
+  // very few queries: the helpers compute the likely next hop's distances ahead (2); few: they only pull its rows
+  // through L2 (1); both trade traffic for latency
+  b.wide_pull = W != 16 ? 0u : nq <= kWideAheadQueries ? 2u : nq <= kWidePullQueries ? 1u : 0u;
   if (a.filt_off)  // the filtered walk (search.go:33-51,93-95): a hybrid REST query is one query with a filter
     hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, W, true>), dim3(nq), dim3(64 * W),
                        lds + HashVisited<kHashCapResult>::kWords * sizeof(uint32_t), stream, b);

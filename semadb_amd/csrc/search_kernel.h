@@ -418,11 +418,14 @@ struct PlainDist {
 // publishes the rank-compacted slot list (the one hop_fast builds anyway), every wave takes a contiguous share of it,
 // two rows per instruction, and leaves the raw sums at the rows' ranks; the walker reads them back.  Same pairs, same
 // arithmetic, same bits, same visit order; two workgroup barriers per hop.
+constexpr uint32_t kWideAheadPad = 24;  // spare entry + rows_range's dump behind the 64 positions (kHopSlots = 64 + U, U <= 8)
 struct WideShared {
-  uint32_t cnt;  // pending rows of the hop the walker has published; kWideDone: the walk is over
-  uint32_t pad;
+  uint32_t cnt;        // pending rows of the hop the walker has published; kWideDone: the walk is over
+  uint32_t ahead_done; // helper waves that have finished their share of the distances ahead, ever (monotonic)
   unsigned long long ahead;  // adjacency row of the candidate the walk will most likely expand next (0: none)
   uint32_t dump[64];         // where the helpers retire the words they pulled through the cache
+  uint32_t ahead_slot[64 + kWideAheadPad];  // that row's slots by edge position
+  float ahead_res[64 + kWideAheadPad];      // raw sums of distFn(query, neighbour) by edge position
 };
 constexpr uint32_t kWideDone = 0xFFFFFFFFu;
 
@@ -430,26 +433,34 @@ template <int NG, bool L2, int W>
 struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
   // a wave's share of a hop is at most 64 / W rows (rounded up to even): one chunk of 32 / W pairs holds it
   using Base = PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)>;
-  // A call of few queries has bandwidth to spare and a dependent chain to shorten: with every hop the walker also fetches
-  // the adjacency row of the candidate that will be expanded next unless this hop's neighbours overtake it (search_body);
-  // when the guess holds the next hop starts with its row in a register.  256 bytes per hop, never used for a decision
-  // before the real pick has been made.
+  // A call of few queries has bandwidth to spare and a dependent chain to shorten.  70 % of the hops expand the candidate
+  // that was first in line one hop earlier (tools/spec_hits.py), so with every hop the walker names that candidate
+  // (search_body, Dist::kSpeculate) and fetches its adjacency row; while it inserts this hop's points the helper waves
+  //   wide_pull = 1: pull the vectors of that candidate's neighbours through the XCD's L2, one word per 64-byte sector,
+  //   wide_pull = 2: COMPUTE the raw distances to all of its neighbours (by edge position, visited or not),
+  // and a hop whose pick is the guess starts with its row in a register and -- in mode 2 -- its distances in LDS: what
+  // is left of it is the visited-set test and AddWithLimit.  Nothing is decided on a guess: the pick, the visited set,
+  // the order of the inserts are the walk's own; a wrong guess costs traffic.
   static constexpr bool kSpeculate = true;
   static constexpr size_t kLdsBytes = Base::kLdsBytes + sizeof(WideShared);
+  static constexpr int kAheadPer = ((64 + W - 2) / (W - 1) + 1) & ~1;  // rows ahead per helper wave (even), W - 1 helpers
   WideShared *sh;
   int wave;
   const uint32_t *pub_ahead;
+  bool hit_cur;         // walker: this hop expands the candidate named one hop ago, and its distances were computed ahead
+  bool ahead_computed;  // walker: the helpers were handed a row to compute ahead during the last handshake
+  uint32_t ahead_expect;  // walker: value of sh->ahead_done once every helper has finished what it was handed
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lds) {
     Base::init(a, q, lane, lds);  // every wave keeps the query in its registers
     sh = reinterpret_cast<WideShared *>(reinterpret_cast<char *>(lds) + Base::kLdsBytes);
-    wave = w;
-    pub_ahead = nullptr;
+    wave = w, args_ = &a;
+    pub_ahead = nullptr, hit_cur = false, ahead_computed = false, ahead_expect = 0;
+    if (w == 0 && lane == 0) sh->ahead_done = 0;
   }
-  __device__ __forceinline__ void speculation(bool, const uint32_t *spec_rowp) { pub_ahead = spec_rowp; }
-  // Calls of very few queries (SearchArgs::wide_pull) leave the memory system idle, and 70 % of the hops expand the
-  // candidate that was first in line one hop earlier: while the walker inserts this hop's points the helpers pull the
-  // vectors of THAT candidate's neighbours through the XCD's L2, one 4-byte read per 64-byte sector, so that the next
-  // hop's row loads -- the longest wait of a hop -- find them there.  Nothing is decided on these reads.
+  __device__ __forceinline__ void speculation(bool use, const uint32_t *spec_rowp) {
+    hit_cur = use && ahead_computed;
+    pub_ahead = spec_rowp;
+  }
   __device__ __forceinline__ void pull_ahead(const SearchArgs &a, const uint32_t *rowp, int lane, uint32_t (&got)[2]) {
     const uint32_t sectors = a.ld / 16;  // 64-byte sectors of a slab row
     got[0] = got[1] = 0u;
@@ -464,6 +475,23 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
       }
     }
   }
+  // helper waves, mode 2: this wave's share of the distances to the neighbours of the candidate ahead
+  __device__ __forceinline__ void compute_ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+    const uint32_t nb = rowp[lane];
+    const uint64_t m = __ballot(nb != kNoSlot);
+    const int deg = __popcll(m);  // rows are padded with kNoSlot behind their edges
+    sh->ahead_slot[lane] = nb != kNoSlot ? nb : 0u;  // every helper writes the same words
+    if (lane == deg - 1) sh->ahead_slot[deg] = nb;  // the spare entry behind the list
+    wave_lds_sync();
+    const int first = (wave - 1) * kAheadPer;
+    const int count = deg - first < kAheadPer ? deg - first : kAheadPer;
+    if (count > 0) {
+      if (a.tail) this->template rows_range<true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
+      else this->template rows_range<false>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
+    }
+    wave_lds_sync();  // the sums before the count
+    if (lane == 0) atomicAdd(&sh->ahead_done, 1u);
+  }
   // this wave's share of `cnt` pending rows: contiguous ranks, an even number per wave so that only the list's last row
   // can be the odd one out (its spare entry sits behind the list)
   __device__ __forceinline__ void share(const SearchArgs &a, int cnt, int lane) {
@@ -477,9 +505,27 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
     else this->template rows_range<false>(a, s_slot, s_res, first, count, lane);
   }
   // ---- the walker (wave 0)
+  // one handshake with the helpers: `cnt` pending rows to share (their list is in place) and the row to work ahead on
+  __device__ __forceinline__ void handshake(const SearchArgs &a, int cnt, int lane) {
+    const uint32_t *ahead = a.wide_pull ? pub_ahead : nullptr;
+    if (lane == 0) sh->cnt = (uint32_t)cnt, sh->ahead = reinterpret_cast<unsigned long long>(ahead);
+    ahead_computed = a.wide_pull == 2 && ahead != nullptr;
+    if (ahead_computed) ahead_expect += (uint32_t)(W - 1);
+    pub_ahead = nullptr;  // one hand-over per speculation (the start node's overflow chunks carry none)
+    __syncthreads();  // B1: the list is published
+    share(a, cnt, lane);
+    __syncthreads();  // B2: every share has been written
+  }
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
     const int cnt = __popcll(pend);
     const bool mine = (pend >> lane) & 1ull;
+    if (hit_cur) {  // this row's distances were computed while the last hop's points were inserted: by edge position
+      hit_cur = false;
+      while (__atomic_load_n(&sh->ahead_done, __ATOMIC_RELAXED) != ahead_expect) __builtin_amdgcn_s_sleep(1);
+      const float raw = sh->ahead_res[lane];
+      handshake(a, 0, lane);  // nothing to share; the helpers get the next row to work ahead on
+      return mine ? metric_finish(raw, a.metric) : 0.0f;
+    }
     const uint32_t rank =
         __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
     uint32_t *s_slot = this->hs;
@@ -488,11 +534,18 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
       s_slot[rank] = nb;
       if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
     }
-    if (lane == 0) sh->cnt = (uint32_t)cnt, sh->ahead = a.wide_pull ? reinterpret_cast<unsigned long long>(pub_ahead) : 0ull;
-    __syncthreads();  // B1: the list is published
-    share(a, cnt, lane);
-    __syncthreads();  // B2: every share has been written
+    handshake(a, cnt, lane);
     return mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
+  }
+  // a chunk without a new neighbour: the helpers still get the next row to work ahead on
+  __device__ __forceinline__ void skip(int lane) {
+    hit_cur = false;
+    if (pub_ahead) handshake_skip(lane);
+  }
+  SearchArgs const *args_;  // for skip(), which search_body calls without the arguments
+  __device__ __forceinline__ void handshake_skip(int lane) {
+    if (args_->wide_pull == 2) handshake(*args_, 0, lane);
+    else pub_ahead = nullptr;
   }
   __device__ __forceinline__ void finish(int lane) {
     if (lane == 0) sh->cnt = kWideDone;
@@ -506,10 +559,11 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
       const uint32_t cnt = sh->cnt;
       if (cnt == kWideDone) return;
       const uint32_t *ahead = reinterpret_cast<const uint32_t *>(sh->ahead);
-      if (a.wide_pull) sh->dump[lane] = got[0] ^ got[1];  // the last hop's pulls have long arrived: retire them
+      if (a.wide_pull == 1) sh->dump[lane] = got[0] ^ got[1];  // the last hop's pulls have long arrived: retire them
       share(a, (int)cnt, lane);
       __syncthreads();  // B2
-      if (a.wide_pull) pull_ahead(a, ahead, lane, got);
+      if (a.wide_pull == 1) pull_ahead(a, ahead, lane, got);
+      else if (a.wide_pull == 2 && ahead) compute_ahead(a, ahead, lane);
     }
   }
 };
