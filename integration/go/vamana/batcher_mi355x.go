@@ -71,6 +71,7 @@ type searchBatcher struct {
 	streak   int
 	stopped  bool
 	stopping atomic.Bool // the same, readable without b.mu on the fast path
+	busy     atomic.Int32 // workers inside a device call
 	wg       sync.WaitGroup
 }
 
@@ -282,7 +283,9 @@ func (b *searchBatcher) loop() {
 			if first != 0 {
 				age = time.Duration(time.Now().UnixNano() - first)
 			}
-			if first != 0 && (age >= b.window || b.stopped) {
+			// ... or at once when no device batch is running: waiting then buys nothing and the window would only be
+			// added to the request's latency (a lone Search call); under load arrivals pile up behind the running batch
+			if first != 0 && (age >= b.window || b.stopped || b.busy.Load() == 0) {
 				if got := b.seal(c); got < uint32(b.maxBatch) {
 					b.rotateLocked(c, got) // ours to seal
 				} else {
@@ -307,7 +310,10 @@ func (b *searchBatcher) loop() {
 		}
 		b.mu.Unlock()
 		if fb != nil {
+			b.busy.Add(1)
 			b.flushSlab(fb)
+			b.busy.Add(-1)
+			b.cond.Signal() // what piled up behind this batch can go now
 			b.mu.Lock()
 			b.free = append(b.free, fb)
 			if b.cur.Load() == nil {
@@ -327,8 +333,11 @@ func (b *searchBatcher) loop() {
 					}
 				}
 				others = rest
+				b.busy.Add(1)
 				b.flush(batch)
+				b.busy.Add(-1)
 			}
+			b.cond.Signal()
 		}
 	}
 }

@@ -525,7 +525,10 @@ class SearchBatcher {
           Batch *c = cur_.load(std::memory_order_acquire);
           const int64_t first = c ? c->t_first_ns.load(std::memory_order_relaxed) : 0;
           const int64_t age = first ? nowNs() - first : 0;
-          if (c && first && (age >= window_.count() * 1000 || stop_)) {
+          // ... or at once when no device batch is running: waiting then buys nothing, the window would only be added to
+          // the request's latency (a lone Search call: 0.37 ms instead of 0.37 + window).  Under load a batch is running,
+          // arrivals pile up behind it for a window or until it ends, and the batches stay large.
+          if (c && first && (age >= window_.count() * 1000 || stop_ || busy_.load(std::memory_order_acquire) == 0)) {
             const uint32_t got = seal(c);
             if (got < max_batch_) rotateLocked(c, got);  // ours to seal (otherwise the submit that filled it is rotating)
             else lk.unlock(), std::this_thread::yield(), lk.lock();
@@ -541,13 +544,19 @@ class SearchBatcher {
         }
       }
       if (b) {
+        busy_.fetch_add(1, std::memory_order_acq_rel);
         runBatch(b, (uint64_t *)p_ids, (float *)p_d, (uint32_t *)p_c);
+        busy_.fetch_sub(1, std::memory_order_acq_rel);
+        qcv_.notify_one();  // what piled up behind this batch can go now
         std::lock_guard<std::mutex> g(qmu_);
         free_.push_back(b);
         if (!cur_.load(std::memory_order_acquire)) cur_.store(takeFree(), std::memory_order_release);
         fcv_.notify_all();
       } else if (!others.empty()) {
+        busy_.fetch_add(1, std::memory_order_acq_rel);
         runQueued(others);
+        busy_.fetch_sub(1, std::memory_order_acq_rel);
+        qcv_.notify_one();
       }
     }
   }
@@ -663,6 +672,7 @@ class SearchBatcher {
   size_t max_batch_, cap_ = 0;
   std::chrono::microseconds window_;
   std::atomic<uint64_t> n_batches_{0}, n_queries_{0};
+  std::atomic<int> busy_{0};  // workers inside a device call
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,4 +1,2 @@
-timeout 300 python -m pytest tests/test_gpu_search.py tests/test_gpu_nonfinite.py tests/test_gpu_filter.py -m gpu -q -x --timeout 120 > gpurun_out/r04ac_tests.log 2>&1; echo "tests rc $?" > gpurun_out/r04ac_rc.log
-timeout 300 python tools/bench_latency.py > gpurun_out/r04ac_latency_ahead64.json 2>> gpurun_out/r04ac.err; echo "lat rc $?" >> gpurun_out/r04ac_rc.log
-SEMADB_AMD_LIB=$PWD/build/ahead0/libsemadb_amd.so timeout 300 python tools/bench_latency.py > gpurun_out/r04ac_latency_ahead0.json 2>> gpurun_out/r04ac.err
-SEMADB_AMD_LIB=$PWD/build/ahead256/libsemadb_amd.so timeout 300 python tools/bench_latency.py > gpurun_out/r04ac_latency_ahead256.json 2>> gpurun_out/r04ac.err
+timeout 1500 python -m pytest tests -m gpu -q -x --timeout 1200 > gpurun_out/r04ad_full_gpu_tests.log 2>&1; echo "tests rc $?" > gpurun_out/r04ad_rc.log
+for seed in 411 412; do timeout 400 python tools/fuzz_parity.py --trials 200 --seed $seed > gpurun_out/r04ad_fuzz_$seed.json 2> gpurun_out/r04ad_fuzz_$seed.err; echo "seed $seed rc $?" >> gpurun_out/r04ad_rc.log; done
