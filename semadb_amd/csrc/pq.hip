@@ -569,7 +569,12 @@ __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ quer
   float rt[31];
 #pragma unroll
   for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? row[NB * 32 + e] : 0.0f;
-  for (uint32_t q = q0; q < q1; q++) {
+  // a fixed trip count: the sub-vectors of all kLutQT queries are wave-uniform scalar loads, and unrolled the compiler
+  // issues them together instead of one query's, a wait, the next query's
+  (void)q1;
+#pragma unroll
+  for (uint32_t k = 0; k < kLutQT; k++) {
+    const uint32_t q = q0 + k < nq ? q0 + k : nq - 1;  // past the end: the last query again (the same value is stored twice)
     const float *x = queries + (size_t)q * dim + (size_t)i * sub_len;
     float d = dist_regs<L2, NB>(r, x, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);

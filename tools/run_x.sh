@@ -1,2 +1,2 @@
-timeout 1500 python -m pytest tests -m gpu -q -x --timeout 1200 > gpurun_out/r04ad_full_gpu_tests.log 2>&1; echo "tests rc $?" > gpurun_out/r04ad_rc.log
-for seed in 411 412; do timeout 400 python tools/fuzz_parity.py --trials 200 --seed $seed > gpurun_out/r04ad_fuzz_$seed.json 2> gpurun_out/r04ad_fuzz_$seed.err; echo "seed $seed rc $?" >> gpurun_out/r04ad_rc.log; done
+timeout 600 python -m pytest tests/test_gpu_host_mirror.py tests/test_gpu_cluster.py -m gpu -q -x --timeout 300 > gpurun_out/r04ae_host_tests.log 2>&1; echo "tests rc $?" > gpurun_out/r04ae_rc.log
+timeout 1500 bash tools/collect_profiles.sh r04b > gpurun_out/r04b_collect.log 2>&1; echo "collect rc $?" >> gpurun_out/r04ae_rc.log
