@@ -874,6 +874,17 @@ def host_rates(a, ix, queries, k, L, last_device_result):
                                 "request goroutines), coalesced by semadb_host.hpp SearchBatcher into host-memory " \
                                 "batches of <= %d, %d batches in flight; mean device batch %.0f queries; rc %d" % (
                                     threads, depth, nq, workers, served.value / max(1, batches.value), rc)
+    # the other end of the load range: 1 and 8 requests outstanding (a lone REST client; a handful).  The batcher seals a
+    # partial batch at once when no device batch is running, so a lone request does not wait out the window
+    light = {}
+    for t_, d_ in ((1, 1), (8, 1)):
+        q2, b2, s2, p50b, p99b = C.c_double(0), C.c_uint64(0), C.c_uint64(0), C.c_double(0), C.c_double(0)
+        rc2 = hb.sdb_hostbench_batcher(ix._h, d, flat_q.ctypes.data, nb * nq, k, L, t_, d_, nq, 300, workers, 0.5, None, None,
+                                       C.byref(q2), C.byref(b2), C.byref(s2), C.byref(p50b), C.byref(p99b))
+        light["%d_outstanding" % (t_ * d_)] = {"p50_us": round(p50b.value, 1), "p99_us": round(p99b.value, 1),
+                                               "qps": round(q2.value, 1), "mean_batch": round(s2.value / max(1, b2.value), 2),
+                                               "rc": rc2}
+    out["batcher_light_load"] = light
     # the batcher's answers are the same answers: compare the first batch with a direct call
     ids0, _, c0, _ = ix.search_batch(q_np[0], k, L)
     out["batcher_matches_direct_call"] = bool(np.array_equal(first_ids[:nq], ids0) and np.array_equal(first_c[:nq], c0))
