@@ -189,7 +189,8 @@ typedef struct {
  * query.SearchSize; search_size < limit is an error (search.go:23-25).
  * Optional filter (the roaring bitmap argument): filter_offsets[nq+1] into filter_ids, each
  * query's ids ascending; NULL = no filter.  Filter arrays are host memory (pinned -- sdb_host_alloc -- they go up
- * in one DMA); for a table with consecutive ids they are resolved to slots on the device.
+ * in one DMA); they are resolved to slots on the device (a subtraction for a table with consecutive ids, a probe of
+ * the committed view's id -> slot table otherwise).
  * Outputs: out_ids[nq*limit], out_dists[nq*limit] (ascending distance, start node removed),
  * out_counts[nq].  HybridScore = -1 * dist * weight is left to the caller (vamana.go:303). */
 int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
@@ -205,7 +206,8 @@ int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uin
  * million is an eighth of the bytes of its id list in this form -- what a large filter costs is its upload.  Unknown ids
  * (bits outside the table) are skipped like GetMany does (itemcache.go:109-128); the seeds are the first searchSize set
  * bits (:41-48).  Filter arrays are host memory; everything else as sdb_index_search_batch, same answers bit for bit.
- * For a table with consecutive ids the bitmaps are expanded to slots on the device; otherwise on the host. */
+ * The bitmaps are expanded to slots on the device (for a table whose ids are not consecutive: to 64-bit ids first,
+ * which the view's id -> slot table resolves). */
 int sdb_index_search_batch_bitmap(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit, uint32_t search_size,
                                   const uint64_t *filter_first_id, const uint64_t *filter_word_offsets,
                                   const uint64_t *filter_words, uint64_t *out_ids, float *out_dists, uint32_t *out_counts,
@@ -238,12 +240,13 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        four-wave walk that keeps it in LDS and registers; 2: M = 192 takes the four-wave variant with
  *                        one query per CU instead of two
  *   SDB_TUNE_WIDE_WALK   the walk of calls with few queries (one REST request is one query, vamana.go:278-310): a
- *                        workgroup of four waves per query -- one walks, all four split every hop's rows -- instead of
- *                        one wave per query.  0 (default): calls of up to 256 queries on a full-precision store,
- *                        unfiltered, vectors of 32 .. 1055 floats; 1: never; 2: always (any number of queries).
+ *                        workgroup of sixteen waves per query -- one walks, all split every hop's rows and compute the
+ *                        likely next hop's distances ahead -- instead of one wave per query (eight waves for 257 .. 512
+ *                        queries).  0 (default): calls of up to 512 queries on a full-precision store, plain or
+ *                        filtered, vectors of 32 .. 1055 floats; 1: never; 2: always (any number of queries).
  *                        Same ids, distance bits, visit order and counters either way.
  *   SDB_TUNE_HOST_FILTERS  != 0: the filter ids of a search are turned into slots by the host (hash map, threads) even
- *                        when the table's ids are consecutive and the device would do it (A/B and parity tests)
+ *                        where the device would do it (A/B and parity tests)
  *   SDB_TUNE_HASH16_PROBES  buckets a key of the 16-bit-cell set may try before the walk spills to the HBM bitset
  *                        (0 = all 15; 1..15).  With 15 that spill is a one-in-ten-million event; a test sets 1 or 2
  *                        to walk through it */

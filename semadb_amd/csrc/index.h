@@ -125,6 +125,20 @@ struct sdb_index {
   // readers: shared from taking `view` until their kernels are enqueued and their event recorded; writers:
   // exclusive while they change the host-side id tables or publish a view
   mutable sdb::ViewMutex view_mu;
+  uint64_t view_gen = 1;  // counts the views published (view_mu held exclusively)
+  // The committed view's id -> slot table on the device, for the filters of a table whose ids are no longer
+  // consecutive (deletes, arbitrary ids): an open-addressing table over view.ids[0, view.n), tombstones left out,
+  // built by the first filtered search of a view and kept until the next view is published.  A search reads it
+  // under the shared view lock, so a rebuild (another view) never meets a reader of the old one.
+  struct IdMap {
+    uint64_t *keys = nullptr;  // 0 = empty cell (0 is no node id)
+    uint32_t *vals = nullptr;
+    uint32_t cells = 0;        // power of two, >= 2 * view.n
+    uint64_t gen = 0;          // the view it was built from; 0 = none
+    std::mutex mu;
+  };
+  mutable IdMap idmap;
+  int ensure_idmap(const View &vw, hipStream_t stream) const;  // view_mu held (shared)
   bool in_tx = false, tx_explicit = false;
   bool tx_dirty = false;  // the open transaction has changed the writer's copy or the host tables (sdb_index_abort_write)
   uint32_t tx_n0 = 0;  // rows at the start of the open transaction

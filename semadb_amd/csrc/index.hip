@@ -183,26 +183,74 @@ __global__ __launch_bounds__(64) void k_compact_rows(const uint32_t *__restrict_
 // The filter of a search is a set of node ids (a roaring bitmap in the reference, search.go:33-51,93); the walk wants
 // slots: per query the slots of the ids that exist, ascending (Contains, :93), and how many of the first searchSize ids
 // exist (the seeds, :41-48).  One wave per query resolves its ids in place -- the compacted slots at the start of the
-// query's own segment -- for a table whose ids are consecutive (id = base + slot: resolving is a subtraction, and
-// ascending ids are ascending slots).  Tables with holes or arbitrary ids keep the host's hash map (below).
+// query's own segment.  MAP = false: a table whose ids are consecutive (id = base + slot: resolving is a subtraction,
+// and ascending ids are ascending slots).  MAP = true: any other table -- a probe of the committed view's id -> slot
+// table (sdb_index::IdMap); rows are appended in the order they arrive, so ascending ids USUALLY are ascending slots,
+// and a query for which they are not raises flags[2] (the host's translation, which sorts, takes the batch then).
 // flags[0]: != 0 when some query's ids are not strictly ascending; flags[1]: one such query.
+__device__ __forceinline__ uint32_t idmap_hash(uint64_t id) { return (uint32_t)((id * 0x9E3779B97F4A7C15ull) >> 32); }
+__global__ void k_idmap_build(const uint64_t *__restrict__ ids, uint32_t n, uint64_t *__restrict__ keys,
+                              uint32_t *__restrict__ vals, uint32_t mask) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint64_t id = ids[s];
+  if (id == 0) return;  // tombstone
+  uint32_t h = idmap_hash(id) & mask;
+  while (true) {
+    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(keys + h), 0ull, (unsigned long long)id);
+    if (old == 0ull || old == id) {
+      vals[h] = s;
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+template <bool MAP>
 __global__ __launch_bounds__(64) void k_filter_resolve(const uint64_t *__restrict__ ids, const uint32_t *__restrict__ off,
                                                        uint64_t base_id, uint32_t view_n, uint32_t search_size,
                                                        uint32_t *__restrict__ slots, uint32_t *__restrict__ fcnt,
-                                                       uint32_t *__restrict__ scnt, uint32_t *__restrict__ flags) {
+                                                       uint32_t *__restrict__ scnt, uint32_t *__restrict__ flags,
+                                                       const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                       uint32_t mask) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
   const uint32_t b = off[q], e = off[q + 1];
   uint32_t pos = 0, ns = 0;
-  bool bad = false;
+  bool bad = false, unsorted = false;
+  int64_t last = -1;  // MAP: the slot of the last id that resolved (wave-uniform)
   for (uint32_t base = b; base < e; base += 64) {
     const uint32_t i = base + lane;
     const bool has = i < e;
     const uint64_t id = has ? ids[i] : 0;
     if (has && i > b && id <= ids[i - 1]) bad = true;
-    const uint64_t s = id - base_id;
-    const bool ok = has && id >= base_id && s < (uint64_t)view_n;  // rows past the committed count do not exist yet
+    uint64_t s = id - base_id;
+    bool ok = has && id >= base_id && s < (uint64_t)view_n;  // rows past the committed count do not exist yet
+    if constexpr (MAP) {
+      ok = false;
+      if (has && id != 0) {
+        uint32_t h = idmap_hash(id) & mask;
+        while (true) {
+          const uint64_t k = keys[h];
+          if (k == id) {
+            s = vals[h], ok = true;
+            break;
+          }
+          if (k == 0) break;
+          h = (h + 1) & mask;
+        }
+      }
+    }
     const uint64_t m = __ballot(ok);
+    if constexpr (MAP) {
+      if (m) {
+        const uint64_t below = m & ((1ull << lane) - 1);
+        const int prev_lane = below ? 63 - __clzll((long long)below) : lane;
+        const uint32_t sp = (uint32_t)__shfl((int)(uint32_t)s, prev_lane, 64);
+        const int64_t prev = below ? (int64_t)sp : last;
+        if (ok && (int64_t)s <= prev) unsorted = true;
+        last = (int64_t)(uint32_t)__shfl((int)(uint32_t)s, 63 - __clzll((long long)m), 64);
+      }
+    }
     if (ok) slots[b + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)s;
     if (base - b < search_size) {  // GetMany(first searchSize ids) skips the unknown ones (itemcache.go:109-128)
       const uint32_t left = search_size - (base - b);
@@ -211,6 +259,7 @@ __global__ __launch_bounds__(64) void k_filter_resolve(const uint64_t *__restric
     pos += (uint32_t)__popcll(m);
   }
   if (__ballot(bad) && lane == 0) atomicOr(flags, 1u), flags[1] = q;
+  if (MAP && __ballot(unsorted) && lane == 0) flags[2] = 1u;
   if (lane == 0) fcnt[q] = pos, scnt[q] = ns;
 }
 
@@ -240,6 +289,7 @@ __device__ __forceinline__ uint64_t lowest_set_bits(uint64_t w, uint32_t k) {  /
   }
   return out;
 }
+template <bool ALL>  // ALL: every bit counts (the ids are resolved afterwards, k_filter_resolve<true>); scnt is not written
 __global__ __launch_bounds__(64) void k_filter_bitmap_count(const uint64_t *__restrict__ words, const uint32_t *__restrict__ woff,
                                                             const uint64_t *__restrict__ first_id, uint64_t base_id,
                                                             uint32_t view_n, uint32_t search_size, uint32_t *__restrict__ fcnt,
@@ -252,7 +302,7 @@ __global__ __launch_bounds__(64) void k_filter_bitmap_count(const uint64_t *__re
   for (uint32_t base = b; base < e; base += 64) {
     const uint32_t w = base + lane;
     const uint64_t word = w < e ? words[w] : 0ull;
-    const uint64_t valid = word & bitmap_valid_mask(f0 + (uint64_t)(w - b) * 64u, base_id, view_n);
+    const uint64_t valid = ALL ? word : (word & bitmap_valid_mask(f0 + (uint64_t)(w - b) * 64u, base_id, view_n));
     uint32_t pc = (uint32_t)__popcll(word), incl = pc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {  // inclusive scan of the words' populations over the lanes
@@ -269,7 +319,10 @@ __global__ __launch_bounds__(64) void k_filter_bitmap_count(const uint64_t *__re
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64), seeds += __shfl_down(seeds, o, 64);
-  if (lane == 0) fcnt[q] = total, scnt[q] = seeds;
+  if (lane == 0) {
+    fcnt[q] = total;
+    if (!ALL) scnt[q] = seeds;
+  }
 }
 // exclusive scan of the per-query counts -> where each query's slot list starts (one workgroup; nq is a batch size)
 __global__ __launch_bounds__(1024) void k_filter_offsets(const uint32_t *__restrict__ cnt, uint32_t nq, uint32_t *__restrict__ off,
@@ -294,10 +347,11 @@ __global__ __launch_bounds__(1024) void k_filter_offsets(const uint32_t *__restr
   for (uint32_t i = t * per; i < min(nq, (t + 1) * per); i++) off[i] = (uint32_t)run, run += cnt[i];
 }
 // pass 2: the slots, ascending, at the query's place in the list
+template <bool IDS>  // IDS: every bit, as the id it stands for (64-bit), for k_filter_resolve<true>
 __global__ __launch_bounds__(64) void k_filter_bitmap_expand(const uint64_t *__restrict__ words, const uint32_t *__restrict__ woff,
                                                              const uint64_t *__restrict__ first_id, uint64_t base_id,
                                                              uint32_t view_n, const uint32_t *__restrict__ off,
-                                                             uint32_t *__restrict__ slots) {
+                                                             uint32_t *__restrict__ slots, uint64_t *__restrict__ ids_out) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
   const uint32_t b = woff[q], e = woff[q + 1];
@@ -306,7 +360,7 @@ __global__ __launch_bounds__(64) void k_filter_bitmap_expand(const uint64_t *__r
   for (uint32_t base = b; base < e; base += 64) {
     const uint32_t w = base + lane;
     const uint64_t id0 = f0 + (uint64_t)(w - b) * 64u;
-    uint64_t valid = w < e ? (words[w] & bitmap_valid_mask(id0, base_id, view_n)) : 0ull;
+    uint64_t valid = w < e ? (IDS ? words[w] : (words[w] & bitmap_valid_mask(id0, base_id, view_n))) : 0ull;
     const uint32_t pc = (uint32_t)__popcll(valid);
     uint32_t incl = pc;
 #pragma unroll
@@ -318,7 +372,8 @@ __global__ __launch_bounds__(64) void k_filter_bitmap_expand(const uint64_t *__r
     while (valid) {
       const int bit = __ffsll((unsigned long long)valid) - 1;
       valid &= valid - 1;
-      slots[at++] = (uint32_t)(id0 + (uint64_t)bit - base_id);
+      if constexpr (IDS) ids_out[at++] = id0 + (uint64_t)bit;
+      else slots[at++] = (uint32_t)(id0 + (uint64_t)bit - base_id);
     }
     pos += __shfl(incl, 63, 64);
   }
@@ -603,6 +658,7 @@ int sdb_index::reserve(uint32_t rows) {
     fresh.keep = true;
     cap = ncap;
     view.adj = r_adj, view.ids = r_ids;
+    view_gen++;
   }
   return SDB_OK;
 }
@@ -660,6 +716,36 @@ int sdb_index::begin_write() {
   return SDB_OK;
 }
 
+int sdb_index::ensure_idmap(const View &vw, hipStream_t stream) const {
+  std::lock_guard<std::mutex> g(idmap.mu);
+  if (idmap.gen == view_gen) return SDB_OK;
+  // every reader of the previous table held the shared view lock over its probe kernel and the wait behind it, and
+  // the view has been published (exclusively) since: nothing reads the old cells any more
+  uint32_t cells = 1024;
+  while (cells < 2ull * vw.n && cells < (1u << 31)) cells <<= 1;
+  if (cells < 2ull * vw.n) return fail(SDB_ERR_INVALID, "too many rows for the id table");
+  idmap.gen = 0;
+  if (cells > idmap.cells) {
+    if (idmap.keys) (void)hipFree(idmap.keys);
+    if (idmap.vals) (void)hipFree(idmap.vals);
+    idmap.keys = nullptr, idmap.vals = nullptr, idmap.cells = 0;
+    if (hipMalloc(&idmap.keys, (size_t)cells * 8) != hipSuccess || hipMalloc(&idmap.vals, (size_t)cells * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      if (idmap.keys) (void)hipFree(idmap.keys);
+      idmap.keys = nullptr;
+      return fail(SDB_ERR_DEVICE, "out of device memory for the id table (%u cells)", cells);
+    }
+    idmap.cells = cells;
+  }
+  SDB_HIP(hipMemsetAsync(idmap.keys, 0, (size_t)idmap.cells * 8, stream));
+  hipLaunchKernelGGL(sdb::k_idmap_build, dim3((vw.n + 255) / 256), dim3(256), 0, stream, vw.ids, vw.n, idmap.keys, idmap.vals,
+                     idmap.cells - 1);
+  SDB_HIP(hipGetLastError());
+  SDB_HIP(hipStreamSynchronize(stream));  // other searches probe it from their own streams
+  idmap.gen = view_gen;
+  return SDB_OK;
+}
+
 int64_t sdb_index::slot_of_committed(uint64_t id, uint32_t view_n) const {
   int64_t s = slot_of(id);
   if ((s < 0 || (uint32_t)s >= view_n) && in_tx) {  // removed or replaced by the open transaction: the committed row is still there for a search on the committed graph
@@ -687,6 +773,7 @@ int sdb_index::commit(hipStream_t stream) {
     std::swap(start_ext_cap, r_start_ext_cap);
     view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
     view.start_ext_n = (uint32_t)h_start_ext.size();
+    view_gen++;
     tx_deleted.clear();
     in_tx = false, tx_explicit = false, tx_dirty = false;
   }
@@ -770,6 +857,7 @@ int sdb_index::publish_full() {
   }
   view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
   view.start_ext_n = (uint32_t)h_start_ext.size();
+  view_gen++;
   tx_deleted.clear();
   in_tx = false, tx_explicit = false, tx_dirty = false;
   return SDB_OK;
@@ -916,6 +1004,8 @@ int sdb_index_destroy(sdb_index *ix) {
   if (ix->d_ids) (void)hipFree(ix->d_ids);
   if (ix->r_adj) (void)hipFree(ix->r_adj);
   if (ix->r_ids) (void)hipFree(ix->r_ids);
+  if (ix->idmap.keys) (void)hipFree(ix->idmap.keys);
+  if (ix->idmap.vals) (void)hipFree(ix->idmap.vals);
   if (ix->r_start_ext) (void)hipFree(ix->r_start_ext);
   if (ix->d_dirty) (void)hipFree(ix->d_dirty);
   if (ix->d_start_ext) (void)hipFree(ix->d_start_ext);
@@ -1185,7 +1275,11 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
   if (bm) {
     // bitmaps: two passes on the device (count, expand) turn them into the same ascending slot lists; only for a table
     // with consecutive ids, where id -> slot is a subtraction
-    if (!(ix->dense_ids && ix->n > 0) || ix->tune_host_filters) return kBitmapNeedsIds;
+    if (ix->n == 0 || vw.n == 0 || ix->tune_host_filters) return kBitmapNeedsIds;
+    // a table whose ids are not consecutive: the bitmaps become id lists ON THE DEVICE (every bit, as the id it stands
+    // for) and those are resolved through the committed view's id -> slot table like uploaded id lists are
+    const bool by_map = !ix->dense_ids;
+    if (by_map && ix->ensure_idmap(vw, stream) != SDB_OK) return kBitmapNeedsIds;
     for (uint64_t q = 0; q < nq; q++)
       if (bm->word_offsets[q + 1] < bm->word_offsets[q]) return fail(SDB_ERR_INVALID, "filter_word_offsets must be non-decreasing");
     const uint64_t total_words = bm->word_offsets[nq] - bm->word_offsets[0];
@@ -1207,20 +1301,38 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
     SDB_HIP(hipMemcpyAsync(d_first, bm->first_id, nq * 8, hipMemcpyHostToDevice, stream));
     if (total_words)
       SDB_HIP(hipMemcpyAsync(d_words, bm->words + bm->word_offsets[0], total_words * 8, hipMemcpyHostToDevice, stream));
-    SDB_HIP(hipMemsetAsync(d_flags, 0, 8, stream));
-    hipLaunchKernelGGL(k_filter_bitmap_count, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
-                       search_size, d_fc, d_sc);
+    SDB_HIP(hipMemsetAsync(d_flags, 0, 16, stream));
+    if (by_map)
+      hipLaunchKernelGGL(k_filter_bitmap_count<true>, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
+                         search_size, d_fc, d_sc);
+    else
+      hipLaunchKernelGGL(k_filter_bitmap_count<false>, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
+                         search_size, d_fc, d_sc);
     hipLaunchKernelGGL(k_filter_offsets, dim3(1), dim3(1024), 0, stream, d_fc, (uint32_t)nq, d_off, d_flags);
     SDB_HIP(hipGetLastError());
     SDB_HIP(hipMemcpyAsync(h_back, d_off + nq, 4, hipMemcpyDeviceToHost, stream));
     SDB_HIP(hipMemcpyAsync(h_back + 1, d_flags, 4, hipMemcpyDeviceToHost, stream));
     SDB_HIP(hipStreamSynchronize(stream));  // the slot list's size; the caller's arrays are free again
     if (h_back[1]) return fail(SDB_ERR_INVALID, "the filters of one batch name more than 2^32 stored ids");
-    SDB_TRY(ws->ensure_filter((size_t)h_back[0] * 4 + 256));
+    const size_t b_sl = up((size_t)h_back[0] * 4);
+    SDB_TRY(ws->ensure_filter(b_sl + (by_map ? (size_t)h_back[0] * 8 : 0) + 256));
     uint32_t *d_sl = static_cast<uint32_t *>(ws->filter);
-    hipLaunchKernelGGL(k_filter_bitmap_expand, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n, d_off,
-                       d_sl);
-    SDB_HIP(hipGetLastError());
+    if (by_map) {
+      uint64_t *d_ids64 = reinterpret_cast<uint64_t *>(static_cast<char *>(ws->filter) + b_sl);
+      hipLaunchKernelGGL(k_filter_bitmap_expand<true>, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
+                         d_off, d_sl, d_ids64);
+      // d_flags[0] is the offsets' overflow word (zero here); the resolve kernel's three words follow it
+      hipLaunchKernelGGL(k_filter_resolve<true>, dim3((unsigned)nq), dim3(64), 0, stream, d_ids64, d_off, base_id, vw.n, search_size, d_sl,
+                         d_fc, d_sc, d_flags + 1, ix->idmap.keys, ix->idmap.vals, ix->idmap.cells - 1);
+      SDB_HIP(hipGetLastError());
+      SDB_HIP(hipMemcpyAsync(h_back, d_flags + 3, 4, hipMemcpyDeviceToHost, stream));
+      SDB_HIP(hipStreamSynchronize(stream));
+      if (h_back[0]) return kBitmapNeedsIds;  // ids and slots disagree on the order somewhere: the host's translation sorts
+    } else {
+      hipLaunchKernelGGL(k_filter_bitmap_expand<false>, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
+                         d_off, d_sl, nullptr);
+      SDB_HIP(hipGetLastError());
+    }
     a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
     a.rbitsets = ws->bitsets + (size_t)nq * words;
   } else if (filtered) {
@@ -1233,10 +1345,14 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
       // are and one wave per query turns them into slots on the device.  What the host did for this -- a hash lookup per
       // id on up to 16 threads, two passes, an upload of the slots -- cost 1.2 ms per batch at 1 000 ids per query next
       // to a 1.5 ms walk, 26 ms at 100 000.  The ids of the open transaction's appended rows resolve to slots past the
-      // committed count and are dropped; deletes end the table's consecutiveness and with it this path.
+      // committed count and are dropped; deletes end the table's consecutiveness (the table below takes over).
       // (the id tables only change under the view lock, which this call holds shared)
-      on_device = ix->dense_ids && ix->n > 0 && total_ids < (1ull << 32) && !ix->tune_host_filters;
+      on_device = ix->n > 0 && vw.n > 0 && total_ids < (1ull << 32) && !ix->tune_host_filters;
     }
+    // Any other table (deletes left holes, arbitrary ids): the same kernel probes the committed view's id -> slot
+    // table, built on the device by the first filtered search of the view (sdb_index::IdMap).
+    const bool by_map = on_device && !ix->dense_ids;
+    if (by_map && ix->ensure_idmap(vw, stream) != SDB_OK) on_device = false;  // no memory for the table: the host's map
     if (on_device) {
       for (uint64_t q = 0; q < nq; q++)
         if (filter_offsets[q + 1] < filter_offsets[q]) return fail(SDB_ERR_INVALID, "filter_offsets must be non-decreasing");
@@ -1257,16 +1373,24 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
       SDB_HIP(hipMemcpyAsync(d_off, h_off, (nq + 1) * 4, hipMemcpyHostToDevice, stream));
       // straight from the caller's array: one DMA when it is pinned (sdb_host_alloc), a staged copy otherwise
       if (total_ids) SDB_HIP(hipMemcpyAsync(d_raw, filter_ids + filter_offsets[0], total_ids * 8, hipMemcpyHostToDevice, stream));
-      SDB_HIP(hipMemsetAsync(d_flags, 0, 8, stream));
-      hipLaunchKernelGGL(k_filter_resolve, dim3((unsigned)nq), dim3(64), 0, stream, d_raw, d_off, base_id, vw.n, search_size, d_sl, d_fc,
-                         d_sc, d_flags);
+      SDB_HIP(hipMemsetAsync(d_flags, 0, 12, stream));
+      if (by_map)
+        hipLaunchKernelGGL(k_filter_resolve<true>, dim3((unsigned)nq), dim3(64), 0, stream, d_raw, d_off, base_id, vw.n, search_size, d_sl,
+                           d_fc, d_sc, d_flags, ix->idmap.keys, ix->idmap.vals, ix->idmap.cells - 1);
+      else
+        hipLaunchKernelGGL(k_filter_resolve<false>, dim3((unsigned)nq), dim3(64), 0, stream, d_raw, d_off, base_id, vw.n, search_size, d_sl,
+                           d_fc, d_sc, d_flags, nullptr, nullptr, 0u);
       SDB_HIP(hipGetLastError());
-      SDB_HIP(hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, stream));
+      SDB_HIP(hipMemcpyAsync(h_flags, d_flags, 12, hipMemcpyDeviceToHost, stream));
       SDB_HIP(hipStreamSynchronize(stream));  // the caller's arrays are free again; an invalid filter is an error, not a search
       if (h_flags[0])
         return fail(SDB_ERR_INVALID, "filter ids of query %llu are not strictly ascending", (unsigned long long)h_flags[1]);
-      a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
-      a.rbitsets = ws->bitsets + (size_t)nq * words;
+      if (h_flags[2]) {
+        on_device = false;  // ids and slots disagree on the order somewhere: the host's translation sorts
+      } else {
+        a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
+        a.rbitsets = ws->bitsets + (size_t)nq * words;
+      }
     }
     std::vector<uint32_t> off_seed(on_device ? 0 : nq + 1, 0), off_filt(on_device ? 0 : nq + 1, 0);
     if (!on_device) {
@@ -1761,6 +1885,7 @@ int sdb_index_compact(sdb_index *ix) {
   }
   ix->view.n = nn, ix->view.adj = ix->r_adj, ix->view.ids = ix->r_ids, ix->view.start_ext = ix->r_start_ext;
   ix->view.start_ext_n = (uint32_t)ix->h_start_ext.size();
+  ix->view_gen++;
   (void)hipDeviceSynchronize();
   return SDB_OK;
 }

@@ -158,6 +158,59 @@ def test_filter_on_rows_stored_out_of_id_order(oracle):
     ix.close()
 
 
+def test_filters_on_a_table_with_holes_resolve_on_the_device(oracle):
+    """after deletes the ids are no longer consecutive: the filter ids are resolved by a probe of the committed view's
+    id -> slot table on the device (sdb_index::IdMap), rebuilt for every published view.  Same answers as the host's
+    translation (tuning host_filters) and as the oracle -- ids of deleted rows and unknown ids are skipped, rows added
+    after the deletes resolve once committed, and a batch for which ids and slots disagree on the order (an id that
+    was deleted and inserted again sits behind later ids) is handed to the host's translation."""
+    rng = np.random.default_rng(404)
+    n, d, L, k = 2000, 32, 50, 10
+    base = unit_rows(rng, n + 300, d)
+    o = build_oracle_index(oracle, base[:n], "cosine", R=32, L=50)
+    ix = _gpu(o, d, "cosine", 32, 50)
+    gone = np.array(sorted(int(v) for v in rng.choice(np.arange(2, n + 2), size=150, replace=False)), dtype=np.uint64)
+    ix.delete_batch(gone)
+    assert o.delete(gone) == 0
+    nq = 16
+    q = unit_rows(rng, nq, d)
+
+    def check(filters, label):
+        g = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+        ix.set_tuning("host_filters", 1)
+        h = ix.search_batch(q, k, L, filters=filters, trace=True, visit_cap=1024)
+        ix.set_tuning("host_filters", 0)
+        assert np.array_equal(g[0], h[0]) and np.array_equal(bits(g[1]), bits(h[1])) and np.array_equal(g[2], h[2]), label
+        assert np.array_equal(g[3].visit_ids, h[3].visit_ids) and np.array_equal(g[3].n_dist, h[3].n_dist), label
+        for i in range(nq):
+            o_ids, o_d, o_vis, o_tr = o.search(q[i], k, L, filter_ids=sorted(filters[i]))
+            assert int(g[2][i]) == len(o_ids), (label, i)
+            assert np.array_equal(g[0][i, :len(o_ids)], o_ids) and np.array_equal(bits(g[1][i, :len(o_ids)]), bits(o_d)), (label, i)
+            assert np.array_equal(g[3].visit_ids[i, :o_tr.n_hop], o_vis), (label, i)
+
+    live = np.setdiff1d(np.arange(2, n + 2), gone.astype(np.int64))
+    sizes = (4, L, 300, n // 2) * 4
+    filters = [set(int(v) for v in rng.choice(live, size=s, replace=False)) | set(int(v) for v in rng.choice(gone, size=5))
+               | {n + 5000 + i, 2 ** 40 + i} for i, s in enumerate(sizes)]
+    check(filters, "holes")
+    # rows appended after the deletes: new, larger ids (ids and slots still agree on the order)
+    new_ids = np.arange(n + 2, n + 202, dtype=np.uint64)
+    ix.insert_batch(new_ids, base[n:n + 200], round_size=1)
+    for i in range(200):
+        assert o.insert(int(new_ids[i]), base[n + i]) == 0
+    filters2 = [f | set(int(v) for v in rng.choice(new_ids, size=20, replace=False)) for f in filters]
+    check(filters2, "appended")
+    # ids that were deleted come back: their rows sit behind rows with larger ids
+    back = gone[:100]
+    ix.insert_batch(back, base[n + 200:n + 300], round_size=1)
+    for i in range(100):
+        assert o.insert(int(back[i]), base[n + 200 + i]) == 0
+    filters3 = [f | set(int(v) for v in back[:30]) for f in filters2]
+    check(filters3, "re-inserted ids")
+    check([set(int(v) for v in live[:40])] * nq, "a batch that does not meet the re-inserted ids")
+    ix.close()
+
+
 def test_filter_argument_errors(oracle):
     from semadb_amd import vamana, SemaDBError, _lib
     import ctypes as C
@@ -209,8 +262,8 @@ def test_filtered_walk_is_the_same_under_every_visited_set(oracle):
 @pytest.mark.parametrize("dense", [True, False])
 def test_filters_as_bitmaps_give_the_same_walk(oracle, dense):
     """sdb_index_search_batch_bitmap: the filter as the bitmap it is in the reference (roaring64, search.go:33-51,93) --
-    {first_id + i : bit i} -- expanded to slots on the device for a table with consecutive ids, on the host otherwise
-    (dense = False: a delete leaves a hole).  Same answers as the id lists and as the oracle: ids, distance bits, visit
+    {first_id + i : bit i} -- expanded to slots on the device: directly for a table with consecutive ids, through 64-bit ids
+    and the view's id -> slot table otherwise (dense = False: a delete leaves a hole).  Same answers as the id lists and as the oracle: ids, distance bits, visit
     order, counters; unknown ids (bits outside the table, a window that starts below the first id), empty bitmaps,
     windows that are not word-aligned with each other, bits of the start node."""
     from semadb_amd import vamana

@@ -19,6 +19,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1_000_000)
 ap.add_argument("--dim", type=int, default=384)
 ap.add_argument("--sizes", default="10,1000,100000")
+ap.add_argument("--holes", type=int, default=0, help="delete this many rows first: ids are no longer consecutive (id -> slot table on the device)")
+ap.add_argument("--host-filters", action="store_true", help="the host's translation (tuning host_filters)")
 a0 = ap.parse_args()
 
 
@@ -32,6 +34,12 @@ queries = bench.gen_rows(4 * 1024, a0.dim, 20250621, "latent:24", dev).view(4, 1
 ix, build_s = bench.build_index(A, base, 0)
 out = {"rows": a0.rows, "dim": a0.dim, "build_s": round(build_s, 2), "tuning": os.environ.get("BENCH_TUNE", "")}
 rng = np.random.default_rng(3)
+if a0.holes:
+    ix.delete_batch(np.sort(rng.choice(a0.rows, size=a0.holes, replace=False).astype(np.uint64) + 2))
+    out["holes"] = a0.holes
+if a0.host_filters:
+    ix.set_tuning("host_filters", 1)
+    out["host_filters"] = True
 ix.set_profiling(True)
 # unfiltered reference point
 for b in range(2):
