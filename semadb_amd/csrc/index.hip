@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64) void k_compact_rows(const uint32_t *__restrict_
 // query's own segment.  MAP = false: a table whose ids are consecutive (id = base + slot: resolving is a subtraction,
 // and ascending ids are ascending slots).  MAP = true: any other table -- a probe of the committed view's id -> slot
 // table (sdb_index::IdMap); rows are appended in the order they arrive, so ascending ids USUALLY are ascending slots,
-// and a query for which they are not raises flags[2] (the host's translation, which sorts, takes the batch then).
+// and a query for which they are not raises flags[2]: the walk then answers Contains from the ids themselves
+// (SearchArgs::filt_ids); the seeds are the first slots in id order either way.
 // flags[0]: != 0 when some query's ids are not strictly ascending; flags[1]: one such query.
 __device__ __forceinline__ uint32_t idmap_hash(uint64_t id) { return (uint32_t)((id * 0x9E3779B97F4A7C15ull) >> 32); }
 __global__ void k_idmap_build(const uint64_t *__restrict__ ids, uint32_t n, uint64_t *__restrict__ keys,
@@ -1327,7 +1328,7 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
       SDB_HIP(hipGetLastError());
       SDB_HIP(hipMemcpyAsync(h_back, d_flags + 3, 4, hipMemcpyDeviceToHost, stream));
       SDB_HIP(hipStreamSynchronize(stream));
-      if (h_back[0]) return kBitmapNeedsIds;  // ids and slots disagree on the order somewhere: the host's translation sorts
+      if (h_back[0]) a.filt_ids = d_ids64;  // ids and slots disagree on the order somewhere: Contains by id (search_kernel.h)
     } else {
       hipLaunchKernelGGL(k_filter_bitmap_expand<false>, dim3((unsigned)nq), dim3(64), 0, stream, d_words, d_woff, d_first, base_id, vw.n,
                          d_off, d_sl, nullptr);
@@ -1385,12 +1386,11 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
       SDB_HIP(hipStreamSynchronize(stream));  // the caller's arrays are free again; an invalid filter is an error, not a search
       if (h_flags[0])
         return fail(SDB_ERR_INVALID, "filter ids of query %llu are not strictly ascending", (unsigned long long)h_flags[1]);
-      if (h_flags[2]) {
-        on_device = false;  // ids and slots disagree on the order somewhere: the host's translation sorts
-      } else {
-        a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
-        a.rbitsets = ws->bitsets + (size_t)nq * words;
-      }
+      a.seed_off = d_off, a.filt_off = d_off, a.seeds = d_sl, a.filt_slots = d_sl, a.seed_cnt = d_sc, a.filt_cnt = d_fc;
+      // ids and slots disagree on the order somewhere (an id deleted and inserted again sits behind larger ids): the
+      // seeds are the first slots in ID order either way; Contains is answered from the ids themselves then
+      if (h_flags[2]) a.filt_ids = d_raw;
+      a.rbitsets = ws->bitsets + (size_t)nq * words;
     }
     std::vector<uint32_t> off_seed(on_device ? 0 : nq + 1, 0), off_filt(on_device ? 0 : nq + 1, 0);
     if (!on_device) {

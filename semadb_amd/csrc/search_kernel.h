@@ -62,6 +62,10 @@ struct SearchArgs {
   // filter lists resolved on the device (index.hip k_filter_resolve): the counts are not offset differences then
   // (segments keep the caller's offsets, unknown ids leave gaps at their ends); NULL: offset differences
   const uint32_t *seed_cnt, *filt_cnt;
+  // != NULL: Contains (:93) is answered from the filter's IDS -- the uploaded lists, strictly ascending, at filt_off's
+  // offsets -- with the id of the expanded node (ids[slot]), for tables where ascending ids are not ascending slots
+  // (an id that was deleted and inserted again sits behind larger ids); filt_slots is not read then
+  const uint64_t *filt_ids;
   uint32_t *rbitsets;
   // build path, full-precision store: every evaluated (slot, distance) also goes into the query's
   // direct-mapped table of 2^(32 - dcache_shift) entries (last writer wins); the back-edge prunes of the
@@ -969,20 +973,20 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
 }
 
 // roaring Contains on this query's ascending slot list: 64-ary search, all lanes probe at once
-__device__ __forceinline__ bool filter_contains(const uint32_t *__restrict__ arr, uint32_t n, uint32_t target,
-                                                int lane) {
+template <typename T>  // uint32_t slots or uint64_t ids
+__device__ __forceinline__ bool filter_contains(const T *__restrict__ arr, uint32_t n, T target, int lane) {
   uint32_t lo = 0, hi = n;
   while (hi - lo > 64) {
     const uint32_t step = (hi - lo + 63) / 64;
     const uint32_t idx = lo + (uint32_t)lane * step;
-    const uint32_t v = idx < hi ? arr[idx] : 0xFFFFFFFFu;
+    const T v = idx < hi ? arr[idx] : ~(T)0;
     const uint64_t m = __ballot(idx < hi && v <= target);
     if (!m) return false;  // target below the first pivot
     const uint32_t k = (uint32_t)__popcll(m);
     lo = lo + (k - 1) * step;
     hi = (lo + step < hi) ? lo + step : hi;
   }
-  const uint32_t v = (lo + (uint32_t)lane < hi) ? arr[lo + lane] : 0xFFFFFFFFu;
+  const T v = (lo + (uint32_t)lane < hi) ? arr[lo + lane] : ~(T)0;
   return __ballot(lo + (uint32_t)lane < hi && v == target) != 0ull;
 }
 
@@ -1234,12 +1238,14 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
   int rlen = 0;
   const int rcap = (int)a.limit;
   const uint32_t *__restrict__ fsorted = nullptr;
+  const uint64_t *__restrict__ fids = nullptr;
   uint32_t nfilt = 0;
   if constexpr (FILT) {
 #pragma unroll
     for (int r = 0; r < NREG; r++) rid[r] = kNoSlot, rd[r] = 0.0f;
     fsorted = a.filt_slots + a.filt_off[q];
     nfilt = a.filt_cnt ? a.filt_cnt[q] : a.filt_off[q + 1] - a.filt_off[q];
+    if (a.filt_ids) fids = a.filt_ids + a.filt_off[q], nfilt = a.filt_off[q + 1] - a.filt_off[q];
     // seeds: the first <= searchSize filter ids in ascending id order that exist (:41-48)
     const uint32_t s0 = a.seed_off[q], ns = a.seed_cnt ? a.seed_cnt[q] : a.seed_off[q + 1] - s0;
     for (uint32_t base = 0; base < ns; base += 64) {
@@ -1329,6 +1335,9 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       }
     }
     n_hop++;
+    uint64_t pid_id = 0;  // FILT by ids: asked for now, looked at after the hop
+    if constexpr (FILT)
+      if (fids) pid_id = a.ids[pid];
 
     // node.neighbours in edge order :77-91.  One pass per 64 edges: every node has one, except a start node
     // that carries an overflow list (index.h h_start_ext) -- its chunks follow in the same edge order, which
@@ -1411,7 +1420,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       ext_left = ext_left > 64 ? ext_left - 64 : 0;
     }
     if constexpr (FILT) {  // :93-95 resultSet.AddWithLimit(distElem.Point) when the node passes the filter
-      if (filter_contains(fsorted, nfilt, pid, lane)) {
+      if (fids ? filter_contains(fids, nfilt, pid_id, lane) : filter_contains(fsorted, nfilt, pid, lane)) {
         const bool rnew = rvis.test_and_set(lane == 0, pid, lane);  // CheckAndVisit of the result set
         if (__ballot(rnew)) {
           n_dist++;  // distFn is evaluated again by the reference; same inputs, same bits as pdist

@@ -162,8 +162,8 @@ def test_filters_on_a_table_with_holes_resolve_on_the_device(oracle):
     """after deletes the ids are no longer consecutive: the filter ids are resolved by a probe of the committed view's
     id -> slot table on the device (sdb_index::IdMap), rebuilt for every published view.  Same answers as the host's
     translation (tuning host_filters) and as the oracle -- ids of deleted rows and unknown ids are skipped, rows added
-    after the deletes resolve once committed, and a batch for which ids and slots disagree on the order (an id that
-    was deleted and inserted again sits behind later ids) is handed to the host's translation."""
+    after the deletes resolve once committed, and in a batch for which ids and slots disagree on the order (an id that
+    was deleted and inserted again sits behind later ids) the walk answers Contains from the ids themselves."""
     rng = np.random.default_rng(404)
     n, d, L, k = 2000, 32, 50, 10
     base = unit_rows(rng, n + 300, d)

@@ -21,6 +21,7 @@ ap.add_argument("--dim", type=int, default=384)
 ap.add_argument("--sizes", default="10,1000,100000")
 ap.add_argument("--holes", type=int, default=0, help="delete this many rows first: ids are no longer consecutive (id -> slot table on the device)")
 ap.add_argument("--host-filters", action="store_true", help="the host's translation (tuning host_filters)")
+ap.add_argument("--pinned", action="store_true", help="the filter arrays in page-locked host memory (what sdb_host_alloc gives a host program)")
 a0 = ap.parse_args()
 
 
@@ -55,6 +56,10 @@ for size in [int(x) for x in a0.sizes.split(",")]:
     off = np.zeros(1025, dtype=np.uint64)
     off[1:] = np.cumsum([len(f) for f in filt])
     flat = np.concatenate(filt)
+    if a0.pinned:
+        keep = torch.from_numpy(flat.view(np.int64)).pin_memory()  # `keep` owns the pages
+        flat = keep.numpy().view(np.uint64)
+        out["pinned"] = True
     for _ in range(3):  # the first filtered calls size their workspaces (bitsets for the spill path, filter arrays)
         ix.search_batch(queries[0], 10, 75, filters=(off, flat))
         torch.cuda.synchronize()
@@ -77,6 +82,9 @@ for size in [int(x) for x in a0.sizes.split(",")]:
     # the same filters as bitmaps (sdb_index_search_batch_bitmap)
     from semadb_amd import vamana
     bm = vamana.FilterBitmaps.from_sets(filt)
+    if a0.pinned:
+        keep_w = torch.from_numpy(bm.words.view(np.int64)).pin_memory()
+        bm = vamana.FilterBitmaps(bm.first_id, bm.word_offsets, keep_w.numpy().view(np.uint64))
     for _ in range(2):
         ix.search_batch(queries[0], 10, 75, filters=bm)
         torch.cuda.synchronize()
