@@ -264,6 +264,7 @@ struct PlainDist {
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
+  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int) {}
   // hooks of the multi-wave quantized walk (PQWideDist); nothing to do for a one-wave policy
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
@@ -426,7 +427,9 @@ constexpr uint32_t kWideAheadPad = 24;  // spare entry + rows_range's dump behin
 struct WideShared {
   uint32_t cnt;        // pending rows of the hop the walker has published; kWideDone: the walk is over
   uint32_t ahead_done; // helper waves that have finished their share of the distances ahead, ever (monotonic)
-  unsigned long long ahead;  // adjacency row of the candidate the walk will most likely expand next (0: none)
+  uint32_t ahead_seq;  // rows to work ahead on that the walker has named, ever (one per handshake; monotonic)
+  uint32_t pad_;
+  unsigned long long ahead;  // adjacency row of the candidate the walk will expand next (0: none)
   uint32_t dump[64];         // where the helpers retire the words they pulled through the cache
   uint32_t ahead_slot[64 + kWideAheadPad];  // that row's slots by edge position
   float ahead_res[64 + kWideAheadPad];      // raw sums of distFn(query, neighbour) by edge position
@@ -450,20 +453,36 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
   static constexpr int kAheadPer = ((64 + W - 2) / (W - 1) + 1) & ~1;  // rows ahead per helper wave (even), W - 1 helpers
   WideShared *sh;
   int wave;
-  const uint32_t *pub_ahead;
   bool hit_cur;         // walker: this hop expands the candidate named one hop ago, and its distances were computed ahead
-  bool ahead_computed;  // walker: the helpers were handed a row to compute ahead during the last handshake
+  bool ahead_computed;  // walker: the helpers were handed a row to compute ahead after the last handshake
+  bool ahead_owed;      // walker: a handshake has happened whose word on the row ahead is still to come (ahead())
   uint32_t ahead_expect;  // walker: value of sh->ahead_done once every helper has finished what it was handed
+  uint32_t seq;           // rows ahead named (walker) / taken (helpers)
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lds) {
     Base::init(a, q, lane, lds);  // every wave keeps the query in its registers
     sh = reinterpret_cast<WideShared *>(reinterpret_cast<char *>(lds) + Base::kLdsBytes);
     wave = w, args_ = &a;
-    pub_ahead = nullptr, hit_cur = false, ahead_computed = false, ahead_expect = 0;
-    if (w == 0 && lane == 0) sh->ahead_done = 0;
+    hit_cur = false, ahead_computed = false, ahead_owed = false, ahead_expect = 0, seq = 0;
+    if (w == 0 && lane == 0) sh->ahead_done = 0, sh->ahead_seq = 0;
   }
-  __device__ __forceinline__ void speculation(bool use, const uint32_t *spec_rowp) {
-    hit_cur = use && ahead_computed;
-    pub_ahead = spec_rowp;
+  __device__ __forceinline__ void speculation(bool use, const uint32_t *) { hit_cur = use && ahead_computed; }
+  // The walker's word on the row to work ahead on, once per hop and AFTER the hop's distances are known (search_body):
+  // the helpers, through with their shares, wait for it.  Chunks of the start node's overflow list carry none.
+  __device__ __forceinline__ void ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+    if (!a.wide_pull) return;
+    if (!ahead_owed) handshake(a, 0, lane);  // a chunk without a new neighbour: the helpers have to be fetched first
+    name_ahead(a, rowp, lane);
+  }
+  __device__ __forceinline__ void name_ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+    ahead_owed = false;
+    ahead_computed = a.wide_pull == 2 && rowp != nullptr;
+    if (ahead_computed) ahead_expect += (uint32_t)(W - 1);
+    seq++;
+    if (lane == 0) {
+      sh->ahead = reinterpret_cast<unsigned long long>(rowp);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __atomic_store_n(&sh->ahead_seq, seq, __ATOMIC_RELAXED);
+    }
   }
   __device__ __forceinline__ void pull_ahead(const SearchArgs &a, const uint32_t *rowp, int lane, uint32_t (&got)[2]) {
     const uint32_t sectors = a.ld / 16;  // 64-byte sectors of a slab row
@@ -511,14 +530,12 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
   // ---- the walker (wave 0)
   // one handshake with the helpers: `cnt` pending rows to share (their list is in place) and the row to work ahead on
   __device__ __forceinline__ void handshake(const SearchArgs &a, int cnt, int lane) {
-    const uint32_t *ahead = a.wide_pull ? pub_ahead : nullptr;
-    if (lane == 0) sh->cnt = (uint32_t)cnt, sh->ahead = reinterpret_cast<unsigned long long>(ahead);
-    ahead_computed = a.wide_pull == 2 && ahead != nullptr;
-    if (ahead_computed) ahead_expect += (uint32_t)(W - 1);
-    pub_ahead = nullptr;  // one hand-over per speculation (the start node's overflow chunks carry none)
+    if (ahead_owed) name_ahead(a, nullptr, lane);  // the last handshake's word never came (an overflow chunk): none
+    if (lane == 0) sh->cnt = (uint32_t)cnt;
     __syncthreads();  // B1: the list is published
     share(a, cnt, lane);
     __syncthreads();  // B2: every share has been written
+    ahead_owed = a.wide_pull != 0;
   }
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
     const int cnt = __popcll(pend);
@@ -541,17 +558,11 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
     handshake(a, cnt, lane);
     return mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
   }
-  // a chunk without a new neighbour: the helpers still get the next row to work ahead on
-  __device__ __forceinline__ void skip(int lane) {
-    hit_cur = false;
-    if (pub_ahead) handshake_skip(lane);
-  }
-  SearchArgs const *args_;  // for skip(), which search_body calls without the arguments
-  __device__ __forceinline__ void handshake_skip(int lane) {
-    if (args_->wide_pull == 2) handshake(*args_, 0, lane);
-    else pub_ahead = nullptr;
-  }
+  // a chunk without a new neighbour: nothing to share (search_body's ahead() fetches the helpers when it has a row for them)
+  __device__ __forceinline__ void skip(int) { hit_cur = false; }
+  SearchArgs const *args_;
   __device__ __forceinline__ void finish(int lane) {
+    if (ahead_owed) name_ahead(*args_, nullptr, lane);
     if (lane == 0) sh->cnt = kWideDone;
     __syncthreads();  // B1: the helpers leave
   }
@@ -562,12 +573,16 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
       __syncthreads();  // B1
       const uint32_t cnt = sh->cnt;
       if (cnt == kWideDone) return;
-      const uint32_t *ahead = reinterpret_cast<const uint32_t *>(sh->ahead);
       if (a.wide_pull == 1) sh->dump[lane] = got[0] ^ got[1];  // the last hop's pulls have long arrived: retire them
       share(a, (int)cnt, lane);
       __syncthreads();  // B2
+      if (!a.wide_pull) continue;
+      seq++;  // the walker names the row ahead once it has looked at this hop's distances
+      while (__atomic_load_n(&sh->ahead_seq, __ATOMIC_RELAXED) != seq) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const uint32_t *ahead = reinterpret_cast<const uint32_t *>(sh->ahead);
       if (a.wide_pull == 1) pull_ahead(a, ahead, lane, got);
-      else if (a.wide_pull == 2 && ahead) compute_ahead(a, ahead, lane);
+      else if (ahead) compute_ahead(a, ahead, lane);
     }
   }
 };
@@ -598,6 +613,7 @@ struct PQDist {
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
+  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
   // M == 8 (the documented configuration): the 8 code bytes of every neighbour are fetched as one 8-byte
@@ -750,6 +766,7 @@ struct PQWideDist {
   // ---- the walker's side (wave 0): the policy interface search_body calls
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
+  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *rowp, int lane) {
     if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u;
     __syncthreads();  // B0
@@ -1300,6 +1317,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #define SDB_STAMP(acc)
 #endif
   uint32_t spec_pid = kNoSlot, spec_nb = kNoSlot;  // Dist::kSpeculate: the row fetched ahead, and whose it is
+  float spec_d = 0.0f;                             // ... and that candidate's distance
 #ifdef SDB_SPEC_STATS
   uint32_t n_spec_hit = 0;  // measurement builds: hops that found their row fetched ahead, reported in place of n_edges
 #endif
@@ -1357,9 +1375,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         if (sel2 < 0 && m2) sel2 = r * 64 + __ffsll((unsigned long long)m2) - 1;
       }
       spec_pid = kNoSlot;
+      spec_d = __int_as_float(0x7f800000);
 #pragma unroll
       for (int r = 0; r < NREG; r++)
-        if (sel2 >= 0 && (sel2 >> 6) == r) spec_pid = rl(cid[r], sel2 & 63) & ~kVisBit;
+        if (sel2 >= 0 && (sel2 >> 6) == r) spec_pid = rl(cid[r], sel2 & 63) & ~kVisBit, spec_d = rlf(cd[r], sel2 & 63);
       if (spec_pid != kNoSlot) spec_rowp = a.adj + (size_t)spec_pid * kAdjStride;
       dist.speculation(use_spec, spec_rowp);
     }
@@ -1399,6 +1418,32 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         asm volatile("" ::"v"(mydist));
 #endif
         SDB_STAMP(st_vec)
+        if constexpr (Dist::kSpeculate) {
+          // With this hop's distances the next pick is no guess any more: it is the nearest of the new points when that
+          // one is nearer than the candidate first in line (and gets into the array), else that candidate.  Known
+          // BEFORE the points are inserted -- so the row to fetch and work ahead on is named now, and the insert below
+          // runs beside that work.  (A tie or a NaN can still make it wrong; the next hop checks pid == spec_pid.)
+          if (first_chunk) {
+            if (ext_left == 0) {
+              uint64_t nearer = __ballot(((pend >> lane) & 1ull) && mydist < spec_d);
+              if (nearer) {
+                int bj = -1;
+                float bd = spec_d;
+                for (; nearer; nearer &= nearer - 1) {
+                  const int j = __ffsll((unsigned long long)nearer) - 1;
+                  const float dj = rlf(mydist, j);
+                  if (dj < bd) bd = dj, bj = j;
+                }
+                if (bj >= 0 && (len < cap || !(bd > list_tail(cd, cap)))) {
+                  spec_pid = rl(nb, bj);
+                  spec_rowp = a.adj + (size_t)spec_pid * kAdjStride;
+                  spec_nb = spec_rowp[lane];
+                }
+              }
+            }
+            dist.ahead(a, spec_rowp, lane);
+          }
+        }
         // AddWithLimit over the new neighbours, in edge order distset.go:184-198
         if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
 #ifdef SDB_STAMPS
@@ -1409,6 +1454,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         SDB_STAMP(st_ins)
       } else {
         dist.skip(lane);
+        if constexpr (Dist::kSpeculate)
+          if (first_chunk) dist.ahead(a, spec_rowp, lane);  // no new point: the candidate first in line stays it
       }
       if constexpr (Dist::kSpeculate) {
         if (first_chunk && spec_rowp) dist.fetch_ahead(a, spec_nb);
