@@ -264,7 +264,7 @@ struct PlainDist {
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
-  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int) {}
+  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   // hooks of the multi-wave quantized walk (PQWideDist); nothing to do for a one-wave policy
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
@@ -281,7 +281,12 @@ struct PlainDist {
   // rows of the chunk), the row's elements walk down to lane 0 with one wave_shl DPP move per step.
   // raw distances of the pending rows of ranks [first, first + count) of the list in s_slot (one spare entry behind its
   // last rank), two rows per wave instruction, into s_res by rank.  `first` is even.
-  template <bool TAIL>
+  // ALL: every one of the U row slots of a round is loaded and summed, the ones past the range as copies of its last row
+  // (their sums go to the dump) -- no branch between the rows, so that all loads of a round are in flight at once.  (With
+  // the rows conditional, as the one-wave kernels have them, the compiler here -- inside the multi-wave kernels -- placed
+  // each row's wait and arithmetic right behind its three loads: one memory round trip PER ROW, three in sequence for a
+  // wave's six rows ahead.)
+  template <bool TAIL, bool ALL = false>
   __device__ __forceinline__ void rows_range(const SearchArgs &a, const uint32_t *s_slot, float *s_res, int first, int count,
                                              int lane) {
     const int L = lane & 31, half = lane >> 5;
@@ -298,11 +303,11 @@ struct PlainDist {
 #endif
       uint32_t sl[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) sl[u] = s_slot[base + u];
+      for (int u = 0; u < U; u++) sl[u] = s_slot[base + (ALL ? (u < h0 ? u : h0 - 1) : u)];
       float4 y[U][NGR];
 #pragma unroll
       for (int u = 0; u < U; u++)
-        if (u < h0) {
+        if (ALL || u < h0) {
           const float4 *r4 = reinterpret_cast<const float4 *>(baseL + (uint64_t)sl[u] * row_bytes);
 #pragma unroll
           for (int g = 0; g < NG; g++) y[u][g] = r4[g * 32];
@@ -313,7 +318,7 @@ struct PlainDist {
 #pragma unroll
         for (int u = 0; u < U; u++) {
           yt[u] = 0.0f;
-          if (u < h0) yt[u] = *reinterpret_cast<const float *>(baseT + (uint64_t)sl[u] * row_bytes);
+          if (ALL || u < h0) yt[u] = *reinterpret_cast<const float *>(baseT + (uint64_t)sl[u] * row_bytes);
         }
       }
 #ifdef SDB_STAMPS
@@ -326,18 +331,20 @@ struct PlainDist {
       if constexpr (!TAIL) {
 #pragma unroll
         for (int u = 0; u < U; u++)
-          if (u < h0) {
+          if (ALL || u < h0) {
             float acc = 0.0f;
 #pragma unroll
             for (int g = 0; g < NG; g++) acc = chain4<L2>(acc, xq[g], y[u][g]);
-            wp[u] = asm_reduce(acc, 0.0f, lane);
+            const float r = asm_reduce(acc, 0.0f, lane);
+            if constexpr (ALL) (u < h0 ? wp : s_res + kHopSlots)[u] = r;
+            else wp[u] = r;
           }
       } else {
         float acc[U], t[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
           acc[u] = 0.0f, t[u] = 0.0f;
-          if (u < h0) {
+          if (ALL || u < h0) {
 #pragma unroll
             for (int g = 0; g < NG; g++) acc[u] = chain4<L2>(acc[u], xq[g], y[u][g]);
           }
@@ -352,7 +359,11 @@ struct PlainDist {
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-          if (u < h0) wp[u] = asm_reduce(acc[u], t[u], lane);
+          if (ALL || u < h0) {
+            const float r = asm_reduce(acc[u], t[u], lane);
+            if constexpr (ALL) (u < h0 ? wp : s_res + kHopSlots)[u] = r;
+            else wp[u] = r;
+          }
       }
 #ifdef SDB_STAMPS
       unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -428,7 +439,11 @@ struct WideShared {
   uint32_t cnt;        // pending rows of the hop the walker has published; kWideDone: the walk is over
   uint32_t ahead_done; // helper waves that have finished their share of the distances ahead, ever (monotonic)
   uint32_t ahead_seq;  // rows to work ahead on that the walker has named, ever (one per handshake; monotonic)
+  uint32_t mark_on;    // != 0: the marker wave also runs the visited-set test of that row's neighbours
+  uint32_t mark_seq;   // rows the marker has been through, ever (monotonic)
   uint32_t pad_;
+  unsigned long long mark_pend;  // the neighbours (by edge position) that were new to the visited set
+  uint32_t mark_cell[64];        // where each of those went in the table
   unsigned long long ahead;  // adjacency row of the candidate the walk will expand next (0: none)
   uint32_t dump[64];         // where the helpers retire the words they pulled through the cache
   uint32_t ahead_slot[64 + kWideAheadPad];  // that row's slots by edge position
@@ -436,10 +451,18 @@ struct WideShared {
 };
 constexpr uint32_t kWideDone = 0xFFFFFFFFu;
 
+// pairs of rows per round of loads: a wave's share of a hop is at most 64 / W rows (rounded up to even), so 32 / W pairs
+// hold it -- but its share of the distances AHEAD is 6 rows at W = 16 (14 waves compute), and two rounds of loads in
+// sequence are two memory round trips on the path that bounds the hop: three pairs where the registers allow it (rows of
+// up to 512 floats; 128 registers per wave at 16 waves)
+template <int NG, int W>
+struct WidePairs {
+  static constexpr int kMin = 32 / W > 0 ? 32 / W : 1;
+  static constexpr int value = (kMin < 3 && NG <= 4) ? 3 : kMin;
+};
 template <int NG, bool L2, int W>
-struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
-  // a wave's share of a hop is at most 64 / W rows (rounded up to even): one chunk of 32 / W pairs holds it
-  using Base = PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)>;
+struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W>::value> {
+  using Base = PlainDist<NG, L2, true, WidePairs<NG, W>::value>;
   // A call of few queries has bandwidth to spare and a dependent chain to shorten.  70 % of the hops expand the candidate
   // that was first in line one hop earlier (tools/spec_hits.py), so with every hop the walker names that candidate
   // (search_body, Dist::kSpeculate) and fetches its adjacency row; while it inserts this hop's points the helper waves
@@ -450,7 +473,14 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
   // the order of the inserts are the walk's own; a wrong guess costs traffic.
   static constexpr bool kSpeculate = true;
   static constexpr size_t kLdsBytes = Base::kLdsBytes + sizeof(WideShared);
-  static constexpr int kAheadPer = ((64 + W - 2) / (W - 1) + 1) & ~1;  // rows ahead per helper wave (even), W - 1 helpers
+  // Wave 1 is the MARKER when rows are worked ahead on (W >= 4): it runs the visited-set test of the named row's
+  // neighbours on the walker's table while the walker inserts the last hop's points (CheckAndVisit marks before any
+  // distance is looked at, distset.go:174, and nothing else touches the set in between, so when the walk does expand
+  // that row -- 99 % of the time -- the marks are exactly the ones its own test would have made; otherwise the walker
+  // takes them back before it tests anything).  Waves kFirstAhead .. W-1 compute the distances ahead.
+  static constexpr int kFirstAhead = W >= 4 ? 2 : 1;
+  static constexpr int kAheadWaves = W - kFirstAhead;
+  static constexpr int kAheadPer = ((64 + kAheadWaves - 1) / kAheadWaves + 1) & ~1;  // rows ahead per computing wave (even)
   WideShared *sh;
   int wave;
   bool hit_cur;         // walker: this hop expands the candidate named one hop ago, and its distances were computed ahead
@@ -458,27 +488,33 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
   bool ahead_owed;      // walker: a handshake has happened whose word on the row ahead is still to come (ahead())
   uint32_t ahead_expect;  // walker: value of sh->ahead_done once every helper has finished what it was handed
   uint32_t seq;           // rows ahead named (walker) / taken (helpers)
+  bool marked;            // walker: the marker was sent through the row named last
+  uint32_t mark_expect;   // walker: value of sh->mark_seq once it is through
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lds) {
     Base::init(a, q, lane, lds);  // every wave keeps the query in its registers
     sh = reinterpret_cast<WideShared *>(reinterpret_cast<char *>(lds) + Base::kLdsBytes);
     wave = w, args_ = &a;
     hit_cur = false, ahead_computed = false, ahead_owed = false, ahead_expect = 0, seq = 0;
-    if (w == 0 && lane == 0) sh->ahead_done = 0, sh->ahead_seq = 0;
+    marked = false, mark_expect = 0;
+    if (w == 0 && lane == 0) sh->ahead_done = 0, sh->ahead_seq = 0, sh->mark_seq = 0, sh->mark_on = 0;
   }
   __device__ __forceinline__ void speculation(bool use, const uint32_t *) { hit_cur = use && ahead_computed; }
   // The walker's word on the row to work ahead on, once per hop and AFTER the hop's distances are known (search_body):
   // the helpers, through with their shares, wait for it.  Chunks of the start node's overflow list carry none.
-  __device__ __forceinline__ void ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+  __device__ __forceinline__ void ahead(const SearchArgs &a, const uint32_t *rowp, int lane, bool markable) {
     if (!a.wide_pull) return;
     if (!ahead_owed) handshake(a, 0, lane);  // a chunk without a new neighbour: the helpers have to be fetched first
-    name_ahead(a, rowp, lane);
+    name_ahead(a, rowp, lane, markable);
   }
-  __device__ __forceinline__ void name_ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+  __device__ __forceinline__ void name_ahead(const SearchArgs &a, const uint32_t *rowp, int lane, bool markable = false) {
     ahead_owed = false;
     ahead_computed = a.wide_pull == 2 && rowp != nullptr;
-    if (ahead_computed) ahead_expect += (uint32_t)(W - 1);
+    if (ahead_computed) ahead_expect += (uint32_t)kAheadWaves;
+    marked = ahead_computed && markable && kFirstAhead == 2;
+    if (marked) mark_expect++;
     seq++;
     if (lane == 0) {
+      sh->mark_on = marked ? 1u : 0u;
       sh->ahead = reinterpret_cast<unsigned long long>(rowp);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __atomic_store_n(&sh->ahead_seq, seq, __ATOMIC_RELAXED);
@@ -500,19 +536,34 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
   }
   // helper waves, mode 2: this wave's share of the distances to the neighbours of the candidate ahead
   __device__ __forceinline__ void compute_ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+#ifdef SDB_STAMPS
+    unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     const uint32_t nb = rowp[lane];
+#ifdef SDB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    this->st[0] += c1 - c0;  // the adjacency row's round trip
+#endif
     const uint64_t m = __ballot(nb != kNoSlot);
     const int deg = __popcll(m);  // rows are padded with kNoSlot behind their edges
     sh->ahead_slot[lane] = nb != kNoSlot ? nb : 0u;  // every helper writes the same words
     if (lane == deg - 1) sh->ahead_slot[deg] = nb;  // the spare entry behind the list
     wave_lds_sync();
-    const int first = (wave - 1) * kAheadPer;
+    const int first = (wave - kFirstAhead) * kAheadPer;
     const int count = deg - first < kAheadPer ? deg - first : kAheadPer;
     if (count > 0) {
-      if (a.tail) this->template rows_range<true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
-      else this->template rows_range<false>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
+      if (a.tail) this->template rows_range<true, true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
+      else this->template rows_range<false, true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
     }
     wave_lds_sync();  // the sums before the count
+#ifdef SDB_STAMPS
+    unsigned long long c2 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    this->st[1] += c2 - c1;  // list into LDS + the rows
+#endif
     if (lane == 0) atomicAdd(&sh->ahead_done, 1u);
   }
   // this wave's share of `cnt` pending rows: contiguous ranks, an even number per wave so that only the list's last row
@@ -524,10 +575,18 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
     if (count <= 0) return;
     uint32_t *s_slot = this->hs;
     float *s_res = reinterpret_cast<float *>(this->hs + Base::kHopSlots);
-    if (a.tail) this->template rows_range<true>(a, s_slot, s_res, first, count, lane);
-    else this->template rows_range<false>(a, s_slot, s_res, first, count, lane);
+    if (a.tail) this->template rows_range<true, true>(a, s_slot, s_res, first, count, lane);
+    else this->template rows_range<false, true>(a, s_slot, s_res, first, count, lane);
   }
   // ---- the walker (wave 0)
+  // what the marker found for the row named last: the neighbours that were new to the set, and where they went
+  __device__ __forceinline__ void take_marks(int lane, uint64_t &mask, uint32_t &cell) {
+    while (__atomic_load_n(&sh->mark_seq, __ATOMIC_RELAXED) != mark_expect) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    mask = sh->mark_pend;
+    cell = sh->mark_cell[lane];
+    marked = false;
+  }
   // one handshake with the helpers: `cnt` pending rows to share (their list is in place) and the row to work ahead on
   __device__ __forceinline__ void handshake(const SearchArgs &a, int cnt, int lane) {
     if (ahead_owed) name_ahead(a, nullptr, lane);  // the last handshake's word never came (an overflow chunk): none
@@ -567,22 +626,74 @@ struct PlainWideDist : PlainDist<NG, L2, true, (32 / W > 0 ? 32 / W : 1)> {
     __syncthreads();  // B1: the helpers leave
   }
   // ---- waves 1 .. W-1
-  __device__ __forceinline__ void serve(const SearchArgs &a, int lane) {
+  template <class HV>  // HV: the walker's visited set (its table is `tab`)
+  __device__ __forceinline__ void serve(const SearchArgs &a, int lane, uint32_t *tab) {
     uint32_t got[2] = {0u, 0u};
+    uint32_t marks = 0;  // rows this wave has been through as the marker
+#ifdef SDB_STAMPS  // waves 1 (marker) and 2 (first computing wave): waiting at B1, waiting for the walker's word, the work ahead
+    unsigned long long hs_b1 = 0, hs_word = 0, hs_work = 0, hs_share = 0, hs_n = 0;
+#define SDB_HSTAMP(acc)                                         \
+  {                                                             \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    acc += _t - hs_t0;                                          \
+    hs_t0 = _t;                                                 \
+  }
+    unsigned long long hs_t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define SDB_HSTAMP(acc)
+#endif
     for (;;) {
       __syncthreads();  // B1
+      SDB_HSTAMP(hs_b1)
       const uint32_t cnt = sh->cnt;
-      if (cnt == kWideDone) return;
+      if (cnt == kWideDone) {
+#ifdef SDB_STAMPS
+        if (lane == 0 && a.tr_visit && a.visit_cap >= 44) a.tr_visit[(size_t)blockIdx.x * a.visit_cap + 28 + wave] = hs_work;
+        if (lane == 0 && (wave == 1 || wave == 2) && a.tr_visit && a.visit_cap >= 24) {
+          uint64_t *o = a.tr_visit + (size_t)blockIdx.x * a.visit_cap + (wave == 1 ? 12 : 18);
+          o[0] = hs_b1, o[1] = hs_share, o[2] = hs_word, o[3] = hs_work, o[4] = hs_n, o[5] = (this->st[0] << 32) | (this->st[1] & 0xFFFFFFFFull);
+        }
+#endif
+        return;
+      }
       if (a.wide_pull == 1) sh->dump[lane] = got[0] ^ got[1];  // the last hop's pulls have long arrived: retire them
       share(a, (int)cnt, lane);
       __syncthreads();  // B2
+      SDB_HSTAMP(hs_share)
       if (!a.wide_pull) continue;
       seq++;  // the walker names the row ahead once it has looked at this hop's distances
       while (__atomic_load_n(&sh->ahead_seq, __ATOMIC_RELAXED) != seq) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      SDB_HSTAMP(hs_word)
+#ifdef SDB_STAMPS
+      hs_n++;
+#endif
       const uint32_t *ahead = reinterpret_cast<const uint32_t *>(sh->ahead);
-      if (a.wide_pull == 1) pull_ahead(a, ahead, lane, got);
-      else if (ahead) compute_ahead(a, ahead, lane);
+      if (a.wide_pull == 1) {
+        pull_ahead(a, ahead, lane, got);
+      } else if (ahead) {
+        if (kFirstAhead == 2 && wave == 1) {
+          if (sh->mark_on) {
+            const uint32_t nb = ahead[lane];
+            uint32_t cell;
+            const bool isnew = HV::claim(tab, nb != kNoSlot, nb, cell);
+            const uint64_t pend = __ballot(isnew);
+            sh->mark_cell[lane] = cell;
+            if (lane == 0) sh->mark_pend = pend;
+            wave_lds_sync();
+            marks++;
+            if (lane == 0) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __atomic_store_n(&sh->mark_seq, marks, __ATOMIC_RELAXED);
+            }
+          }
+        } else {
+          compute_ahead(a, ahead, lane);
+        }
+      }
+      SDB_HSTAMP(hs_work)
     }
   }
 };
@@ -613,7 +724,7 @@ struct PQDist {
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
-  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int) {}
+  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
   // M == 8 (the documented configuration): the 8 code bytes of every neighbour are fetched as one 8-byte
@@ -766,7 +877,7 @@ struct PQWideDist {
   // ---- the walker's side (wave 0): the policy interface search_body calls
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
-  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int) {}
+  __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *rowp, int lane) {
     if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u;
     __syncthreads();  // B0
@@ -1117,6 +1228,62 @@ struct HashVisited {
     if (count > limit) spill(lane);  // at most 64 keys past the limit: the table never fills
     return isnew;
   }
+  // test_and_set's probe-and-claim as ANOTHER wave of the workgroup runs it on the walker's table, ahead of the walk
+  // (PlainWideDist's marker wave): no count, no spill; `cell` is where a new key went, so that the walker can take the
+  // marks back should the walk not go there after all (unmark).  The walker stays away from the table meanwhile.
+  static __device__ __forceinline__ bool claim(uint32_t *tab, bool active, uint32_t slot, uint32_t &cell) {
+    bool isnew = false, done = !active;
+    uint32_t h = (uint32_t)(((uint64_t)(slot * 2654435761u) * CAP) >> 32);
+    uint32_t step = 1u + (uint32_t)(((uint64_t)(slot * 0x9E3779B1u) * (CAP - 1)) >> 32);
+    if (kPow2) step |= 1u;
+    auto next = [&](uint32_t x) {
+      x += step;
+      if (kPow2) x &= CAP - 1;
+      else if (x >= CAP) x -= CAP;
+      return x;
+    };
+    cell = 0;
+    while (__ballot(!done)) {
+      uint32_t hp[kProbes], kp[kProbes];
+      hp[0] = h;
+#pragma unroll
+      for (int i = 1; i < kProbes; i++) hp[i] = next(hp[i - 1]);
+#pragma unroll
+      for (int i = 0; i < kProbes; i++) kp[i] = tab[hp[i]];
+      bool any = false;
+      uint32_t hs = hp[kProbes - 1], ks = kp[kProbes - 1];
+#pragma unroll
+      for (int i = kProbes - 1; i >= 0; i--) {
+        const bool si = kp[i] == slot || kp[i] == kNoSlot;
+        hs = si ? hp[i] : hs, ks = si ? kp[i] : ks;
+        any |= si;
+      }
+      if (!done) {
+        if (!any) {
+          h = next(hp[kProbes - 1]);
+        } else if (ks == slot) {
+          done = true;
+        } else {
+          const uint32_t old = atomicCAS(&tab[hs], kNoSlot, slot);
+          if (old == kNoSlot) isnew = true, done = true, cell = hs;
+          else if (old == slot) done = true;
+          else h = hs;
+        }
+      }
+    }
+    return isnew;
+  }
+  __device__ __forceinline__ bool markable() const { return !spilled; }
+  // marks made by claim() on the walker's behalf: now part of the set ...
+  __device__ __forceinline__ void credit(uint32_t n, int lane) {
+    count += n;
+    if (count > limit) spill(lane);  // at most 128 keys past the limit
+  }
+  // ... or taken back (nothing has been added since they were made: the table is as it was before them)
+  __device__ __forceinline__ void unmark(bool mine, uint32_t cell) {
+    if (mine) tab[cell] = kNoSlot;
+    wave_lds_sync();
+  }
 };
 
 // The same exact set in half the LDS, for stores of up to 2^24 rows: 16-bit cells.  h = slot * odd mod 2^24 is a
@@ -1306,6 +1473,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #ifdef SDB_STAMPS  // diagnostic build only: where does a hop spend its cycles (never in the shipped library)
   unsigned long long st_adj = 0, st_atom = 0, st_vec = 0, st_ins = 0, st_t0 = 0;
   unsigned long long st_m[4] = {0, 0, 0, 0};  // inside the merge: preamble, <2-candidates path, per-point pass, scatter
+  unsigned long long st_w[4] = {0, 0, 0, 0};  // Dist::kSpeculate: pick + guess, the marker's verdict, the late guess, naming the row
 #define SDB_STAMP(acc)                                              \
   {                                                                 \
     unsigned long long _t = __builtin_amdgcn_s_memtime();           \
@@ -1318,6 +1486,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #endif
   uint32_t spec_pid = kNoSlot, spec_nb = kNoSlot;  // Dist::kSpeculate: the row fetched ahead, and whose it is
   float spec_d = 0.0f;                             // ... and that candidate's distance
+  bool have_marks = false;                         // ... and whether its neighbours have been through the visited set
+  uint64_t mark_mask = 0;
 #ifdef SDB_SPEC_STATS
   uint32_t n_spec_hit = 0;  // measurement builds: hops that found their row fetched ahead, reported in place of n_edges
 #endif
@@ -1381,6 +1551,16 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         if (sel2 >= 0 && (sel2 >> 6) == r) spec_pid = rl(cid[r], sel2 & 63) & ~kVisBit, spec_d = rlf(cd[r], sel2 & 63);
       if (spec_pid != kNoSlot) spec_rowp = a.adj + (size_t)spec_pid * kAdjStride;
       dist.speculation(use_spec, spec_rowp);
+      SDB_STAMP(st_w[0])
+      // the visited-set test of the row named last has been run ahead (PlainWideDist's marker): its verdict, or back out
+      have_marks = false;
+      if (dist.marked) {
+        uint32_t cell;
+        dist.take_marks(lane, mark_mask, cell);
+        if (use_spec) have_marks = true, vis.credit((uint32_t)__popcll(mark_mask), lane);
+        else vis.unmark((mark_mask >> lane) & 1ull, cell);
+      }
+      SDB_STAMP(st_w[1])
     }
     bool first_chunk = true;
     while (true) {
@@ -1394,17 +1574,17 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       } else {
         nb = rowp[lane];
       }
-      if constexpr (Dist::kSpeculate)
-        if (first_chunk && spec_rowp) spec_nb = spec_rowp[lane];
       const bool valid = nb != kNoSlot;
       n_edges += (uint32_t)__popcll(__ballot(valid));
 #ifdef SDB_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the adjacency round trip to st_adj
+      if (!Dist::kSpeculate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the adjacency round trip to st_adj
 #endif
       SDB_STAMP(st_adj)
       dist.prefetch(a, nb, valid);
       // CheckAndVisit distset.go:174 -- marks before any distance test
-      const bool isnew = vis.test_and_set(valid, nb, lane);
+      bool isnew;
+      if (Dist::kSpeculate && have_marks && first_chunk) isnew = (mark_mask >> lane) & 1ull;
+      else isnew = vis.test_and_set(valid, nb, lane);
       const uint64_t pend = __ballot(isnew);
       SDB_STAMP(st_atom)
       if (pend) {
@@ -1437,11 +1617,15 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
                 if (bj >= 0 && (len < cap || !(bd > list_tail(cd, cap)))) {
                   spec_pid = rl(nb, bj);
                   spec_rowp = a.adj + (size_t)spec_pid * kAdjStride;
-                  spec_nb = spec_rowp[lane];
                 }
               }
             }
-            dist.ahead(a, spec_rowp, lane);
+            // its row, for the next hop: asked for HERE and not when the hop began -- a load in flight is waited for at
+            // every workgroup barrier (the fence of __syncthreads), and the hop's handshake would stand still for it
+            if (spec_rowp) spec_nb = spec_rowp[lane];
+            SDB_STAMP(st_w[2])
+            dist.ahead(a, spec_rowp, lane, vis.markable());
+            SDB_STAMP(st_w[3])
           }
         }
         // AddWithLimit over the new neighbours, in edge order distset.go:184-198
@@ -1455,7 +1639,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       } else {
         dist.skip(lane);
         if constexpr (Dist::kSpeculate)
-          if (first_chunk) dist.ahead(a, spec_rowp, lane);  // no new point: the candidate first in line stays it
+          if (first_chunk) {  // no new point: the candidate first in line stays it
+            if (spec_rowp) spec_nb = spec_rowp[lane];
+            dist.ahead(a, spec_rowp, lane, vis.markable());
+          }
       }
       if constexpr (Dist::kSpeculate) {
         if (first_chunk && spec_rowp) dist.fetch_ahead(a, spec_nb);
@@ -1490,6 +1677,10 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         a.tr_visit[(size_t)q * a.visit_cap + 4] = dist.st[0];
         a.tr_visit[(size_t)q * a.visit_cap + 5] = dist.st[1];
         a.tr_visit[(size_t)q * a.visit_cap + 6] = dist.st[2];
+        if (a.visit_cap >= 12)
+          for (int i = 0; i < 4; i++) a.tr_visit[(size_t)q * a.visit_cap + 8 + i] = st_m[i];
+        if (a.visit_cap >= 28)
+          for (int i = 0; i < 4; i++) a.tr_visit[(size_t)q * a.visit_cap + 24 + i] = st_w[i];
       }
   }
 #endif
@@ -1647,7 +1838,8 @@ __global__ __launch_bounds__(64 * W) void k_greedy_search_wide(const SearchArgs 
                      a.rbitsets + (size_t)q * a.words_per_query, a.words_per_query, lane, a.hash_limit);
   }
   __syncthreads();
-  if (wave != 0) return dist.serve(a, lane);
+  if (wave != 0) return dist.template serve<HashVisited<kHashCap>>(a, lane, reinterpret_cast<uint32_t *>(lds_f));
+  __builtin_amdgcn_s_setprio(3);  // the walk is the serial part: its wave goes first on the SIMD it shares with three helpers
   if constexpr (FILT) {
     search_body<PlainWideDist<NG, L2, W>, 2, true>(a, q, lane, dist, hv, rv);
   } else {
