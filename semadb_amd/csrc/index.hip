@@ -474,10 +474,6 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 // Past 256 queries eight waves per query (0.58 ms at 512 against 0.66 for one wave per query, 0.80 for sixteen).  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
 // rounds of thousands).
 constexpr uint32_t kWideMaxQueries = 256;
-#ifndef SDB_WIDE_PULL
-#define SDB_WIDE_PULL 256
-#endif
-constexpr uint32_t kWidePullQueries = SDB_WIDE_PULL;
 #ifndef SDB_WIDE_AHEAD
 #define SDB_WIDE_AHEAD 256
 #endif
@@ -495,10 +491,8 @@ static int launch_wide_w(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   using D = PlainWideDist<NG, L2, W>;
   const size_t lds = HashVisited<kHashCap>::kWords * sizeof(uint32_t) + D::kLdsBytes;
   SearchArgs b = a;
-  // the pull-ahead doubles the call's traffic: for calls that leave most of the memory system idle
-  // very few queries: the helpers compute the likely next hop's distances ahead (2); few: they only pull its rows
-  // through L2 (1); both trade traffic for latency
-  b.wide_pull = W != 16 ? 0u : nq <= kWideAheadQueries ? 2u : nq <= kWidePullQueries ? 1u : 0u;
+  // calls of up to 256 queries (a workgroup per CU at most): the other waves work ahead on the row the walk expands next
+  b.wide_pull = (W == 16 && nq <= kWideAheadQueries) ? 2u : 0u;
   if (a.filt_off)  // the filtered walk (search.go:33-51,93-95): a hybrid REST query is one query with a filter
     hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, W, true>), dim3(nq), dim3(64 * W),
                        lds + HashVisited<kHashCapResult>::kWords * sizeof(uint32_t), stream, b);

@@ -78,7 +78,7 @@ struct SearchArgs {
   uint32_t hash16_probes;  // test knob: buckets a key of HashVisited16 may try (0 = all 15); fewer make the `stuck` spill common
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
   uint32_t wide_mode;      // the workgroup-per-query walk: 0 = calls of up to kWideMaxQueries queries, 1 = never, 2 = always
-  uint32_t wide_pull;      // that walk's helpers pull the next hop's rows through L2 ahead of time (calls of very few queries)
+  uint32_t wide_pull;      // 2: that walk's other waves work ahead on the row the walk expands next (PlainWideDist); 0: they only share a hop's rows
 };
 
 // pairs of candidate rows a wave keeps in flight per chunk.  DEEP (one wave per SIMD, the batch-search
@@ -435,26 +435,29 @@ struct PlainDist {
 // two rows per instruction, and leaves the raw sums at the rows' ranks; the walker reads them back.  Same pairs, same
 // arithmetic, same bits, same visit order; two workgroup barriers per hop.
 constexpr uint32_t kWideAheadPad = 24;  // spare entry + rows_range's dump behind the 64 positions (kHopSlots = 64 + U, U <= 8)
+// The walker talks to the other waves in WORDS: it fills the fields, then raises `word` by one; a wave that is through
+// with the last word spins on it.  The walker sends a word only when every other wave has taken the one before -- it
+// has waited for their completion counts by then -- so a field is never overwritten under a reader.
+constexpr uint32_t kWordShare = 1u;  // `cnt` pending rows are listed: take your share (one barrier behind it)
+constexpr uint32_t kWordAhead = 2u;  // `ahead` is the adjacency row of the candidate the walk expands next: work ahead on it
+constexpr uint32_t kWordDone = 3u;   // the walk is over
 struct WideShared {
-  uint32_t cnt;        // pending rows of the hop the walker has published; kWideDone: the walk is over
-  uint32_t ahead_done; // helper waves that have finished their share of the distances ahead, ever (monotonic)
-  uint32_t ahead_seq;  // rows to work ahead on that the walker has named, ever (one per handshake; monotonic)
-  uint32_t mark_on;    // != 0: the marker wave also runs the visited-set test of that row's neighbours
-  uint32_t mark_seq;   // rows the marker has been through, ever (monotonic)
-  uint32_t pad_;
+  uint32_t word;       // words sent, ever (monotonic)
+  uint32_t kind;       // what the last one says
+  uint32_t cnt;        // kWordShare: pending rows of the hop
+  uint32_t mark_on;    // kWordAhead: != 0: the marker wave runs the visited-set test of that row's neighbours
+  unsigned long long ahead;  // kWordAhead: the row
+  uint32_t ahead_done; // rows ahead the computing waves are through with, times their number (monotonic)
+  uint32_t mark_seq;   // kWordAhead words the marker is through with (monotonic)
   unsigned long long mark_pend;  // the neighbours (by edge position) that were new to the visited set
   uint32_t mark_cell[64];        // where each of those went in the table
-  unsigned long long ahead;  // adjacency row of the candidate the walk will expand next (0: none)
-  uint32_t dump[64];         // where the helpers retire the words they pulled through the cache
   uint32_t ahead_slot[64 + kWideAheadPad];  // that row's slots by edge position
   float ahead_res[64 + kWideAheadPad];      // raw sums of distFn(query, neighbour) by edge position
 };
-constexpr uint32_t kWideDone = 0xFFFFFFFFu;
 
 // pairs of rows per round of loads: a wave's share of a hop is at most 64 / W rows (rounded up to even), so 32 / W pairs
-// hold it -- but its share of the distances AHEAD is 6 rows at W = 16 (14 waves compute), and two rounds of loads in
-// sequence are two memory round trips on the path that bounds the hop: three pairs where the registers allow it (rows of
-// up to 512 floats; 128 registers per wave at 16 waves)
+// hold it -- but its share of the distances AHEAD is 6 rows at W = 16 (14 waves compute): three pairs where the registers
+// allow it (rows of up to 512 floats; 128 registers per wave at 16 waves)
 template <int NG, int W>
 struct WidePairs {
   static constexpr int kMin = 32 / W > 0 ? 32 / W : 1;
@@ -463,108 +466,81 @@ struct WidePairs {
 template <int NG, bool L2, int W>
 struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W>::value> {
   using Base = PlainDist<NG, L2, true, WidePairs<NG, W>::value>;
-  // A call of few queries has bandwidth to spare and a dependent chain to shorten.  70 % of the hops expand the candidate
-  // that was first in line one hop earlier (tools/spec_hits.py), so with every hop the walker names that candidate
-  // (search_body, Dist::kSpeculate) and fetches its adjacency row; while it inserts this hop's points the helper waves
-  //   wide_pull = 1: pull the vectors of that candidate's neighbours through the XCD's L2, one word per 64-byte sector,
-  //   wide_pull = 2: COMPUTE the raw distances to all of its neighbours (by edge position, visited or not),
-  // and a hop whose pick is the guess starts with its row in a register and -- in mode 2 -- its distances in LDS: what
-  // is left of it is the visited-set test and AddWithLimit.  Nothing is decided on a guess: the pick, the visited set,
-  // the order of the inserts are the walk's own; a wrong guess costs traffic.
+  // A call of few queries has bandwidth to spare and a dependent chain to shorten.  Once a hop's distances are known, so
+  // is the candidate the walk expands next (search_body, Dist::kSpeculate: 99 % of the hops expand exactly it) -- BEFORE
+  // the hop's points are inserted.  The walker names it there (a.wide_pull = 2), and while it inserts
+  //   * the marker (wave 1) runs the visited-set test of that candidate's neighbours on the walker's table,
+  //   * the computing waves (2 .. W-1) COMPUTE the raw distances to all of its neighbours, by edge position,
+  // so that the next hop starts with its adjacency row in a register, its CheckAndVisit verdict and its distances in LDS:
+  // what is left of it is AddWithLimit.  Nothing is decided on a guess: should the walk go elsewhere (a tie, a NaN, the
+  // start node's overflow list), the marks are taken back, the rows are shared out the plain way (kWordShare), and the
+  // guess has cost traffic.  Same pairs, same arithmetic, same bits, same visit order.
   static constexpr bool kSpeculate = true;
   static constexpr size_t kLdsBytes = Base::kLdsBytes + sizeof(WideShared);
-  // Wave 1 is the MARKER when rows are worked ahead on (W >= 4): it runs the visited-set test of the named row's
-  // neighbours on the walker's table while the walker inserts the last hop's points (CheckAndVisit marks before any
-  // distance is looked at, distset.go:174, and nothing else touches the set in between, so when the walk does expand
-  // that row -- 99 % of the time -- the marks are exactly the ones its own test would have made; otherwise the walker
-  // takes them back before it tests anything).  Waves kFirstAhead .. W-1 compute the distances ahead.
+  // Wave 1 is the MARKER (W >= 4): CheckAndVisit marks before any distance is looked at (distset.go:174) and nothing else
+  // touches the set between the naming and the next hop, so the marks are exactly the ones the walker's own test would
+  // have made.  Waves kFirstAhead .. W-1 compute the distances ahead.
   static constexpr int kFirstAhead = W >= 4 ? 2 : 1;
   static constexpr int kAheadWaves = W - kFirstAhead;
   static constexpr int kAheadPer = ((64 + kAheadWaves - 1) / kAheadWaves + 1) & ~1;  // rows ahead per computing wave (even)
   WideShared *sh;
   int wave;
   bool hit_cur;         // walker: this hop expands the candidate named one hop ago, and its distances were computed ahead
-  bool ahead_computed;  // walker: the helpers were handed a row to compute ahead after the last handshake
-  bool ahead_owed;      // walker: a handshake has happened whose word on the row ahead is still to come (ahead())
-  uint32_t ahead_expect;  // walker: value of sh->ahead_done once every helper has finished what it was handed
-  uint32_t seq;           // rows ahead named (walker) / taken (helpers)
-  bool marked;            // walker: the marker was sent through the row named last
-  uint32_t mark_expect;   // walker: value of sh->mark_seq once it is through
+  bool ahead_computed;  // walker: the last hop named a row
+  bool marked;          // walker: ... and the marker was sent through it
+  uint32_t ahead_expect;  // walker: value of sh->ahead_done once every computing wave is through with what was named
+  uint32_t mark_expect;   // walker: value of sh->mark_seq once the marker is
+  uint32_t words;         // words sent (walker) / taken (the others)
+  SearchArgs const *args_;
+#ifdef SDB_STAMPS
+  unsigned long long t_named = 0;
+#endif
   __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lds) {
     Base::init(a, q, lane, lds);  // every wave keeps the query in its registers
     sh = reinterpret_cast<WideShared *>(reinterpret_cast<char *>(lds) + Base::kLdsBytes);
     wave = w, args_ = &a;
-    hit_cur = false, ahead_computed = false, ahead_owed = false, ahead_expect = 0, seq = 0;
-    marked = false, mark_expect = 0;
-    if (w == 0 && lane == 0) sh->ahead_done = 0, sh->ahead_seq = 0, sh->mark_seq = 0, sh->mark_on = 0;
+    hit_cur = false, ahead_computed = false, marked = false, ahead_expect = 0, mark_expect = 0, words = 0;
+    if (w == 0 && lane == 0) sh->word = 0, sh->ahead_done = 0, sh->mark_seq = 0, sh->mark_on = 0;
   }
   __device__ __forceinline__ void speculation(bool use, const uint32_t *) { hit_cur = use && ahead_computed; }
-  // The walker's word on the row to work ahead on, once per hop and AFTER the hop's distances are known (search_body):
-  // the helpers, through with their shares, wait for it.  Chunks of the start node's overflow list carry none.
-  __device__ __forceinline__ void ahead(const SearchArgs &a, const uint32_t *rowp, int lane, bool markable) {
-    if (!a.wide_pull) return;
-    if (!ahead_owed) handshake(a, 0, lane);  // a chunk without a new neighbour: the helpers have to be fetched first
-    name_ahead(a, rowp, lane, markable);
+
+  // ---- the walker (wave 0)
+  // every other wave is through with the last word (and spins for the next)
+  __device__ __forceinline__ void quiesce() {
+    while (__atomic_load_n(&sh->ahead_done, __ATOMIC_RELAXED) != ahead_expect) __builtin_amdgcn_s_sleep(1);
+    if (kFirstAhead == 2)
+      while (__atomic_load_n(&sh->mark_seq, __ATOMIC_RELAXED) != mark_expect) __builtin_amdgcn_s_sleep(1);
   }
-  __device__ __forceinline__ void name_ahead(const SearchArgs &a, const uint32_t *rowp, int lane, bool markable = false) {
-    ahead_owed = false;
-    ahead_computed = a.wide_pull == 2 && rowp != nullptr;
-    if (ahead_computed) ahead_expect += (uint32_t)kAheadWaves;
-    marked = ahead_computed && markable && kFirstAhead == 2;
-    if (marked) mark_expect++;
-    seq++;
+  __device__ __forceinline__ void send(uint32_t kind, int lane) {  // the fields are written (lane 0)
+    words++;
     if (lane == 0) {
-      sh->mark_on = marked ? 1u : 0u;
-      sh->ahead = reinterpret_cast<unsigned long long>(rowp);
+      sh->kind = kind;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __atomic_store_n(&sh->ahead_seq, seq, __ATOMIC_RELAXED);
+      __atomic_store_n(&sh->word, words, __ATOMIC_RELAXED);
     }
   }
-  __device__ __forceinline__ void pull_ahead(const SearchArgs &a, const uint32_t *rowp, int lane, uint32_t (&got)[2]) {
-    const uint32_t sectors = a.ld / 16;  // 64-byte sectors of a slab row
-    got[0] = got[1] = 0u;
-    if (!rowp || wave == 0) return;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const uint32_t p = ((uint32_t)(wave - 1) * 2u + (uint32_t)r) * 64u + (uint32_t)lane;
-      const uint32_t i = p / sectors, j = p - i * sectors;
-      if (i < kAdjStride) {
-        const uint32_t nb = rowp[i];
-        if (nb != kNoSlot) got[r] = reinterpret_cast<const uint32_t *>(a.slab)[(size_t)nb * a.ld + j * 16u];
-      }
-    }
+  // The walker's word on the row to work ahead on, once per hop and AFTER the hop's distances are known (search_body).
+  __device__ __forceinline__ void ahead(const SearchArgs &a, const uint32_t *rowp, int lane, bool markable) {
+    ahead_computed = a.wide_pull == 2 && rowp != nullptr;
+    marked = ahead_computed && markable && kFirstAhead == 2;
+    if (!ahead_computed) return;
+    quiesce();
+#ifdef SDB_STAMPS
+    t_named = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    ahead_expect += (uint32_t)kAheadWaves;
+    if (kFirstAhead == 2) mark_expect++;
+    if (lane == 0) sh->mark_on = marked ? 1u : 0u, sh->ahead = reinterpret_cast<unsigned long long>(rowp);
+    send(kWordAhead, lane);
   }
-  // helper waves, mode 2: this wave's share of the distances to the neighbours of the candidate ahead
-  __device__ __forceinline__ void compute_ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
-#ifdef SDB_STAMPS
-    unsigned long long c0 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-    const uint32_t nb = rowp[lane];
-#ifdef SDB_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long c1 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    this->st[0] += c1 - c0;  // the adjacency row's round trip
-#endif
-    const uint64_t m = __ballot(nb != kNoSlot);
-    const int deg = __popcll(m);  // rows are padded with kNoSlot behind their edges
-    sh->ahead_slot[lane] = nb != kNoSlot ? nb : 0u;  // every helper writes the same words
-    if (lane == deg - 1) sh->ahead_slot[deg] = nb;  // the spare entry behind the list
-    wave_lds_sync();
-    const int first = (wave - kFirstAhead) * kAheadPer;
-    const int count = deg - first < kAheadPer ? deg - first : kAheadPer;
-    if (count > 0) {
-      if (a.tail) this->template rows_range<true, true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
-      else this->template rows_range<false, true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
-    }
-    wave_lds_sync();  // the sums before the count
-#ifdef SDB_STAMPS
-    unsigned long long c2 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    this->st[1] += c2 - c1;  // list into LDS + the rows
-#endif
-    if (lane == 0) atomicAdd(&sh->ahead_done, 1u);
+  // what the marker found for the row named last: the neighbours that were new to the set, and where they went
+  __device__ __forceinline__ void take_marks(int lane, uint64_t &mask, uint32_t &cell) {
+    while (__atomic_load_n(&sh->mark_seq, __ATOMIC_RELAXED) != mark_expect) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    mask = sh->mark_pend;
+    cell = sh->mark_cell[lane];
+    marked = false;
   }
   // this wave's share of `cnt` pending rows: contiguous ranks, an even number per wave so that only the list's last row
   // can be the odd one out (its spare entry sits behind the list)
@@ -578,60 +554,73 @@ struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W>::value> {
     if (a.tail) this->template rows_range<true, true>(a, s_slot, s_res, first, count, lane);
     else this->template rows_range<false, true>(a, s_slot, s_res, first, count, lane);
   }
-  // ---- the walker (wave 0)
-  // what the marker found for the row named last: the neighbours that were new to the set, and where they went
-  __device__ __forceinline__ void take_marks(int lane, uint64_t &mask, uint32_t &cell) {
-    while (__atomic_load_n(&sh->mark_seq, __ATOMIC_RELAXED) != mark_expect) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    mask = sh->mark_pend;
-    cell = sh->mark_cell[lane];
-    marked = false;
-  }
-  // one handshake with the helpers: `cnt` pending rows to share (their list is in place) and the row to work ahead on
-  __device__ __forceinline__ void handshake(const SearchArgs &a, int cnt, int lane) {
-    if (ahead_owed) name_ahead(a, nullptr, lane);  // the last handshake's word never came (an overflow chunk): none
-    if (lane == 0) sh->cnt = (uint32_t)cnt;
-    __syncthreads();  // B1: the list is published
-    share(a, cnt, lane);
-    __syncthreads();  // B2: every share has been written
-    ahead_owed = a.wide_pull != 0;
-  }
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
     const int cnt = __popcll(pend);
     const bool mine = (pend >> lane) & 1ull;
     if (hit_cur) {  // this row's distances were computed while the last hop's points were inserted: by edge position
       hit_cur = false;
+#ifdef SDB_STAMPS  // st[2]: from naming the row to needing its distances (the walker's own work); st[0]: waiting for them
+      const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      this->st[2] += w0 - t_named;
+#endif
       while (__atomic_load_n(&sh->ahead_done, __ATOMIC_RELAXED) != ahead_expect) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const float raw = sh->ahead_res[lane];
-      handshake(a, 0, lane);  // nothing to share; the helpers get the next row to work ahead on
+#ifdef SDB_STAMPS
+      asm volatile("" ::"v"(raw));
+      const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      this->st[0] += w1 - w0;
+#endif
       return mine ? metric_finish(raw, a.metric) : 0.0f;
     }
     const uint32_t rank =
         __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
     uint32_t *s_slot = this->hs;
     float *s_res = reinterpret_cast<float *>(this->hs + Base::kHopSlots);
+    quiesce();  // the others may still be at a row the walk did not go to
     if (mine) {
       s_slot[rank] = nb;
       if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
     }
-    handshake(a, cnt, lane);
+    if (lane == 0) sh->cnt = (uint32_t)cnt;
+    send(kWordShare, lane);
+    share(a, cnt, lane);
+    __syncthreads();  // every share has been written
     return mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
   }
-  // a chunk without a new neighbour: nothing to share (search_body's ahead() fetches the helpers when it has a row for them)
-  __device__ __forceinline__ void skip(int) { hit_cur = false; }
-  SearchArgs const *args_;
+  __device__ __forceinline__ void skip(int) { hit_cur = false; }  // a chunk without a new neighbour: nothing to share
   __device__ __forceinline__ void finish(int lane) {
-    if (ahead_owed) name_ahead(*args_, nullptr, lane);
-    if (lane == 0) sh->cnt = kWideDone;
-    __syncthreads();  // B1: the helpers leave
+    quiesce();
+    send(kWordDone, lane);
   }
+
   // ---- waves 1 .. W-1
+  // a computing wave's share of the distances to the neighbours of the candidate ahead
+  __device__ __forceinline__ void compute_ahead(const SearchArgs &a, const uint32_t *rowp, int lane) {
+    const uint32_t nb = rowp[lane];
+    const uint64_t m = __ballot(nb != kNoSlot);
+    const int deg = __popcll(m);  // rows are padded with kNoSlot behind their edges
+    sh->ahead_slot[lane] = nb != kNoSlot ? nb : 0u;  // every computing wave writes the same words
+    if (lane == deg - 1) sh->ahead_slot[deg] = nb;  // the spare entry behind the list
+    wave_lds_sync();
+    const int first = (wave - kFirstAhead) * kAheadPer;
+    const int count = deg - first < kAheadPer ? deg - first : kAheadPer;
+    if (count > 0) {
+      if (a.tail) this->template rows_range<true, true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
+      else this->template rows_range<false, true>(a, sh->ahead_slot, sh->ahead_res, first, count, lane);
+    }
+    wave_lds_sync();  // the sums before the count
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      atomicAdd(&sh->ahead_done, 1u);
+    }
+  }
   template <class HV>  // HV: the walker's visited set (its table is `tab`)
   __device__ __forceinline__ void serve(const SearchArgs &a, int lane, uint32_t *tab) {
-    uint32_t got[2] = {0u, 0u};
-    uint32_t marks = 0;  // rows this wave has been through as the marker
-#ifdef SDB_STAMPS  // waves 1 (marker) and 2 (first computing wave): waiting at B1, waiting for the walker's word, the work ahead
-    unsigned long long hs_b1 = 0, hs_word = 0, hs_work = 0, hs_share = 0, hs_n = 0;
+#ifdef SDB_STAMPS  // per wave: waiting for a word, the shares, the work ahead
+    unsigned long long hs_word = 0, hs_share = 0, hs_work = 0, hs_n = 0;
 #define SDB_HSTAMP(acc)                                         \
   {                                                             \
     unsigned long long _t = __builtin_amdgcn_s_memtime();       \
@@ -645,57 +634,53 @@ struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W>::value> {
 #define SDB_HSTAMP(acc)
 #endif
     for (;;) {
-      __syncthreads();  // B1
-      SDB_HSTAMP(hs_b1)
-      const uint32_t cnt = sh->cnt;
-      if (cnt == kWideDone) {
+      words++;
+      while (__atomic_load_n(&sh->word, __ATOMIC_RELAXED) != words) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      SDB_HSTAMP(hs_word)
+      const uint32_t kind = sh->kind;
+      if (kind == kWordDone) {
 #ifdef SDB_STAMPS
         if (lane == 0 && a.tr_visit && a.visit_cap >= 44) a.tr_visit[(size_t)blockIdx.x * a.visit_cap + 28 + wave] = hs_work;
         if (lane == 0 && (wave == 1 || wave == 2) && a.tr_visit && a.visit_cap >= 24) {
           uint64_t *o = a.tr_visit + (size_t)blockIdx.x * a.visit_cap + (wave == 1 ? 12 : 18);
-          o[0] = hs_b1, o[1] = hs_share, o[2] = hs_word, o[3] = hs_work, o[4] = hs_n, o[5] = (this->st[0] << 32) | (this->st[1] & 0xFFFFFFFFull);
+          o[0] = 0, o[1] = hs_share, o[2] = hs_word, o[3] = hs_work, o[4] = hs_n, o[5] = 0;
         }
 #endif
         return;
       }
-      if (a.wide_pull == 1) sh->dump[lane] = got[0] ^ got[1];  // the last hop's pulls have long arrived: retire them
-      share(a, (int)cnt, lane);
-      __syncthreads();  // B2
-      SDB_HSTAMP(hs_share)
-      if (!a.wide_pull) continue;
-      seq++;  // the walker names the row ahead once it has looked at this hop's distances
-      while (__atomic_load_n(&sh->ahead_seq, __ATOMIC_RELAXED) != seq) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      SDB_HSTAMP(hs_word)
+      if (kind == kWordShare) {
+        share(a, (int)sh->cnt, lane);
+        __syncthreads();
+        SDB_HSTAMP(hs_share)
+        continue;
+      }
 #ifdef SDB_STAMPS
       hs_n++;
 #endif
       const uint32_t *ahead = reinterpret_cast<const uint32_t *>(sh->ahead);
-      if (a.wide_pull == 1) {
-        pull_ahead(a, ahead, lane, got);
-      } else if (ahead) {
-        if (kFirstAhead == 2 && wave == 1) {
-          if (sh->mark_on) {
-            const uint32_t nb = ahead[lane];
-            uint32_t cell;
-            const bool isnew = HV::claim(tab, nb != kNoSlot, nb, cell);
-            const uint64_t pend = __ballot(isnew);
-            sh->mark_cell[lane] = cell;
-            if (lane == 0) sh->mark_pend = pend;
-            wave_lds_sync();
-            marks++;
-            if (lane == 0) {
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-              __atomic_store_n(&sh->mark_seq, marks, __ATOMIC_RELAXED);
-            }
-          }
-        } else {
-          compute_ahead(a, ahead, lane);
+      if (kFirstAhead == 2 && wave == 1) {
+        if (sh->mark_on) {
+          const uint32_t nb = ahead[lane];
+          uint32_t cell;
+          const bool isnew = HV::claim(tab, nb != kNoSlot, nb, cell);
+          const uint64_t pend = __ballot(isnew);
+          sh->mark_cell[lane] = cell;
+          if (lane == 0) sh->mark_pend = pend;
+          wave_lds_sync();
         }
+        n_ahead++;
+        if (lane == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __atomic_store_n(&sh->mark_seq, n_ahead, __ATOMIC_RELAXED);
+        }
+      } else {
+        compute_ahead(a, ahead, lane);
       }
       SDB_HSTAMP(hs_work)
     }
   }
+  uint32_t n_ahead = 0;  // marker: kWordAhead words it is through with
 };
 
 // Fitted product quantizer: dist = sum_i lut[i*K + code_i], plain fp32 adds in index order
@@ -1839,7 +1824,6 @@ __global__ __launch_bounds__(64 * W) void k_greedy_search_wide(const SearchArgs 
   }
   __syncthreads();
   if (wave != 0) return dist.template serve<HashVisited<kHashCap>>(a, lane, reinterpret_cast<uint32_t *>(lds_f));
-  __builtin_amdgcn_s_setprio(3);  // the walk is the serial part: its wave goes first on the SIMD it shares with three helpers
   if constexpr (FILT) {
     search_body<PlainWideDist<NG, L2, W>, 2, true>(a, q, lane, dist, hv, rv);
   } else {

@@ -40,7 +40,7 @@ for mode in (1, 2):
                 h = full[:, o:o + 5].mean(axis=0)
                 packed = full[:, o + 5].astype(np.uint64)
                 print("      inside the work ahead, per hop: adjacency row %.0f, rows %.0f" % ((packed >> np.uint64(32)).mean() / nh, (packed & np.uint64(0xFFFFFFFF)).mean() / nh))
-                print("   %s, per hop: at B1 %.0f, share + B2 %.0f, waiting for the walker's word %.0f, work ahead %.0f (%.1f rows named per walk)"
-                      % (name, h[0] / nh, h[1] / nh, h[2] / nh, h[3] / nh, h[4]))
+                print("   %s, per hop: shares %.0f, waiting for the walker's word %.0f, work ahead %.0f (%.1f rows named per walk)"
+                      % (name, h[1] / nh, h[2] / nh, h[3] / nh, h[4]))
         print("mode %d nq %4d hops %.1f | per hop (memtime ticks): adj %.0f atom %.0f vec %.0f ins %.0f total %.0f | inside vec: issue %.0f wait %.0f compute %.0f"
               % (mode, nq, nh, *(v.mean(axis=0) / nh), v.sum(axis=1).mean() / nh, *(sub.mean(axis=0) / nh)))
