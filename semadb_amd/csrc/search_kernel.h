@@ -203,7 +203,7 @@ template <int NG, bool L2, bool DEEP = false, int UPAIRS = 0>  // UPAIRS != 0: t
 struct PlainDist {
   static constexpr bool kHasStamps = true;
   static constexpr bool kPointDistances = true;  // dist(query, row) is distFn between two stored vectors
-  static constexpr bool kSpeculate = false;      // search_body: no adjacency row is fetched ahead of its hop
+  static constexpr bool kSpeculate = false;      // search_body: nothing is worked ahead on between the hops
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = UPAIRS ? UPAIRS : (NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4);
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
@@ -263,7 +263,6 @@ struct PlainDist {
 
   __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
-  __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
   __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   // hooks of the multi-wave quantized walk (PQWideDist); nothing to do for a one-wave policy
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
@@ -708,7 +707,6 @@ struct PQDist {
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
-  __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
   __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
@@ -861,7 +859,6 @@ struct PQWideDist {
 
   // ---- the walker's side (wave 0): the policy interface search_body calls
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
-  __device__ __forceinline__ void fetch_ahead(const SearchArgs &, uint32_t) {}
   __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *rowp, int lane) {
     if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u;
@@ -1517,8 +1514,9 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     // is all AddWithLimit(neighbours...) depends on.
     const uint32_t *__restrict__ rowp = a.adj + (size_t)pid * kAdjStride;
     uint32_t ext_left = pid == a.start_slot ? a.start_ext_n : 0u, ext_done = 0;
-    // Dist::kSpeculate: is this hop's row the one fetched ahead, and which row to fetch ahead now -- the first
-    // unvisited entry as the array stands (this hop's own entry is marked already)
+    // Dist::kSpeculate: is this hop's row the one named during the last hop (then its adjacency row is in spec_nb), and
+    // who is first in line now -- this hop's own entry is marked already -- with its distance: the hop names either it
+    // or a nearer new point once its distances are known (below)
     bool use_spec = false;
     const uint32_t *spec_rowp = nullptr;
     if constexpr (Dist::kSpeculate) {
@@ -1629,10 +1627,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
             dist.ahead(a, spec_rowp, lane, vis.markable());
           }
       }
-      if constexpr (Dist::kSpeculate) {
-        if (first_chunk && spec_rowp) dist.fetch_ahead(a, spec_nb);
-        first_chunk = false;
-      }
+      if constexpr (Dist::kSpeculate) first_chunk = false;
       if (__builtin_expect(ext_left == 0, 1)) break;
       rowp = a.start_ext + ext_done;
       ext_done += 64;
