@@ -1603,11 +1603,12 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
                 }
               }
             }
+            // (the marker only when no overflow chunk follows: the walker's own tests of those must have the table to themselves)
             // its row, for the next hop: asked for HERE and not when the hop began -- a load in flight is waited for at
             // every workgroup barrier (the fence of __syncthreads), and the hop's handshake would stand still for it
             if (spec_rowp) spec_nb = spec_rowp[lane];
             SDB_STAMP(st_w[2])
-            dist.ahead(a, spec_rowp, lane, vis.markable());
+            dist.ahead(a, spec_rowp, lane, vis.markable() && ext_left == 0);
             SDB_STAMP(st_w[3])
           }
         }
@@ -1624,7 +1625,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         if constexpr (Dist::kSpeculate)
           if (first_chunk) {  // no new point: the candidate first in line stays it
             if (spec_rowp) spec_nb = spec_rowp[lane];
-            dist.ahead(a, spec_rowp, lane, vis.markable());
+            dist.ahead(a, spec_rowp, lane, vis.markable() && ext_left == 0);
           }
       }
       if constexpr (Dist::kSpeculate) first_chunk = false;
