@@ -1,3 +1,4 @@
+#include <type_traits>
 // pq.hip -- K5..K8: k-means (utils/kmeans.go:34-150) and the product quantizer
 // (shard/vectorstore/product.go) as batched assignment / LUT-distance kernels.
 //
@@ -51,8 +52,9 @@ __device__ __forceinline__ float dist_serial_metric(const float *x, const float 
 // elements in memory (sub_len % 32 of them), chained sequentially as the asm does.
 constexpr int kRegBlocksMax = 8;  // sub-vectors of up to 8 * 32 + 31 floats take the register path
 typedef float pq_f2v __attribute__((ext_vector_type(2)));
-template <bool L2, int NB, typename UP = const float *__restrict__>
-__device__ __forceinline__ float dist_regs(const float *r, UP u, const float *__restrict__ rt, uint32_t tail) {
+template <bool L2, int NB, typename UP = const float *__restrict__, int TC = -1>  // TC >= 0: the tail's length, known at compile time
+__device__ __forceinline__ float dist_regs(const float *r, UP u, const float *__restrict__ rt, uint32_t tail_rt) {
+  const uint32_t tail = TC >= 0 ? (uint32_t)TC : tail_rt;
   // partial sums 2p and 2p + 1 advance together: one v_pk_fma_f32 (and, for euclidean, one packed subtract, rounded per
   // element like VSUBPS) per pair of elements -- each half is the reference's own operation on its own chain
   pq_f2v acc2[16];
@@ -555,10 +557,11 @@ __global__ void k_pq_lut(const float *__restrict__ queries, uint32_t dim, const 
 #define SDB_LUT_QT 16
 #endif
 constexpr uint32_t kLutQT = SDB_LUT_QT;
-template <bool L2, int NB>
+template <bool L2, int NB, int SL = 0>  // SL: the sub-vector length when it is a usual short one (k_pq_encode_pair), 0 = any
 __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ queries, uint32_t nq, uint32_t dim,
                                                   const float *__restrict__ cent, uint32_t M, uint32_t K,
-                                                  uint32_t sub_len, int metric, float *__restrict__ lut) {
+                                                  uint32_t sub_len_rt, int metric, float *__restrict__ lut) {
+  const uint32_t sub_len = SL > 0 ? (uint32_t)SL : sub_len_rt;
   const uint32_t i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
   const uint32_t q0 = blockIdx.z * kLutQT, q1 = min(q0 + kLutQT, nq);
   const float *row = cent + ((size_t)i * K + min(j, K - 1)) * sub_len;
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ quer
   for (uint32_t k = 0; k < kLutQT; k++) {
     const uint32_t q = q0 + k < nq ? q0 + k : nq - 1;  // past the end: the last query again (the same value is stored twice)
     const float *x = queries + (size_t)q * dim + (size_t)i * sub_len;
-    float d = dist_regs<L2, NB>(r, x, rt, tail);
+    float d = dist_regs<L2, NB, const float *__restrict__, (SL > 0 ? SL - NB * 32 : -1)>(r, x, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);
     if (j < K) lut[((size_t)q * M + i) * K + j] = d;
   }
@@ -612,10 +615,14 @@ __global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ v
 // can: the chains of vector 2t and 2t + 1 against the same centroid advance together in the halves of one packed
 // subtract and one packed FMA (the centroid element broadcast to both halves) -- each half is the reference's own
 // operation on its own chain.  Half the instructions per (vector, centroid).
-template <bool L2>
+// SL: the sub-vector length when it is one of the usual ones (4, 8, 16, 24: d = 768 at M = 192, 96, 48, 32), 0 = any.  With
+// the length a run-time value every element of the 31-slot chain is a compare and a branch around two operations -- at
+// 4 floats 27 of 31 steps are nothing but that, per centroid.
+template <bool L2, int SL = 0>
 __global__ __launch_bounds__(256) void k_pq_encode_pair(const float *__restrict__ vecs, uint64_t n, uint32_t dim,
                                                         const float *__restrict__ cent, uint32_t M, uint32_t K,
-                                                        uint32_t sub_len, int metric, uint8_t *__restrict__ codes) {
+                                                        uint32_t sub_len_rt, int metric, uint8_t *__restrict__ codes) {
+  const uint32_t sub_len = SL > 0 ? (uint32_t)SL : sub_len_rt;
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t va = 2 * t, vb = 2 * t + 1;
   const uint32_t i = blockIdx.y;
@@ -655,24 +662,47 @@ __global__ __launch_bounds__(256) void k_pq_encode_pair(const float *__restrict_
 template <int NB>
 static void launch_lut_t(const sdb_pq *pq, const float *d_queries, uint64_t nq, float *d_lut, hipStream_t stream) {
   const dim3 grid((pq->K + 255) / 256, pq->M, (unsigned)((nq + kLutQT - 1) / kLutQT));
-  if (pq->metric == SDB_METRIC_EUCLIDEAN)
-    hipLaunchKernelGGL((k_pq_lut_t<true, NB>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
-                       pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
-  else
-    hipLaunchKernelGGL((k_pq_lut_t<false, NB>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
-                       pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+  auto go = [&](auto sl) {
+    constexpr int SL = decltype(sl)::value;
+    if (pq->metric == SDB_METRIC_EUCLIDEAN)
+      hipLaunchKernelGGL((k_pq_lut_t<true, NB, SL>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
+                         pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+    else
+      hipLaunchKernelGGL((k_pq_lut_t<false, NB, SL>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
+                         pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+  };
+  if constexpr (NB == 0) {
+    switch (pq->sub_len) {
+      case 4: go(std::integral_constant<int, 4>{}); return;
+      case 8: go(std::integral_constant<int, 8>{}); return;
+      case 16: go(std::integral_constant<int, 16>{}); return;
+      case 24: go(std::integral_constant<int, 24>{}); return;
+      default: break;
+    }
+  }
+  go(std::integral_constant<int, 0>{});
 }
 
 template <int NB>
 static void launch_encode_t(const sdb_pq *pq, const float *d_vecs, uint64_t n, uint8_t *d_codes, hipStream_t stream) {
   if constexpr (NB == 0) {
     const dim3 pgrid((unsigned)(((n + 1) / 2 + 255) / 256), pq->M);
-    if (pq->metric == SDB_METRIC_EUCLIDEAN)
-      hipLaunchKernelGGL((k_pq_encode_pair<true>), pgrid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M, pq->K,
-                         pq->sub_len, pq->metric, d_codes);
-    else
-      hipLaunchKernelGGL((k_pq_encode_pair<false>), pgrid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M, pq->K,
-                         pq->sub_len, pq->metric, d_codes);
+    auto go = [&](auto sl) {
+      constexpr int SL = decltype(sl)::value;
+      if (pq->metric == SDB_METRIC_EUCLIDEAN)
+        hipLaunchKernelGGL((k_pq_encode_pair<true, SL>), pgrid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M,
+                           pq->K, pq->sub_len, pq->metric, d_codes);
+      else
+        hipLaunchKernelGGL((k_pq_encode_pair<false, SL>), pgrid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M,
+                           pq->K, pq->sub_len, pq->metric, d_codes);
+    };
+    switch (pq->sub_len) {
+      case 4: go(std::integral_constant<int, 4>{}); break;
+      case 8: go(std::integral_constant<int, 8>{}); break;
+      case 16: go(std::integral_constant<int, 16>{}); break;
+      case 24: go(std::integral_constant<int, 24>{}); break;
+      default: go(std::integral_constant<int, 0>{}); break;
+    }
     return;
   }
   const dim3 grid((unsigned)((n + 255) / 256), pq->M);

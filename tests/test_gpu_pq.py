@@ -44,6 +44,8 @@ def test_kmeans_reference_kat():
 @pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
 @pytest.mark.parametrize("d,M,K,n", [(4, 2, 256, 5), (32, 8, 16, 600), (96, 2, 32, 400), (768, 8, 64, 700),
                                      (64, 16, 256, 1200),
+                                     # the short sub-vector lengths with kernels of their own (4 above; 8, 16, 24) and one without (12)
+                                     (64, 8, 32, 500), (128, 8, 64, 500), (96, 4, 16, 300), (96, 8, 16, 300),
                                      # sub-vector lengths 100 (3 blocks + tail), 256 (8 blocks), 320 (generic kernel)
                                      (200, 2, 16, 300), (512, 2, 8, 200), (640, 2, 8, 200),
                                      # whole 32-float blocks and K % 16 == 0: the LUT of dot / cosine is built on the matrix cores
