@@ -586,10 +586,11 @@ __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ quer
 }
 
 // encode: thread = vector (its sub-vector in registers), the K centroids are wave-uniform
-template <bool L2, int NB>
+template <bool L2, int NB, bool WHOLE = false>  // WHOLE: sub_len == 32 NB, no tail chain
 __global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ vecs, uint64_t n, uint32_t dim,
                                                      const float *__restrict__ cent, uint32_t M, uint32_t K,
-                                                     uint32_t sub_len, int metric, uint8_t *__restrict__ codes) {
+                                                     uint32_t sub_len_rt, int metric, uint8_t *__restrict__ codes) {
+  const uint32_t sub_len = WHOLE ? (uint32_t)NB * 32 : sub_len_rt;
   const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t i = blockIdx.y;
   const float *sub = vecs + (v < n ? v : n - 1) * dim + (size_t)i * sub_len;
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ v
   float best = FLT_MAX;
   uint32_t best_id = 0;
   for (uint32_t j = 0; j < K; j++) {
-    float d = dist_regs<L2, NB>(r, cent + ((size_t)i * K + j) * sub_len, rt, tail);
+    float d = dist_regs<L2, NB, const float *__restrict__, (WHOLE ? 0 : -1)>(r, cent + ((size_t)i * K + j) * sub_len, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);
     if (d < best) best = d, best_id = j;
   }
@@ -671,6 +672,12 @@ static void launch_lut_t(const sdb_pq *pq, const float *d_queries, uint64_t nq, 
       hipLaunchKernelGGL((k_pq_lut_t<false, NB, SL>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
                          pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
   };
+  if constexpr (NB > 0) {
+    if (pq->sub_len == (uint32_t)NB * 32) {  // whole blocks, no tail chain at all (M = 8 at d = 768: 96 floats)
+      go(std::integral_constant<int, NB * 32>{});
+      return;
+    }
+  }
   if constexpr (NB == 0) {
     switch (pq->sub_len) {
       case 4: go(std::integral_constant<int, 4>{}); return;
@@ -706,12 +713,16 @@ static void launch_encode_t(const sdb_pq *pq, const float *d_vecs, uint64_t n, u
     return;
   }
   const dim3 grid((unsigned)((n + 255) / 256), pq->M);
-  if (pq->metric == SDB_METRIC_EUCLIDEAN)
-    hipLaunchKernelGGL((k_pq_encode_t<true, NB>), grid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids,
-                       pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
-  else
-    hipLaunchKernelGGL((k_pq_encode_t<false, NB>), grid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids,
-                       pq->M, pq->K, pq->sub_len, pq->metric, d_codes);
+  const bool whole = NB > 0 && pq->sub_len == (uint32_t)NB * 32;
+  const bool l2 = pq->metric == SDB_METRIC_EUCLIDEAN;
+#define SDB_ENC(L2_, WH_)                                                                                                \
+  hipLaunchKernelGGL((k_pq_encode_t<L2_, NB, WH_>), grid, dim3(256), 0, stream, d_vecs, n, pq->dim, pq->d_centroids, pq->M, \
+                     pq->K, pq->sub_len, pq->metric, d_codes)
+  if (l2 && whole) SDB_ENC(true, true);
+  else if (l2) SDB_ENC(true, false);
+  else if (whole) SDB_ENC(false, true);
+  else SDB_ENC(false, false);
+#undef SDB_ENC
 }
 
 // The same table on the matrix cores, for dot / cosine sub-vectors of whole 32-float blocks and K a multiple of 16: per
