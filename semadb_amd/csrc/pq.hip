@@ -52,7 +52,7 @@ __device__ __forceinline__ float dist_serial_metric(const float *x, const float 
 // elements in memory (sub_len % 32 of them), chained sequentially as the asm does.
 constexpr int kRegBlocksMax = 8;  // sub-vectors of up to 8 * 32 + 31 floats take the register path
 typedef float pq_f2v __attribute__((ext_vector_type(2)));
-template <bool L2, int NB, typename UP = const float *__restrict__, int TC = -1>  // TC >= 0: the tail's length, known at compile time
+template <bool L2, int NB, int TC = -1, typename UP = const float *__restrict__>  // TC >= 0: the tail's length, known at compile time
 __device__ __forceinline__ float dist_regs(const float *r, UP u, const float *__restrict__ rt, uint32_t tail_rt) {
   const uint32_t tail = TC >= 0 ? (uint32_t)TC : tail_rt;
   // partial sums 2p and 2p + 1 advance together: one v_pk_fma_f32 (and, for euclidean, one packed subtract, rounded per
@@ -235,8 +235,10 @@ __global__ __launch_bounds__(1024) void k_km_init(const KmArgs a) {
 
 // assignment (kmeans.go:100-115): argmin over centroids, strict '<' starting from centroid 0.  Thread = point, its
 // sub-vector in registers, the centroids wave-uniform through the scalar cache (k_pq_encode_t's scheme).
-template <int NB>
-__global__ __launch_bounds__(256) void k_km_assign_t(const KmArgs a) {
+template <int NB, int LEN = 0>  // LEN: the sub-vector length when it is a usual one (k_pq_encode_pair), 0 = any
+__global__ __launch_bounds__(256) void k_km_assign_t(const KmArgs a_in) {
+  KmArgs a = a_in;
+  if (LEN > 0) a.len = LEN;
   const uint32_t m = blockIdx.y;
   if (a.done[m]) return;
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -248,10 +250,11 @@ __global__ __launch_bounds__(256) void k_km_assign_t(const KmArgs a) {
   float rt[31];
 #pragma unroll
   for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? sub[NB * 32 + e] : 0.0f;
-  float best = dist_regs<true, NB>(r, as_uniform(km_centroid(a, m, 0)), rt, tail);
+  constexpr int TCV = LEN > 0 ? LEN - NB * 32 : -1;
+  float best = dist_regs<true, NB, TCV>(r, as_uniform(km_centroid(a, m, 0)), rt, tail);
   uint32_t best_id = 0;
   for (uint32_t j = 1; j < a.K; j++) {
-    const float d = dist_regs<true, NB>(r, as_uniform(km_centroid(a, m, j)), rt, tail);
+    const float d = dist_regs<true, NB, TCV>(r, as_uniform(km_centroid(a, m, j)), rt, tail);
     if (d < best) best = d, best_id = j;
   }
   uint8_t *lab = a.labels + (size_t)m * a.lab_stride;
@@ -406,7 +409,22 @@ __global__ void k_km_scatter_labels(const uint8_t *__restrict__ labels, uint32_t
 
 template <int NB>
 static void launch_km_assign_t(const KmArgs &a, hipStream_t stream) {
-  hipLaunchKernelGGL((k_km_assign_t<NB>), dim3((a.n + 255) / 256, a.M), dim3(256), 0, stream, a);
+  const dim3 grid((a.n + 255) / 256, a.M);
+  if constexpr (NB > 0) {
+    if (a.len == (uint32_t)NB * 32) {
+      hipLaunchKernelGGL((k_km_assign_t<NB, NB * 32>), grid, dim3(256), 0, stream, a);
+      return;
+    }
+  } else {
+    switch (a.len) {
+      case 4: hipLaunchKernelGGL((k_km_assign_t<0, 4>), grid, dim3(256), 0, stream, a); return;
+      case 8: hipLaunchKernelGGL((k_km_assign_t<0, 8>), grid, dim3(256), 0, stream, a); return;
+      case 16: hipLaunchKernelGGL((k_km_assign_t<0, 16>), grid, dim3(256), 0, stream, a); return;
+      case 24: hipLaunchKernelGGL((k_km_assign_t<0, 24>), grid, dim3(256), 0, stream, a); return;
+      default: break;
+    }
+  }
+  hipLaunchKernelGGL((k_km_assign_t<NB>), grid, dim3(256), 0, stream, a);
 }
 
 // KMeans.Fit for M problems on device buffers: problem m = columns [offset0 + m * len, + len) of dX's rows, first
@@ -579,7 +597,7 @@ __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ quer
   for (uint32_t k = 0; k < kLutQT; k++) {
     const uint32_t q = q0 + k < nq ? q0 + k : nq - 1;  // past the end: the last query again (the same value is stored twice)
     const float *x = queries + (size_t)q * dim + (size_t)i * sub_len;
-    float d = dist_regs<L2, NB, const float *__restrict__, (SL > 0 ? SL - NB * 32 : -1)>(r, x, rt, tail);
+    float d = dist_regs<L2, NB, (SL > 0 ? SL - NB * 32 : -1)>(r, x, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);
     if (j < K) lut[((size_t)q * M + i) * K + j] = d;
   }
@@ -604,7 +622,7 @@ __global__ __launch_bounds__(256) void k_pq_encode_t(const float *__restrict__ v
   float best = FLT_MAX;
   uint32_t best_id = 0;
   for (uint32_t j = 0; j < K; j++) {
-    float d = dist_regs<L2, NB, const float *__restrict__, (WHOLE ? 0 : -1)>(r, cent + ((size_t)i * K + j) * sub_len, rt, tail);
+    float d = dist_regs<L2, NB, (WHOLE ? 0 : -1)>(r, cent + ((size_t)i * K + j) * sub_len, rt, tail);
     if constexpr (!L2) d = metric_finish(d, metric);
     if (d < best) best = d, best_id = j;
   }
