@@ -1125,7 +1125,7 @@ int store_rows_public(sdb_index *ix, uint32_t first, uint32_t n, const float *de
 }
 
 extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem,
-                                      uint32_t round_size, void *stream_) {
+                                      uint32_t round_size, void *stream_) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
   if (!vectors) return fail(SDB_ERR_INVALID, "vectors is NULL");
@@ -1166,6 +1166,15 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   } cleanup{{}, stream};
   // ---- every allocation of the call comes first: an out-of-memory failure must leave the index as it was
   SDB_TRY(ix->reserve(n0 + (uint32_t)n));
+  // ... the host tables' room included: the per-round bookkeeping (`commit` below) then cannot run out of memory with
+  // rounds already applied
+  {
+    std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // a rehash moves what the searches' id lookups read
+    ix->h_ids.reserve((size_t)n0 + n);
+    bool stays_dense = ix->dense_ids && ix->h_ids.size() > 0;
+    for (uint64_t i = 0; i < n && stays_dense; i++) stays_dense = new_ids[i] == ix->h_ids[0] + ix->h_ids.size() + i;
+    if (!stays_dense) ix->id2slot.reserve(((size_t)n0 + n) * 2);
+  }
   static_assert(SDB_BUILD_STATS <= sdb_index::kStatStride, "stat slots per copy");
   const size_t bstats_bytes = (size_t)sdb_index::kStatCopies * sdb_index::kStatStride * sizeof(uint64_t);
   if (!ix->d_bstats) SDB_HIP(hipMalloc(&ix->d_bstats, bstats_bytes));
@@ -1279,6 +1288,8 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
       return write_failed(sdb::fail(SDB_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                                     __LINE__));                                                                 \
   } while (0)
+  bool in_round = false;  // a round's prune / back-edge kernels may have started
+  auto run = [&]() -> int {
   SDB_W_HIP(hipMemsetAsync(ix->d_bstats, 0, bstats_bytes, stream));
   SDB_W_HIP(hipMemsetAsync(big_count, 0, 8, stream));
   const float *dvec = vectors;  // the vectors (original layout) on device; they double as the search queries
@@ -1375,6 +1386,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done, ba.dirty = ix->d_dirty;
     ba.pair_tab = pair_tab, ba.pair_slots = pair_slots, ba.pair_dists = pair_dists;
     bool start_pruned = false;
+    in_round = true;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
          : ix->P.metric == SDB_METRIC_EUCLIDEAN
              ? launch_round_ng<true>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)
@@ -1382,6 +1394,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     if (rc != SDB_OK) return round_failed(rc);
     if (start_pruned) ix->h_start_ext.clear();  // the device copy is simply no longer referenced (count 0)
     commit(done, done + rs);
+    in_round = false;
     done += rs;
     n_rounds++;
   }
@@ -1395,8 +1408,17 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_W_HIP(hipStreamSynchronize(stream));
   }
   return SDB_OK;
+  };
+  // a C++ exception past this point (a hub list that finds no host memory) takes the same two doors
+  try {
+    return run();
+  } catch (...) {
+    const int rc = sdb::on_exception("sdb_index_insert_batch");
+    return in_round ? round_failed(rc) : write_failed(rc);
+  }
 #undef SDB_W_TRY
 #undef SDB_W_HIP
 }
+SDB_API_CATCH("sdb_index_insert_batch")
 
 #include "delete.inc"

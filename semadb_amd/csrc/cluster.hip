@@ -397,9 +397,43 @@ static int verdict_slot(sdb_cluster *c, uint64_t seq, int *vi) {
 }
 
 // Common body of the two collective calls.  ix == nullptr: the caller's own block (allgather_merge).
+// how far a collective call had got when a C++ exception (out of host memory) ended it: collective() below puts the
+// handle into the state the same point reaches through its error returns
+struct CallProgress {
+  sdb_cluster::Slot *slot = nullptr;
+  int vi = -1;
+  bool numbered = false;  // took a sequence number ...
+  bool entered = false;   // ... and its block is in the exchange
+};
+
+static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries, uint32_t per_shard,
+                           void *user_block, uint32_t limit, uint32_t search_size, uint64_t *out_ids, float *out_dists,
+                           uint32_t *out_shards, uint32_t *out_counts, int mem, hipStream_t user_stream, bool skip,
+                           CallProgress &prog);
+
 static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries, uint32_t per_shard,
                       void *user_block, uint32_t limit, uint32_t search_size, uint64_t *out_ids, float *out_dists,
                       uint32_t *out_shards, uint32_t *out_counts, int mem, hipStream_t user_stream, bool skip = false) {
+  CallProgress prog;
+  try {
+    return collective_impl(c, ix, ticket, nq, queries, per_shard, user_block, limit, search_size, out_ids, out_dists, out_shards,
+                           out_counts, mem, user_stream, skip, prog);
+  } catch (...) {
+    const int rc = on_exception("shard exchange");
+    std::lock_guard<std::mutex> g(*c->mu);  // the call's own lock went with the unwinding (after its turn was given on)
+    if (prog.numbered && !prog.entered) c->desync = true;  // a number was spent and the peers wait for its block
+    if (prog.slot) prog.slot->busy = false, prog.slot->pending = prog.entered && prog.slot->pending;
+    if (prog.vi >= 0 && c->vhost[prog.vi]) c->vhost[prog.vi] = false, c->verdicts[prog.vi].state = kVerdictNone;
+    c->cv->notify_all();
+    if (mem == SDB_MEM_HOST && out_counts && nq) memset(out_counts, 0, nq * 4);
+    return rc;
+  }
+}
+
+static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries, uint32_t per_shard,
+                           void *user_block, uint32_t limit, uint32_t search_size, uint64_t *out_ids, float *out_dists,
+                           uint32_t *out_shards, uint32_t *out_counts, int mem, hipStream_t user_stream, bool skip,
+                           CallProgress &prog) {
   const bool host = mem == SDB_MEM_HOST;
   std::unique_lock<std::mutex> lk(*c->mu);
   Turn turn{c, ticket};
@@ -450,11 +484,15 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
     if (ix || skip) stream = slot->hs;
   }
   // ---- from here on this rank WILL enter the exchange; a failure of its own goes into the tag
+  // (the group's arrival list for this sequence number gets its room first: nothing between taking the number and
+  // registering the arrival may need host memory -- a rank that took a number and then stayed out is out of step)
+  if (c->group) c->group->rv[c->seq].reserve((size_t)c->world);
   const uint64_t seq = c->seq++;
+  prog.numbered = true, prog.slot = slot, prog.vi = vi;
   int local_rc = SDB_OK;
-  std::string local_msg;
+  char local_msg[kErrBytes] = {0};
   auto note = [&](int rc) {
-    if (rc != SDB_OK && local_rc == SDB_OK) local_rc = rc, local_msg = last_error_ref();
+    if (rc != SDB_OK && local_rc == SDB_OK) local_rc = rc, memcpy(local_msg, last_error_buf(), kErrBytes);
   };
   const float *dq = queries;
   if (skip) {  // the fan-out gave this request up for this rank: an empty answer under an error flag, so that the
@@ -510,6 +548,7 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
       entered = false;
     }
   }
+  prog.entered = entered;
   if (!entered) {  // the device refused an enqueue: this rank is out of step from now on
     c->desync = true;
     slot->pending = false;
@@ -519,7 +558,7 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
   if (!host) {
     // asynchronous: the verdict arrives with sdb_cluster_synchronize; a failure of this rank's own search is known now
     if (local_rc != SDB_OK) {
-      last_error_ref() = local_msg;
+      memcpy(last_error_buf(), local_msg, kErrBytes);
       return local_rc;
     }
     return SDB_OK;
@@ -581,7 +620,7 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
   if (rc == SDB_OK) {
     const ExchangeVerdict v = c->verdicts[vi];
     if (v.state >= kVerdictMismatch) {
-      if (local_rc != SDB_OK) rc = fail(local_rc, "%s", local_msg.c_str());  // this shard's own failure, in its own words
+      if (local_rc != SDB_OK) rc = fail(local_rc, "%s", local_msg);  // this shard's own failure, in its own words
       else rc = fail(SDB_ERR_STATE, "%s", describe(v, c->world).c_str());
     } else if (v.state != kVerdictOk) {
       rc = fail(SDB_ERR_DEVICE, "the merge of exchange %llu left no verdict", (unsigned long long)seq);
@@ -605,7 +644,7 @@ static int collective(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t n
 
 extern "C" {
 
-int sdb_cluster_unique_id(uint8_t *id) {
+int sdb_cluster_unique_id(uint8_t *id) try {
   if (!id) return fail(SDB_ERR_INVALID, "id is NULL");
   static_assert(sizeof(ncclUniqueId) == SDB_CLUSTER_ID_BYTES, "unique id size");
   ncclUniqueId u;
@@ -613,8 +652,9 @@ int sdb_cluster_unique_id(uint8_t *id) {
   memcpy(id, &u, sizeof(u));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_unique_id")
 
-int sdb_cluster_create(int rank, int world, const uint8_t *id, int device, sdb_cluster **out) {
+int sdb_cluster_create(int rank, int world, const uint8_t *id, int device, sdb_cluster **out) try {
   if (!id || !out) return fail(SDB_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (world < 1 || world > 64 || rank < 0 || rank >= world)
@@ -624,7 +664,7 @@ int sdb_cluster_create(int rank, int world, const uint8_t *id, int device, sdb_c
   if (device < 0 || device >= ndev) return fail(SDB_ERR_INVALID, "device %d out of range", device);
   DeviceGuard dg(device);
   if (!dg.ok) return fail(SDB_ERR_DEVICE, "hipSetDevice(%d) failed", device);
-  auto *c = new sdb_cluster();
+  auto *c = new sdb_cluster();  // (std::bad_alloc here: nothing to undo)
   c->rank = rank, c->world = world, c->device = device;
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
@@ -642,8 +682,9 @@ int sdb_cluster_create(int rank, int world, const uint8_t *id, int device, sdb_c
   *out = c;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_create")
 
-int sdb_cluster_create_local(int n, const int *devices, sdb_cluster **out) {
+int sdb_cluster_create_local(int n, const int *devices, sdb_cluster **out) try {
   if (!out) return fail(SDB_ERR_INVALID, "out is NULL");
   for (int i = 0; i < n; i++) out[i] = nullptr;
   if (n < 1 || n > 64) return fail(SDB_ERR_INVALID, "shard count %d out of range (1..64)", n);
@@ -672,22 +713,37 @@ int sdb_cluster_create_local(int n, const int *devices, sdb_cluster **out) {
     SDB_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
   }
   int rc = SDB_OK;
-  for (int i = 0; i < n; i++) {
-    auto *c = new sdb_cluster();
+  for (int i = 0; i < n && rc == SDB_OK; i++) {
+    auto *c = new (std::nothrow) sdb_cluster();
+    if (!c) {
+      rc = fail(SDB_ERR_DEVICE, "out of host memory for rank %d's handle", i);
+      break;
+    }
     c->rank = i, c->world = n, c->device = devs[i], c->comm = comms[i], c->group = g;
     if (g) c->mu = &g->mu, c->cv = &g->cv;
     out[i] = c;
-    if (rc == SDB_OK) rc = cluster_finish_init(c);
+    rc = cluster_finish_init(c);
   }
-  if (rc != SDB_OK)
+  if (rc != SDB_OK) {
+    char msg[kErrBytes];
+    memcpy(msg, last_error_buf(), kErrBytes);
+    int made = 0;
     for (int i = 0; i < n; i++) {
-      sdb_cluster_destroy(out[i]);
+      if (out[i]) made++, sdb_cluster_destroy(out[i]);  // the last of the group's ranks frees the group
+      else if (comms[i]) (void)ncclCommDestroy(comms[i]);
       out[i] = nullptr;
     }
+    if (g && made < n) {  // ranks that were never made cannot be the last to leave
+      g->alive -= n - made;
+      if (made == 0 || g->alive <= 0) delete g;
+    }
+    memcpy(last_error_buf(), msg, kErrBytes);
+  }
   return rc;
 }
+SDB_API_CATCH("sdb_cluster_create_local")
 
-int sdb_cluster_destroy(sdb_cluster *c) {
+int sdb_cluster_destroy(sdb_cluster *c) try {
   if (!c) return SDB_OK;
   DeviceGuard dg(c->device);
   {
@@ -740,24 +796,27 @@ int sdb_cluster_destroy(sdb_cluster *c) {
   delete c;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_destroy")
 
-int sdb_cluster_info(const sdb_cluster *c, int *rank, int *world, int *device) {
+int sdb_cluster_info(const sdb_cluster *c, int *rank, int *world, int *device) try {
   if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
   if (rank) *rank = c->rank;
   if (world) *world = c->world;
   if (device) *device = c->device;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_info")
 
-int sdb_cluster_set_deadline(sdb_cluster *c, uint32_t milliseconds) {
+int sdb_cluster_set_deadline(sdb_cluster *c, uint32_t milliseconds) try {
   if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
   std::lock_guard<std::mutex> g(*c->mu);
   c->deadline_ms = milliseconds;
   c->cv->notify_all();
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_set_deadline")
 
-int sdb_cluster_transport(const sdb_cluster *c, char *buf, size_t cap) {
+int sdb_cluster_transport(const sdb_cluster *c, char *buf, size_t cap) try {
   if (!c || !buf || cap == 0) return fail(SDB_ERR_INVALID, "NULL argument");
   if (c->group) {
     snprintf(buf, cap, "shared-device: %d ranks on GPU %d, device-to-device copies behind a host rendezvous", c->world, c->device);
@@ -773,8 +832,9 @@ int sdb_cluster_transport(const sdb_cluster *c, char *buf, size_t cap) {
            (ver / 100) % 100, ver % 100, path, count, urank, c->device);
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_transport")
 
-int sdb_cluster_skip_ticket(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32_t per_shard, uint32_t limit) {
+int sdb_cluster_skip_ticket(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32_t per_shard, uint32_t limit) try {
   if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
   if (!ticket) return fail(SDB_ERR_INVALID, "ticket 0 is not a ticket");
   if (nq == 0) {  // no rank has entered or will enter for this ticket: the turn passes over it
@@ -790,9 +850,10 @@ int sdb_cluster_skip_ticket(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32
   return collective(c, nullptr, ticket, nq, nullptr, per_shard, nullptr, limit, 0, nullptr, nullptr, nullptr, nullptr,
                     SDB_MEM_HOST, nullptr, true);
 }
+SDB_API_CATCH("sdb_cluster_skip_ticket")
 
 int sdb_cluster_block_layout(uint64_t nq, uint32_t per_shard, size_t *off_dists, size_t *off_counts, size_t *off_tag,
-                             size_t *bytes) {
+                             size_t *bytes) try {
   if (per_shard == 0) return fail(SDB_ERR_INVALID, "per_shard must be positive");
   const BlockLayout bl(nq, per_shard);
   if (off_dists) *off_dists = bl.off_d;
@@ -801,13 +862,15 @@ int sdb_cluster_block_layout(uint64_t nq, uint32_t per_shard, size_t *off_dists,
   if (bytes) *bytes = bl.bytes;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_block_layout")
 
-int sdb_cluster_next_ticket(const sdb_cluster *c, uint64_t *ticket) {
+int sdb_cluster_next_ticket(const sdb_cluster *c, uint64_t *ticket) try {
   if (!c || !ticket) return fail(SDB_ERR_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(*c->mu);
   *ticket = c->next_ticket;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_next_ticket")
 
 // shared transport: the exchanges this rank registered are on its stream only once the last rank has arrived
 static void wait_enqueued(sdb_cluster *c, std::unique_lock<std::mutex> &lk) {
@@ -819,7 +882,7 @@ static void wait_enqueued(sdb_cluster *c, std::unique_lock<std::mutex> &lk) {
   });
 }
 
-int sdb_cluster_wait(sdb_cluster *c, void *stream) {
+int sdb_cluster_wait(sdb_cluster *c, void *stream) try {
   if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
   std::unique_lock<std::mutex> lk(*c->mu);
   wait_enqueued(c, lk);
@@ -828,8 +891,9 @@ int sdb_cluster_wait(sdb_cluster *c, void *stream) {
   SDB_HIP(hipStreamWaitEvent(as_stream(stream), c->finished, 0));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_wait")
 
-int sdb_cluster_synchronize(sdb_cluster *c) {
+int sdb_cluster_synchronize(sdb_cluster *c) try {
   if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
   DeviceGuard dg(c->device);
   std::unique_lock<std::mutex> lk(*c->mu);
@@ -848,30 +912,33 @@ int sdb_cluster_synchronize(sdb_cluster *c) {
   if (!first.empty()) return fail(SDB_ERR_STATE, "%s", first.c_str());
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_cluster_synchronize")
 
 int sdb_cluster_allgather_merge(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32_t per_shard, void *block,
                                 uint32_t limit, uint64_t *out_ids, float *out_dists, uint32_t *out_shards,
-                                uint32_t *out_counts, int mem, void *stream_) {
+                                uint32_t *out_counts, int mem, void *stream_) try {
   if (!c) return fail(SDB_ERR_INVALID, "cluster is NULL");
   if (nq && (!block || !out_ids || !out_dists || !out_counts)) return fail(SDB_ERR_INVALID, "NULL argument");
   if (nq && per_shard == 0) return fail(SDB_ERR_INVALID, "per_shard must be positive");
   return collective(c, nullptr, ticket, nq, nullptr, per_shard, block, limit, 0, out_ids, out_dists, out_shards, out_counts,
                     mem, as_stream(stream_));
 }
+SDB_API_CATCH("sdb_cluster_allgather_merge")
 
 int sdb_cluster_search_batch(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint64_t nq, const float *queries,
                              uint32_t limit, uint32_t search_size, uint64_t *out_ids, float *out_dists,
-                             uint32_t *out_shards, uint32_t *out_counts, int mem, void *stream_) {
+                             uint32_t *out_shards, uint32_t *out_counts, int mem, void *stream_) try {
   if (!c || !ix) return fail(SDB_ERR_INVALID, "NULL handle");
   const bool no_out = mem == SDB_MEM_HOST && !out_ids && !out_dists && !out_shards && !out_counts;  // answer not wanted here
   if (nq && (!queries || (!no_out && (!out_ids || !out_dists || !out_counts)))) return fail(SDB_ERR_INVALID, "NULL argument");
   return collective(c, ix, ticket, nq, queries, 0, nullptr, limit, search_size, out_ids, out_dists, out_shards, out_counts,
                     mem, as_stream(stream_));
 }
+SDB_API_CATCH("sdb_cluster_search_batch")
 
 int sdb_cluster_stamp_block(void *block, uint64_t nq, uint32_t per_shard, uint32_t limit, uint32_t rank, uint64_t seq,
                             uint64_t ticket, uint32_t status, const float *queries, uint32_t dim, int device,
-                            void *stream_) {
+                            void *stream_) try {
   if (!block || per_shard == 0 || nq == 0) return fail(SDB_ERR_INVALID, "bad argument");
   int ndev = 0;
   SDB_TRY(sdb_device_count(&ndev));
@@ -880,10 +947,11 @@ int sdb_cluster_stamp_block(void *block, uint64_t nq, uint32_t per_shard, uint32
   return stamp_tag(block, BlockLayout(nq, per_shard), nq, per_shard, limit, rank, seq, ticket, status, queries, dim,
                    as_stream(stream_));
 }
+SDB_API_CATCH("sdb_cluster_stamp_block")
 
 int sdb_cluster_merge_gathered(uint32_t world, uint64_t nq, uint32_t per_shard, const void *gathered, uint32_t limit,
                                uint64_t *out_ids, float *out_dists, uint32_t *out_shards, uint32_t *out_counts,
-                               int device, void *stream_) {
+                               int device, void *stream_) try {
   if (nq == 0) return SDB_OK;
   if (!gathered || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
   SDB_TRY(check_merge_shape(world, per_shard, limit));
@@ -905,5 +973,6 @@ int sdb_cluster_merge_gathered(uint32_t world, uint64_t nq, uint32_t per_shard, 
   (void)hipHostFree((void *)v);
   return rc;
 }
+SDB_API_CATCH("sdb_cluster_merge_gathered")
 
 }  // extern "C"

@@ -15,9 +15,21 @@
 
 namespace sdb {
 
-// thread-local last error (the C ABI never throws and never aborts)
-std::string &last_error_ref();
-int fail(int code, const char *fmt, ...);
+// thread-local last error (the C ABI never throws and never aborts).  A fixed buffer: reporting "out of host memory"
+// must not itself allocate.
+constexpr size_t kErrBytes = 1024;
+char *last_error_buf() noexcept;
+int fail(int code, const char *fmt, ...) noexcept;
+
+// The C ABI's "never aborts the process" (CONTRIBUTING.md:150: no panics; the reference returns an `error`): no C++
+// exception may leave an extern "C" function -- through cgo it would reach std::terminate and take the whole database
+// down.  Every entry point is a function-try-block that ends in SDB_API_CATCH: std::bad_alloc (a 3 GB host staging
+// vector at 12.5 M rows) -> SDB_ERR_DEVICE "out of host memory", std::system_error (no thread to be had) and anything
+// else -> SDB_ERR_STATE with what(); locks, workspaces and device buffers are released by the destructors on the way.
+// Entry points that change an index decide in their own handlers what the index is afterwards (as it was / unusable).
+int on_exception(const char *fn) noexcept;  // inside a catch (...) handler only
+#define SDB_API_CATCH(fn) \
+  catch (...) { return sdb::on_exception(fn); }
 
 #define SDB_HIP(expr)                                                                        \
   do {                                                                                       \

@@ -117,7 +117,7 @@ using namespace sdb;
 extern "C" {
 
 int sdb_distance_batch(int metric, uint32_t dim, const float *queries, uint64_t nq, const float *candidates,
-                       uint64_t nc, float *out, int mem, int device, void *stream_) {
+                       uint64_t nc, float *out, int mem, int device, void *stream_) try {
   if (metric < 0 || metric > SDB_METRIC_DOT) return fail(SDB_ERR_INVALID, "unknown float32 distance function: %d", metric);
   if (dim < 1 || dim > 4096) return fail(SDB_ERR_INVALID, "vector size must be between 1 and 4096, got %u", dim);
   if (nq == 0 || nc == 0) return SDB_OK;
@@ -173,9 +173,10 @@ int sdb_distance_batch(int metric, uint32_t dim, const float *queries, uint64_t 
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "distance_batch failed: %s", hipGetErrorString(e));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_distance_batch")
 
 int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, uint64_t nc,
-                             const uint64_t *cand_ids, float *out, int mem, void *stream_) {
+                             const uint64_t *cand_ids, float *out, int mem, void *stream_) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (nq == 0 || nc == 0) return SDB_OK;
   if (!queries || !cand_ids || !out) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -225,5 +226,6 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "index_distance_batch failed: %s", hipGetErrorString(e));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_distance_batch")
 
 }  // extern "C"

@@ -631,7 +631,7 @@ using namespace sdb;
 
 extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
                                      const uint64_t *filter_offsets, const uint64_t *filter_ids, uint64_t *out_ids,
-                                     float *out_dists, uint32_t *out_counts, int mem, void *stream_) {
+                                     float *out_dists, uint32_t *out_counts, int mem, void *stream_) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (nq == 0) return SDB_OK;
   if (!queries || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -840,6 +840,7 @@ extern "C" int sdb_index_flat_search(sdb_index *ix, uint64_t nq, const float *qu
   }
   return SDB_OK;  // `fr` synchronises and frees
 }
+SDB_API_CATCH("sdb_index_flat_search")
 
 // vecStore.Set for a flat index (flat.go:46-49): store vectors without touching the graph.
 namespace sdb {
@@ -891,7 +892,7 @@ static int flat_tombstone(sdb_index *ix, std::vector<uint32_t> &slots) {
 // vecStore.Delete as IndexFlat.InsertUpdateDelete calls it for a point without a vector (flat.go:50-52): ids that are
 // not stored are skipped (ItemCache.Delete of a missing key is not an error).  Only for an index without a graph
 // (no start node); a graph index deletes through sdb_index_delete_batch.
-extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids) {
+extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
   if (!ids) return fail(SDB_ERR_INVALID, "ids is NULL");
@@ -906,9 +907,15 @@ extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_
   DeviceGuard dg(ix->P.device);
   SDB_TRY(ix->begin_write());
   ix->tx_dirty = true;
-  if (int rc = flat_tombstone(ix, slots)) {  // device rows may be half-marked: no way back (index.h `broken`)
+  int trc;
+  try {
+    trc = flat_tombstone(ix, slots);
+  } catch (...) {
+    trc = sdb::on_exception("sdb_index_remove_vectors");
+  }
+  if (trc != SDB_OK) {  // device rows / host tables may be half-marked: no way back (index.h `broken`)
     ix->broken = true;
-    return rc;
+    return trc;
   }
   if (!ix->tx_explicit) {
     SDB_TRY(ix->commit(nullptr));
@@ -916,8 +923,9 @@ extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_
   }
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_remove_vectors")
 
-extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem) {
+extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors, int mem) try {
   if (!ix || !vectors) return fail(SDB_ERR_INVALID, "NULL argument");
   if (n == 0) return SDB_OK;
   if ((uint64_t)ix->n + n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "too many nodes");
@@ -965,10 +973,8 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "id copy failed: %s", hipGetErrorString(e));
   SDB_TRY(ix->begin_write());  // appended rows become visible to searches at commit
   ix->tx_dirty = true;
-  if (int rc = flat_tombstone(ix, replaced)) {
-    ix->broken = true;
-    return rc;
-  }
+  auto tables = [&]() -> int {
+  SDB_TRY(flat_tombstone(ix, replaced));
   std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
   bool dense = ix->dense_ids;
   for (uint64_t i = 0; i < n; i++) {
@@ -983,10 +989,22 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   }
   ix->dense_ids = dense;
   ix->n = n0 + (uint32_t)n;
-  wl.unlock();
+  return SDB_OK;
+  };
+  int trc;
+  try {
+    trc = tables();
+  } catch (...) {  // the id tables are half-way between two states
+    trc = sdb::on_exception("sdb_index_set_vectors");
+  }
+  if (trc != SDB_OK) {
+    ix->broken = true;
+    return trc;
+  }
   if (!ix->tx_explicit) {
     SDB_TRY(ix->commit(nullptr));
     SDB_HIP(hipDeviceSynchronize());
   }
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_set_vectors")

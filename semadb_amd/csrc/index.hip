@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <memory>
 #include <new>
+#include <stdexcept>
 
 #include "pq.h"
 #include "search_kernel.h"
@@ -13,19 +14,30 @@ namespace sdb {
 // ------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------
-std::string &last_error_ref() {
-  static thread_local std::string e;
+char *last_error_buf() noexcept {
+  static thread_local char e[kErrBytes] = {0};
   return e;
 }
 
-int fail(int code, const char *fmt, ...) {
-  char buf[1024];
+int fail(int code, const char *fmt, ...) noexcept {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
+  vsnprintf(last_error_buf(), kErrBytes, fmt, ap);
   va_end(ap);
-  last_error_ref() = buf;
   return code;
+}
+
+// the one place where exceptions end (common.h SDB_API_CATCH)
+int on_exception(const char *fn) noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    return fail(SDB_ERR_DEVICE, "%s: out of host memory", fn);
+  } catch (const std::exception &e) {
+    return fail(SDB_ERR_STATE, "%s: %s", fn, e.what());
+  } catch (...) {
+    return fail(SDB_ERR_STATE, "%s: unknown C++ exception", fn);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -877,11 +889,11 @@ Workspace *sdb_index::acquire_ws(hipStream_t stream, bool async) const {
     w->busy = true;
     return w;
   }
-  auto *w = new Workspace();
+  std::unique_ptr<Workspace> w(new Workspace());
   w->device = P.device;
   w->busy = true;
-  pool.push_back(w);
-  return w;
+  pool.push_back(w.get());
+  return w.release();
 }
 
 void sdb_index::release_ws(Workspace *ws, hipStream_t stream, bool async) const {
@@ -922,11 +934,11 @@ int sdb_index::sync_start_ext() {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *sdb_last_error(void) { return last_error_ref().c_str(); }
+const char *sdb_last_error(void) { return last_error_buf(); }
 
 int sdb_abi_version(void) { return SDB_ABI_VERSION; }
 
-int sdb_device_count(int *count) {
+int sdb_device_count(int *count) try {
   if (!count) return fail(SDB_ERR_INVALID, "count is NULL");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -937,21 +949,24 @@ int sdb_device_count(int *count) {
   *count = n;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_device_count")
 
-int sdb_host_alloc(size_t bytes, void **out) {
+int sdb_host_alloc(size_t bytes, void **out) try {
   if (!out) return fail(SDB_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (bytes == 0) return SDB_OK;
   SDB_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_host_alloc")
 
-int sdb_host_free(void *p) {
+int sdb_host_free(void *p) try {
   if (p) SDB_HIP(hipHostFree(p));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_host_free")
 
-int sdb_index_create(const sdb_index_params *p, sdb_index **out) {
+int sdb_index_create(const sdb_index_params *p, sdb_index **out) try {
   if (!p || !out) return fail(SDB_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (p->dim < 1 || p->dim > 4096)  // models/index.go:285-287
@@ -974,19 +989,16 @@ int sdb_index_create(const sdb_index_params *p, sdb_index **out) {
   if (p->device < 0 || p->device >= ndev) return fail(SDB_ERR_INVALID, "device %d out of range", p->device);
   DeviceGuard dg(p->device);
   if (!dg.ok) return fail(SDB_ERR_DEVICE, "hipSetDevice(%d) failed", p->device);
-  auto *ix = new sdb_index();
+  std::unique_ptr<sdb_index> ix(new sdb_index());
   ix->P = *p;
   ix->lay = RowLayout(p->dim);
-  int rc = ix->reserve((uint32_t)std::max<uint64_t>(p->capacity ? p->capacity : 1024, 16));
-  if (rc != SDB_OK) {
-    delete ix;
-    return rc;
-  }
-  *out = ix;
+  SDB_TRY(ix->reserve((uint32_t)std::max<uint64_t>(p->capacity ? p->capacity : 1024, 16)));
+  *out = ix.release();
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_create")
 
-int sdb_index_destroy(sdb_index *ix) {
+int sdb_index_destroy(sdb_index *ix) try {
   if (!ix) return SDB_OK;
   DeviceGuard dg(ix->P.device);
   (void)hipDeviceSynchronize();
@@ -1017,6 +1029,7 @@ int sdb_index_destroy(sdb_index *ix) {
   delete ix;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_destroy")
 
 // copies n original-layout rows (host or device) into slab rows [first, first+n)
 static int store_rows(sdb_index *ix, uint32_t first, uint32_t n, const float *vectors, int mem, hipStream_t stream);
@@ -1046,7 +1059,7 @@ static int store_rows(sdb_index *ix, uint32_t first, uint32_t n, const float *ve
   return SDB_OK;
 }
 
-int sdb_index_set_start(sdb_index *ix, const float *vec, int mem) {
+int sdb_index_set_start(sdb_index *ix, const float *vec, int mem) try {
   if (!ix || !vec) return fail(SDB_ERR_INVALID, "NULL argument");
   if (ix->start_slot >= 0) return SDB_OK;  // vamana.go:95-97: already there
   if (ix->n != 0) return fail(SDB_ERR_STATE, "start node must be the first node of an empty index");
@@ -1062,15 +1075,33 @@ int sdb_index_set_start(sdb_index *ix, const float *vec, int mem) {
   ix->start_slot = 0;
   return ix->publish_full();
 }
+SDB_API_CATCH("sdb_index_set_start")
 
 int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *vectors,
-                   const uint64_t *offsets, const uint64_t *edges, int mem) {
+                   const uint64_t *offsets, const uint64_t *edges, int mem) try {
   if (!ix || !vectors || !offsets) return fail(SDB_ERR_INVALID, "NULL argument");
   if (ix->n != 0) return fail(SDB_ERR_STATE, "index is not empty");
   if (n == 0 || n >= 0x7FFFFFFFull) return fail(SDB_ERR_INVALID, "node count %llu out of range", (unsigned long long)n);
   if (offsets[n] && !edges) return fail(SDB_ERR_INVALID, "edges is NULL");
   DeviceGuard dg(ix->P.device);
   SDB_TRY(ix->reserve((uint32_t)n));
+  // whatever ends this call early -- an error return, a host allocation that fails (the adjacency staging is 3.2 GB at
+  // 12.5 M rows) -- leaves the index empty, as it was
+  struct Undo {
+    sdb_index *ix;
+    bool keep = false;
+    uint32_t wrote = 0;  // device rows that may hold part of the graph: empty again (rows past n are assumed empty)
+    ~Undo() {
+      if (keep) return;
+      ix->n = 0, ix->start_slot = -1, ix->max_node_id = 0, ix->dense_ids = true;
+      ix->h_ids.clear(), ix->id2slot.clear(), ix->h_start_ext.clear();
+      if (wrote) {
+        (void)hipMemset(ix->d_adj, 0xFF, (size_t)wrote * kAdjStride * 4);
+        (void)hipMemset(ix->d_deg, 0, (size_t)wrote * 4);
+        (void)hipDeviceSynchronize();
+      }
+    }
+  } undo{ix};
   // id table
   ix->h_ids.resize(n);
   bool dense = true;
@@ -1129,24 +1160,23 @@ int sdb_index_load(sdb_index *ix, uint64_t n, const uint64_t *ids, const float *
     deg[i] = dcnt;
   }
   SDB_TRY(ix->sync_start_ext());
+  undo.wrote = (uint32_t)n;
   SDB_HIP(hipMemcpy(ix->d_adj, adj.data(), adj.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SDB_HIP(hipMemcpy(ix->d_deg, deg.data(), deg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SDB_HIP(hipMemcpy(ix->d_ids, ix->h_ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  int rc = store_rows(ix, 0, (uint32_t)n, vectors, mem, nullptr);
-  if (rc != SDB_OK) {
-    ix->n = 0;
-    ix->h_start_ext.clear();
-    return rc;
-  }
-  return ix->publish_full();
+  SDB_TRY(store_rows(ix, 0, (uint32_t)n, vectors, mem, nullptr));
+  SDB_TRY(ix->publish_full());
+  undo.keep = true;
+  return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_load")
 
 // IndexVamana.InsertUpdateDelete is ONE write transaction made of several calls here (inserts, one delete scan,
 // re-inserts of the updated points); the shard runs it under its write lock while searches keep being served --
 // by a cold index built from the bucket when the cached one is locked (shard/cache/manager.go:159-181).  Here the
 // searches simply keep walking the last committed graph: between begin_write and commit every insert_batch /
 // delete_batch changes the writer's copy only.  Without begin_write each such call is a transaction by itself.
-int sdb_index_begin_write(sdb_index *ix) {
+int sdb_index_begin_write(sdb_index *ix) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (ix->in_tx && ix->tx_explicit) return fail(SDB_ERR_STATE, "a write transaction is already open");
@@ -1154,8 +1184,9 @@ int sdb_index_begin_write(sdb_index *ix) {
   ix->tx_explicit = true;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_begin_write")
 
-int sdb_index_commit(sdb_index *ix, void *stream_) {
+int sdb_index_commit(sdb_index *ix, void *stream_) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (!ix->in_tx) return fail(SDB_ERR_STATE, "no write transaction is open");
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
@@ -1165,6 +1196,7 @@ int sdb_index_commit(sdb_index *ix, void *stream_) {
   SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_commit")
 
 // The way out of a transaction that will not be committed (a host that found a bad point after begin_write, a failed
 // call, a cancelled request).  Searches never saw the transaction: they walk the committed copy of the graph (index.h
@@ -1173,7 +1205,7 @@ int sdb_index_commit(sdb_index *ix, void *stream_) {
 // error inside a transaction its cache manager scraps the shard's cache and rebuilds it from the bucket
 // (shard/cache/manager.go:231-240); here the index is what it was at begin_write, in milliseconds.  Only a handle that
 // a device failure left half-written (index.h `broken`) cannot be brought back.
-int sdb_index_abort_write(sdb_index *ix) {
+int sdb_index_abort_write(sdb_index *ix) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (!ix->in_tx) return SDB_OK;
@@ -1184,13 +1216,19 @@ int sdb_index_abort_write(sdb_index *ix) {
     return SDB_OK;
   }
   DeviceGuard dg(ix->P.device);
-  const int rc = ix->rollback();
-  if (rc != SDB_OK) ix->broken = true;  // a device error half-way through the restore
+  int rc;
+  try {
+    rc = ix->rollback();
+  } catch (...) {
+    rc = on_exception("sdb_index_abort_write");
+  }
+  if (rc != SDB_OK) ix->broken = true;  // a device error (or no host memory for the id tables) half-way through the restore
   return rc;
 }
+SDB_API_CATCH("sdb_index_abort_write")
 
 // test support: the number of rows on which the two graph copies differ (0 whenever no transaction is open)
-int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows) {
+int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows) try {
   if (!ix || !rows) return fail(SDB_ERR_INVALID, "NULL argument");
   *rows = 0;
   if (ix->n == 0) return SDB_OK;
@@ -1215,6 +1253,7 @@ int sdb_index_version_diff(const sdb_index *ix, uint64_t *rows) {
   }
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_version_diff")
 
 // a filter handed over as bitmaps (sdb_index_search_batch_bitmap)
 struct BitmapFilters {
@@ -1402,11 +1441,20 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
         for (uint64_t q = 0; q < nq; q++) fn(q);
         return;
       }
+      // a thread that cannot be had (std::system_error, or no memory for its state) must not leave joinable threads
+      // behind -- their destructors would end the process: whatever did start is joined, the rest of the queries are
+      // done here
       std::vector<std::thread> pool;
-      for (unsigned t = 0; t < nthr; t++)
-        pool.emplace_back([&, t] {
-          for (uint64_t q = (uint64_t)nq * t / nthr; q < (uint64_t)nq * (t + 1) / nthr; q++) fn(q);
-        });
+      unsigned started = 0;
+      try {
+        pool.reserve(nthr);
+        for (; started < nthr; started++)
+          pool.emplace_back([&, t = started] {
+            for (uint64_t q = (uint64_t)nq * t / nthr; q < (uint64_t)nq * (t + 1) / nthr; q++) fn(q);
+          });
+      } catch (...) {
+      }
+      for (uint64_t q = (uint64_t)nq * started / nthr; q < nq; q++) fn(q);
       for (auto &th : pool) th.join();
     };
     for_queries([&](uint64_t q) {
@@ -1568,15 +1616,16 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
 int sdb_index_search_batch(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit,
                            uint32_t search_size, const uint64_t *filter_offsets,
                            const uint64_t *filter_ids, uint64_t *out_ids, float *out_dists,
-                           uint32_t *out_counts, const sdb_search_trace *trace, int mem, void *stream_) {
+                           uint32_t *out_counts, const sdb_search_trace *trace, int mem, void *stream_) try {
   return search_batch_impl(ix, nq, queries, limit, search_size, filter_offsets, filter_ids, nullptr, out_ids, out_dists, out_counts,
                            trace, mem, stream_);
 }
+SDB_API_CATCH("sdb_index_search_batch")
 
 int sdb_index_search_batch_bitmap(sdb_index *ix, uint64_t nq, const float *queries, uint32_t limit, uint32_t search_size,
                                   const uint64_t *filter_first_id, const uint64_t *filter_word_offsets,
                                   const uint64_t *filter_words, uint64_t *out_ids, float *out_dists, uint32_t *out_counts,
-                                  const sdb_search_trace *trace, int mem, void *stream_) {
+                                  const sdb_search_trace *trace, int mem, void *stream_) try {
   if (!filter_first_id || !filter_word_offsets) return fail(SDB_ERR_INVALID, "NULL filter argument");
   if (nq && filter_word_offsets[nq] > filter_word_offsets[0] && !filter_words) return fail(SDB_ERR_INVALID, "filter_words is NULL");
   const BitmapFilters bm{filter_first_id, filter_word_offsets, filter_words};
@@ -1597,8 +1646,9 @@ int sdb_index_search_batch_bitmap(sdb_index *ix, uint64_t nq, const float *queri
   return search_batch_impl(ix, nq, queries, limit, search_size, off.data(), ids.data(), nullptr, out_ids, out_dists, out_counts, trace,
                            mem, stream_);
 }
+SDB_API_CATCH("sdb_index_search_batch_bitmap")
 
-int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
+int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   switch (key) {
     case SDB_TUNE_HUB_MIN:
@@ -1639,8 +1689,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) {
       return fail(SDB_ERR_INVALID, "unknown tuning key %d", key);
   }
 }
+SDB_API_CATCH("sdb_index_set_tuning")
 
-int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) {
+int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) try {
   if (!ix || !out) return fail(SDB_ERR_INVALID, "NULL argument");
 #ifdef SDB_BACK_PROFILE  // measurement builds: the five spare slots carry k_backedges' cycle counters (tools/backprof.py)
   const uint32_t n = cap < sdb_index::kStatStride ? cap : sdb_index::kStatStride;
@@ -1657,8 +1708,9 @@ int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) {
     for (uint32_t i = 0; i < n; i++) out[i] += all[(size_t)c * sdb_index::kStatStride + i];
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_build_stats")
 
-int sdb_index_get_vectors(const sdb_index *ix, uint64_t n, const uint64_t *ids, float *out, uint8_t *found) {
+int sdb_index_get_vectors(const sdb_index *ix, uint64_t n, const uint64_t *ids, float *out, uint8_t *found) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
   if (!ids || !out) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -1692,8 +1744,9 @@ int sdb_index_get_vectors(const sdb_index *ix, uint64_t n, const uint64_t *ids, 
   SDB_HIP(hipMemcpy(out, b.out, n * l.dim * 4, hipMemcpyDeviceToHost));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_get_vectors")
 
-int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *out) {
+int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *out) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n == 0) return SDB_OK;
   if (!ids || !out) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -1701,8 +1754,9 @@ int sdb_index_exists_batch(const sdb_index *ix, uint64_t n, const uint64_t *ids,
   for (uint64_t i = 0; i < n; i++) out[i] = ix->slot_of(ids[i]) >= 0 ? 1 : 0;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_exists_batch")
 
-int sdb_index_set_profiling(sdb_index *ix, int enabled) {
+int sdb_index_set_profiling(sdb_index *ix, int enabled) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   DeviceGuard dg(ix->P.device);
   if (enabled && ix->ev0.empty()) {
@@ -1717,8 +1771,9 @@ int sdb_index_set_profiling(sdb_index *ix, int enabled) {
   ix->prof_count = 0;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_set_profiling")
 
-int sdb_index_profile_read(sdb_index *ix, float *ms, uint32_t cap, uint32_t *n) {
+int sdb_index_profile_read(sdb_index *ix, float *ms, uint32_t cap, uint32_t *n) try {
   if (!ix || !ms || !n) return fail(SDB_ERR_INVALID, "NULL argument");
   *n = 0;
   if (ix->ev0.empty()) return fail(SDB_ERR_STATE, "profiling was never enabled");
@@ -1734,8 +1789,9 @@ int sdb_index_profile_read(sdb_index *ix, float *ms, uint32_t cap, uint32_t *n) 
   ix->prof_count = 0;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_profile_read")
 
-int sdb_index_last_search_ms(sdb_index *ix, float *ms) {
+int sdb_index_last_search_ms(sdb_index *ix, float *ms) try {
   if (!ix || !ms) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!ix->profiling || ix->prof_count == 0) return fail(SDB_ERR_STATE, "no profiled search_batch yet");
   DeviceGuard dg(ix->P.device);
@@ -1744,16 +1800,18 @@ int sdb_index_last_search_ms(sdb_index *ix, float *ms) {
   SDB_HIP(hipEventElapsedTime(ms, ix->ev0[slot], ix->ev1[slot]));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_last_search_ms")
 
-int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) {
+int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) try {
   if (!ix || !bytes) return fail(SDB_ERR_INVALID, "NULL argument");
   // vecStore.SizeInMemory + nodeStore.SizeInMemory (vamana.go:83-85), as held in HBM
   // slab row + adjacency row + its distance cache + degree / clean / cached counters + id (+ code row)
   *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + 2 * kAdjStride * 4 + 3 * 4 + 8 + (ix->pq ? ix->pq->M : 0));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_size_in_memory")
 
-int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id) {
+int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *max_node_id) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (n_nodes) *n_nodes = ix->n - ix->n_dead;  // live nodes (start node included)
   if (max_node_id) *max_node_id = ix->max_node_id;
@@ -1767,15 +1825,17 @@ int sdb_index_stats(const sdb_index *ix, uint64_t *n_nodes, uint64_t *n_edges, u
   }
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_stats")
 
-int sdb_index_row_usage(const sdb_index *ix, uint64_t *rows, uint64_t *dead) {
+int sdb_index_row_usage(const sdb_index *ix, uint64_t *rows, uint64_t *dead) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (rows) *rows = ix->n;
   if (dead) *dead = ix->n_dead;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_row_usage")
 
-int sdb_index_compact(sdb_index *ix) {
+int sdb_index_compact(sdb_index *ix) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   if (ix->in_tx) return fail(SDB_ERR_STATE, "a write transaction is open");
@@ -1839,6 +1899,19 @@ int sdb_index_compact(sdb_index *ix) {
   uint32_t lost = 0;
   SDB_HIP(hipMemcpy(&lost, d_lost, 4, hipMemcpyDeviceToHost));
   if (lost) return fail(SDB_ERR_STATE, "%u edges point at deleted rows: the graph is inconsistent, nothing was changed", lost);
+  // the host tables of the compacted index, complete before anything changes hands (their memory may not be there)
+  std::vector<uint64_t> h(nn);
+  bool dense = true;
+  for (uint32_t j = 0; j < nn; j++) {
+    h[j] = ix->h_ids[live[j]];
+    if (j && h[j] != h[0] + j) dense = false;
+  }
+  std::unordered_map<uint64_t, uint32_t> nmap;
+  if (!dense) {
+    nmap.reserve((size_t)nn * 2);
+    for (uint32_t j = 0; j < nn; j++) nmap.emplace(h[j], j);
+  }
+  std::vector<uint32_t> padded((ix->h_start_ext.size() + 63) / 64 * 64, kNoSlot);
   // ---- swap in (nothing below can fail)
   for (void *x : {(void *)ix->d_slab, (void *)ix->d_adj, (void *)ix->r_adj, (void *)ix->d_adjdist, (void *)ix->d_deg,
                   (void *)ix->d_clean, (void *)ix->d_dcount, (void *)ix->d_ids, (void *)ix->r_ids})
@@ -1849,25 +1922,14 @@ int sdb_index_compact(sdb_index *ix) {
   ix->d_dcount = ndc, ix->d_ids = nids, ix->r_ids = nrids;
   if (M) ix->d_codes = ncodes;
   (void)hipMemset(ix->d_dirty, 0, cap);
-  std::vector<uint64_t> h(nn);
-  bool dense = true;
-  for (uint32_t j = 0; j < nn; j++) {
-    h[j] = ix->h_ids[live[j]];
-    if (j && h[j] != h[0] + j) dense = false;
-  }
   ix->h_ids.swap(h);
-  ix->id2slot.clear();
+  ix->id2slot.swap(nmap);
   ix->dense_ids = dense;
-  if (!dense) {
-    ix->id2slot.reserve((size_t)nn * 2);
-    for (uint32_t j = 0; j < nn; j++) ix->id2slot.emplace(ix->h_ids[j], j);
-  }
   if (ix->start_slot >= 0) ix->start_slot = (int64_t)map[(uint32_t)ix->start_slot];  // a flat index has none
   for (auto &t : ix->h_start_ext) t = map[t];
   ix->n = nn, ix->n_dead = 0;
   const uint32_t need = (uint32_t)((ix->h_start_ext.size() + 63) / 64 * 64);
   if (need) {  // both copies of the overflow list, renumbered
-    std::vector<uint32_t> padded(need, kNoSlot);
     std::copy(ix->h_start_ext.begin(), ix->h_start_ext.end(), padded.begin());
     (void)hipMemcpy(ix->d_start_ext, padded.data(), (size_t)need * 4, hipMemcpyHostToDevice);
     if (need > ix->r_start_ext_cap) {
@@ -1883,8 +1945,9 @@ int sdb_index_compact(sdb_index *ix) {
   (void)hipDeviceSynchronize();
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_compact")
 
-int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets, uint64_t *edges) {
+int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_t *offsets, uint64_t *edges) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (ix->broken) return fail(SDB_ERR_STATE, "index is unusable after a failed write; reload it from the bucket");
   DeviceGuard dg(ix->P.device);
@@ -1937,6 +2000,7 @@ int sdb_index_export(const sdb_index *ix, uint64_t *ids, float *vectors, uint64_
   }
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_export")
 
 }  // extern "C"
 
@@ -1970,7 +2034,7 @@ static int forget_prune_state(sdb_index *ix) {
   return SDB_OK;
 }
 
-extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream_) {
+extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream_) try {
   if (!ix || !pq) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");
   if (pq->dim != ix->lay.dim) return fail(SDB_ERR_INVALID, "quantizer dim %u != index dim %u", pq->dim, ix->lay.dim);
@@ -2016,10 +2080,11 @@ extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream
   ix->pq = pq;
   return forget_prune_state(ix);
 }
+SDB_API_CATCH("sdb_index_attach_pq")
 
 // Centroid ids that do NOT come from encode(): the k-means labels productQuantizer.Fit leaves on its
 // training points (product.go:216-218) and the codes a bucket persisted under 'q' (product.go:349-383).
-extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *ids, const uint8_t *codes) {
+extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *ids, const uint8_t *codes) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (!ix->pq) return fail(SDB_ERR_STATE, "no quantizer attached");
   if (n == 0) return SDB_OK;
@@ -2042,8 +2107,9 @@ extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *id
   }
   return forget_prune_state(ix);
 }
+SDB_API_CATCH("sdb_index_set_codes")
 
-extern "C" int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *codes) {
+extern "C" int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *codes) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (!ix->pq) return fail(SDB_ERR_STATE, "no quantizer attached");
   if (n == 0) return SDB_OK;
@@ -2061,3 +2127,4 @@ extern "C" int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64
   }
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_index_get_codes")

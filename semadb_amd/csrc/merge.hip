@@ -148,7 +148,7 @@ using namespace sdb;
 
 extern "C" {
 
-int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit, uint32_t *out) {
+int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit, uint32_t *out) try {
   if (!out || n_shards == 0) return fail(SDB_ERR_INVALID, "bad argument");
   // actions.go:291-299: int(float32(limit) * (1/float32(nShards)) * 1.42 + 10)
   int target = (int)((float)limit * (1.0f / (float)n_shards) * 1.42f + 10.0f);
@@ -157,10 +157,11 @@ int sdb_shard_limit(uint32_t limit, uint32_t n_shards, uint32_t max_search_limit
   *out = (uint32_t)target;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_shard_limit")
 
 int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uint64_t *ids, const float *dists,
                    const uint32_t *counts, uint32_t limit, uint64_t *out_ids, float *out_dists,
-                   uint32_t *out_shards, uint32_t *out_counts, int mem, int device, void *stream_) {
+                   uint32_t *out_shards, uint32_t *out_counts, int mem, int device, void *stream_) try {
   if (nq == 0) return SDB_OK;
   if (!ids || !dists || !counts || !out_ids || !out_dists || !out_counts) return fail(SDB_ERR_INVALID, "NULL argument");
   SDB_TRY(check_merge_shape(n_shards, per_shard, limit));
@@ -203,5 +204,6 @@ int sdb_topk_merge(uint32_t n_shards, uint64_t nq, uint32_t per_shard, const uin
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "topk_merge failed: %s", hipGetErrorString(e));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_topk_merge")
 
 }  // extern "C"

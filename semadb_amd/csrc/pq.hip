@@ -901,7 +901,7 @@ extern "C" {
 
 int sdb_kmeans_fit(float *X, uint32_t n, uint32_t stride, uint32_t offset, uint32_t len, uint32_t K,
                    uint32_t max_iter, uint32_t first_idx, int alias, float *centroids_out, uint8_t *labels_out,
-                   uint32_t *iters_out, int mem, int device, void *stream_) {
+                   uint32_t *iters_out, int mem, int device, void *stream_) try {
   if (!X || !centroids_out || !labels_out) return fail(SDB_ERR_INVALID, "NULL argument");
   int ndev = 0;
   SDB_TRY(sdb_device_count(&ndev));
@@ -924,9 +924,10 @@ int sdb_kmeans_fit(float *X, uint32_t n, uint32_t stride, uint32_t offset, uint3
   SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_kmeans_fit")
 
 int sdb_pq_create(uint32_t dim, uint32_t metric, uint32_t num_subvectors, uint32_t num_centroids, int device,
-                  sdb_pq **out) {
+                  sdb_pq **out) try {
   if (!out) return fail(SDB_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (dim < 1 || dim > 4096) return fail(SDB_ERR_INVALID, "vector size must be between 1 and 4096, got %u", dim);
@@ -955,8 +956,9 @@ int sdb_pq_create(uint32_t dim, uint32_t metric, uint32_t num_subvectors, uint32
   *out = pq;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_pq_create")
 
-int sdb_pq_destroy(sdb_pq *pq) {
+int sdb_pq_destroy(sdb_pq *pq) try {
   if (!pq) return SDB_OK;
   DeviceGuard dg(pq->device);
   (void)hipDeviceSynchronize();
@@ -965,9 +967,10 @@ int sdb_pq_destroy(sdb_pq *pq) {
   delete pq;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_pq_destroy")
 
 int sdb_pq_fit(sdb_pq *pq, float *X, uint32_t n, const uint32_t *first_idx, int alias, uint8_t *codes_out, int mem,
-               void *stream_) {
+               void *stream_) try {
   if (!pq || !X || !first_idx) return fail(SDB_ERR_INVALID, "NULL argument");
   if (n == 0) return fail(SDB_ERR_INVALID, "no vectors to fit");
   DeviceGuard dg(pq->device);
@@ -986,8 +989,9 @@ int sdb_pq_fit(sdb_pq *pq, float *X, uint32_t n, const uint32_t *first_idx, int 
   if (rc == SDB_OK) pq->fitted = true;
   return rc;
 }
+SDB_API_CATCH("sdb_pq_fit")
 
-int sdb_pq_set_codebook(sdb_pq *pq, const float *flat_centroids, int mem) {
+int sdb_pq_set_codebook(sdb_pq *pq, const float *flat_centroids, int mem) try {
   if (!pq || !flat_centroids) return fail(SDB_ERR_INVALID, "NULL argument");
   DeviceGuard dg(pq->device);
   SDB_HIP(hipMemcpy(pq->d_centroids, flat_centroids, (size_t)pq->M * pq->K * pq->sub_len * 4,
@@ -997,8 +1001,9 @@ int sdb_pq_set_codebook(sdb_pq *pq, const float *flat_centroids, int mem) {
   pq->fitted = true;
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_pq_set_codebook")
 
-int sdb_pq_get_codebook(const sdb_pq *pq, float *flat_centroids, float *centroid_dists) {
+int sdb_pq_get_codebook(const sdb_pq *pq, float *flat_centroids, float *centroid_dists) try {
   if (!pq) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");
   DeviceGuard dg(pq->device);
@@ -1009,8 +1014,9 @@ int sdb_pq_get_codebook(const sdb_pq *pq, float *flat_centroids, float *centroid
     SDB_HIP(hipMemcpy(centroid_dists, pq->d_cdists, (size_t)pq->M * pq->K * pq->K * 4, hipMemcpyDeviceToHost));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_pq_get_codebook")
 
-int sdb_pq_encode(const sdb_pq *pq, const float *vectors, uint64_t n, uint8_t *codes, int mem, void *stream_) {
+int sdb_pq_encode(const sdb_pq *pq, const float *vectors, uint64_t n, uint8_t *codes, int mem, void *stream_) try {
   if (!pq || !vectors || !codes) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");  // encode returns nil, product.go:137-139
   if (n == 0) return SDB_OK;
@@ -1024,9 +1030,10 @@ int sdb_pq_encode(const sdb_pq *pq, const float *vectors, uint64_t n, uint8_t *c
   if (mem == SDB_MEM_HOST) SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_pq_encode")
 
 int sdb_pq_lut_distance(const sdb_pq *pq, const float *queries, uint64_t nq, const uint8_t *codes, uint64_t nc,
-                        float *out, int mem, void *stream_) {
+                        float *out, int mem, void *stream_) try {
   if (!pq || !queries || !codes || !out) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");
   if (nq == 0 || nc == 0) return SDB_OK;
@@ -1050,9 +1057,10 @@ int sdb_pq_lut_distance(const sdb_pq *pq, const float *queries, uint64_t nq, con
   (void)hipFree(lut);
   return rc;
 }
+SDB_API_CATCH("sdb_pq_lut_distance")
 
 int sdb_pq_sym_distance(const sdb_pq *pq, const uint8_t *codes_x, const uint8_t *codes_y, uint64_t n, float *out,
-                        int mem, void *stream_) {
+                        int mem, void *stream_) try {
   if (!pq || !codes_x || !codes_y || !out) return fail(SDB_ERR_INVALID, "NULL argument");
   if (!pq->fitted) return fail(SDB_ERR_STATE, "quantizer is not fitted");
   if (n == 0) return SDB_OK;
@@ -1069,5 +1077,6 @@ int sdb_pq_sym_distance(const sdb_pq *pq, const uint8_t *codes_x, const uint8_t 
   if (mem == SDB_MEM_HOST) SDB_HIP(hipStreamSynchronize(stream));
   return SDB_OK;
 }
+SDB_API_CATCH("sdb_pq_sym_distance")
 
 }  // extern "C"

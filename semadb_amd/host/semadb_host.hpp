@@ -501,10 +501,24 @@ class SearchBatcher {
   void loop() {
     // this worker's pinned result slabs, for the largest limit the API allows (models/search.go:287-297)
     const size_t kMaxLimit = 128;
-    void *p_ids = nullptr, *p_d = nullptr, *p_c = nullptr;
-    sdb_host_alloc(cap_ * kMaxLimit * 8, &p_ids);
-    sdb_host_alloc(cap_ * kMaxLimit * 4, &p_d);
-    sdb_host_alloc(cap_ * 4, &p_c);
+    // pinned when that can be had (the limit on locked memory), else ordinary pages: the device call then stages the
+    // copies back, slower, same answers -- like the query slabs (newBatch)
+    struct Slab {
+      void *p = nullptr;
+      bool pinned = false;
+      void get(size_t bytes) {
+        pinned = sdb_host_alloc(bytes, &p) == SDB_OK && p;
+        if (!pinned) p = std::calloc(1, bytes + 8);
+      }
+      void drop() {
+        if (pinned) sdb_host_free(p);
+        else std::free(p);
+        p = nullptr;
+      }
+    } s_ids, s_d, s_c;
+    s_ids.get(cap_ * kMaxLimit * 8), s_d.get(cap_ * kMaxLimit * 4), s_c.get(cap_ * 4);
+    void *p_ids = s_ids.p, *p_d = s_d.p, *p_c = s_c.p;
+    // (not even pageable memory: runBatch answers every request of this worker with an error)
     for (;;) {
       Batch *b = nullptr;
       std::vector<Request *> others;
@@ -536,7 +550,7 @@ class SearchBatcher {
           }
           if (stop_) {
             lk.unlock();
-            sdb_host_free(p_ids), sdb_host_free(p_d), sdb_host_free(p_c);
+            s_ids.drop(), s_d.drop(), s_c.drop();
             return;
           }
           if (c && first) qcv_.wait_for(lk, std::chrono::nanoseconds(window_.count() * 1000 - age));
@@ -565,11 +579,13 @@ class SearchBatcher {
     const uint32_t nq = b->count, limit = (uint32_t)(b->key >> 32), L = (uint32_t)b->key;
     while (b->written.load(std::memory_order_acquire) < nq) std::this_thread::yield();  // the last copies in flight
     int rc;
-    if (limit > 128) rc = SDB_ERR_INVALID;
+    const char *why = nullptr;
+    if (limit > 128) rc = SDB_ERR_INVALID, why = "limit beyond the batcher's result slabs (128)";
+    else if (!ids || !dists || !counts) rc = SDB_ERR_DEVICE, why = "out of host memory for the batcher's result slabs";
     else rc = sdb_index_search_batch(h_, nq, b->queries, limit, L, nullptr, nullptr, ids, dists, counts, nullptr, SDB_MEM_HOST, nullptr);
     n_batches_++;
     n_queries_ += nq;
-    const Error err = rc ? Error(std::string(sdb_last_error())) : Error();
+    const Error err = rc ? Error(std::string(why ? why : sdb_last_error())) : Error();
     Told told;
     for (uint32_t i = 0; i < nq; i++) {
       Request *r = b->reqs[i];

@@ -75,3 +75,31 @@ def test_product_path_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "sdb_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_every_entry_point_ends_exceptions():
+    """CONTRIBUTING.md:150 (no panics) at the C boundary: every extern "C" function of the library is a
+    function-try-block that ends in SDB_API_CATCH, so that no C++ exception (std::bad_alloc from a multi-GB host
+    staging vector, std::system_error from a thread) unwinds through cgo into std::terminate.  The run-time proof is
+    tests/host/test_faults.cpp (operator-new fault injection, on the GPU)."""
+    import glob
+    csrc = os.path.join(ROOT, "semadb_amd", "csrc")
+    text = "".join(open(p).read() for p in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc"))))
+    trivial = {"sdb_last_error", "sdb_abi_version"}  # a pointer to a thread-local buffer / a constant
+    unguarded = []
+    for name in declared_functions():
+        if name in trivial:
+            continue
+        m = re.search(r'^(?:extern "C" )?int\s+%s\(' % name + r"[^;{]*?\)\s*(try)?\s*\{", text, flags=re.M | re.S)
+        assert m, "no definition of %s found" % name
+        if not m.group(1) or 'SDB_API_CATCH("%s")' % name not in text:
+            unguarded.append(name)
+    assert not unguarded, "entry points that let exceptions out: %s" % unguarded
+
+
+def test_fault_injection_program_compiles(tmp_path):
+    import subprocess
+    libdir = os.path.join(ROOT, "semadb_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "host", "test_faults.cpp"), "-o",
+                           str(tmp_path / "test_faults"), "-L" + libdir, "-lsemadb_amd", "-ldl", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
