@@ -149,21 +149,17 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     if (D && n_clean > 0 && nc - n_clean <= kMaxDirty && nc <= kPairMax) {
       sparse = true;
       int nd = 0;
-      int dpos[kMaxDirty];
-#pragma unroll
-      for (int k = 0; k < kMaxDirty; k++) dpos[k] = 0;
+      // positions of the dirty candidates, in LDS behind D's rows (sixteen scalar registers and a select chain per
+      // look-up otherwise -- the kernel sat two registers over its three-waves-per-SIMD budget)
+      uint32_t *dpos = reinterpret_cast<uint32_t *>(D + kMaxDirty * kPairMax);
       for (int base = 0; base < nc; base += 64) {
         const int j = base + lane;
         const bool dirty = j < nc && !(s_rem[j] & 2u);
         const uint64_t m = __ballot(dirty);
-        if (j < nc) dord[j] = dirty ? (uint32_t)(nd + __popcll(m & ((1ull << lane) - 1))) : 0xFFFFFFFFu;
-        for (uint64_t t = m; t; t &= t - 1) {
-          const int jj = base + __ffsll((unsigned long long)t) - 1;
-#pragma unroll
-          for (int k = 0; k < kMaxDirty; k++)
-            if (k == nd) dpos[k] = jj;
-          nd++;
-        }
+        const uint32_t ord = (uint32_t)(nd + __popcll(m & ((1ull << lane) - 1)));
+        if (j < nc) dord[j] = dirty ? ord : 0xFFFFFFFFu;
+        if (dirty) dpos[ord] = (uint32_t)j;
+        nd += __popcll(m);
       }
       __syncthreads();
       // one row of pair distances per dirty candidate: D[k][j] = distFn(c_dirty_k, c_j).  When the dirty
@@ -173,10 +169,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
       // and only the misses are computed from rows.
       uint32_t *miss = reinterpret_cast<uint32_t *>(const_cast<float *>(in_dist));  // free after the sort
       for (int k = 0; k < nd; k++) {
-        int dk = 0;
-#pragma unroll
-        for (int kk = 0; kk < kMaxDirty; kk++)
-          if (kk == k) dk = dpos[kk];
+        const int dk = __builtin_amdgcn_readfirstlane((int)dpos[k]);
         const uint32_t sd = s_slot[dk];
         const uint2 *tab = nullptr;
         if (a.dcache && sd >= a.first_slot && sd - a.first_slot < a.nnew)
@@ -204,19 +197,21 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
           if (NG == 0) pr.xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
           pr.xt = a.tail ? prow[NG * 128 + L] : 0.0f;
           for (int m0 = 0; m0 < nmiss; m0 += 2 * U) {
+            // each half-wave its own candidate of a pair: one index per pair and lane (not two wave-wide ones), and the
+            // sum leaves lane 0 of its half straight to its place
             uint32_t slot[U];
             float res[U];
-            int cidx[2 * U];
-#pragma unroll
-            for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (int)miss[m0 + k2 < nmiss ? m0 + k2 : nmiss - 1];
-#pragma unroll
-            for (int u = 0; u < U; u++) slot[u] = lane < 32 ? s_slot[cidx[2 * u]] : s_slot[cidx[2 * u + 1]];
-            chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+            int cidx[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-              const float d0 = metric_finish(rlf(res[u], 0), a.metric);
-              const float d1 = metric_finish(rlf(res[u], 32), a.metric);
-              if (lane == 0) D[k * kPairMax + cidx[2 * u]] = d0, D[k * kPairMax + cidx[2 * u + 1]] = d1;
+              const int at = m0 + 2 * u + (lane >> 5);
+              cidx[u] = (int)miss[at < nmiss ? at : nmiss - 1];
+              slot[u] = s_slot[cidx[u]];
+            }
+            chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+            if (L == 0) {
+#pragma unroll
+              for (int u = 0; u < U; u++) D[k * kPairMax + cidx[u]] = metric_finish(res[u], a.metric);
             }
           }
         }
@@ -238,10 +233,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
         const bool ok0 = v0 && sl0 != self_slot, ok1 = v1 && sl1 != self_slot;  // :115-117
         bool rem0 = false, rem1 = false;
         for (int k = 0; k < nd; k++) {
-          int pd = 0;
-#pragma unroll
-          for (int kk = 0; kk < kMaxDirty; kk++)
-            if (kk == k) pd = dpos[kk];
+          const int pd = __builtin_amdgcn_readfirstlane((int)dpos[k]);
           const float dpd = s_dist[pd];
           const float e0 = v0 ? D[k * kPairMax + j0] : 0.0f, e1 = v1 ? D[k * kPairMax + j1] : 0.0f;
           const bool kills0 = ok0 && !rem0 && j0 < pd && a.alpha * e0 < dpd;  // :132 seen from the victim
@@ -340,43 +332,42 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
       for (uint32_t t = lane; t < a.ld; t += 64) qs[t] = prow[t];
       __syncthreads();
     }
+    // The candidates still alive behind `found`, 64 positions at a time: their slots go into a list by rank (the input
+    // arrays are free after the sort), each half-wave takes its candidate of a pair from there, and the sums come back
+    // through the list's twin -- no per-pair scalar bookkeeping (sixteen lane numbers in scalar registers, a readlane
+    // per row and result: the kernel sat two registers over its budget of three waves per SIMD and spilled them).
+    uint32_t *lst = const_cast<uint32_t *>(in_slot);
+    float *lres = const_cast<float *>(in_dist);
     for (int base = (found + 1) & ~63; base < nc; base += 64) {
       const int j = base + lane;
       const bool live = j > found && j < nc && !(s_rem[j] & 1u);
-      const uint32_t cs = live ? s_slot[j] : 0u;
-      const float cdj = live ? s_dist[j] : 0.0f;
-      uint64_t todo = __ballot(live);
-      ev += (uint32_t)__popcll(todo);
-      bool rm = false;
-      while (todo) {
-        int jj[2 * U];
-#pragma unroll
-        for (int k = 0; k < 2 * U; k++) {
-          if (todo) {
-            jj[k] = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-          } else {
-            jj[k] = jj[k > 0 ? k - 1 : 0];
-          }
-        }
+      const uint64_t todo = __ballot(live);
+      const int nl = __popcll(todo);
+      if (nl == 0) continue;
+      ev += (uint32_t)nl;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+      if (live) lst[rank] = s_slot[j];
+      __syncthreads();
+      for (int m0 = 0; m0 < nl; m0 += 2 * U) {
         uint32_t slot[U];
         float res[U];
+        int at[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          const uint32_t s0 = rl(cs, jj[2 * u]), s1 = rl(cs, jj[2 * u + 1]);
-          slot[u] = lane < 32 ? s0 : s1;
+          const int x = m0 + 2 * u + (lane >> 5);
+          at[u] = x < nl ? x : nl - 1;
+          slot[u] = lst[at[u]];
         }
         if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
         else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, qs, slot, res, lane);
+        if (L == 0) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const float d0 = metric_finish(rlf(res[u], 0), a.metric);
-          const float d1 = metric_finish(rlf(res[u], 32), a.metric);
-          if (lane == jj[2 * u]) rm = a.alpha * d0 < cdj;  // :132
-          if (lane == jj[2 * u + 1]) rm = a.alpha * d1 < cdj;
+          for (int u = 0; u < U; u++) lres[at[u]] = metric_finish(res[u], a.metric);
         }
       }
-      if (live && rm) s_rem[j] |= 1u;
+      __syncthreads();
+      if (live && a.alpha * lres[rank] < s_dist[j]) s_rem[j] |= 1u;  // :132
+      __syncthreads();  // the list is written again for the next 64 positions
     }
     __syncthreads();
     i = found + 1;
@@ -408,7 +399,7 @@ struct PruneLds {
   __device__ PruneLds(char *base, uint32_t cap, bool with_pairs = false) {
     D = with_pairs ? reinterpret_cast<float *>(base + (size_t)cap * 20) : nullptr;
     base_init(base, cap);
-    if (with_pairs) qs = D + kMaxDirty * kPairMax;
+    if (with_pairs) qs = D + kMaxDirty * kPairMax + kMaxDirty;  // (the positions of the dirty candidates sit behind D's rows)
   }
   __device__ void base_init(char *base, uint32_t cap) {
     in_slot = reinterpret_cast<uint32_t *>(base);
@@ -463,7 +454,7 @@ __device__ void dists_from_point(const BuildArgs &a, uint32_t point, uint32_t nc
 }
 
 static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld, bool with_pairs = false) {
-  return (size_t)cap * 20 + (with_pairs ? (size_t)kMaxDirty * kPairMax * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
+  return (size_t)cap * 20 + (with_pairs ? (size_t)kMaxDirty * (kPairMax + 1) * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
 }
 
 // robustPrune(nodeA, visitedSet) for every new node of the round (insert.go:29-31), then emit the
@@ -967,18 +958,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
         for (int m0 = 0; m0 < nmiss; m0 += 2 * U) {
           uint32_t slot[U];
           float res[U];
-          int cidx[2 * U];
-#pragma unroll
-          for (int k2 = 0; k2 < 2 * U; k2++) cidx[k2] = (int)l.s_slot[m0 + k2 < nmiss ? m0 + k2 : nmiss - 1];
-#pragma unroll
-          for (int u = 0; u < U; u++) slot[u] = lane < 32 ? l.in_slot[cidx[2 * u]] : l.in_slot[cidx[2 * u + 1]];
-          if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
-          else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+          int cidx[U];  // this half-wave's candidate of each pair
 #pragma unroll
           for (int u = 0; u < U; u++) {
-            const float d0 = metric_finish(rlf(res[u], 0), a.metric);
-            const float d1 = metric_finish(rlf(res[u], 32), a.metric);
-            if (lane == 0) l.in_dist[cidx[2 * u]] = d0, l.in_dist[cidx[2 * u + 1]] = d1;
+            const int at = m0 + 2 * u + (lane >> 5);
+            cidx[u] = (int)l.s_slot[at < nmiss ? at : nmiss - 1];
+            slot[u] = l.in_slot[cidx[u]];
+          }
+          if constexpr (NG >= 0) chunk_dist<NG, L2, U>(a.slab, a.ld, a.tail, pr.xq, pr.xt, slot, res, lane);
+          else chunk_dist_lds<L2, U>(a.slab, a.ld, a.ng, a.tail, l.qs, slot, res, lane);
+          if (L == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) l.in_dist[cidx[u]] = metric_finish(res[u], a.metric);
           }
         }
       }
@@ -1166,14 +1157,38 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   } cleanup{{}, stream};
   // ---- every allocation of the call comes first: an out-of-memory failure must leave the index as it was
   SDB_TRY(ix->reserve(n0 + (uint32_t)n));
-  // ... the host tables' room included: the per-round bookkeeping (`commit` below) then cannot run out of memory with
-  // rounds already applied
+  // ... the host tables included: the ids of the new points go into the id -> slot map NOW, at the slots they will
+  // have (slots past ix->n resolve to nothing, sdb_index::slot_of), so that the per-round bookkeeping (`commit` below)
+  // only moves counters and cannot run out of memory with rounds already applied
+  uint64_t done = 0;  // points whose rounds have been applied
+  struct PreMapped {
+    sdb_index *ix;
+    const std::vector<uint64_t> *ids;
+    const uint64_t *done;
+    bool active = false, was_dense = false;
+    ~PreMapped() {  // whatever was not applied leaves the map again (erase does not allocate)
+      if (!active || *done == ids->size()) return;
+      std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+      if (was_dense && *done == 0) ix->id2slot.clear();
+      else
+        for (uint64_t i = *done; i < ids->size(); i++) ix->id2slot.erase((*ids)[i]);
+    }
+  } premap{ix, &new_ids, &done};
   {
     std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // a rehash moves what the searches' id lookups read
     ix->h_ids.reserve((size_t)n0 + n);
     bool stays_dense = ix->dense_ids && ix->h_ids.size() > 0;
     for (uint64_t i = 0; i < n && stays_dense; i++) stays_dense = new_ids[i] == ix->h_ids[0] + ix->h_ids.size() + i;
-    if (!stays_dense) ix->id2slot.reserve(((size_t)n0 + n) * 2);
+    if (!stays_dense) {
+      premap.was_dense = ix->dense_ids;
+      premap.active = true;  // from here on a failure erases what got in
+      if (ix->dense_ids) ix->id2slot.clear();  // (a dense table ignores the map: filling it changes no answer)
+      ix->id2slot.reserve(((size_t)n0 + n) * 2);
+      if (ix->dense_ids)
+        for (size_t sl = 0; sl < ix->h_ids.size(); sl++)
+          if (ix->h_ids[sl] != 0) ix->id2slot.emplace(ix->h_ids[sl], (uint32_t)sl);
+      for (uint64_t i = 0; i < n; i++) ix->id2slot.emplace(new_ids[i], n0 + (uint32_t)i);
+    }
   }
   static_assert(SDB_BUILD_STATS <= sdb_index::kStatStride, "stat slots per copy");
   const size_t bstats_bytes = (size_t)sdb_index::kStatCopies * sdb_index::kStatStride * sizeof(uint64_t);
@@ -1259,7 +1274,6 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   // ---- from here on the call writes, into the writer's copy of the graph (index.h graph versions): searches
   // issued meanwhile keep walking the last committed version.  Rows beyond ix->n first.
   SDB_TRY(ix->begin_write());
-  uint64_t done = 0;
   // Every exit below this line goes through one of two doors.  write_failed: nothing of this call has reached the
   // graph or the host tables yet when done == 0 (rows past ix->n are invisible) -- the transaction this call opened
   // for itself closes again and the index is as it was; with rounds already applied the rows they appended and the
@@ -1310,13 +1324,8 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ix->tx_dirty = true;
     bool dense = ix->dense_ids;
     for (uint64_t i = from; i < to; i++) {
-      if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
-        dense = false;  // switch to the hash map
-        ix->id2slot.reserve((ix->h_ids.size() + (n - i)) * 2);
-        for (size_t s = 0; s < ix->h_ids.size(); s++) ix->id2slot.emplace(ix->h_ids[s], (uint32_t)s);
-      }
-      if (!dense) ix->id2slot.emplace(new_ids[i], (uint32_t)ix->h_ids.size());
-      ix->h_ids.push_back(new_ids[i]);
+      if (dense && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) dense = false;  // the map has been filled (above)
+      ix->h_ids.push_back(new_ids[i]);                                           // (room reserved above)
       if (new_ids[i] > ix->max_node_id) ix->max_node_id = new_ids[i];  // vamana.go:166-168
     }
     ix->dense_ids = dense;

@@ -417,23 +417,23 @@ static int pq_wide_shape(const SearchArgs &a) {
   }
 }
 
-template <int NL, int RT, int W = 4>
+template <int NL, int RT, int W = 4, int NLW = NL>
 static int launch_pqw(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   const bool h16 = (uint64_t)a.words_per_query * 32 <= (1u << 24) && !a.wide_hash;
-  const size_t lut = (size_t)W * NL * a.pq_K * sizeof(float);
+  const size_t lut = (size_t)((W - 1) * NL + NLW) * a.pq_K * sizeof(float);
   static std::atomic<uint64_t> at16{0}, at32{0};
   if (h16) {
     const size_t lds = HashVisited16::kWords * 4 + sizeof(PQWideShared) + lut;
     if (first_use_on_this_device(at16))
-      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHash16, W>),
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHash16, W, NLW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHash16, W>), dim3(nq), dim3(64 * W), lds, stream, a);
+    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHash16, W, NLW>), dim3(nq), dim3(64 * W), lds, stream, a);
   } else {
     const size_t lds = HashVisited<kHashCapPQ>::kWords * 4 + sizeof(PQWideShared) + lut;
     if (first_use_on_this_device(at32))
-      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHashCapPQ, W>),
+      SDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy_search_pqw<NL, RT, kHashCapPQ, W, NLW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHashCapPQ, W>), dim3(nq), dim3(64 * W), lds, stream, a);
+    hipLaunchKernelGGL((k_greedy_search_pqw<NL, RT, kHashCapPQ, W, NLW>), dim3(nq), dim3(64 * W), lds, stream, a);
   }
   SDB_HIP(hipGetLastError());
   return SDB_OK;
@@ -504,7 +504,7 @@ static int launch_wide_w(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   const size_t lds = HashVisited<kHashCap>::kWords * sizeof(uint32_t) + D::kLdsBytes;
   SearchArgs b = a;
   // calls of up to 256 queries (a workgroup per CU at most): the other waves work ahead on the row the walk expands next
-  b.wide_pull = (W == 16 && nq <= kWideAheadQueries) ? 2u : 0u;
+  b.wide_pull = ((W == 16 || NG == 8) && nq <= kWideAheadQueries) ? 2u : 0u;
   if (a.filt_off)  // the filtered walk (search.go:33-51,93-95): a hybrid REST query is one query with a filter
     hipLaunchKernelGGL((k_greedy_search_wide<NG, L2, W, true>), dim3(nq), dim3(64 * W),
                        lds + HashVisited<kHashCapResult>::kWords * sizeof(uint32_t), stream, b);
@@ -515,9 +515,12 @@ static int launch_wide_w(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
 }
 // up to 256 queries: 16 waves per query (one workgroup per CU); up to 512: 8 waves (two per CU: 0.56 ms per call against
 // 0.66 for one wave per query and 0.78 for 16 waves)
+// rows of 1 024 floats: at sixteen waves (128 registers each) the query and two pairs of rows do not fit -- 17 .. 57
+// registers spilled -- so every small call of that shape takes the eight-wave workgroup (214 registers, none spilled)
 template <int NG, bool L2>
 static int launch_wide(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
-  if (nq <= kWideMaxQueries || kWideWaves != 16) return launch_wide_w<NG, L2, kWideWaves>(a, nq, stream);
+  if constexpr (NG != 8)
+    if (nq <= kWideMaxQueries || kWideWaves != 16) return launch_wide_w<NG, L2, kWideWaves>(a, nq, stream);
   return launch_wide_w<NG, L2, 8>(a, nq, stream);
 }
 
@@ -562,7 +565,7 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
       // selects the latter for comparison
       case 2: return a.pq_narrow == 2 ? launch_pqw<32, 16>(a, nq, stream) : launch_pqw<15, 33>(a, nq, stream);
       case 3: return launch_pqw<32, 32>(a, nq, stream);
-      case 4: return launch_pqw<15, 33, 8>(a, nq, stream);  // M = 384: eight waves with M = 192's per-wave layout
+      case 4: return launch_pqw<15, 33, 8, 32>(a, nq, stream);  // M = 384: eight waves with M = 192's per-wave layout, the walker 32 + 16
       default: break;
     }
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
@@ -592,7 +595,8 @@ int64_t sdb_index::slot_of(uint64_t id) const {
     return (int64_t)(id - base);
   }
   auto it = id2slot.find(id);
-  return it == id2slot.end() ? -1 : (int64_t)it->second;
+  // (an insert in progress has entered its ids at the slots they will have: rows past n are not there yet)
+  return it == id2slot.end() || it->second >= n ? -1 : (int64_t)it->second;
 }
 
 int sdb_index::reserve(uint32_t rows) {

@@ -457,14 +457,17 @@ struct WideShared {
 // pairs of rows per round of loads: a wave's share of a hop is at most 64 / W rows (rounded up to even), so 32 / W pairs
 // hold it -- but its share of the distances AHEAD is 6 rows at W = 16 (14 waves compute): three pairs where the registers
 // allow it (rows of up to 512 floats; 128 registers per wave at 16 waves)
-template <int NG, int W>
+// -- euclidean from 384 floats up stays at two: its separately rounded differences are live beside the rows, and the
+// third pair spilled (1 register at 384 floats, 33 .. 69 at 512; tools/kernel_table.py --check holds every walk kernel
+// to zero scratch)
+template <int NG, int W, bool L2>
 struct WidePairs {
   static constexpr int kMin = 32 / W > 0 ? 32 / W : 1;
-  static constexpr int value = (kMin < 3 && NG <= 4) ? 3 : kMin;
+  static constexpr int value = (kMin < 3 && (NG <= 2 || (NG <= 4 && !L2))) ? 3 : kMin;
 };
 template <int NG, bool L2, int W>
-struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W>::value> {
-  using Base = PlainDist<NG, L2, true, WidePairs<NG, W>::value>;
+struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W, L2>::value> {
+  using Base = PlainDist<NG, L2, true, WidePairs<NG, W, L2>::value>;
   // A call of few queries has bandwidth to spare and a dependent chain to shorten.  Once a hop's distances are known, so
   // is the candidate the walk expands next (search_body, Dist::kSpeculate: 99 % of the hops expand exactly it) -- BEFORE
   // the hop's points are inserted.  The walker names it there (a.wide_pull = 2), and while it inserts
@@ -789,10 +792,13 @@ struct PQWideDist {
   // entries here instead -- no 200 MB block written and read back per batch -- was built and measured: the loads and
   // chains of the build share the walk's register budget, and the two-per-CU variant went from 1.04 to 1.23 ms per
   // batch with a loop per entry, to 1.89 ms with the loads batched; removed.  The block costs 0.12 ms per batch.)
-  __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lut_lds, PQWideShared *shared) {
+  // `before`: tables of the waves in front of this one in the workgroup's LDS block (w * NL when every wave has the same
+  // split; the walker of the eight-wave form keeps more of its tables in LDS, k_greedy_search_pqw)
+  __device__ __forceinline__ void init_wave(const SearchArgs &a, uint32_t q, int lane, int w, float *lut_lds, PQWideShared *shared,
+                                            uint32_t before) {
     sh = shared, wave = w, K = a.pq_K, lo = (uint32_t)w * MS;
 
-    float *dst = lut_lds + (size_t)w * NL * K;
+    float *dst = lut_lds + (size_t)before * K;
     lds_lut = dst;
     const float *g = a.pq_lut + ((size_t)q * a.pq_M + lo) * K;
     for (uint32_t i = lane; i < NL * K; i += 64) dst[i] = g[i];
@@ -1761,7 +1767,11 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
 // The multi-wave quantized walk: one query per workgroup of four waves (PQWideDist above).  Dynamic LDS: the visited
 // set's table, the command area, the LDS-resident tables [4][NL][K].
 // NL < 16: the variant meant to run two queries per CU (half the LDS each) -- its registers are capped accordingly
-template <int NL, int RT, uint32_t HCAP, int W = 4>
+// NLW: tables the WALKER keeps in LDS (the rest of its NL + RT in registers).  The walker carries search_body's state
+// (candidate array, visited set, ~100 registers) on top of what every wave holds; at eight waves per query (M = 384,
+// 256 registers per wave) that state plus 33 register tables plus the 48 looked-up values did not fit -- 43 registers
+// spilled.  There the walker takes 32 of its 48 tables from LDS and 16 from registers; the helpers keep 15 + 33.
+template <int NL, int RT, uint32_t HCAP, int W = 4, int NLW = NL>
 __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_search_pqw(const SearchArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1776,23 +1786,30 @@ __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_
   constexpr uint32_t kVisWords = HCAP == kHash16 ? HashVisited16::kWords : HashVisited<HCAP == kHash16 ? 4u : HCAP>::kWords;
   PQWideShared *sh = reinterpret_cast<PQWideShared *>(lds_f + kVisWords);
   float *lut_lds = lds_f + kVisWords + kPqwSharedWords;
-  PQWideDist<NL, RT, W> dist;
-  dist.init_wave(a, q, lane, wave, lut_lds, sh);
+  static_assert(NLW == NL || W == 8, "a walker with its own split is wave 0 of the eight-wave form");
+  using Walker = PQWideDist<NLW, NL + RT - NLW, W>;
+  using Helper = PQWideDist<NL, RT, W>;
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
+  if (wave != walker) {
+    Helper dist;
+    // (NLW != NL: the walker is wave 0 and its NLW tables come first in the block)
+    dist.init_wave(a, q, lane, wave, lut_lds, sh, NLW == NL ? (uint32_t)wave * NL : (uint32_t)(NLW + (wave - 1) * NL));
+    __syncthreads();  // tables and visited set in place
+    return dist.serve(a, lane);
+  }
+  Walker dist;
+  dist.init_wave(a, q, lane, wave, lut_lds, sh, NLW == NL ? (uint32_t)wave * NL : 0u);
+  NoVisited rv;
   if constexpr (HCAP == kHash16) {
     HashVisited16 hv;
-    if (wave == walker) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
+    hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
     __syncthreads();  // tables and visited set in place
-    if (wave != walker) return dist.serve(a, lane);
-    NoVisited rv;
-    search_body<PQWideDist<NL, RT, W>, 2, false>(a, q, lane, dist, hv, rv);
+    search_body<Walker, 2, false>(a, q, lane, dist, hv, rv);
   } else {
     HashVisited<HCAP == kHash16 ? 4u : HCAP> hv;
-    if (wave == walker) hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
     __syncthreads();
-    if (wave != walker) return dist.serve(a, lane);
-    NoVisited rv;
-    search_body<PQWideDist<NL, RT, W>, 2, false>(a, q, lane, dist, hv, rv);
+    search_body<Walker, 2, false>(a, q, lane, dist, hv, rv);
   }
   dist.finish(lane);
 }

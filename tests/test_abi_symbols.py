@@ -103,3 +103,14 @@ def test_fault_injection_program_compiles(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "host", "test_faults.cpp"), "-o",
                            str(tmp_path / "test_faults"), "-L" + libdir, "-lsemadb_amd", "-ldl", "-Wl,-rpath," + libdir,
                            "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_hot_kernels_have_no_scratch():
+    """tools/kernel_table.py reads the register / scratch figures from the built library's gfx950 code objects: no
+    instantiation of the walk kernels (k_greedy_search, k_greedy_search_wide, k_greedy_search_pqw) and none of
+    k_backedges for d = 384 / 768 / 1536 may spill a register or carry scratch memory."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_table.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " 0 with scratch" in out.stdout

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Register / scratch / LDS figures of every kernel in the built libsemadb_amd.so, read from the gfx950 code
+objects' own metadata notes (.vgpr_count, .agpr_count, .sgpr_count, .vgpr_spill_count, .private_segment_fixed_size,
+.group_segment_fixed_size, .max_flat_workgroup_size) -- the figures DESIGN.md quotes come from here, not from memory.
+
+    python3 tools/kernel_table.py                       # markdown table of the walk / build kernels
+    python3 tools/kernel_table.py --all                 # every kernel
+    python3 tools/kernel_table.py --json out.json       # machine-readable
+    python3 tools/kernel_table.py --check               # exit 1 if a hot kernel has scratch or spills (tests use this)
+
+Needs only the ROCm LLVM tools (llvm-objdump --offloading, llvm-readelf; binutils c++filt); no GPU."""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "semadb_amd", "libsemadb_amd.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernels on the measured paths: no instantiation of these may carry scratch memory or spilled registers
+HOT = re.compile(r"^sdb::(k_greedy_search\w*|k_backedges)<")
+# k_backedges: the instantiations the build of the usual dimensions takes (NG = 3, 6, 12: d = 384, 768, 1536)
+HOT_BACKEDGES_NG = {"3", "6", "12"}
+
+FIELDS = [".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count",
+          ".private_segment_fixed_size", ".group_segment_fixed_size", ".max_flat_workgroup_size"]
+
+
+def code_objects(so, tmp):
+    dst = os.path.join(tmp, os.path.basename(so))
+    shutil.copy(so, dst)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", dst], cwd=tmp, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f)
+
+
+def kernels(so=SO):
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in code_objects(so, tmp):
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                                   text=True).stdout
+            cur = None
+            for line in notes.splitlines():
+                if line.startswith("  - ") and cur is not None and ".name" in cur:
+                    out.append(cur)
+                    cur = {}
+                elif line.startswith("  - "):
+                    cur = {}
+                if cur is None:
+                    continue
+                m = re.match(r"^(?:  - |    )(\.[a-z_]+):\s+(\S.*)$", line)
+                if m and m.group(1) in FIELDS + [".name"]:
+                    cur[m.group(1)] = m.group(2).strip()
+                if line.startswith("amdhsa.target") or line.startswith("amdhsa.version"):
+                    if cur and ".name" in cur:
+                        out.append(cur)
+                    cur = None
+            if cur and ".name" in cur:
+                out.append(cur)
+    names = "\n".join(k[".name"] for k in out)
+    dem = subprocess.run(["c++filt"], input=names, capture_output=True, text=True, check=True).stdout.splitlines()
+    rows = []
+    for k, d in zip(out, dem):
+        d = re.sub(r"\s*\[clone .*\]$", "", d)
+        d = re.sub(r"^void ", "", d)
+        d = re.sub(r"\(.*\)$", "", d)  # drop the parameter list
+        row = {"kernel": d}
+        for f in FIELDS:
+            row[f[1:]] = int(k.get(f, "0"))
+        rows.append(row)
+    rows.sort(key=lambda r: r["kernel"])
+    return rows
+
+
+def waves_per_simd(r):
+    # gfx950: 512 VGPRs per SIMD lane shared by arch + acc registers, allocation granule 8, at most 8 waves per SIMD
+    regs = r["vgpr_count"] + r["agpr_count"]
+    regs = max(8, (regs + 7) // 8 * 8)
+    return min(8, 512 // regs)
+
+
+def is_hot(name):
+    if not HOT.match(name):
+        return False
+    m = re.match(r"^sdb::k_backedges<(-?\d+)", name)
+    if m:
+        return m.group(1) in HOT_BACKEDGES_NG
+    return True
+
+
+def offenders(rows):
+    # (spilled SGPRs live in lanes of a VGPR, not in memory: they show up as VGPR pressure, not as scratch)
+    return [r for r in rows if is_hot(r["kernel"]) and (r["vgpr_spill_count"] or r["private_segment_fixed_size"])]
+
+
+def markdown(rows):
+    lines = ["| kernel | VGPR | AGPR | SGPR | spilled VGPR | scratch B | static LDS B | max WG | waves/SIMD by registers |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        lines.append("| `%s` | %d | %d | %d | %d | %d | %d | %d | %d |" % (
+            r["kernel"], r["vgpr_count"], r["agpr_count"], r["sgpr_count"], r["vgpr_spill_count"],
+            r["private_segment_fixed_size"], r["group_segment_fixed_size"], r["max_flat_workgroup_size"], waves_per_simd(r)))
+    return "\n".join(lines)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--so", default=SO)
+    ap.add_argument("--all", action="store_true")
+    ap.add_argument("--match", default=None, help="regular expression on the demangled name")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+    rows = kernels(a.so)
+    if a.check:
+        bad = offenders(rows)
+        for r in bad:
+            print("SPILL %s: %d VGPRs spilled, %d B scratch" % (r["kernel"], r["vgpr_spill_count"], r["private_segment_fixed_size"]))
+        print("%d kernels, %d hot, %d with scratch" % (len(rows), sum(is_hot(r["kernel"]) for r in rows), len(bad)))
+        return 1 if bad else 0
+    sel = rows
+    if a.match:
+        sel = [r for r in rows if re.search(a.match, r["kernel"])]
+    elif not a.all:
+        sel = [r for r in rows if re.match(r"^sdb::(k_greedy_search|k_backedges|k_prune_new|k_pq_lut|k_flat_scan|k_k1_)", r["kernel"])]
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(sel, f, indent=1)
+    print(markdown(sel))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
