@@ -49,6 +49,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+LDS_B32_READS_PER_S = 75e12 / 4  # MI355X_MICROARCH.md: ~75 TB/s aggregate for ds_read_b32 with every CU streaming
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: packed FP32 FMA, 256 CUs x 256 flop/clk x 2.4 GHz
 
 
@@ -102,11 +103,11 @@ def exact_topk(queries, base, k, chunk=262144):
     return best_s, best_i
 
 
-def build_index(a, base, dev_index, name="bench"):
+def build_index(a, base, dev_index, name="bench", strict=True):
     from semadb_amd import vamana
     d = base.shape[1]
     params = vamana.IndexVectorVamanaParameters(d, a.metric, a.search_size, a.degree_bound, a.alpha)
-    ix = vamana.NewIndexVamana(name, params, device=dev_index, capacity=base.shape[0] + 1, strict=True)
+    ix = vamana.NewIndexVamana(name, params, device=dev_index, capacity=base.shape[0] + 1, strict=strict)
     ix.set_start(start_vector(d))
     if os.environ.get("BENCH_NO_TILE"):  # measurement only (tools/pmc_build.sh): the one-wave prune of new nodes
         ix.set_tuning("no_tile", int(os.environ["BENCH_NO_TILE"]))
@@ -131,8 +132,13 @@ def build_roofline(ix, n, d, build_s):
     # what has to come from HBM at least once: the searches' rows, and each prune's candidate rows once
     unique_b = search_b + (st["staged_rows"] + st["backedge_pairs"]) * d * 4 if st["staged_rows"] else None
     ach = alg / build_s / 1e9
-    out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+    # `frac` prices the bytes that have to come from HBM at least once (the searches' rows, each prune's candidate rows
+    # once) against the build's wall clock; the all-pairs figure -- pair distances the prunes take from rows staged in
+    # LDS are no HBM traffic -- stays beside it as `frac_mixed`
+    uni = (unique_b if unique_b else alg) / build_s / 1e9
+    out = {"bound": "hbm", "achieved": round(uni, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(uni / HBM_PEAK_GBS, 4), "achieved_mixed": round(ach, 1), "frac_mixed": round(ach / HBM_PEAK_GBS, 4),
+           "traffic": None,
            "algorithmic_bytes": int(alg), "search_bytes": int(search_b), "prune_pair_bytes": int(pair_b),
            "build_s": round(build_s, 3), "inserts_per_s": round(n / build_s, 1),
            "note": "whole build (all kernels, %d rounds), wall clock; the prunes take pair distances from rows "
@@ -311,14 +317,27 @@ def run_c2(a, ctx):
     ms_per_step, roofline), then replicas and c5 under config.modes."""
     world = ctx["world"]
     ctx["ex"] = Exchange(ctx["backend"], ctx["dev"], ctx["dev_index"]) if ctx["use_dist"] else None
+    # BENCH_REHEARSE_ALL=1: ONE rank walks the whole N > 1 schedule (shards, replicas, c5 at --c5-rows per GPU; none of
+    # the single-GPU extras), so that the wall time of the driver's 8-GPU lease can be budgeted on a 1-GPU box -- per-rank
+    # work does not depend on N except for the shards mode's 1/N split, which makes N = 1 the slowest case.  With
+    # BENCH_FORCE_EXCHANGE=1 on top the exchange is the library's RCCL all-gather (one rank).  The driver sets neither.
+    ctx["rehearse"] = os.environ.get("BENCH_REHEARSE_ALL") == "1"
+    t_all = time.time()
     try:
-        if world == 1 or a.mode != "all":
-            return measure_mode(a, ctx, "shards" if (world == 1 or a.mode == "all") else a.mode, a.rows, primary=True)
+        if (world == 1 and not ctx["rehearse"]) or a.mode != "all":
+            res = measure_mode(a, ctx, "shards" if (world == 1 or a.mode == "all") else a.mode, a.rows, primary=True)
+            res["config"]["wall_s_total"] = round(time.time() - t_all, 1)
+            return res
         res = measure_mode(a, ctx, "shards", a.rows, primary=True)
+        walls = ["shards: " + res["config"]["wall_s_by_phase"]]
         modes = {}
         for m, rows in (("replicas", a.rows), ("c5", a.c5_rows)):
             r = measure_mode(a, ctx, m, rows, primary=False)
             cfg = r["config"]
+            walls.append("%s: %s" % (m, cfg["wall_s_by_phase"]))
+            res["config"]["%s_qps" % m] = r["value"]  # scalars: nested objects do not survive the driver's record
+            res["config"]["%s_recall_at_10" % m] = cfg["recall_at_10"]
+            res["config"]["%s_roofline_frac" % m] = r["roofline"]["frac"]
             modes[m] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],
                         "workload": cfg["workload"], "parallelism": cfg["parallelism"], "dataset": cfg["dataset"],
                         "recall_at_10": cfg["recall_at_10"], "build_s": cfg["build_s"], "mean_n_dist": cfg["mean_n_dist"],
@@ -328,6 +347,10 @@ def run_c2(a, ctx):
             if r.get("invalid"):
                 modes[m]["invalid"] = r["invalid"]
         res["config"]["primary_mode"] = "shards"
+        res["config"]["wall_s_by_phase"] = "; ".join(walls)
+        res["config"]["wall_s_total"] = round(time.time() - t_all, 1)
+        if ctx["rehearse"]:
+            res["config"]["rehearsal"] = "BENCH_REHEARSE_ALL=1: one rank walked the N > 1 schedule; not a measurement of the metric"
         res["config"]["modes"] = modes
         return res
     finally:
@@ -341,6 +364,15 @@ def measure_mode(a, ctx, mode, rows, primary):
     use_dist, dist, barrier = ctx["use_dist"], ctx["dist"], ctx["barrier"]
     d, nq, k, L = a.dim, a.batch, a.k, a.search_size
     a_rows = rows
+
+    phases = []  # (name, seconds) of this mode's wall time, in order
+    t_phase = [time.time()]
+
+    def phase(name):
+        torch.cuda.synchronize()
+        now = time.time()
+        phases.append("%s %.1f" % (name, now - t_phase[0]))
+        t_phase[0] = now
 
     # ---- data.  shards / replicas: ONE database of --rows rows (seed 20250620), identical on every rank;
     # c5: shard `rank` = --rows rows of its own (seed 20250620 + rank, SURVEY 8d per-shard offset)
@@ -361,7 +393,9 @@ def measure_mode(a, ctx, mode, rows, primary):
     nb_recall, nb_timed = a.recall_batches, a.timed_batches
     queries = gen_rows((nb_recall + nb_timed) * nq, d, 20250621, a.dist, dev).view(nb_recall + nb_timed, nq, d)
     t1 = time.time()
+    phase("data")
     ix, build_s = build_index(a, base, dev_index)
+    phase("build")
     n_nodes, n_edges, _ = ix.stats()
     broof = build_roofline(ix, n, d, build_s)
     log("rank %d: data %.1fs, build %.2fs (%.0f inserts/s), avg degree %.2f" %
@@ -438,6 +472,7 @@ def measure_mode(a, ctx, mode, rows, primary):
     flat_ms = (time.perf_counter() - t_f) / 3 * 1e3
     log("flat exact scan: %.2f ms per %d queries over %d rows" % (flat_ms, nq, n))
 
+    phase("recall+scan")
     # ---- timed region: batches the recall phase never walked, trace counters OFF, one batch at a time
     tb = [nb_recall + (i % nb_timed) for i in range(a.warmup + a.steps)]
     ix.set_profiling(True)
@@ -482,6 +517,7 @@ def measure_mode(a, ctx, mode, rows, primary):
     alg_bytes = [per_batch[b] for b in tb[a.warmup:]][-len(kernel_ms):]
     achieved = float(np.sum(alg_bytes) / (np.sum(kernel_ms) * 1e-3) / 1e9) if len(kernel_ms) else 0.0
 
+    phase("timed+counters")
     # value: user-visible queries answered per second -- every query counts once however many shards walked it
     qps = nq * a.steps / elapsed
     scaling = "weak" if mode == "c5" else "strong"
@@ -573,7 +609,7 @@ def measure_mode(a, ctx, mode, rows, primary):
         except Exception:
             pass
 
-    if rank == 0 and world == 1 and primary:
+    if rank == 0 and world == 1 and primary and not ctx.get("rehearse"):
         cfg = result["config"]
         # not the metric (one batch at a time): the same batches with two of them in flight on two streams, the way a
         # serving process (the host batcher) runs -- a second batch fills the SIMDs the first one's finished walks left
@@ -619,17 +655,69 @@ def measure_mode(a, ctx, mode, rows, primary):
     ix.close()
     del base
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and primary and not a.no_secondary:
+    phase("extras")
+    if rank == 0 and world == 1 and primary and not a.no_secondary and not ctx.get("rehearse"):
         try:
             result["config"]["secondary_datasets"] = secondary_points(a, dev, dev_index)
         except Exception as e:
             result["config"]["secondary_datasets"] = {"error": repr(e)}
+        phase("secondary")
         if a.c4_rows:
             try:
                 result["config"]["c4"] = c4_point(a, dev, dev_index)
             except Exception as e:
                 result["config"]["c4"] = {"error": repr(e)}
+            phase("c4")
+    result["config"]["wall_s_by_phase"] = ", ".join(phases)
+    flatten_summary(result)
     return result
+
+
+def flatten_summary(result):
+    """The driver's record keeps the scalars of `config` and drops nested objects: the figures a reader of that record
+    needs are repeated as scalars (the nested objects stay for whoever reads the full line)."""
+    cfg = result["config"]
+    flat = {}
+    if "value_host" in result:
+        flat["value_host"] = result["value_host"]  # SURVEY 8d's protocol figure (H2D + D2H inside the timed region)
+    sec = cfg.get("secondary_datasets") or {}
+    for name, rec in sec.items():
+        if isinstance(rec, dict) and "qps" in rec:
+            key = name.replace(":", "")
+            flat["%s_qps" % key] = rec["qps"]
+            flat["%s_recall_at_10" % key] = rec["recall_at_10"]
+            if "search_size_for_recall_0.95" in rec:
+                flat["%s_search_size_for_recall_0.95" % key] = rec["search_size_for_recall_0.95"]
+    c4 = cfg.get("c4") or {}
+    for mk, rec in c4.items():
+        if mk.startswith("M=") and isinstance(rec, dict):
+            tag = "c4_" + mk.replace("=", "")
+            for src, dst in (("call_qps", "call_qps"), ("kernel_ms", "kernel_ms"), ("recall_at_10", "recall_at_10"),
+                             ("traffic_over_algorithmic", "traffic_over_algorithmic"), ("lookups_per_s", "lookups_per_s"),
+                             ("bound_by", "bound_by")):
+                if rec.get(src) is not None:
+                    flat["%s_%s" % (tag, dst)] = rec[src]
+            if isinstance(rec.get("roofline"), dict):
+                flat["%s_roofline_frac" % tag] = rec["roofline"].get("frac")
+    if isinstance(c4.get("full_precision"), dict):
+        flat["c4_full_precision_call_qps"] = c4["full_precision"].get("call_qps")
+        flat["c4_full_precision_recall_at_10"] = c4["full_precision"].get("recall_at_10")
+    lat = cfg.get("latency_ms") or {}
+    for key in ("1", "256"):
+        v = (lat.get("workgroup_per_query") or {}).get(key) if isinstance(lat, dict) else None
+        if isinstance(v, (int, float)):
+            flat["latency_ms_%s_queries" % key] = v
+        h = (lat.get("host_memory_call") or {}).get(key) if isinstance(lat, dict) else None
+        if isinstance(h, (int, float)):
+            flat["latency_ms_%s_queries_host_memory" % key] = h
+    br = result.get("build_roofline")
+    if isinstance(br, dict):
+        for key in ("frac", "frac_mixed", "hbm_unique_bytes", "build_s"):
+            if key in br:
+                flat["build_roofline_%s" % key] = br[key]
+    # scalars first: rebuild config with the summary in front
+    result["config"] = {**{k: v for k, v in cfg.items() if k in ("workload", "mode", "dataset", "recall_at_10")}, **flat,
+                        **{k: v for k, v in cfg.items() if k not in ("workload", "mode", "dataset", "recall_at_10")}}
 
 
 def side_points(a, ix, base, queries, dev):
@@ -771,15 +859,16 @@ def c4_point(a, dev, dev_index):
         torch.cuda.synchronize()
         call_ms = e0.elapsed_time(e1) / (3 * nbq)
         kms = float(np.mean(ix.profile_read()))
-        hits = nd = ne = 0
+        hits = nd = ne = nh = 0
         for b in range(nbq):
             ids, _, _, tr = ix.search_batch(queries[b], k, L, trace=True)
             hits += int((ids.to(torch.int64).unsqueeze(2) == truth[b * nq:(b + 1) * nq].unsqueeze(1)).any(2).sum().item())
             nd += int(tr.n_dist.to(torch.int64).sum().item())
             ne += int(tr.n_edges.to(torch.int64).sum().item())
+            nh += int(tr.n_hop.to(torch.int64).sum().item())
         return {"call_qps": round(nq / call_ms * 1e3, 1), "call_ms": round(call_ms, 4), "kernel_ms": round(kms, 4),
                 "kernel_qps": round(nq / kms * 1e3, 1), "recall_at_10": round(hits / (nbq * nq * k), 4),
-                "n_dist_per_batch": nd / nbq, "n_edges_per_batch": ne / nbq}
+                "n_dist_per_batch": nd / nbq, "n_edges_per_batch": ne / nbq, "n_hop_per_batch": nh / nbq}
 
     out = {"workload": "vectorVamana + product quantizer %dx%d %s, K=256, searchSize=%d degreeBound=%d, batch=%d" %
                        (n, d, a.metric, L, a.degree_bound, nq), "build_s": round(build_s, 2),
@@ -822,6 +911,24 @@ def c4_point(a, dev, dev_index):
                          "achieved": round(alg / m["kernel_ms"] / 1e6, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / m["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4),
                          "traffic": None}
+        if M <= 32:
+            # the neighbours' code rows sit behind the adjacency row (index.h d_adjcodes): a hop FETCHES 256 B of ids and
+            # 64 M B of codes whatever the visited set then says -- the model of the bytes requested, beside the algorithmic ones
+            fetched = m["n_hop_per_batch"] * (256 + 64 * M)
+            m["fetched_bytes_model_over_algorithmic"] = round(fetched / alg, 3)
+            m["layout"] = "neighbour code rows behind the adjacency row: one fetch per hop (node.go:37-54)"
+        else:
+            # the table look-ups, not bytes, are this kernel's work: M per distance, from LDS (ds_read_b32) or from the
+            # register tables (four ds_bpermute + selects each).  The guide's aggregate ds_read_b32 rate is ~75 TB/s =
+            # 18.75 T look-ups/s: the walk is far below it and far below HBM -- what binds is latency at low occupancy
+            lookups = m["n_dist_per_batch"] * M / (m["kernel_ms"] * 1e-3)
+            m["lookups_per_s"] = round(lookups / 1e12, 3)
+            m["lookups_unit"] = "T table look-ups/s (M x n_dist / kernel time)"
+            m["frac_of_lds_read_rate"] = round(lookups / LDS_B32_READS_PER_S, 4)
+            m["bound_by"] = ("latency at two walks per CU: a distance is M dependent look-ups (ds_read_b32 ~50 cycles issue to "
+                             "use; 132 of 192 tables sit in registers and cost four ds_bpermute each) summed in index order "
+                             "across the four waves' turns; neither HBM (roofline.frac) nor the LDS array "
+                             "(frac_of_lds_read_rate) is near its limit")
         out["M=%d" % M] = m
         log("c4 point M=%d: %s" % (M, json.dumps(m)))
         keep.append(pq)
@@ -907,7 +1014,9 @@ def secondary_points(a, dev, dev_index):
     for dist_name in ("latent:28", "gaussian"):
         base = gen_rows(a.rows, d, 20250620, dist_name, dev)
         queries = gen_rows(6 * nq, d, 20250621, dist_name, dev).view(6, nq, d)
-        ix, build_s = build_index(a, base, dev_index, name="sec")
+        # (not strict: the sweep below searches beyond the API's searchSize range of 25 .. 75; the build's own parameters
+        # are inside it either way)
+        ix, build_s = build_index(a, base, dev_index, name="sec", strict=False)
         hits = 0
         for b in range(2):
             ids, _, _, _ = ix.search_batch(queries[b], k, L)
@@ -924,6 +1033,20 @@ def secondary_points(a, dev, dev_index):
         dt = time.perf_counter() - t0
         out[dist_name] = {"qps": round(reps * nq / dt, 1), "recall_at_10": round(hits / (2 * nq * k), 4),
                           "build_s": round(build_s, 2), "passes_gate": hits / (2 * nq * k) >= 0.95}
+        if hits / (2 * nq * k) < 0.95:
+            # "report the searchSize needed for recall 0.95 separately" -- the device walk takes searchSize up
+            # to 512 (the API's maximum is 75, models/search.go:287-297)
+            truth0 = exact_topk(queries[0], base, k)[1] + 2
+            need, sweep = None, {}
+            for L2 in (128, 192, 256, 384, 512):
+                ids, _, _, _ = ix.search_batch(queries[0], k, L2)
+                r = float((ids.to(torch.int64).unsqueeze(2) == truth0.unsqueeze(1)).any(2).float().mean().item())
+                sweep[str(L2)] = round(r, 4)
+                if r >= 0.95:
+                    need = L2
+                    break
+            out[dist_name]["recall_by_search_size"] = sweep
+            out[dist_name]["search_size_for_recall_0.95"] = need if need is not None else "none <= 512"
         log("secondary %s: %.0f QPS, recall %.4f, build %.2fs" %
             (dist_name, out[dist_name]["qps"], out[dist_name]["recall_at_10"], build_s))
         ix.close()
@@ -978,6 +1101,12 @@ def cpu_baseline(a, ix, queries, k, L):
                   (len(sample), nb, nq, a.cpu_repeat),
         "single_thread_qps": round(n1 / t_one, 1),
         "cpu_seconds": round(t_all * threads, 1),
+        # parity at full size, as scalars (nested objects do not survive the driver's record): the GPU's answers to the
+        # same batches against the oracle's -- result ids, distance bits, distFn evaluation counts
+        "parity_queries": nb * nq,
+        "parity_id_mismatch_queries": mism_ids,
+        "parity_dist_bits_mismatch_queries": mism_d,
+        "parity_n_dist_mismatch_queries": mism_nd,
         "parity_full_size": {"queries": nb * nq, "id_mismatch_queries": mism_ids,
                              "dist_bits_mismatch_queries": mism_d, "n_dist_mismatch_queries": mism_nd},
     }

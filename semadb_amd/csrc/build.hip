@@ -1364,7 +1364,10 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     sa.hash_limit = ix->tune_hash_limit, sa.prefer_bitset = ix->tune_no_hash ? 1u : 0u;
     sa.wide_hash = ix->tune_wide_hash ? 1u : 0u, sa.hash16_probes = ix->tune_hash16_probes;
     sa.pq_narrow = ix->tune_pq_narrow;
-    sa.wide_mode = 1;  // rounds of searches with their visit logs: one wave per query
+    // the warm-up rounds (a round is at most 2 % of the graph: ~330 rounds of up to 512 points before the graph holds
+    // 25 600) are small calls like a REST request's and take the workgroup-per-query walk (0.32 instead of 0.54 ms per
+    // round); the big rounds one wave per query
+    sa.wide_mode = (rs <= 512 && ix->tune_wide_walk != 1) ? 0u : 1u;
     sa.totals = reinterpret_cast<unsigned long long *>(ix->d_bstats);  // [0] n_dist, [1] n_edges
     if (dcache) {
       SDB_W_HIP(hipMemsetAsync(dcache, 0xFF, ((size_t)rs << kDcacheBits) * sizeof(uint2), stream));  // no slot is ~0

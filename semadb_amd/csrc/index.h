@@ -102,6 +102,20 @@ struct sdb_index {
   // product quantizer attachment (product.go): codes per slot + tables
   const sdb_pq *pq = nullptr;
   uint8_t *d_codes = nullptr;
+  // Quantizers of up to kAdjCodesMaxM sub-vectors: every node's neighbours' code rows once more, BEHIND ITS ADJACENCY
+  // ROW -- [cap][kAdjStride][M] bytes, entry e = the code row of edge e -- the way the reference keeps a node's
+  // neighbours as cached point objects (node.go:37-54 LoadNeighbours: one fetch gives ids and codes).  A hop of the
+  // quantized walk then reads 256 B of ids and 64 M contiguous bytes of codes with ONE round trip, where the gather
+  // by slot was a second, dependent one and paid a 64-byte sector per 8-byte code (M = 8: 6.1 x the algorithmic
+  // bytes).  One block per adjacency copy (graph versions below): searches read the committed one; the writer's is
+  // brought up to date from the dirty-row flags when a transaction commits (k_adjcodes_rows) -- no write kernel
+  // maintains it, and the build's own searches gather by slot as before.
+  uint8_t *d_adjcodes = nullptr;  // the writer's copy (beside d_adj)
+  uint8_t *r_adjcodes = nullptr;  // the committed copy (beside r_adj)
+  static constexpr uint32_t kAdjCodesMaxM = 32;
+  bool has_adjcodes() const { return d_adjcodes != nullptr; }
+  int alloc_adjcodes();                       // after a quantizer has been attached (cap rows)
+  int rebuild_adjcodes(hipStream_t stream);   // every row of both copies from (adjacency, codes); maintenance calls
   // ---- graph versions (SURVEY 8b Threading; shard/cache/manager.go:159-181) --------------------------------
   // A search walks the last COMMITTED graph while a write transaction changes the graph: everything a walk reads
   // and a write changes in place exists twice -- adjacency rows, the slot -> id table, the start node's overflow
@@ -121,6 +135,7 @@ struct sdb_index {
     const uint64_t *ids = nullptr;
     const uint32_t *start_ext = nullptr;
     uint32_t start_ext_n = 0;
+    const uint8_t *adj_codes = nullptr;  // r_adjcodes, or NULL
   } view;
   // readers: shared from taking `view` until their kernels are enqueued and their event recorded; writers:
   // exclusive while they change the host-side id tables or publish a view

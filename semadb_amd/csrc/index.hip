@@ -483,8 +483,7 @@ static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, siz
 // 0.361 / 0.416 ms -- a hop's ~50 rows are 2 pairs per wave then, one short burst of loads each.  With the helpers
 // pulling the likely next hop's rows through L2 (PlainWideDist::pull_ahead): 0.336 / 0.419 ms; 0.371 at 128 queries
 // (0.408 without); with the helpers COMPUTING that hop's distances ahead (compute_ahead): 0.316 / 0.405 ms, 0.362 at 128.
-// Past 256 queries eight waves per query (0.58 ms at 512 against 0.66 for one wave per query, 0.80 for sixteen).  Plain store, unfiltered, query in registers, search log not wanted (the build's searches come in
-// rounds of thousands).
+// Past 256 queries eight waves per query (0.58 ms at 512 against 0.66 for one wave per query, 0.80 for sixteen).  Plain store, query in registers; the build's warm-up rounds (up to 512 points) included.
 constexpr uint32_t kWideMaxQueries = 256;
 #ifndef SDB_WIDE_AHEAD
 #define SDB_WIDE_AHEAD 256
@@ -495,8 +494,12 @@ constexpr uint32_t kWideAheadQueries = SDB_WIDE_AHEAD;
 #endif
 constexpr int kWideWaves = SDB_WIDE_WAVES;
 static bool wide_walk(const SearchArgs &a, uint32_t nq) {
-  if (a.wide_mode == 1 || a.vis_slots || a.dcache || a.pq_codes || !search_uses_hash(a, nq)) return false;
-  return a.wide_mode == 2 || nq <= 2 * kWideMaxQueries;
+  // (the build's warm-up rounds come here too -- rounds of up to 512 points while the graph is small, ~330 of a 1M
+  // build's ~580 rounds: their visit logs and distance tables are written by the walker like any other wave's)
+  if (a.wide_mode == 1 || a.pq_codes || !search_uses_hash(a, nq)) return false;
+  // 257 .. 512 queries (eight waves per query): faster than one wave per query for rows of up to 384 floats only
+  // (d = 384: 0.56 against 0.65 ms; 512: 0.98 against 0.78; 768: 1.20 against 1.05; profiles/r05_latency.json)
+  return a.wide_mode == 2 || nq <= (a.ng <= 3 ? 2 : 1) * kWideMaxQueries;
 }
 template <int NG, bool L2, int W>
 static int launch_wide_w(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
@@ -565,7 +568,9 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
       // selects the latter for comparison
       case 2: return a.pq_narrow == 2 ? launch_pqw<32, 16>(a, nq, stream) : launch_pqw<15, 33>(a, nq, stream);
       case 3: return launch_pqw<32, 32>(a, nq, stream);
-      case 4: return launch_pqw<15, 33, 8, 32>(a, nq, stream);  // M = 384: eight waves with M = 192's per-wave layout, the walker 32 + 16
+      // M = 384: eight waves with M = 192's per-wave layout, the walker 24 + 24 (129 tables in LDS: with the 32-bit-cell
+      // visited set 162 064 of the 162 816 bytes a workgroup may ask for)
+      case 4: return launch_pqw<15, 33, 8, 24>(a, nq, stream);
       default: break;
     }
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
@@ -633,6 +638,12 @@ int sdb_index::reserve(uint32_t rows) {
   SDB_TRY(fresh.get((void **)&nad, (size_t)ncap * kAdjStride * sizeof(float)));  // edge-distance cache of the write path (index.h)
   SDB_TRY(fresh.get((void **)&ndc, (size_t)ncap * sizeof(uint32_t)));
   if (pq) SDB_TRY(fresh.get((void **)&ncodes, (size_t)ncap * pq->M));  // the code rows of a quantized store grow with it
+  uint8_t *nacw = nullptr, *nacr = nullptr;  // ... and the neighbours' code rows behind both adjacency copies
+  const size_t ac_row = has_adjcodes() ? (size_t)kAdjStride * pq->M : 0;
+  if (ac_row) {
+    SDB_TRY(fresh.get((void **)&nacw, (size_t)ncap * ac_row));
+    SDB_TRY(fresh.get((void **)&nacr, (size_t)ncap * ac_row));
+  }
   // the old buffers are freed below: nothing may still be walking them (searches run on streams of their own)
   if (cap) SDB_HIP(hipDeviceSynchronize());
   SDB_HIP(hipMemset(nadj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
@@ -655,6 +666,10 @@ int sdb_index::reserve(uint32_t rows) {
     SDB_HIP(hipMemcpy(nad, d_adjdist, (size_t)n * kAdjStride * sizeof(float), hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(ndc, d_dcount, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     if (pq) SDB_HIP(hipMemcpy(ncodes, d_codes, (size_t)n * pq->M, hipMemcpyDeviceToDevice));
+    if (ac_row) {
+      SDB_HIP(hipMemcpy(nacw, d_adjcodes, (size_t)n * ac_row, hipMemcpyDeviceToDevice));
+      SDB_HIP(hipMemcpy(nacr, r_adjcodes, (size_t)n * ac_row, hipMemcpyDeviceToDevice));
+    }
   }
   SDB_HIP(hipDeviceSynchronize());
   {
@@ -663,12 +678,13 @@ int sdb_index::reserve(uint32_t rows) {
                     (void *)r_ids, (void *)d_dirty, (void *)d_adjdist, (void *)d_dcount})
       if (p) (void)hipFree(p);
     if (pq && d_codes) (void)hipFree(d_codes);
+    if (ac_row) (void)hipFree(d_adjcodes), (void)hipFree(r_adjcodes), d_adjcodes = nacw, r_adjcodes = nacr;
     d_slab = nslab, d_adj = nadj, r_adj = nradj, d_deg = ndeg, d_clean = nclean, d_ids = nids, r_ids = nrids;
     d_dirty = ndirty, d_adjdist = nad, d_dcount = ndc;
     if (pq) d_codes = ncodes;
     fresh.keep = true;
     cap = ncap;
-    view.adj = r_adj, view.ids = r_ids;
+    view.adj = r_adj, view.ids = r_ids, view.adj_codes = r_adjcodes;
     view_gen++;
   }
   return SDB_OK;
@@ -678,16 +694,46 @@ int sdb_index::reserve(uint32_t rows) {
 // graph versions
 // ------------------------------------------------------------------------------------------
 namespace sdb {
-// rows the transaction wrote (dirty flags) and rows it appended: committed copy -> the writer's stale copy
+// rows the transaction wrote (dirty flags) and rows it appended: committed copy -> the writer's stale copy; with the
+// neighbours' code rows behind them (index.h d_adjcodes; code_bytes = 64 M per row, 0: none)
 __global__ void k_sync_rows(const uint32_t *__restrict__ src_adj, uint32_t *__restrict__ dst_adj,
                             const uint64_t *__restrict__ src_ids, uint64_t *__restrict__ dst_ids,
-                            uint8_t *__restrict__ dirty, uint32_t n, uint32_t first_new) {
+                            uint8_t *__restrict__ dirty, uint32_t n, uint32_t first_new,
+                            const uint8_t *__restrict__ src_codes, uint8_t *__restrict__ dst_codes, uint32_t code_bytes) {
   const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
   if (row < first_new && !dirty[row]) return;
   dst_adj[(size_t)row * kAdjStride + lane] = src_adj[(size_t)row * kAdjStride + lane];
+  if (code_bytes) {  // a multiple of 64: whole words when M is a multiple of four, bytes otherwise
+    if ((code_bytes & 255u) == 0) {
+      const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src_codes + (size_t)row * code_bytes);
+      uint32_t *d4 = reinterpret_cast<uint32_t *>(dst_codes + (size_t)row * code_bytes);
+      for (uint32_t i = lane; i < code_bytes / 4; i += 64) d4[i] = s4[i];
+    } else {
+      for (uint32_t i = lane; i < code_bytes; i += 64) dst_codes[(size_t)row * code_bytes + i] = src_codes[(size_t)row * code_bytes + i];
+    }
+  }
   if (lane == 0) dst_ids[row] = src_ids[row], dirty[row] = 0;
+}
+// The neighbours' code rows behind the adjacency rows (index.h d_adjcodes): out[row][e] = codes[adj[row][e]], zeros behind
+// the edges.  dirty != NULL: only the rows a transaction wrote or appended (first_new: rows at its start).
+__global__ __launch_bounds__(256) void k_adjcodes_rows(const uint32_t *__restrict__ adj, const uint8_t *__restrict__ codes,
+                                                       uint8_t *__restrict__ out, const uint8_t *__restrict__ dirty, uint32_t n,
+                                                       uint32_t first_new, uint32_t M) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  if (dirty && row < first_new && !dirty[row]) return;
+  const uint32_t nb = adj[(size_t)row * kAdjStride + lane];
+  const size_t at = ((size_t)row * kAdjStride + lane) * M;
+  if ((M & 7u) == 0) {
+    const uint2 *src = reinterpret_cast<const uint2 *>(codes + (size_t)(nb == kNoSlot ? 0u : nb) * M);
+    uint2 *dst = reinterpret_cast<uint2 *>(out + at);
+    for (uint32_t i = 0; i < M / 8; i++) dst[i] = nb == kNoSlot ? make_uint2(0u, 0u) : src[i];
+  } else {
+    for (uint32_t i = 0; i < M; i++) out[at + i] = nb == kNoSlot ? (uint8_t)0 : codes[(size_t)nb * M + i];
+  }
 }
 // sdb_index_abort_write: the rows the transaction wrote take the committed copy back, the rows it appended become
 // empty again.  What only the write path keeps per row -- degree, clean prefix, cached edge distances -- is rebuilt
@@ -766,9 +812,47 @@ int64_t sdb_index::slot_of_committed(uint64_t id, uint32_t view_n) const {
   return (s >= 0 && (uint32_t)s < view_n) ? s : -1;  // rows past the committed count belong to the transaction
 }
 
+int sdb_index::alloc_adjcodes() {
+  if (d_adjcodes) (void)hipFree(d_adjcodes);
+  if (r_adjcodes) (void)hipFree(r_adjcodes);
+  d_adjcodes = r_adjcodes = nullptr;
+  view.adj_codes = nullptr;
+  if (!pq || pq->M > kAdjCodesMaxM) return SDB_OK;
+  const size_t bytes = (size_t)cap * kAdjStride * pq->M;
+  // a cache of what the code rows hold: without room for it the walk gathers by slot, as it does for larger M
+  if (hipMalloc(&d_adjcodes, bytes) != hipSuccess || hipMalloc(&r_adjcodes, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    if (d_adjcodes) (void)hipFree(d_adjcodes);
+    d_adjcodes = r_adjcodes = nullptr;
+  }
+  return SDB_OK;
+}
+
+int sdb_index::rebuild_adjcodes(hipStream_t stream) {
+  if (!has_adjcodes()) return SDB_OK;
+  const uint32_t M = pq->M;
+  if (n) hipLaunchKernelGGL(sdb::k_adjcodes_rows, dim3((n + 3) / 4), dim3(256), 0, stream, d_adj, d_codes, d_adjcodes, nullptr, n, 0u, M);
+  if (view.n)
+    hipLaunchKernelGGL(sdb::k_adjcodes_rows, dim3((view.n + 3) / 4), dim3(256), 0, stream, r_adj, d_codes, r_adjcodes, nullptr, view.n,
+                       0u, M);
+  SDB_HIP(hipGetLastError());
+  SDB_HIP(hipStreamSynchronize(stream));
+  view.adj_codes = r_adjcodes;
+  return SDB_OK;
+}
+
 int sdb_index::commit(hipStream_t stream) {
   if (!in_tx) return SDB_OK;
   const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
+  const uint32_t ac_bytes = has_adjcodes() ? kAdjStride * pq->M : 0;
+  if (ac_bytes && n) {
+    // the writer's copy of the neighbours' code rows catches up with what the transaction did to the adjacency rows --
+    // before the copies change hands, while the searches still walk the other one
+    hipLaunchKernelGGL(sdb::k_adjcodes_rows, dim3((n + 3) / 4), dim3(256), 0, stream, d_adj, d_codes, d_adjcodes, d_dirty, n,
+                       tx_n0 < n ? tx_n0 : n, pq->M);
+    SDB_HIP(hipGetLastError());
+    SDB_HIP(hipStreamSynchronize(stream));
+  }
   {
     std::unique_lock<sdb::ViewMutex> wl(view_mu);
     // every search that took the old view has enqueued its kernels and recorded its event by now (it held the
@@ -779,11 +863,13 @@ int sdb_index::commit(hipStream_t stream) {
         if (w->launched_valid) SDB_HIP(hipStreamWaitEvent(stream, w->launched, 0));
     }
     std::swap(d_adj, r_adj);
+    std::swap(d_adjcodes, r_adjcodes);
     std::swap(d_ids, r_ids);
     std::swap(d_start_ext, r_start_ext);
     std::swap(start_ext_cap, r_start_ext_cap);
     view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
     view.start_ext_n = (uint32_t)h_start_ext.size();
+    view.adj_codes = r_adjcodes;
     view_gen++;
     tx_deleted.clear();
     in_tx = false, tx_explicit = false, tx_dirty = false;
@@ -791,7 +877,7 @@ int sdb_index::commit(hipStream_t stream) {
   // the writer's copy is now the one the last version's searches walked: bring it up to date
   if (n) {
     hipLaunchKernelGGL(sdb::k_sync_rows, dim3((n + 3) / 4), dim3(256), 0, stream, r_adj, d_adj, r_ids, d_ids, d_dirty, n,
-                       tx_n0 < n ? tx_n0 : n);
+                       tx_n0 < n ? tx_n0 : n, r_adjcodes, d_adjcodes, ac_bytes);
     SDB_HIP(hipGetLastError());
   }
   if (need) {
@@ -855,6 +941,11 @@ int sdb_index::publish_full() {
     SDB_HIP(hipMemcpy(r_adj, d_adj, (size_t)n * kAdjStride * 4, hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemcpy(r_ids, d_ids, (size_t)n * 8, hipMemcpyDeviceToDevice));
     SDB_HIP(hipMemset(d_dirty, 0, n));
+    if (has_adjcodes()) {
+      hipLaunchKernelGGL(sdb::k_adjcodes_rows, dim3((n + 3) / 4), dim3(256), 0, nullptr, d_adj, d_codes, d_adjcodes, nullptr, n, 0u, pq->M);
+      SDB_HIP(hipGetLastError());
+      SDB_HIP(hipMemcpy(r_adjcodes, d_adjcodes, (size_t)n * kAdjStride * pq->M, hipMemcpyDeviceToDevice));
+    }
   }
   const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
   if (need) {
@@ -868,6 +959,7 @@ int sdb_index::publish_full() {
   }
   view.n = n, view.adj = r_adj, view.ids = r_ids, view.start_ext = r_start_ext;
   view.start_ext_n = (uint32_t)h_start_ext.size();
+  view.adj_codes = r_adjcodes;
   view_gen++;
   tx_deleted.clear();
   in_tx = false, tx_explicit = false, tx_dirty = false;
@@ -1021,6 +1113,8 @@ int sdb_index_destroy(sdb_index *ix) try {
   if (ix->d_dirty) (void)hipFree(ix->d_dirty);
   if (ix->d_start_ext) (void)hipFree(ix->d_start_ext);
   if (ix->d_codes) (void)hipFree(ix->d_codes);
+  if (ix->d_adjcodes) (void)hipFree(ix->d_adjcodes);
+  if (ix->r_adjcodes) (void)hipFree(ix->r_adjcodes);
   if (ix->d_bstats) (void)hipFree(ix->d_bstats);
   for (auto e : ix->ev0)
     if (e) (void)hipEventDestroy(e);
@@ -1309,6 +1403,7 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
 
   SearchArgs a{};
   a.slab = ix->d_slab, a.adj = vw.adj, a.ids = vw.ids;
+  a.adj_codes = vw.adj_codes, a.adj_rows = vw.n;
   a.bitsets = ws->bitsets, a.words_per_query = words;
   if (bm) {
     // bitmaps: two passes on the device (count, expand) turn them into the same ascending slot lists; only for a table
@@ -1810,7 +1905,9 @@ int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) try {
   if (!ix || !bytes) return fail(SDB_ERR_INVALID, "NULL argument");
   // vecStore.SizeInMemory + nodeStore.SizeInMemory (vamana.go:83-85), as held in HBM
   // slab row + adjacency row + its distance cache + degree / clean / cached counters + id (+ code row)
-  *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + 2 * kAdjStride * 4 + 3 * 4 + 8 + (ix->pq ? ix->pq->M : 0));
+  // (+ the second adjacency / id copy of the graph versions, + the neighbours' code rows behind both adjacency copies)
+  *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + 3 * kAdjStride * 4 + 3 * 4 + 2 * 8 + (ix->pq ? ix->pq->M : 0) +
+                               (ix->has_adjcodes() ? 2 * kAdjStride * ix->pq->M : 0));
   return SDB_OK;
 }
 SDB_API_CATCH("sdb_index_size_in_memory")
@@ -1884,6 +1981,11 @@ int sdb_index_compact(sdb_index *ix) try {
   SDB_TRY(nb.get((void **)&nids, (size_t)cap * 8));
   SDB_TRY(nb.get((void **)&nrids, (size_t)cap * 8));
   if (M) SDB_TRY(nb.get((void **)&ncodes, (size_t)cap * M));
+  uint8_t *nacw = nullptr, *nacr = nullptr;  // the neighbours' code rows follow the renumbered adjacency
+  if (ix->has_adjcodes()) {
+    SDB_TRY(nb.get((void **)&nacw, (size_t)cap * kAdjStride * M));
+    SDB_TRY(nb.get((void **)&nacr, (size_t)cap * kAdjStride * M));
+  }
   SDB_TRY(tmp.get((void **)&d_live, (size_t)nn * 4 + 4));
   SDB_TRY(tmp.get((void **)&d_map, (size_t)n * 4));
   SDB_TRY(tmp.get((void **)&d_lost, 4));
@@ -1900,6 +2002,11 @@ int sdb_index_compact(sdb_index *ix) try {
   SDB_HIP(hipGetLastError());
   SDB_HIP(hipMemcpy(nradj, nadj, (size_t)cap * kAdjStride * 4, hipMemcpyDeviceToDevice));
   SDB_HIP(hipMemcpy(nrids, nids, (size_t)nn * 8, hipMemcpyDeviceToDevice));
+  if (nacw && nn) {
+    hipLaunchKernelGGL(k_adjcodes_rows, dim3((nn + 3) / 4), dim3(256), 0, nullptr, nadj, ncodes, nacw, nullptr, nn, 0u, M);
+    SDB_HIP(hipGetLastError());
+    SDB_HIP(hipMemcpy(nacr, nacw, (size_t)nn * kAdjStride * M, hipMemcpyDeviceToDevice));
+  }
   uint32_t lost = 0;
   SDB_HIP(hipMemcpy(&lost, d_lost, 4, hipMemcpyDeviceToHost));
   if (lost) return fail(SDB_ERR_STATE, "%u edges point at deleted rows: the graph is inconsistent, nothing was changed", lost);
@@ -1921,6 +2028,7 @@ int sdb_index_compact(sdb_index *ix) try {
                   (void *)ix->d_clean, (void *)ix->d_dcount, (void *)ix->d_ids, (void *)ix->r_ids})
     (void)hipFree(x);
   if (M) (void)hipFree(ix->d_codes);
+  if (nacw) (void)hipFree(ix->d_adjcodes), (void)hipFree(ix->r_adjcodes), ix->d_adjcodes = nacw, ix->r_adjcodes = nacr;
   nb.keep = true;
   ix->d_slab = nslab, ix->d_adj = nadj, ix->r_adj = nradj, ix->d_adjdist = nad, ix->d_deg = ndeg, ix->d_clean = nclean;
   ix->d_dcount = ndc, ix->d_ids = nids, ix->r_ids = nrids;
@@ -1945,6 +2053,7 @@ int sdb_index_compact(sdb_index *ix) try {
   }
   ix->view.n = nn, ix->view.adj = ix->r_adj, ix->view.ids = ix->r_ids, ix->view.start_ext = ix->r_start_ext;
   ix->view.start_ext_n = (uint32_t)ix->h_start_ext.size();
+  ix->view.adj_codes = ix->r_adjcodes;
   ix->view_gen++;
   (void)hipDeviceSynchronize();
   return SDB_OK;
@@ -2082,6 +2191,9 @@ extern "C" int sdb_index_attach_pq(sdb_index *ix, const sdb_pq *pq, void *stream
   if (ix->d_codes) (void)hipFree(ix->d_codes);
   ix->d_codes = ncodes;
   ix->pq = pq;
+  // the neighbours' code rows behind the adjacency rows, for the new codes (M <= 32; index.h d_adjcodes)
+  SDB_TRY(ix->alloc_adjcodes());
+  SDB_TRY(ix->rebuild_adjcodes(stream));
   return forget_prune_state(ix);
 }
 SDB_API_CATCH("sdb_index_attach_pq")
@@ -2109,6 +2221,7 @@ extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *id
     SDB_HIP(hipMemcpy(ix->d_codes + (size_t)s0 * M, codes + i * M, (j - i) * M, hipMemcpyHostToDevice));
     i = j;
   }
+  SDB_TRY(ix->rebuild_adjcodes(nullptr));  // every node that has one of these as a neighbour carries a copy of its code row
   return forget_prune_state(ix);
 }
 SDB_API_CATCH("sdb_index_set_codes")

@@ -53,6 +53,10 @@ struct SearchArgs {
   const float *pq_lut;
   const uint8_t *pq_codes;
   uint32_t pq_M, pq_K;
+  // != NULL: the code rows of every node's neighbours behind its adjacency row, [rows][64][M] (index.h d_adjcodes), for
+  // the copy of the graph `adj` points at
+  const uint8_t *adj_codes;
+  uint32_t adj_rows;  // rows of `adj` (what tells an adjacency row from a chunk of the start node's overflow list)
   uint32_t pq_lut_in_lds;  // != 0: the kernel copies its LUT into LDS first
   uint32_t pq_narrow;      // 1: never the multi-wave walk (k_greedy_search_pqw); 2: its one-query-per-CU variant for M = 192
 
@@ -702,28 +706,86 @@ struct PQDist {
       lut = g;
     }
   }
-  __device__ __forceinline__ float sum(const SearchArgs &a, uint32_t slot) const {
-    const uint8_t *__restrict__ c = a.pq_codes + (size_t)slot * a.pq_M;
+  // dist = 0; dist += lut[i][code_i] for i = 0 .. M-1, plain fp32 adds in index order (product.go:271-275), over the
+  // code row at `c` (M bytes; rows are M apart from an aligned base, so whole words when M is a multiple of four)
+  __device__ __forceinline__ float sum_row(const SearchArgs &a, const uint8_t *__restrict__ c) const {
     float dist = 0.0f;
-    for (uint32_t i = 0; i < a.pq_M; i++) dist += lut[i * a.pq_K + c[i]];
+    const uint32_t K = a.pq_K;
+    if ((a.pq_M & 3u) == 0) {
+      const uint32_t *__restrict__ w = reinterpret_cast<const uint32_t *>(c);
+      for (uint32_t i = 0; i < a.pq_M; i += 4) {
+        const uint32_t v = w[i >> 2];
+        dist += lut[(i + 0) * K + (v & 0xFF)];
+        dist += lut[(i + 1) * K + ((v >> 8) & 0xFF)];
+        dist += lut[(i + 2) * K + ((v >> 16) & 0xFF)];
+        dist += lut[(i + 3) * K + (v >> 24)];
+      }
+    } else {
+      for (uint32_t i = 0; i < a.pq_M; i++) dist += lut[i * K + c[i]];
+    }
     return dist;
+  }
+  __device__ __forceinline__ float sum(const SearchArgs &a, uint32_t slot) const {
+    return sum_row(a, a.pq_codes + (size_t)slot * a.pq_M);
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) { return sum(a, s); }
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
-  __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *, int) {}
   __device__ __forceinline__ void skip(int) {}
+  // The chunk's code rows.  With the neighbours' codes stored behind the adjacency row (SearchArgs::adj_codes) lane j's
+  // row is at a fixed place next to edge j: it is asked for TOGETHER with the row of ids -- one round trip per hop, 64 M
+  // contiguous bytes -- instead of after it, by slot (64 scattered M-byte reads, a 64-byte sector each).  The start
+  // node's overflow chunks and the filter's seeds are no adjacency rows: those gather by slot.
+  const uint8_t *row_codes = nullptr;  // this lane's code row of the chunk being expanded, or NULL: by slot
+  __device__ __forceinline__ void begin_row(const SearchArgs &a, const uint32_t *rowp, int lane) {
+    row_codes = nullptr;
+    pre_ready = false;
+    if (a.adj_codes && rowp >= a.adj && rowp < a.adj + (size_t)a.adj_rows * kAdjStride) {  // not a chunk of the overflow list
+      const size_t e0 = (size_t)(rowp - a.adj);  // = row * 64
+      row_codes = a.adj_codes + (e0 + (size_t)lane) * a.pq_M;
+      if (a.pq_M == 8) {
+        pre = *reinterpret_cast<const uint2 *>(row_codes), pre_ready = true;
+      } else if (a.pq_M == 16) {
+        prew[0] = *reinterpret_cast<const uint4 *>(row_codes), pre_ready = true;
+      } else if (a.pq_M == 32) {
+        prew[0] = reinterpret_cast<const uint4 *>(row_codes)[0], prew[1] = reinterpret_cast<const uint4 *>(row_codes)[1];
+        pre_ready = true;
+      }
+    }
+  }
+  uint4 prew[2];  // M = 16 / 32: the lane's code row, asked for with the row of ids
+  __device__ __forceinline__ float add4(float dist, uint32_t v, uint32_t i, uint32_t K) const {
+    dist += lut[(i + 0) * K + (v & 0xFF)];
+    dist += lut[(i + 1) * K + ((v >> 8) & 0xFF)];
+    dist += lut[(i + 2) * K + ((v >> 16) & 0xFF)];
+    dist += lut[(i + 3) * K + (v >> 24)];
+    return dist;
+  }
+  __device__ __forceinline__ float sum16(float dist, const uint4 &v, uint32_t i, uint32_t K) const {
+    dist = add4(dist, v.x, i, K), dist = add4(dist, v.y, i + 4, K);
+    dist = add4(dist, v.z, i + 8, K), dist = add4(dist, v.w, i + 12, K);
+    return dist;
+  }
   // M == 8 (the documented configuration): the 8 code bytes of every neighbour are fetched as one 8-byte
-  // load BEFORE the visited-set test, so the code gather and the test-and-set round trip overlap; codes of
+  // load BEFORE the visited-set test, so the code fetch and the test-and-set round trip overlap; codes of
   // neighbours that turn out to be already visited are simply not used (8 bytes each).
   uint2 pre;
+  bool pre_ready = false;
   __device__ __forceinline__ void prefetch(const SearchArgs &a, uint32_t nb, bool valid) {
+    if (pre_ready) return;  // came with the row
     pre = make_uint2(0u, 0u);
-    if (a.pq_M == 8 && valid) pre = *reinterpret_cast<const uint2 *>(a.pq_codes + (size_t)nb * 8);
+    if (a.pq_M == 8 && valid && !row_codes) pre = *reinterpret_cast<const uint2 *>(a.pq_codes + (size_t)nb * 8);
   }
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
+    const uint8_t *rc = row_codes;
+    const bool ready = pre_ready;
+    row_codes = nullptr, pre_ready = false;  // one chunk's worth (the seeds of a filtered search call hop without begin_row)
     if (!((pend >> lane) & 1ull)) return 0.0f;
-    if (a.pq_M != 8) return sum(a, nb);
+    if (a.pq_M != 8) {
+      if (ready && a.pq_M == 16) return sum16(0.0f, prew[0], 0, a.pq_K);
+      if (ready && a.pq_M == 32) return sum16(sum16(0.0f, prew[0], 0, a.pq_K), prew[1], 16, a.pq_K);
+      return rc ? sum_row(a, rc) : sum(a, nb);
+    }
     float dist = 0.0f;  // same sequential adds in index order (product.go:271-275)
     const uint32_t K = a.pq_K;
     dist += lut[0 * K + (pre.x & 0xFF)];
@@ -1770,7 +1832,7 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
 // NLW: tables the WALKER keeps in LDS (the rest of its NL + RT in registers).  The walker carries search_body's state
 // (candidate array, visited set, ~100 registers) on top of what every wave holds; at eight waves per query (M = 384,
 // 256 registers per wave) that state plus 33 register tables plus the 48 looked-up values did not fit -- 43 registers
-// spilled.  There the walker takes 32 of its 48 tables from LDS and 16 from registers; the helpers keep 15 + 33.
+// spilled.  There the walker takes 24 of its 48 tables from LDS and 24 from registers; the helpers keep 15 + 33.
 template <int NL, int RT, uint32_t HCAP, int W = 4, int NLW = NL>
 __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_search_pqw(const SearchArgs a) {
   const int lane = threadIdx.x & 63;

@@ -9,6 +9,7 @@ the stored row or code; the walk itself on a sample of queries for C2).
 Sizes: SDB_TEST_C2_ROWS / SDB_TEST_C4_ROWS override the row counts (defaults are the BASELINE sizes)."""
 import os
 import sys
+import threading
 import types
 
 import numpy as np
@@ -42,13 +43,46 @@ def _build(n, d):
     return ix, base
 
 
+class _OracleBuild(threading.Thread):
+    def __init__(self, base_rows, d, sv):
+        super().__init__(daemon=True)
+        self.base_rows, self.d, self.sv, self.result, self.error = base_rows, d, sv, None, None
+
+    def run(self):
+        try:
+            from oracle import oracle
+            o = oracle.Index(self.d, "cosine", R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
+            o.set_start(np.asarray(self.sv, dtype=np.float32))
+            rows = self.base_rows.shape[0]
+            rc = o.insert_rounds(np.arange(2, rows + 2, dtype=np.uint64), self.base_rows)
+            if rc != 0:
+                raise RuntimeError("insert_rounds rc=%d" % rc)
+            o_ids, _, o_off, o_e = o.export(with_vectors=False)
+            self.result = (o_ids, o_off, o_e)
+        except BaseException as e:  # reported by the test that joins
+            self.error = e
+
+
+def _start_oracle_build(c2):
+    rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 1_000_000)), c2.n)
+    t = _OracleBuild(c2.base[:rows].cpu().numpy(), c2.d, _bench().start_vector(c2.d))
+    t.start()
+    return t
+
+
 @pytest.fixture(scope="module")
 def c2():
     import torch
     bench = _bench()
     ix, base = _build(C2_ROWS, 384)
     queries = bench.gen_rows(2048, 384, 20250621, "latent:24", "cuda:0")
-    yield types.SimpleNamespace(ix=ix, base=base, queries=queries, n=C2_ROWS, d=384)
+    ns = types.SimpleNamespace(ix=ix, base=base, queries=queries, n=C2_ROWS, d=384, oracle_build=None)
+    # The oracle's restatement of the whole build (test_c3_build_equals_oracle_schedule, the last test of this module)
+    # is ~2.5 minutes of host-core time and touches no GPU: it starts NOW, on a thread of its own (the C library
+    # releases the GIL), and runs under the module's other tests, which mostly wait for the device.
+    ns.oracle_build = _start_oracle_build(ns)
+    yield ns
+    ns.oracle_build.join()
     ix.close()
     del base
     torch.cuda.empty_cache()
@@ -85,34 +119,6 @@ def test_c3_build_is_deterministic(c2):
     _, _, off2, edges2 = ix2.export(with_vectors=False)
     ix2.close()
     assert np.array_equal(off, off2) and np.array_equal(edges, edges2)
-
-
-def test_c3_build_equals_oracle_schedule(c2, oracle):
-    """The batched build of the BASELINE data against the oracle's restatement of the round schedule, edge for
-    edge.  The oracle runs a round's searches and prunes over the host cores: all 1 000 000 rows of C3 by default
-    (about 2.5 minutes on the GPU box's 16 host cores -- the longest test of the suite); SDB_TEST_C3_ORACLE_ROWS
-    shortens it for a quick run."""
-    from semadb_amd import vamana
-    rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 1_000_000)), c2.n)
-    bench = _bench()
-    base = c2.base[:rows].cpu().numpy()
-    sv = bench.start_vector(c2.d)
-    o = oracle.Index(c2.d, "cosine", R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
-    o.set_start(np.asarray(sv, dtype=np.float32))
-    assert o.insert_rounds(np.arange(2, rows + 2, dtype=np.uint64), base) == 0
-    o_ids, _, o_off, o_e = o.export(with_vectors=False)
-    if rows == c2.n:
-        ix = c2.ix
-    else:
-        ix = vamana.NewIndexVamana("c3o", vamana.IndexVectorVamanaParameters(c2.d, "cosine", L, R, 1.2), capacity=rows + 1)
-        ix.set_start(sv)
-        ix.insert_batch(None, c2.base[:rows])
-    g_ids, _, g_off, g_e = ix.export(with_vectors=False)
-    if ix is not c2.ix:
-        ix.close()
-    assert np.array_equal(g_ids, o_ids)
-    assert np.array_equal(g_off, o_off), "degree sequence differs"
-    assert np.array_equal(g_e, o_e), "edge lists differ"
 
 
 def _search(ix, q, k=K, search_size=L):
@@ -429,3 +435,28 @@ def test_c5_one_rank_at_size():
     assert np.array_equal(bits(k1f.cpu().numpy()), bits(f_d[:64].cpu().numpy()))
     ix.close()
     torch.cuda.empty_cache()
+
+
+def test_c3_build_equals_oracle_schedule(c2, oracle):
+    """The batched build of the BASELINE data against the oracle's restatement of the round schedule, edge for
+    edge: all 1 000 000 rows of C3 by default (SDB_TEST_C3_ORACLE_ROWS shortens it for a quick run).  The oracle runs a
+    round's searches and prunes over the host cores, about 2.5 minutes on the GPU box's 16 -- started by the module's
+    fixture on a thread of its own and joined here, at the end of the module, so that it runs under the other tests."""
+    from semadb_amd import vamana
+    c2.oracle_build.join()
+    if c2.oracle_build.error is not None:
+        raise c2.oracle_build.error
+    o_ids, o_off, o_e = c2.oracle_build.result
+    rows = len(o_ids) - 1
+    if rows == c2.n:
+        ix = c2.ix
+    else:
+        ix = vamana.NewIndexVamana("c3o", vamana.IndexVectorVamanaParameters(c2.d, "cosine", L, R, 1.2), capacity=rows + 1)
+        ix.set_start(_bench().start_vector(c2.d))
+        ix.insert_batch(None, c2.base[:rows])
+    g_ids, _, g_off, g_e = ix.export(with_vectors=False)
+    if ix is not c2.ix:
+        ix.close()
+    assert np.array_equal(g_ids, o_ids)
+    assert np.array_equal(g_off, o_off), "degree sequence differs"
+    assert np.array_equal(g_e, o_e), "edge lists differ"

@@ -416,3 +416,78 @@ def test_multi_wave_quantized_walk_parity(oracle, metric, d, M, K):
         assert np.array_equal(got[3].n_dist, tr.n_dist) and np.array_equal(got[3].visit_ids, tr.visit_ids), key
     ix.close()
     gpq.close()
+
+
+@pytest.mark.parametrize("d,M,K", [(96, 8, 64), (96, 16, 32), (64, 32, 16), (96, 12, 32), (90, 6, 16), (96, 3, 32)])
+def test_neighbour_code_rows_follow_the_graph(oracle, d, M, K):
+    """Quantizers of up to 32 sub-vectors: a node's neighbours' code rows are stored once more behind its adjacency row
+    (node.go:37-54: the reference keeps a node's neighbours as cached point objects), so that a hop is one fetch.  That
+    copy has to follow everything that changes adjacency rows or codes -- attach, insert, delete, an aborted and a
+    committed transaction, set_codes, compact, growth of the tables -- and the walk over it is the oracle's walk: ids,
+    distance bits, visit order, counters; with and without filters, over the start node's overflow list too."""
+    from semadb_amd import vamana, vectorstore as vs
+    metric = "euclidean"
+    rng = np.random.default_rng(1000 * d + M)
+    n0, n1 = 500, 300
+    base = unit_rows(rng, n0 + n1, d)
+    o = build_oracle_index(oracle, base[:n0], metric, R=16, L=30)
+    ids, vecs, off, edges = o.export()
+    train = vecs[1:401].copy()
+    first = rng.integers(0, 400, M)
+    opq = oracle.PQ(d, metric, M, K)
+    opq.fit(train.copy(), first, alias=True)
+    assert o.attach_pq(opq, np.stack([opq.encode(v) for v in vecs])) == 0
+    # capacity just above the first load: the inserts below make the tables grow (reserve copies the code rows too)
+    ix = vamana.NewIndexVamana("pq", vamana.IndexVectorVamanaParameters(d, metric, 30, 16, 1.2), strict=False, capacity=n0 + 8)
+    ix.load(ids, vecs, off, edges)
+    gpq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    gpq.Fit(train.copy(), first, alias=True)
+    vs.attach(ix, gpq)
+    q = unit_rows(rng, 24, d)
+
+    def same_walks(tag, filters=None):
+        g_ids, g_d, g_c, tr = ix.search_batch(q, 10, 30, filters=filters, trace=True, visit_cap=512)
+        for k in range(len(q)):
+            o_ids, o_d, o_vis, o_tr = o.search(q[k], 10, 30, filter_ids=sorted(filters[k]) if filters else None)
+            assert int(g_c[k]) == len(o_ids), tag
+            assert np.array_equal(g_ids[k, :len(o_ids)], o_ids), tag
+            assert np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d)), tag
+            assert int(tr.n_hop[k]) == o_tr.n_hop and int(tr.n_dist[k]) == o_tr.n_dist, tag
+            assert np.array_equal(tr.visit_ids[k, :o_tr.n_hop], o_vis), tag
+
+    same_walks("attached")
+    # inserts (sequential rounds = the oracle's loop), the tables grow
+    new_ids = np.arange(n0 + 2, n0 + 2 + n1, dtype=np.uint64)
+    for i in range(n1):
+        assert o.insert(int(new_ids[i]), base[n0 + i]) == 0
+    ix.insert_batch(new_ids, base[n0:], round_size=1)
+    assert_same_graph(ix, o)
+    same_walks("after inserts")
+    live = [int(v) for v in o.export()[0][1:]]
+    same_walks("filtered", [set(int(v) for v in rng.choice(live, size=60, replace=False)) for _ in range(len(q))])
+    # a transaction that is aborted leaves the committed rows and their code rows alone
+    ix.begin_write()
+    ix.delete_batch(new_ids[:40])
+    same_walks("inside an open transaction")  # searches walk the committed copy
+    ix.abort_write()
+    same_walks("after abort")
+    # deletes (stragglers go onto the start node: rows change far from the deleted ones)
+    dead = rng.choice(np.arange(2, n0 + 2 + n1, dtype=np.uint64), 120, replace=False)
+    assert o.delete(dead) == 0
+    ix.delete_batch(dead)
+    assert_same_graph(ix, o)
+    same_walks("after deletes")
+    # set_codes: the code rows of some points change (k-means labels / codes from the bucket); every node that has one of
+    # them as a neighbour carries a copy
+    some = np.array(sorted(rng.choice([v for v in live if v not in set(int(x) for x in dead)], size=50, replace=False)), dtype=np.uint64)
+    newc = rng.integers(0, K, size=(len(some), M)).astype(np.uint8)
+    vs.set_codes(ix, some, newc)
+    live_ids = o.export()[0]
+    assert o.attach_pq(opq, vs.get_codes(ix, live_ids)) == 0  # the oracle takes the whole table (storage order of the live rows)
+    assert np.array_equal(vs.get_codes(ix, some), newc)
+    same_walks("after set_codes")
+    ix.compact()
+    same_walks("after compact")
+    # and a second quantizer with another layout replaces the first
+    ix.close()
+    gpq.close()
