@@ -91,7 +91,10 @@ struct SearchArgs {
 template <int NG, bool DEEP>
 struct ChunkPairs {
   static constexpr int base = NG <= 3 ? 8 : NG <= 4 ? 6 : NG <= 6 ? 4 : NG <= 8 ? 3 : NG <= 12 ? 2 : 1;
-  static constexpr int value = DEEP ? 2 * base : base;  // DEEP: 32 / 24 / 16 / 12 / 8 / 4 rows in flight
+#ifndef SDB_DEEP3_PAIRS
+#define SDB_DEEP3_PAIRS 16  // measurement builds: pairs per round of the d = 384 batch walk (tools/kernel_ab.py)
+#endif
+  static constexpr int value = DEEP ? (NG == 3 ? SDB_DEEP3_PAIRS : 2 * base) : base;  // DEEP: 32 / 24 / 16 / 12 / 8 / 4 rows in flight
 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
@@ -207,7 +210,10 @@ template <int NG, bool L2, bool DEEP = false, int UPAIRS = 0>  // UPAIRS != 0: t
 struct PlainDist {
   static constexpr bool kHasStamps = true;
   static constexpr bool kPointDistances = true;  // dist(query, row) is distFn between two stored vectors
-  static constexpr bool kSpeculate = false;      // search_body: nothing is worked ahead on between the hops
+  // search_body: nothing is worked ahead on between the hops.  (Round 5 tried the walker's naming of the next hop's row
+  // here too -- its adjacency row asked for under AddWithLimit, a round trip less per hop in the batch's tail: 0.983
+  // against 0.975 ms per batch, the naming's ~300 instructions per hop cost a lone wave more than the hidden latency.)
+  static constexpr bool kSpeculate = false;
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = UPAIRS ? UPAIRS : (NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4);
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
@@ -692,6 +698,8 @@ struct PlainWideDist : PlainDist<NG, L2, true, WidePairs<NG, W, L2>::value> {
 // Fitted product quantizer: dist = sum_i lut[i*K + code_i], plain fp32 adds in index order
 // (product.go:271-275).  One lane per neighbour: all new neighbours of a hop in one pass.
 struct PQDist {
+  // (the same naming of the next hop's row, with its code rows fetched ahead: 0.419 against 0.359 ms per batch at
+  // 4M x 768, M = 8 -- a one-wave hop is bound by its instruction count, not by the fetch; measured and removed)
   static constexpr bool kSpeculate = false;
   static constexpr bool kHasStamps = false;
   static constexpr bool kPointDistances = false;  // LUT distance != the centroid-pair distance of the prunes

@@ -156,6 +156,35 @@ def test_topk_merge_with_repeated_items(oracle):
         assert np.array_equal(o_s[q].astype(np.int32), w_s)
 
 
+def test_bench_summary_keys_are_scalars_and_extras_are_single_gpu_only():
+    """The driver's record keeps the scalars of `config`: bench.flatten_summary repeats the figures a reader needs as
+    scalars in front; and every single-GPU extra of measure_mode is gated on world == 1 (the 8-GPU lease runs three
+    modes, each a build of its own -- DESIGN 6 budgets its wall time from a one-rank rehearsal)."""
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    res = {"value_host": 990000.0, "build_roofline": {"frac": 0.62, "frac_mixed": 0.82, "hbm_unique_bytes": 8, "build_s": 1.6},
+           "config": {"workload": "w", "mode": "shards", "dataset": "d", "recall_at_10": 0.98, "x": {"nested": 1},
+                      "secondary_datasets": {"gaussian": {"qps": 6.0, "recall_at_10": 0.03, "search_size_for_recall_0.95": "none <= 512"}},
+                      "c4": {"M=8": {"call_qps": 2.0, "kernel_ms": 0.3, "recall_at_10": 0.1, "traffic_over_algorithmic": 1.26,
+                                     "roofline": {"frac": 0.02}},
+                             "M=192": {"call_qps": 9.0, "kernel_ms": 1.0, "lookups_per_s": 0.8, "bound_by": "latency"}},
+                      "latency_ms": {"workgroup_per_query": {"1": 0.32, "256": 0.38}, "host_memory_call": {"1": 0.35}}}}
+    bench.flatten_summary(res)
+    keys = list(res["config"])
+    assert keys[:4] == ["workload", "mode", "dataset", "recall_at_10"] and keys[4] == "value_host"
+    cfg = res["config"]
+    assert cfg["gaussian_search_size_for_recall_0.95"] == "none <= 512" and cfg["c4_M8_traffic_over_algorithmic"] == 1.26
+    assert cfg["c4_M192_lookups_per_s"] == 0.8 and cfg["latency_ms_1_queries"] == 0.32 and cfg["build_roofline_frac"] == 0.62
+    assert keys.index("c4_M8_call_qps") < keys.index("x")  # the scalars come before the nested objects
+    src = open(os.path.join(root, "bench.py")).read()
+    for guard in re.findall(r"if rank == 0 and world == 1 and primary[^\n]*", src):
+        assert "rehearse" in guard
+    assert len(re.findall(r"if rank == 0 and world == 1 and primary", src)) == 2
+
+
 def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch, capsys):
     """`python3 bench.py --gpus N` (the shape of the driver's single-GPU command, with N > 1): bench.py builds the
     torch.distributed.run command line itself and runs it as a CHILD process before touching the GPU, relays the
@@ -259,6 +288,14 @@ def test_bench_two_ranks_over_gloo(mode, tmp_path):
         assert rep["recall_at_10"] >= 0.95 and rep["value"] > 0 and rep["scaling"] == "strong"
         assert c5["recall_at_10"] >= 0.95 and c5["value"] > 0 and c5["scaling"] == "weak" and c5["ranks_seen"] == [0, 1]
         assert "120000 rows in all" in c5["workload"] and "2 shard(s) x 60000" in c5["workload"]
+        # the N > 1 line carries its wall time by phase and mode, and none of the single-GPU extras (they would put
+        # the driver's 8-GPU lease at risk: secondary datasets, the 10M x 768 C4 point, side kernels, the CPU baseline)
+        cfg = j["config"]
+        assert all(m in cfg["wall_s_by_phase"] for m in ("shards:", "replicas:", "c5:")) and cfg["wall_s_total"] > 0
+        for extra in ("c4", "secondary_datasets", "side_kernels", "latency_ms", "host_qps", "two_batches_in_flight_qps"):
+            assert extra not in cfg, extra
+        assert "cpu_baseline" not in j
+        assert cfg["replicas_qps"] == rep["value"] and cfg["c5_qps"] == c5["value"]
 
 
 def _gloo_exchange_worker(rank, world, port, q):

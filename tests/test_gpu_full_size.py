@@ -9,7 +9,6 @@ the stored row or code; the walk itself on a sample of queries for C2).
 Sizes: SDB_TEST_C2_ROWS / SDB_TEST_C4_ROWS override the row counts (defaults are the BASELINE sizes)."""
 import os
 import sys
-import threading
 import types
 
 import numpy as np
@@ -43,31 +42,12 @@ def _build(n, d):
     return ix, base
 
 
-class _OracleBuild(threading.Thread):
-    def __init__(self, base_rows, d, sv):
-        super().__init__(daemon=True)
-        self.base_rows, self.d, self.sv, self.result, self.error = base_rows, d, sv, None, None
-
-    def run(self):
-        try:
-            from oracle import oracle
-            o = oracle.Index(self.d, "cosine", R, L, 1.2, impl=oracle.IMPL_AVX2 if oracle.has_avx2() else oracle.IMPL_ASM)
-            o.set_start(np.asarray(self.sv, dtype=np.float32))
-            rows = self.base_rows.shape[0]
-            rc = o.insert_rounds(np.arange(2, rows + 2, dtype=np.uint64), self.base_rows)
-            if rc != 0:
-                raise RuntimeError("insert_rounds rc=%d" % rc)
-            o_ids, _, o_off, o_e = o.export(with_vectors=False)
-            self.result = (o_ids, o_off, o_e)
-        except BaseException as e:  # reported by the test that joins
-            self.error = e
-
-
 def _start_oracle_build(c2):
+    """the oracle's restatement of the whole C3 build, on a thread of its own: started when the session's tests have
+    been collected (tests/conftest.py), or here when this module runs without that"""
+    from tests import helpers
     rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 1_000_000)), c2.n)
-    t = _OracleBuild(c2.base[:rows].cpu().numpy(), c2.d, _bench().start_vector(c2.d))
-    t.start()
-    return t
+    return helpers.start_oracle_build(rows, c2.d, R, L, base=c2.base)
 
 
 @pytest.fixture(scope="module")
