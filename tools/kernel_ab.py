@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from semadb_amd import vamana, vectorstore as vs
-out = {"lib": os.environ.get("SEMADB_AMD_LIB", "default")}
+out = {"lib": os.environ.get("SEMADB_AMD_LIB", "default"), "tune": os.environ.get("AB_TUNE", "")}
 
 
 def run(n, d, with_pq):
@@ -15,6 +15,9 @@ def run(n, d, with_pq):
     ix = vamana.NewIndexVamana("ab", vamana.IndexVectorVamanaParameters(d, "cosine", 75, 64, 1.2), capacity=n + 1)
     ix.set_start(bench.start_vector(d))
     ix.insert_batch(None, base)
+    for kv in filter(None, os.environ.get("AB_TUNE", "").split(",")):  # e.g. AB_TUNE=team_walk=1
+        key, value = kv.split("=")
+        ix.set_tuning(key, int(value))
     if with_pq:
         pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(256, 8, 10000), d)
         pq.Fit(base[:10000].cpu().numpy().copy(), np.arange(8) * 7, alias=True)
