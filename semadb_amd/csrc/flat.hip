@@ -855,33 +855,55 @@ __global__ void k_flat_tombstone(uint64_t *ids, uint8_t *dirty, const uint32_t *
 }  // namespace sdb
 
 // rows of a flat index (no graph) leave the store; part of the open transaction (the caller commits)
-static int flat_tombstone(sdb_index *ix, std::vector<uint32_t> &slots) {
+// *changed: set once device rows or host tables have begun to change (a failure before that leaves the index as it was)
+static int flat_tombstone(sdb_index *ix, std::vector<uint32_t> &slots, bool *changed) {
   if (slots.empty()) return SDB_OK;
   std::sort(slots.begin(), slots.end());
   slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+  // ---- the host tables' memory first (a dense id table gets its hash map -- a dense table ignores the map, filling it
+  // changes no answer --, the removed ids enter the transaction's record): running out of it must leave the rows alone
+  struct HostPrep {
+    sdb_index *ix;
+    bool done = false, was_dense = false;
+    std::vector<uint64_t> recorded;
+    ~HostPrep() {
+      if (done) return;
+      std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+      for (uint64_t id : recorded) ix->tx_deleted.erase(id);
+      if (was_dense) ix->id2slot.clear();
+    }
+  } prep{ix};
+  {
+    std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // searches translate filter ids with these tables
+    prep.recorded.reserve(slots.size());
+    if (ix->dense_ids) {
+      prep.was_dense = true;
+      ix->id2slot.clear();
+      ix->id2slot.reserve((size_t)ix->n * 2);
+      for (uint32_t s = 0; s < ix->n; s++)
+        if (ix->h_ids[s] != 0) ix->id2slot.emplace(ix->h_ids[s], s);
+    }
+    // until commit a search on the committed rows still finds a removed id; a row this transaction appended itself was
+    // never visible, and an id keeps the committed row it had when the transaction began (first record wins)
+    for (uint32_t s : slots)
+      if (s < ix->tx_n0 && ix->tx_deleted.emplace(ix->h_ids[s], s).second) prep.recorded.push_back(ix->h_ids[s]);
+  }
   uint32_t *d_dead = nullptr;
   SDB_HIP(hipMalloc(&d_dead, slots.size() * 4));
   hipError_t e = hipMemcpy(d_dead, slots.data(), slots.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
+    *changed = true;
     hipLaunchKernelGGL(sdb::k_flat_tombstone, dim3((unsigned)((slots.size() + 255) / 256)), dim3(256), 0, nullptr, ix->d_ids,
                        ix->d_dirty, d_dead, (uint32_t)slots.size());
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   (void)hipFree(d_dead);
+  prep.done = *changed;  // the device rows are marked (or half-marked: the caller declares the handle unusable)
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "tombstone failed: %s", hipGetErrorString(e));
-  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);  // searches translate filter ids with these tables
-  if (ix->dense_ids) {  // the dense id -> slot shortcut does not survive holes
-    ix->id2slot.clear();
-    ix->id2slot.reserve((size_t)ix->n * 2);
-    for (uint32_t s = 0; s < ix->n; s++)
-      if (ix->h_ids[s] != 0) ix->id2slot.emplace(ix->h_ids[s], s);
-    ix->dense_ids = false;
-  }
+  std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+  ix->dense_ids = false;  // the dense id -> slot shortcut does not survive holes (the map was filled above)
   for (uint32_t s : slots) {
-    // until commit a search on the committed rows still finds it; a row this transaction appended itself was never
-    // visible, and an id keeps the committed row it had when the transaction began (first record wins)
-    if (s < ix->tx_n0) ix->tx_deleted.emplace(ix->h_ids[s], s);
     ix->id2slot.erase(ix->h_ids[s]);
     ix->h_ids[s] = 0;
   }
@@ -906,15 +928,21 @@ extern "C" int sdb_index_remove_vectors(sdb_index *ix, uint64_t n, const uint64_
   if (slots.empty()) return SDB_OK;
   DeviceGuard dg(ix->P.device);
   SDB_TRY(ix->begin_write());
-  ix->tx_dirty = true;
   int trc;
+  bool changed = false;
+  const bool was_dirty = ix->tx_dirty;
+  ix->tx_dirty = true;
   try {
-    trc = flat_tombstone(ix, slots);
+    trc = flat_tombstone(ix, slots, &changed);
   } catch (...) {
     trc = sdb::on_exception("sdb_index_remove_vectors");
   }
-  if (trc != SDB_OK) {  // device rows / host tables may be half-marked: no way back (index.h `broken`)
-    ix->broken = true;
+  if (trc != SDB_OK) {
+    if (changed) ix->broken = true;  // device rows / host tables half-marked: no way back (index.h `broken`)
+    else {  // nothing was touched: the transaction this call opened for itself closes again
+      ix->tx_dirty = was_dirty;
+      if (!ix->tx_explicit && !was_dirty) ix->in_tx = false;
+    }
     return trc;
   }
   if (!ix->tx_explicit) {
@@ -972,10 +1000,14 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
   if (rc != SDB_OK) return rc;
   if (e != hipSuccess) return fail(SDB_ERR_DEVICE, "id copy failed: %s", hipGetErrorString(e));
   SDB_TRY(ix->begin_write());  // appended rows become visible to searches at commit
+  const bool was_dirty = ix->tx_dirty;
   ix->tx_dirty = true;
+  bool changed = false;
   auto tables = [&]() -> int {
-  SDB_TRY(flat_tombstone(ix, replaced));
+  SDB_TRY(flat_tombstone(ix, replaced, &changed));
   std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+  ix->h_ids.reserve(ix->h_ids.size() + n);
+  changed = true;  // from here on the id tables move
   bool dense = ix->dense_ids;
   for (uint64_t i = 0; i < n; i++) {
     if (dense && !ix->h_ids.empty() && new_ids[i] != ix->h_ids[0] + ix->h_ids.size()) {
@@ -998,7 +1030,8 @@ extern "C" int sdb_index_set_vectors(sdb_index *ix, uint64_t n, const uint64_t *
     trc = sdb::on_exception("sdb_index_set_vectors");
   }
   if (trc != SDB_OK) {
-    ix->broken = true;
+    if (changed) ix->broken = true;  // the id tables are half-way between two states
+    else if (!ix->tx_explicit && !was_dirty) ix->tx_dirty = false, ix->in_tx = false;  // (the stored rows lie past n: invisible)
     return trc;
   }
   if (!ix->tx_explicit) {

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <link.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -507,6 +508,153 @@ int main() {
         [&](long, int) { CHECK(cl[0] == nullptr && cl[1] == nullptr); }, [&] { CHECK(cl[0] && cl[1]); });
     drop();
     for (auto *s : sh) OK(sdb_index_destroy(s));
+  }
+
+  // ---- 6b. the flat index's calls, the stored-vector reads, K1 over stored ids, the quantizer's calls
+  {
+    sdb_index *fx = new_index();  // no start node: a flat index (flat.go)
+    std::vector<uint64_t> fids(600);
+    for (uint32_t i = 0; i < 600; i++) fids[i] = 10 + 2 * (uint64_t)i;
+    sweep(
+        "sdb_index_set_vectors", [] {}, [&] { return sdb_index_set_vectors(fx, 600, fids.data(), base.data(), SDB_MEM_HOST); },
+        [&](long k, int) {
+          if (sdb_index_begin_write(fx) == SDB_ERR_STATE) {  // half-changed id tables: unusable, start over
+            OK(sdb_index_destroy(fx));
+            fx = new_index();
+          } else {
+            OK(sdb_index_abort_write(fx));
+            uint64_t rows = 1, dead = 0;
+            OK(sdb_index_row_usage(fx, &rows, &dead));
+            if (rows != 0) std::printf("FAIL set_vectors k=%ld: %llu rows after a failed call\n", k, (unsigned long long)rows), g_fail++;
+          }
+        },
+        [&] {
+          uint64_t rows = 0, dead = 0;
+          OK(sdb_index_row_usage(fx, &rows, &dead));
+          CHECK(rows == 600 && dead == 0);
+        });
+    Answer fa, fb;
+    auto fsearch = [&](Answer *x, bool filtered) {
+      x->ids.assign(NQ * LIMIT, 0), x->d.assign(NQ * LIMIT, 0.f), x->c.assign(NQ, 0);
+      std::vector<uint64_t> o(NQ + 1), ids;  // 50 stored ids per query, ascending (flat.go:100 scans only the filter's ids)
+      for (uint32_t q = 0; q <= NQ; q++) o[q] = (uint64_t)q * 50;
+      for (uint32_t q = 0; q < NQ; q++)
+        for (uint32_t i = 0; i < 50; i++) ids.push_back(fids[q + 11 * i]);
+      return sdb_index_flat_search(fx, NQ, queries.data(), LIMIT, filtered ? o.data() : nullptr, filtered ? ids.data() : nullptr,
+                                   x->ids.data(), x->d.data(), x->c.data(), SDB_MEM_HOST, nullptr);
+    };
+    OK(fsearch(&fa, false));
+    sweep(
+        "sdb_index_flat_search", [] {}, [&] { return fsearch(&fb, false); }, [&](long, int) {}, [&] { CHECK(fb == fa); });
+    Answer ff;
+    OK(fsearch(&ff, true));
+    sweep(
+        "sdb_index_flat_search (filter)", [] {}, [&] { return fsearch(&fb, true); }, [&](long, int) {}, [&] { CHECK(fb == ff); });
+    std::vector<float> got(40 * D), want(40 * D);
+    std::vector<uint8_t> found(40);
+    OK(sdb_index_get_vectors(fx, 40, fids.data(), want.data(), found.data()));
+    sweep(
+        "sdb_index_get_vectors", [] {}, [&] { return sdb_index_get_vectors(fx, 40, fids.data(), got.data(), found.data()); },
+        [&](long, int) {}, [&] { CHECK(got == want && !memcmp(want.data(), base.data(), 40 * D * 4)); });
+    std::vector<float> dd(8 * 40), dw(8 * 40);
+    std::vector<uint64_t> cand(8 * 40);
+    for (uint32_t i = 0; i < 8 * 40; i++) cand[i] = fids[(i * 13) % 600];
+    OK(sdb_index_distance_batch(fx, 8, queries.data(), 40, cand.data(), dw.data(), SDB_MEM_HOST, nullptr));
+    sweep(
+        "sdb_index_distance_batch", [] {},
+        [&] { return sdb_index_distance_batch(fx, 8, queries.data(), 40, cand.data(), dd.data(), SDB_MEM_HOST, nullptr); },
+        [&](long, int) {}, [&] { CHECK(!memcmp(dd.data(), dw.data(), dd.size() * 4)); });
+    long rm_unusable = 0, rm_intact = 0;
+    sweep(
+        "sdb_index_remove_vectors", [] {}, [&] { return sdb_index_remove_vectors(fx, 100, fids.data()); },
+        [&](long k, int) {
+          if (sdb_index_begin_write(fx) == SDB_ERR_STATE) {  // rows half-marked: unusable; a host reloads
+            rm_unusable++;
+            OK(sdb_index_destroy(fx));
+            fx = new_index();
+            OK(sdb_index_set_vectors(fx, 600, fids.data(), base.data(), SDB_MEM_HOST));
+            return;
+          }
+          rm_intact++;
+          OK(sdb_index_abort_write(fx));
+          uint64_t rows = 0, dead = 1;
+          OK(sdb_index_row_usage(fx, &rows, &dead));
+          if (rows != 600 || dead != 0) std::printf("FAIL remove_vectors k=%ld: rows %llu dead %llu\n", k, (unsigned long long)rows, (unsigned long long)dead), g_fail++;
+          Answer b;
+          OK(fsearch(&b, false));
+          CHECK(b == fa);
+        },
+        [&] {
+          uint64_t rows = 0, dead = 0;
+          OK(sdb_index_row_usage(fx, &rows, &dead));
+          CHECK(rows == 600 && dead == 100);
+        },
+        400);
+    std::printf("    remove_vectors: %ld failures left the index as it was, %ld left it unusable (reload)\n", rm_intact, rm_unusable);
+    OK(sdb_index_destroy(fx));
+    // the quantizer: fit, codes, table distances, and an index switched over to it
+    sdb_pq *pq = nullptr;
+    OK(sdb_pq_create(D, SDB_METRIC_EUCLIDEAN, 8, 16, 0, &pq));
+    std::vector<uint32_t> first(8);
+    for (uint32_t i = 0; i < 8; i++) first[i] = 37 * i;
+    std::vector<float> train(base.begin(), base.begin() + 1000 * D);
+    std::vector<uint8_t> codes_w(1000 * 8), codes(1000 * 8);
+    {
+      std::vector<float> t2(train);
+      OK(sdb_pq_fit(pq, t2.data(), 1000, first.data(), 1, codes_w.data(), SDB_MEM_HOST, nullptr));
+    }
+    sweep(
+        "sdb_pq_fit", [] {},
+        [&] {
+          std::vector<float> t2(train);
+          return sdb_pq_fit(pq, t2.data(), 1000, first.data(), 1, codes.data(), SDB_MEM_HOST, nullptr);
+        },
+        [&](long, int) {}, [&] { CHECK(codes == codes_w); });
+    std::vector<uint8_t> enc_w(500 * 8), enc(500 * 8);
+    OK(sdb_pq_encode(pq, base.data(), 500, enc_w.data(), SDB_MEM_HOST, nullptr));
+    sweep(
+        "sdb_pq_encode", [] {}, [&] { return sdb_pq_encode(pq, base.data(), 500, enc.data(), SDB_MEM_HOST, nullptr); },
+        [&](long, int) {}, [&] { CHECK(enc == enc_w); });
+    std::vector<float> ld_w(NQ * 500), ld(NQ * 500);
+    OK(sdb_pq_lut_distance(pq, queries.data(), NQ, enc_w.data(), 500, ld_w.data(), SDB_MEM_HOST, nullptr));
+    sweep(
+        "sdb_pq_lut_distance", [] {},
+        [&] { return sdb_pq_lut_distance(pq, queries.data(), NQ, enc_w.data(), 500, ld.data(), SDB_MEM_HOST, nullptr); },
+        [&](long, int) {}, [&] { CHECK(!memcmp(ld.data(), ld_w.data(), ld.size() * 4)); });
+    sdb_index *qx = new_index();
+    OK(load_graph(qx, g0));
+    sweep(
+        "sdb_index_attach_pq", [] {}, [&] { return sdb_index_attach_pq(qx, pq, nullptr); },
+        [&](long, int) {
+          Answer b;
+          OK(search(qx, queries, &b));
+          CHECK(b == a0);  // still the full-precision store
+        },
+        [&] {
+          Answer b;
+          OK(search(qx, queries, &b));
+          CHECK(b.c == a0.c);
+        });
+    Answer qa, qb;
+    OK(search(qx, queries, &qa));
+    sweep(
+        "search_batch (quantized)", [] {}, [&] { return search(qx, queries, &qb); }, [&](long, int) {}, [&] { CHECK(qb == qa); });
+    std::vector<uint64_t> cid(g0.ids.begin() + 1, g0.ids.begin() + 101);
+    std::vector<uint8_t> cc(100 * 8);
+    for (size_t i = 0; i < cc.size(); i++) cc[i] = (uint8_t)(i % 16);
+    sweep(
+        "sdb_index_set_codes", [] {}, [&] { return sdb_index_set_codes(qx, 100, cid.data(), cc.data()); }, [&](long, int) {},
+        [&] {
+          std::vector<uint8_t> back(100 * 8);
+          OK(sdb_index_get_codes(qx, 100, cid.data(), back.data()));
+          CHECK(back == cc);
+        });
+    uint64_t extra1[3] = {g0.ids[5], g0.ids[9], g0.ids[11]};
+    sweep(
+        "sdb_index_union_prune", [] {}, [&] { return sdb_index_union_prune(qx, g0.ids[3], 3, extra1, 0, nullptr); },
+        [&](long, int) {}, [&] {}, 200);
+    OK(sdb_index_destroy(qx));
+    OK(sdb_pq_destroy(pq));
   }
 
   // ---- 7. create / quantizer objects
