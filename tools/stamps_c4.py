@@ -10,8 +10,9 @@ base = bench.gen_rows(n, d, 20250620, "latent:24", "cuda:0")
 ix = vamana.NewIndexVamana("st", vamana.IndexVectorVamanaParameters(d, "cosine", 75, 64, 1.2), capacity=n + 1)
 ix.set_start(bench.start_vector(d))
 ix.insert_batch(None, base)
-pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(256, 8, 10000), d)
-pq.Fit(base[:10000].cpu().numpy().copy(), np.arange(8) * 7, alias=True)
+M = int(os.environ.get("PQ_M", 8))
+pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(256, M, 10000), d)
+pq.Fit(base[:10000].cpu().numpy().copy(), np.arange(M) * 7, alias=True)
 vs.attach(ix, pq)
 queries = bench.gen_rows(4 * nq, d, 20250621, "latent:24", "cuda:0").view(4, nq, d)
 ix.set_profiling(True)
