@@ -70,6 +70,19 @@ struct BuildArgs {
   uint8_t *dirty;             // [n] set for every row whose adjacency this call writes (index.h graph versions)
   unsigned long long *stats;  // sdb_index_build_stats counters (index.h d_bstats), or NULL
   uint32_t *flags;            // [0] bit 0: a search's visit log did not fit vis_cap
+  // Back-edge targets whose re-prune cannot be settled from a few rows of pair distances -- a node that overflows for
+  // the first time (its edges have never been pruned against each other), or more than kMaxDirty candidates that arrived
+  // since its last prune -- are DEFERRED by k_backedges: it leaves the candidate list (slots + distances from the node)
+  // here, and the LDS-tiled prune (k_prune_new_tiled with a node list, what the delete path uses) takes them in one
+  // launch behind it: the candidates' rows are read ONCE into LDS (~65 rows) where the wave's pick-by-pick walk read
+  // every pair's row from L2 / HBM (~600 rows per such node).  NULL: every re-prune runs in k_backedges.
+  uint32_t *def_count;        // [0] targets deferred this round (may exceed def_cap: the excess was pruned in place)
+  uint32_t def_cap;
+  uint32_t *def_self;         // [def_cap] the target's slot
+  uint32_t *def_nc;           // [def_cap] its candidates (0: nothing here)
+  uint32_t *def_slots;        // [def_cap][kTileMaxCand]
+  float *def_dists;           // [def_cap][kTileMaxCand]
+  uint32_t *def_done;         // [def_cap] the tiled kernel's per-list state (prune_done)
 };
 
 // sdb_index_build_stats slots
@@ -978,9 +991,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
     // the first clean[b] candidates are B's edges as its last prune left them (edges appended since and the
     // new points are not)
     const uint32_t ncl = a.clean[b] < deg ? a.clean[b] : deg;
+    if constexpr (NG >= 1) {
+      // (kTileMaxCand is declared with the tiled kernel above: 128 candidates)
+      const bool few_new = nc <= kPairMax && ncl > 0 && nc - (int)ncl <= kMaxDirty;  // robust_prune_wave's sparse mode
+      if (a.def_count && !few_new && nc <= kTileMaxCand && done + t == m) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(a.def_count, 1u);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at < a.def_cap) {
+          for (int c = lane; c < nc; c += 64) {
+            a.def_slots[(size_t)at * kTileMaxCand + c] = l.in_slot[c];
+            a.def_dists[(size_t)at * kTileMaxCand + c] = l.in_dist[c];
+          }
+          if (lane == 0) a.def_self[at] = b, a.def_nc[at] = (uint32_t)nc;
+          st_reprune++;
+          row_dirty = false;  // the tiled prune writes the row
+          done += t;
+          break;
+        }
+      }
+    }
+#ifdef SDB_BACK_COUNT  // measurement builds: how the re-prunes split into sparse ones and full ones, and the rows each kind reads
+    const uint32_t ev0 = st_eval;
+    const bool sparse_kind = NG >= 0 && nc <= kPairMax && ncl > 0 && nc - (int)ncl <= kMaxDirty;
+#endif
     robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane,
                               (NG >= 0 && nc <= kPairMax) ? l.D : nullptr, (int)ncl, true, &st_eval,
                               &st_cached);  // :57-58
+#ifdef SDB_BACK_COUNT
+    stat_add(a, sparse_kind ? 13 : 11, 1, lane);
+    stat_add(a, sparse_kind ? 14 : 12, st_eval - ev0, lane);
+    if (!sparse_kind && ncl == 0) stat_add(a, 15, 1, lane);  // ... of which: rows that had never been pruned
+#endif
     st_reprune++;
     __syncthreads();
     row = a.adj[(size_t)b * kAdjStride + lane];  // written by this lane just above
@@ -1017,6 +1059,7 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
                         int sort_end_bit, BigScratch *big, bool *start_pruned) {
   BuildArgs a1 = a;
   a1.prune_done = nullptr;
+  bool tiled_ok = false;  // the LDS-tiled prune serves this row shape (and is not switched off by the test knob)
   if constexpr (NG >= 1) {
     // candidate rows staged in LDS when a useful share of a visit list fits beside its pair table
     // (always at d <= 1024 and searchSize 75); what the tiled kernel leaves is pruned by k_prune_new
@@ -1042,6 +1085,7 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
         SDB_HIP(hipGetLastError());
       }
       a1.prune_done = a.prune_done;
+      tiled_ok = true;
     }
   }
   {
@@ -1054,8 +1098,26 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
                                             sort_end_bit, stream));
   const size_t lds2 = prune_lds_bytes(kBackCap, NG, a.ld, NG >= 0);
   if (a.big_count) SDB_HIP(hipMemsetAsync(a.big_count, 0, 4, stream));  // word 1 = BuildArgs::flags, kept
-  hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, a);
+  BuildArgs ab = a;  // k_backedges' view: deferral only where the tiled prune can take what is deferred
+  if (!tiled_ok || a.no_tile) ab.def_count = nullptr;
+  if (ab.def_count) {
+    ab.def_cap = std::min<uint32_t>(a.def_cap, 2 * a.nnew + 64);  // (what does not fit is pruned in place)
+    SDB_HIP(hipMemsetAsync(ab.def_count, 0, 4, stream));
+    SDB_HIP(hipMemsetAsync(ab.def_nc, 0, (size_t)ab.def_cap * 4, stream));
+  }
+  hipLaunchKernelGGL((k_backedges<NG, L2>), dim3(a.nnew * 64), dim3(64), lds2, stream, ab);
   SDB_HIP(hipGetLastError());
+  if constexpr (NG >= 1) {
+    if (ab.def_count) {  // the re-prunes k_backedges deferred: candidate rows staged in LDS once, selection in the kernel
+      BuildArgs d = ab;
+      d.self_list = a.def_self, d.vis_slots = a.def_slots, d.vis_dists = a.def_dists, d.vis_count = a.def_nc;
+      d.vis_cap = kTileMaxCand, d.nnew = ab.def_cap, d.prune_done = a.def_done;
+      d.pair_tab = nullptr, d.pair_slots = nullptr, d.pair_dists = nullptr, d.keys_in = nullptr, d.def_count = nullptr;
+      if (a.tail) hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, true, 4>), dim3(d.nnew), dim3(256), kTileLdsBytes, stream, d);
+      else hipLaunchKernelGGL((k_prune_new_tiled<NG, L2, false, 8>), dim3(d.nnew), dim3(512), kTileLdsBytes, stream, d);
+      SDB_HIP(hipGetLastError());
+    }
+  }
   // the hubs of this round, if any (bigprune.inc).  A target gets at most one request per new node, so a round of
   // fewer than big_min points cannot have one and the host need not wait for the count (the early rounds -- two
   // thirds of all rounds of a 1M build -- then run without a host round trip each)
@@ -1262,6 +1324,18 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_HIP(hipMalloc(&pair_dists, (size_t)max_round * kTileMaxCand * 4));
     cleanup.ptrs.push_back(pair_dists);
   }
+  // back-edge targets whose re-prune is left to the LDS-tiled kernel (BuildArgs::def_*): full-precision store only
+  uint32_t *def_words = nullptr, *def_slots = nullptr;
+  float *def_dists = nullptr;
+  const uint32_t def_cap = 2 * max_round + 64;
+  if (!pq) {
+    SDB_HIP(hipMalloc(&def_words, ((size_t)3 * def_cap + 4) * 4));  // [count, pad x3][self][nc][done]
+    cleanup.ptrs.push_back(def_words);
+    SDB_HIP(hipMalloc(&def_slots, (size_t)def_cap * kTileMaxCand * 4));
+    cleanup.ptrs.push_back(def_slots);
+    SDB_HIP(hipMalloc(&def_dists, (size_t)def_cap * kTileMaxCand * 4));
+    cleanup.ptrs.push_back(def_dists);
+  }
   BigScratch big_scratch;
   // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
   constexpr uint32_t kDcacheBits = SDB_DCACHE_BITS;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
@@ -1397,6 +1471,9 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
     ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done, ba.dirty = ix->d_dirty;
     ba.pair_tab = pair_tab, ba.pair_slots = pair_slots, ba.pair_dists = pair_dists;
+    if (def_words && !ix->tune_no_defer)
+      ba.def_count = def_words, ba.def_cap = def_cap, ba.def_self = def_words + 4, ba.def_nc = def_words + 4 + def_cap,
+      ba.def_done = def_words + 4 + 2 * (size_t)def_cap, ba.def_slots = def_slots, ba.def_dists = def_dists;
     bool start_pruned = false;
     in_round = true;
     int rc = pq ? launch_round<kQuantized, false>(ba, stream, sort_tmp, sort_tmp_bytes, end_bit, &big_scratch, &start_pruned)

@@ -1780,6 +1780,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) try {
     case SDB_TUNE_HOST_FILTERS:
       ix->tune_host_filters = value != 0;
       return SDB_OK;
+    case SDB_TUNE_NO_DEFER:
+      ix->tune_no_defer = value != 0;
+      return SDB_OK;
     case SDB_TUNE_HASH16_PROBES:
       if (value > 15) return fail(SDB_ERR_INVALID, "at most 15 probes");
       ix->tune_hash16_probes = (uint32_t)value;

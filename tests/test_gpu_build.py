@@ -251,12 +251,16 @@ def test_batched_build_identical_to_oracle_schedule(oracle, monkeypatch, metric,
     o.set_start(sv)
     ids = np.arange(2, n + 2, dtype=np.uint64)
     assert o.insert_rounds(ids, base, round_size=round_size, big_min=big_min) == 0
-    ix = _new_gpu(d, metric, R, L)
-    ix.set_tuning("hub_min", big_min)
-    ix.set_start(sv)
-    ix.insert_batch(ids, base, round_size=round_size)
-    assert_same_graph(ix, o)
-    ix.close()
+    # both forms of the back-edge re-prunes that cannot be settled from a few rows of pair distances (a node's first
+    # prune, many new candidates): handed to the LDS-tiled prune behind k_backedges (default), or pruned in place
+    for no_defer in (0, 1):
+        ix = _new_gpu(d, metric, R, L)
+        ix.set_tuning("hub_min", big_min)
+        ix.set_tuning("no_defer", no_defer)
+        ix.set_start(sv)
+        ix.insert_batch(ids, base, round_size=round_size)
+        assert_same_graph(ix, o)
+        ix.close()
 
 
 @pytest.mark.parametrize("metric,d,n,R,L", [("cosine", 16, 60000, 32, 50), ("euclidean", 128, 40000, 64, 75)])

@@ -31,7 +31,8 @@ with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
         f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                                              r["Percentage"], r["MinNs"], r["MaxNs"]))
 tr = list(csv.DictReader(open(one(tag + "_trace/**/*kernel_trace.csv"))))
-gs = [r for r in tr if "k_greedy_search" in r["Kernel_Name"] and r["Grid_Size_X"] == "65536"]
+# the batch kernel only: the build's warm-up rounds run k_greedy_search_wide, 64 queries x 1 024 threads = the same grid size
+gs = [r for r in tr if "k_greedy_search<" in r["Kernel_Name"] and r["Grid_Size_X"] == "65536"]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in gs]
 kname = gs[0]["Kernel_Name"][:120]
 exp = json.load(open(src + "pmc_expected.json"))
@@ -45,10 +46,10 @@ def vals(rs, kn, name, grid=None):
 
 
 cal_fetch = vals(f1, "k_index_distance", "FETCH_SIZE")[0]
-s_fetch = vals(f1, "k_greedy_search", "FETCH_SIZE", "65536")
-s_write = vals(f2, "k_greedy_search", "WRITE_SIZE", "65536")
-s_hit = vals(f2, "k_greedy_search", "TCC_HIT_sum", "65536")
-s_miss = vals(f2, "k_greedy_search", "TCC_MISS_sum", "65536")
+s_fetch = vals(f1, "k_greedy_search<", "FETCH_SIZE", "65536")
+s_write = vals(f2, "k_greedy_search<", "WRITE_SIZE", "65536")
+s_hit = vals(f2, "k_greedy_search<", "TCC_HIT_sum", "65536")
+s_miss = vals(f2, "k_greedy_search<", "TCC_MISS_sum", "65536")
 factor = exp["calibration"]["bytes"] / (cal_fetch * 1024)
 alg = st.mean(r["alg_bytes"] for r in exp["search"])
 read_b = st.mean(s_fetch) * 1024 * factor
