@@ -76,6 +76,15 @@ struct BuildArgs {
   // here, and the LDS-tiled prune (k_prune_new_tiled with a node list, what the delete path uses) takes them in one
   // launch behind it: the candidates' rows are read ONCE into LDS (~65 rows) where the wave's pick-by-pick walk read
   // every pair's row from L2 / HBM (~600 rows per such node).  NULL: every re-prune runs in k_backedges.
+  // Pair distances of APPENDED edges, kept from the round that appended them.  A target with room takes a new point
+  // without a prune (insert.go:62); when it overflows later, that edge is a candidate that "arrived since the last
+  // prune" and robust_prune_wave needs its distances to all other candidates -- a whole row of pair distances, 65 rows
+  // read from HBM, for a point whose own search had evaluated nearly all of them in the round it arrived (the target
+  // was expanded by that search, so its neighbours were looked at) and whose table is gone by now.  So the append
+  // copies them out of the table while it is there: pairc[node][p - clean][e] = distFn(edge p, edge e) for e < p, for
+  // the up to kMaxDirty positions p behind the node's clean prefix; all-ones bits: not known.  Full-precision store
+  // only; lives for one insert_batch call (a cache: what is missing is computed from rows).  NULL: none.
+  float *pairc;               // [rows][kMaxDirty][64]
   uint32_t *def_count;        // [0] targets deferred this round (may exceed def_cap: the excess was pruned in place)
   uint32_t def_cap;
   uint32_t *def_self;         // [def_cap] the target's slot
@@ -123,6 +132,10 @@ struct PointRow {
 constexpr int kPairMax = 80;  // largest candidate set of the few-new-candidates mode (rows of D)
 
 constexpr int kMaxDirty = 16;  // "few new candidates" mode of robust_prune_wave
+// rows of up to 512 floats keep the pair distances of appended edges (BuildArgs::pairc); beyond, the look-ups' registers
+// do not fit k_backedges' budget of three waves per SIMD (768 floats: 1 register spilled, 1 024: 10)
+template <int NG>
+constexpr bool kPairRecords = NG >= 0 && NG <= 4;
 
 // D: LDS scratch of kMaxDirty rows of kPairMax pair distances for the few-new-candidates mode, or nullptr.
 //
@@ -138,8 +151,11 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
                                   const float *in_dist, uint32_t *s_slot, float *s_dist, uint32_t *s_rem,
                                   float *qs, int lane, float *D = nullptr, int n_clean = 0,
                                   bool dists_are_point_to_point = true, uint32_t *n_eval = nullptr,
-                                  uint32_t *n_cached = nullptr) {
+                                  uint32_t *n_cached = nullptr, const float *pairc_row = nullptr, int n_row = 0) {
+  // pairc_row / n_row: the node's record of pair distances of appended edges (BuildArgs::pairc) and how many of the
+  // input candidates are its row's entries, in edge order (the rest are this round's new points)
   uint32_t ev = 0, ca = 0;  // pair distances evaluated / taken from the searches' tables (sdb_index_build_stats)
+  uint32_t *s_org = (D && nc <= kPairMax) ? reinterpret_cast<uint32_t *>(D + kMaxDirty * kPairMax + kMaxDirty) : nullptr;
   constexpr int U = NG >= 0 ? ChunkPairs<NG, false>::value : 4;
   const int L = lane & 31;
   const bool any_nan = wave_any_nan(in_dist, nc, lane);
@@ -149,6 +165,7 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
     s_slot[rank] = in_slot[i];
     s_dist[rank] = d;
     s_rem[rank] = i < n_clean ? 2u : 0u;  // bit 0: pruneRemoved (distset.go:124), bit 1: clean
+    if (s_org) s_org[rank] = (uint32_t)i;  // where the candidate stood in the input (a row entry's edge position)
   }
   __syncthreads();
   // sparse mode: few dirty candidates and room for their distance rows in D
@@ -187,14 +204,33 @@ __device__ void robust_prune_wave(const BuildArgs &a, uint32_t self_slot, int nc
         const uint2 *tab = nullptr;
         if (a.dcache && sd >= a.first_slot && sd - a.first_slot < a.nnew)
           tab = a.dcache + ((size_t)(sd - a.first_slot) << (32 - a.dcache_shift));
+        // ... or an edge that was appended in an earlier round: its pair distances to the row's other entries were
+        // copied out of its search table then (BuildArgs::pairc), and this round's new points have theirs to it
+        const int ok = __builtin_amdgcn_readfirstlane((int)s_org[dk]);
+        const bool k_in_row = kPairRecords<NG> && pairc_row && ok < n_row;
         int nmiss = 0;
         for (int base = 0; base < nc; base += 64) {
           const int j = base + lane;
-          bool need = j < nc;
+          bool need = j < nc && j != dk;  // (a candidate's distance to itself is never asked for)
           if (need && tab) {
             const uint32_t cs = s_slot[j];
             const uint2 e = tab[(cs * 2654435761u) >> a.dcache_shift];
             if (e.x == cs) D[k * kPairMax + j] = __uint_as_float(e.y), need = false;
+          } else if (need && k_in_row) {
+            const int oj = (int)s_org[j];
+            if (oj < n_row) {  // both are row entries: the record of the later one holds the pair
+              const int hi = oj > ok ? oj : ok, lo = oj > ok ? ok : oj, rec = hi - n_clean;
+              if (rec >= 0 && rec < kMaxDirty) {
+                const uint32_t v = __float_as_uint(pairc_row[rec * 64 + lo]);
+                if (v != 0xFFFFFFFFu) D[k * kPairMax + j] = __uint_as_float(v), need = false;
+              }
+            } else if (a.dcache) {  // a new point of this round: its search's table, looked up for the appended edge
+              const uint32_t cs = s_slot[j];
+              if (cs >= a.first_slot && cs - a.first_slot < a.nnew) {
+                const uint2 e = (a.dcache + ((size_t)(cs - a.first_slot) << (32 - a.dcache_shift)))[(sd * 2654435761u) >> a.dcache_shift];
+                if (e.x == sd) D[k * kPairMax + j] = __uint_as_float(e.y), need = false;
+              }
+            }
           }
           const uint64_t mm = __ballot(need);
           if (need) miss[nmiss + __popcll(mm & ((1ull << lane) - 1))] = (uint32_t)j;
@@ -412,7 +448,7 @@ struct PruneLds {
   __device__ PruneLds(char *base, uint32_t cap, bool with_pairs = false) {
     D = with_pairs ? reinterpret_cast<float *>(base + (size_t)cap * 20) : nullptr;
     base_init(base, cap);
-    if (with_pairs) qs = D + kMaxDirty * kPairMax + kMaxDirty;  // (the positions of the dirty candidates sit behind D's rows)
+    if (with_pairs) qs = D + kMaxDirty * kPairMax + kMaxDirty + kPairMax;  // (behind D's rows: the dirty candidates' positions, the candidates' input positions)
   }
   __device__ void base_init(char *base, uint32_t cap) {
     in_slot = reinterpret_cast<uint32_t *>(base);
@@ -467,7 +503,7 @@ __device__ void dists_from_point(const BuildArgs &a, uint32_t point, uint32_t nc
 }
 
 static size_t prune_lds_bytes(uint32_t cap, int NG, uint32_t ld, bool with_pairs = false) {
-  return (size_t)cap * 20 + (with_pairs ? (size_t)kMaxDirty * (kPairMax + 1) * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
+  return (size_t)cap * 20 + (with_pairs ? ((size_t)kMaxDirty * (kPairMax + 1) + kPairMax) * 4 : 0) + (NG == -1 ? (size_t)ld * 4 + 16 : 0);
 }
 
 // robustPrune(nodeA, visitedSet) for every new node of the round (insert.go:29-31), then emit the
@@ -856,9 +892,10 @@ constexpr uint32_t kBackCap = 256;
 #endif
 // Rows of 1 536 floats and more (NG >= 12: the query row alone is 48+ registers, a pair of candidate rows as many again)
 // do not fit that cap: NG = 12 spilled 20 registers, NG = 24 more than 180 (404 bytes of scratch per lane).  They run two
-// waves per SIMD with 256 registers each.
+// waves per SIMD with 256 registers each -- since round 5 also rows of 1 024 floats and the run-time row length (NG = 8,
+// -1: 7 and 10 registers spilled at three waves once the deferral of full re-prunes had joined the kernel).
 template <int NG, bool L2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NG >= 8 || NG == -1) ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   PruneLds l(lds_raw, kBackCap, NG >= 0);
   const int lane = threadIdx.x, L = lane & 31;
@@ -895,6 +932,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
   uint32_t row = a.adj[(size_t)b * kAdjStride + lane];
   float rowd = a.adjdist[(size_t)b * kAdjStride + lane];  // cached distFn(B, edge), valid for lanes < dc
   uint32_t deg = a.deg[b];
+  uint32_t ncl0 = 0;  // the clean prefix the appends below stand behind (rows that keep pair records only)
+  if constexpr (kPairRecords<NG>) ncl0 = a.clean[b] < deg ? a.clean[b] : deg;
   uint32_t dc = a.dcount[b] < deg ? a.dcount[b] : deg;
   bool row_dirty = false;
   auto req_slot = [&](size_t r) { return a.first_slot + (uint32_t)((a.keys_sorted[pos + r] & 0xFFFFFFFFull) >> 6); };
@@ -916,6 +955,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
         const uint32_t anew = req_slot(done + r);
         bool have;
         const float d = req_dist(done + r, &have);
+        if (kPairRecords<NG> && a.pairc && a.dcache) {  // the new edge's distances to the edges in front of it, out of its own search's table
+          const int rec = (int)deg - (int)ncl0;
+          if (rec >= 0 && rec < kMaxDirty && lane < (int)deg) {
+            const uint2 e = (a.dcache + ((size_t)(anew - a.first_slot) << (32 - a.dcache_shift)))[(row * 2654435761u) >> a.dcache_shift];
+            a.pairc[((size_t)b * kMaxDirty + rec) * 64 + lane] = __uint_as_float(e.x == row ? e.y : 0xFFFFFFFFu);
+          }
+        }
         if (lane == (int)deg) row = anew, rowd = d;
         if (dc == deg && have) dc = deg + 1;  // the cached prefix grows only without a gap
         deg++;
@@ -990,7 +1036,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
     __syncthreads();
     // the first clean[b] candidates are B's edges as its last prune left them (edges appended since and the
     // new points are not)
-    const uint32_t ncl = a.clean[b] < deg ? a.clean[b] : deg;
+    uint32_t ncl;
+    if constexpr (kPairRecords<NG>) ncl = ncl0 < deg ? ncl0 : deg;  // (= clean[b]: kept up to date across this wave's own prunes)
+    else ncl = a.clean[b] < deg ? a.clean[b] : deg;
     if constexpr (NG >= 1) {
       // (kTileMaxCand is declared with the tiled kernel above: 128 candidates)
       const bool few_new = nc <= kPairMax && ncl > 0 && nc - (int)ncl <= kMaxDirty;  // robust_prune_wave's sparse mode
@@ -1017,7 +1065,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
 #endif
     robust_prune_wave<NG, L2>(a, b, nc, l.in_slot, l.in_dist, l.s_slot, l.s_dist, l.s_rem, l.qs, lane,
                               (NG >= 0 && nc <= kPairMax) ? l.D : nullptr, (int)ncl, true, &st_eval,
-                              &st_cached);  // :57-58
+                              &st_cached, a.pairc ? a.pairc + (size_t)b * kMaxDirty * 64 : nullptr, (int)deg);  // :57-58
 #ifdef SDB_BACK_COUNT
     stat_add(a, sparse_kind ? 13 : 11, 1, lane);
     stat_add(a, sparse_kind ? 14 : 12, st_eval - ev0, lane);
@@ -1029,6 +1077,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG >= 12 ? 2
     rowd = a.adjdist[(size_t)b * kAdjStride + lane];
     deg = (uint32_t)__popcll(__ballot(row != kNoSlot));
     dc = deg;  // every edge of a freshly pruned row carries its distance
+    if constexpr (kPairRecords<NG>) ncl0 = deg;  // ... and the whole row is clean: later appends of this wave stand behind it
     row_dirty = false;
     done += t;
   }
@@ -1336,6 +1385,19 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_HIP(hipMalloc(&def_dists, (size_t)def_cap * kTileMaxCand * 4));
     cleanup.ptrs.push_back(def_dists);
   }
+  // pair distances of appended edges (BuildArgs::pairc): 4 KB per row for the length of this call -- bulk builds only
+  // (a call that adds at least a quarter to the table); a cache, so no memory for it is no error
+  float *pairc = nullptr;
+  if (!pq && l.ng <= 4 && n >= 256 && n >= (uint64_t)n0 / 4 && !ix->tune_no_defer) {
+    const size_t bytes = (size_t)total_rows * kMaxDirty * 64 * sizeof(float);
+    if (hipMalloc(&pairc, bytes) == hipSuccess) {
+      cleanup.ptrs.push_back(pairc);
+      if (hipMemsetAsync(pairc, 0xFF, bytes, stream) != hipSuccess) pairc = nullptr;
+    } else {
+      (void)hipGetLastError();
+      pairc = nullptr;
+    }
+  }
   BigScratch big_scratch;
   // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
   constexpr uint32_t kDcacheBits = SDB_DCACHE_BITS;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
@@ -1471,6 +1533,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     ba.stats = reinterpret_cast<unsigned long long *>(ix->d_bstats), ba.flags = big_count + 1;
     ba.no_tile = ix->tune_no_tile, ba.prune_done = prune_done, ba.dirty = ix->d_dirty;
     ba.pair_tab = pair_tab, ba.pair_slots = pair_slots, ba.pair_dists = pair_dists;
+    ba.pairc = pairc;
     if (def_words && !ix->tune_no_defer)
       ba.def_count = def_words, ba.def_cap = def_cap, ba.def_self = def_words + 4, ba.def_nc = def_words + 4 + def_cap,
       ba.def_done = def_words + 4 + 2 * (size_t)def_cap, ba.def_slots = def_slots, ba.def_dists = def_dists;
