@@ -247,9 +247,11 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        Same ids, distance bits, visit order and counters either way.
  *   SDB_TUNE_HOST_FILTERS  != 0: the filter ids of a search are turned into slots by the host (hash map, threads) even
  *                        where the device would do it (A/B and parity tests)
- *   SDB_TUNE_NO_DEFER    != 0: the build's back-edge re-prunes all run in the one-wave kernel; by default those that
- *                        cannot be settled from a few rows of pair distances (a node's first prune, many new candidates)
- *                        are handed to the LDS-tiled prune, which reads the candidates' rows once.  Same graph either way.
+ *   SDB_TUNE_NO_DEFER    != 0: the build's back-edge re-prunes all run in the one-wave kernel and recompute what they
+ *                        need from rows; by default those that cannot be settled from a few rows of pair distances (many
+ *                        new candidates) are handed to the LDS-tiled prune, which reads the candidates' rows once, and
+ *                        a bulk insert keeps the pair distances of edges it appends without a prune (4 KB per row for
+ *                        the length of the call) for the re-prune that meets them later.  Same graph either way.
  *   SDB_TUNE_HASH16_PROBES  buckets a key of the 16-bit-cell set may try before the walk spills to the HBM bitset
  *                        (0 = all 15; 1..15).  With 15 that spill is a one-in-ten-million event; a test sets 1 or 2
  *                        to walk through it */
