@@ -132,10 +132,11 @@ struct PointRow {
 constexpr int kPairMax = 80;  // largest candidate set of the few-new-candidates mode (rows of D)
 
 constexpr int kMaxDirty = 16;  // "few new candidates" mode of robust_prune_wave
-// rows of up to 512 floats keep the pair distances of appended edges (BuildArgs::pairc); beyond, the look-ups' registers
-// do not fit k_backedges' budget of three waves per SIMD (768 floats: 1 register spilled, 1 024: 10)
+// rows of up to 768 floats keep the pair distances of appended edges (BuildArgs::pairc).  At 768 floats the look-ups'
+// registers do not fit k_backedges' budget of three waves per SIMD (1 spilled): those rows run two waves per SIMD, which
+// the rows not read more than pay for (1M x 768 build 3.05 - 3.26 -> 2.86 - 3.07 s)
 template <int NG>
-constexpr bool kPairRecords = NG >= 0 && NG <= 4;
+constexpr bool kPairRecords = NG >= 0 && NG <= 6;
 
 // D: LDS scratch of kMaxDirty rows of kPairMax pair distances for the few-new-candidates mode, or nullptr.
 //
@@ -892,10 +893,11 @@ constexpr uint32_t kBackCap = 256;
 #endif
 // Rows of 1 536 floats and more (NG >= 12: the query row alone is 48+ registers, a pair of candidate rows as many again)
 // do not fit that cap: NG = 12 spilled 20 registers, NG = 24 more than 180 (404 bytes of scratch per lane).  They run two
-// waves per SIMD with 256 registers each -- since round 5 also rows of 1 024 floats and the run-time row length (NG = 8,
-// -1: 7 and 10 registers spilled at three waves once the deferral of full re-prunes had joined the kernel).
+// waves per SIMD with 256 registers each -- since round 5 also rows of 768 and 1 024 floats and the run-time row length
+// (NG = 6 with its pair records; NG = 8, -1: 7 and 10 registers spilled at three waves once the deferral of full
+// re-prunes had joined the kernel).
 template <int NG, bool L2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NG >= 8 || NG == -1) ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NG >= 6 || NG == -1) ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   PruneLds l(lds_raw, kBackCap, NG >= 0);
   const int lane = threadIdx.x, L = lane & 31;
@@ -1388,7 +1390,7 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   // pair distances of appended edges (BuildArgs::pairc): 4 KB per row for the length of this call -- bulk builds only
   // (a call that adds at least a quarter to the table); a cache, so no memory for it is no error
   float *pairc = nullptr;
-  if (!pq && l.ng <= 4 && n >= 256 && n >= (uint64_t)n0 / 4 && !ix->tune_no_defer) {
+  if (!pq && l.ng <= 6 && n >= 256 && n >= (uint64_t)n0 / 4 && !ix->tune_no_defer) {
     const size_t bytes = (size_t)total_rows * kMaxDirty * 64 * sizeof(float);
     if (hipMalloc(&pairc, bytes) == hipSuccess) {
       cleanup.ptrs.push_back(pairc);
