@@ -505,7 +505,7 @@ def measure_mode(a, ctx, mode, rows, primary):
 
     # ---- counter pass (separate from the timed loop): algorithmic bytes of every timed batch
     per_batch = {}
-    nd_all, nh_all = [], []
+    nd_all, nh_all, nd_tail = [], [], []
     for b in sorted(set(tb[a.warmup:])):
         qq = queries[b][q_lo:q_hi]
         _, _, _, tr = ix.search_batch(qq, k, L, trace=True)
@@ -514,6 +514,9 @@ def measure_mode(a, ctx, mode, rows, primary):
         per_batch[b] = nd * d * 4 + ne * 4
         nd_all.append(nd / qq.shape[0])
         nh_all.append(float(tr.n_hop.float().mean().item()))
+        # how uneven the walks of ONE batch are: a batch ends on its longest walk
+        ndq = tr.n_dist.float()
+        nd_tail.append(float(ndq.max().item() / ndq.mean().item()))
     alg_bytes = [per_batch[b] for b in tb[a.warmup:]][-len(kernel_ms):]
     achieved = float(np.sum(alg_bytes) / (np.sum(kernel_ms) * 1e-3) / 1e9) if len(kernel_ms) else 0.0
 
@@ -568,6 +571,9 @@ def measure_mode(a, ctx, mode, rows, primary):
             "avg_degree": round(n_edges / n_nodes, 2),
             "mean_n_dist": round(float(np.mean(nd_all)), 1),
             "mean_n_hop": round(float(np.mean(nh_all)), 1),
+            # the longest walk of a batch over its mean walk, in distance evaluations: what one batch in flight idles for at
+            # its end (two batches in flight hide it: two_batches_in_flight_qps)
+            "longest_walk_over_mean": round(float(np.mean(nd_tail)), 3),
         },
         "roofline": {
             "bound": "hbm",

@@ -657,6 +657,40 @@ int main() {
     OK(sdb_pq_destroy(pq));
   }
 
+  // ---- 6c. the calls that take no index: batched distances, the shard merge, k-means
+  {
+    std::vector<float> out_w(NQ * 300), out(NQ * 300);
+    OK(sdb_distance_batch(SDB_METRIC_COSINE, D, queries.data(), NQ, base.data(), 300, out_w.data(), SDB_MEM_HOST, 0, nullptr));
+    sweep(
+        "sdb_distance_batch", [] {},
+        [&] { return sdb_distance_batch(SDB_METRIC_COSINE, D, queries.data(), NQ, base.data(), 300, out.data(), SDB_MEM_HOST, 0, nullptr); },
+        [&](long, int) {}, [&] { CHECK(!memcmp(out.data(), out_w.data(), out.size() * 4)); });
+    const uint32_t S = 3, per = 6, lim = 8;
+    std::vector<uint64_t> mi(S * NQ * per), mo_w(NQ * lim), mo(NQ * lim);
+    std::vector<float> md(S * NQ * per), mdo_w(NQ * lim), mdo(NQ * lim);
+    std::vector<uint32_t> mc(S * NQ, per), msh(NQ * lim), mcnt_w(NQ), mcnt(NQ);
+    for (size_t i = 0; i < mi.size(); i++) mi[i] = 1000 + i, md[i] = (float)((i * 7919) % 1000) + (float)(i % per) * 1000.f;
+    OK(sdb_topk_merge(S, NQ, per, mi.data(), md.data(), mc.data(), lim, mo_w.data(), mdo_w.data(), msh.data(), mcnt_w.data(), SDB_MEM_HOST, 0, nullptr));
+    sweep(
+        "sdb_topk_merge", [] {},
+        [&] { return sdb_topk_merge(S, NQ, per, mi.data(), md.data(), mc.data(), lim, mo.data(), mdo.data(), msh.data(), mcnt.data(), SDB_MEM_HOST, 0, nullptr); },
+        [&](long, int) {}, [&] { CHECK(mo == mo_w && mcnt == mcnt_w && !memcmp(mdo.data(), mdo_w.data(), mdo.size() * 4)); });
+    std::vector<float> X(base.begin(), base.begin() + 800 * D), cent_w(16 * 8), cent(16 * 8);
+    std::vector<uint8_t> lab_w(800), lab(800);
+    uint32_t it_w = 0, it = 0;
+    {
+      std::vector<float> X2(X);
+      OK(sdb_kmeans_fit(X2.data(), 800, D, 8, 8, 16, 100, 5, 0, cent_w.data(), lab_w.data(), &it_w, SDB_MEM_HOST, 0, nullptr));
+    }
+    sweep(
+        "sdb_kmeans_fit", [] {},
+        [&] {
+          std::vector<float> X2(X);
+          return sdb_kmeans_fit(X2.data(), 800, D, 8, 8, 16, 100, 5, 0, cent.data(), lab.data(), &it, SDB_MEM_HOST, 0, nullptr);
+        },
+        [&](long, int) {}, [&] { CHECK(lab == lab_w && it == it_w && !memcmp(cent.data(), cent_w.data(), cent.size() * 4)); });
+  }
+
   // ---- 7. create / quantizer objects
   {
     sdb_index_params p{};
