@@ -1152,9 +1152,10 @@ static int launch_round(const BuildArgs &a, hipStream_t stream, void *sort_tmp, 
   BuildArgs ab = a;  // k_backedges' view: deferral only where the tiled prune can take what is deferred
   if (!tiled_ok || a.no_tile) ab.def_count = nullptr;
   if (ab.def_count) {
-    // (1M x 384: 94 k of 22.7 M re-prunes are deferred, up to ~5 000 in a round of 16 384 points; the grid below has one
-    // workgroup per list, so it is sized for that; what does not fit is pruned in place)
-    ab.def_cap = std::min<uint32_t>(a.def_cap, a.nnew / 2 + 64);
+    // (one workgroup per list in the launch behind k_backedges, most of them empty -- 94 k of a 1M build's 22.7 M
+    // re-prunes are deferred -- but a list that finds no room is pruned in place by a wave that then reads 1 600 rows
+    // and holds its launch up: a grid of nnew / 2 cost the build 4 %, so the room is generous)
+    ab.def_cap = std::min<uint32_t>(a.def_cap, 2 * a.nnew + 64);
     SDB_HIP(hipMemsetAsync(ab.def_count, 0, 4, stream));
     SDB_HIP(hipMemsetAsync(ab.def_nc, 0, (size_t)ab.def_cap * 4, stream));
   }
