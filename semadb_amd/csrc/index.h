@@ -30,6 +30,10 @@ struct Workspace {
   size_t filter_host_bytes = 0;
   hipEvent_t launched = nullptr;   // recorded behind the last search kernels that were given a graph version
   bool launched_valid = false;
+  // a device-memory search returns right behind its kernels: `launched` then also marks the end of the call's device
+  // work, and release_ws lets it stand for `done` instead of recording a second event behind it (one marker packet less
+  // per batch on the stream)
+  bool launched_is_tail = false, done_is_launched = false;
   bool busy = false;               // held by a call that has not returned yet
   bool pending = false;            // device work of an asynchronous call may still be running
   hipStream_t bound_stream = nullptr;

@@ -977,12 +977,14 @@ Workspace *sdb_index::acquire_ws(hipStream_t stream, bool async) const {
     if (w->pending) {
       if (async && w->bound_stream == stream) {
         w->busy = true;
+        w->launched_is_tail = false;
         return w;
       }
-      if (hipEventQuery(w->done) != hipSuccess) continue;
+      if (hipEventQuery(w->done_is_launched ? w->launched : w->done) != hipSuccess) continue;
       w->pending = false;
     }
     w->busy = true;
+    w->launched_is_tail = false;
     return w;
   }
   std::unique_ptr<Workspace> w(new Workspace());
@@ -995,10 +997,15 @@ Workspace *sdb_index::acquire_ws(hipStream_t stream, bool async) const {
 void sdb_index::release_ws(Workspace *ws, hipStream_t stream, bool async) const {
   std::lock_guard<std::mutex> g(mu);
   if (async) {
-    if (!ws->done) (void)hipEventCreateWithFlags(&ws->done, hipEventDisableTiming);
-    if (ws->done && hipEventRecord(ws->done, stream) == hipSuccess) {
-      ws->pending = true;
-      ws->bound_stream = stream;
+    if (ws->launched_is_tail && ws->launched_valid) {  // recorded on `stream` behind everything this call enqueued
+      ws->pending = true, ws->bound_stream = stream, ws->done_is_launched = true;
+    } else {
+      ws->done_is_launched = false;
+      if (!ws->done) (void)hipEventCreateWithFlags(&ws->done, hipEventDisableTiming);
+      if (ws->done && hipEventRecord(ws->done, stream) == hipSuccess) {
+        ws->pending = true;
+        ws->bound_stream = stream;
+      }
     }
   }
   ws->busy = false;
@@ -1655,7 +1662,7 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
     }
     // from here on a commit may hand the copy this batch walks to the writer: it waits for this event first
     if (!ws->launched) (void)hipEventCreateWithFlags(&ws->launched, hipEventDisableTiming);
-    if (ws->launched && hipEventRecord(ws->launched, stream) == hipSuccess) ws->launched_valid = true;
+    if (ws->launched && hipEventRecord(ws->launched, stream) == hipSuccess) ws->launched_valid = true, ws->launched_is_tail = mem == SDB_MEM_DEVICE;
     else if (rc == SDB_OK) (void)hipStreamSynchronize(stream);  // no event: finish before letting go of the version
     rl.unlock();
     return rc;
