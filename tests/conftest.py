@@ -21,7 +21,7 @@ def oracle():
 
 def pytest_collection_finish(session):
     """The longest single piece of the GPU suite is host work: the oracle's restatement of the 1M-row build that
-    tests/test_gpu_full_size.py::test_c3_build_equals_oracle_schedule compares the device's graph with.  When that test
+    tests/test_gpu_zz_c3_build.py::test_c3_build_equals_oracle_schedule (the module that sorts last) compares the device's graph with.  When that test
     is part of the run (and a GPU is there to generate the rows on), the oracle starts now, on its own thread."""
     if not any("test_c3_build_equals_oracle_schedule" in it.nodeid for it in session.items):
         return

@@ -42,7 +42,7 @@ def assert_same_graph(g, o):
     assert np.array_equal(bits(g_v), bits(o_v))
 
 
-# ---- the oracle's restatement of the full-size build (tests/test_gpu_full_size.py::test_c3_build_equals_oracle_schedule)
+# ---- the oracle's restatement of the full-size build (tests/test_gpu_zz_c3_build.py::test_c3_build_equals_oracle_schedule)
 # About 2.5 minutes of host-core time that touches no GPU: it runs on a thread of its own (the C library releases the
 # GIL) under the suite's other tests, which mostly wait for the device, and is joined by the test that compares.
 import threading

@@ -42,27 +42,14 @@ def _build(n, d):
     return ix, base
 
 
-def _start_oracle_build(c2):
-    """the oracle's restatement of the whole C3 build, on a thread of its own: started when the session's tests have
-    been collected (tests/conftest.py), or here when this module runs without that"""
-    from tests import helpers
-    rows = min(int(os.environ.get("SDB_TEST_C3_ORACLE_ROWS", 1_000_000)), c2.n)
-    return helpers.start_oracle_build(rows, c2.d, R, L, base=c2.base)
-
-
 @pytest.fixture(scope="module")
 def c2():
     import torch
     bench = _bench()
     ix, base = _build(C2_ROWS, 384)
     queries = bench.gen_rows(2048, 384, 20250621, "latent:24", "cuda:0")
-    ns = types.SimpleNamespace(ix=ix, base=base, queries=queries, n=C2_ROWS, d=384, oracle_build=None)
-    # The oracle's restatement of the whole build (test_c3_build_equals_oracle_schedule, the last test of this module)
-    # is ~2.5 minutes of host-core time and touches no GPU: it starts NOW, on a thread of its own (the C library
-    # releases the GIL), and runs under the module's other tests, which mostly wait for the device.
-    ns.oracle_build = _start_oracle_build(ns)
+    ns = types.SimpleNamespace(ix=ix, base=base, queries=queries, n=C2_ROWS, d=384)
     yield ns
-    ns.oracle_build.join()
     ix.close()
     del base
     torch.cuda.empty_cache()
@@ -415,28 +402,3 @@ def test_c5_one_rank_at_size():
     assert np.array_equal(bits(k1f.cpu().numpy()), bits(f_d[:64].cpu().numpy()))
     ix.close()
     torch.cuda.empty_cache()
-
-
-def test_c3_build_equals_oracle_schedule(c2, oracle):
-    """The batched build of the BASELINE data against the oracle's restatement of the round schedule, edge for
-    edge: all 1 000 000 rows of C3 by default (SDB_TEST_C3_ORACLE_ROWS shortens it for a quick run).  The oracle runs a
-    round's searches and prunes over the host cores, about 2.5 minutes on the GPU box's 16 -- started by the module's
-    fixture on a thread of its own and joined here, at the end of the module, so that it runs under the other tests."""
-    from semadb_amd import vamana
-    c2.oracle_build.join()
-    if c2.oracle_build.error is not None:
-        raise c2.oracle_build.error
-    o_ids, o_off, o_e = c2.oracle_build.result
-    rows = len(o_ids) - 1
-    if rows == c2.n:
-        ix = c2.ix
-    else:
-        ix = vamana.NewIndexVamana("c3o", vamana.IndexVectorVamanaParameters(c2.d, "cosine", L, R, 1.2), capacity=rows + 1)
-        ix.set_start(_bench().start_vector(c2.d))
-        ix.insert_batch(None, c2.base[:rows])
-    g_ids, _, g_off, g_e = ix.export(with_vectors=False)
-    if ix is not c2.ix:
-        ix.close()
-    assert np.array_equal(g_ids, o_ids)
-    assert np.array_equal(g_off, o_off), "degree sequence differs"
-    assert np.array_equal(g_e, o_e), "edge lists differ"

@@ -381,14 +381,17 @@ def test_multi_wave_quantized_walk_parity(oracle, metric, d, M, K):
     kernel's (table in global memory, SDB_TUNE_PQ_NARROW), and stay equal when the visited set spills or is a bitset."""
     from semadb_amd import vamana, vectorstore as vs
     rng = np.random.default_rng(d + M + K)
-    n = 2500
+    # the oracle's k-means and encoder are one distance call per (point, centroid, sub-vector): the large quantizers train
+    # on 400 rows (more centroids than points per cluster: empty clusters on the way) and encode 1 500
+    big = M * K >= 192 * 256
+    n, nt = (1500, 400) if big else (2500, 900)
     lat = rng.standard_normal((12, d)).astype(np.float32)
     base = rng.standard_normal((n, 12)).astype(np.float32) @ lat + 0.3 * rng.standard_normal((n, d)).astype(np.float32)
     base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
     o = build_oracle_index(oracle, base, metric, R=32, L=50)
     ids, vecs, off, edges = o.export()
-    train = vecs[1:901].copy()
-    first = rng.integers(0, 900, M)
+    train = vecs[1:nt + 1].copy()
+    first = rng.integers(0, nt, M)
     opq = oracle.PQ(d, metric, M, K)
     opq.fit(train.copy(), first, alias=True)
     codes = np.stack([opq.encode(v) for v in vecs])
