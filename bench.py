@@ -913,7 +913,7 @@ def c4_point(a, dev, dev_index):
                 m["traffic_source"] = "profile-derived, not measured in this run: " + rec["source"]
         except Exception:
             pass
-        m["roofline"] = {"bound": "hbm", "kernel": "k_greedy_search<PQDist>" if M * 256 * 4 <= 65536 else "k_greedy_search_pqw",
+        m["roofline"] = {"bound": "hbm", "kernel": pq_walk_kernel(M),
                          "achieved": round(alg / m["kernel_ms"] / 1e6, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / m["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4),
                          "traffic": None}
@@ -923,6 +923,9 @@ def c4_point(a, dev, dev_index):
             fetched = m["n_hop_per_batch"] * (256 + 64 * M)
             m["fetched_bytes_model_over_algorithmic"] = round(fetched / alg, 3)
             m["layout"] = "neighbour code rows behind the adjacency row: one fetch per hop (node.go:37-54)"
+            if M * 256 <= 2048:
+                m["bound_by"] = ("one query's instruction stream, not bytes: two waves per query (the walker fetches, tests the visited "
+                                 "set, sums and names the next node; the merger runs AddWithLimit), a 1 024-query batch is 4 + 4 waves per CU")
         else:
             # the table look-ups, not bytes, are this kernel's work: M per distance, from LDS (ds_read_b32) or from the
             # register tables (four ds_bpermute + selects each).  The guide's aggregate ds_read_b32 rate is ~75 TB/s =
@@ -1163,6 +1166,15 @@ def run_c3(a, ctx):
 # ------------------------------------------------------------------------------------------------------------
 # C4: product-quantized search
 # ------------------------------------------------------------------------------------------------------------
+def pq_walk_kernel(M, K=256):
+    """the kernel index.hip launch_greedy_search takes for an unfiltered quantized search of the reference's searchSize"""
+    if M in (128, 192, 256, 384):
+        return "k_greedy_search_pqw"  # table in LDS + registers of four / eight waves
+    if M * K <= 2048:
+        return "k_greedy_search_pq2"  # table in LDS, walker + merger (two waves per query)
+    return "k_greedy_search<PQDist>"  # table in LDS (up to 64 KB) or in global memory, one wave per query
+
+
 def run_c4(a, ctx):
     """BASELINE configs[3]: vectorVamana + product quantizer, 10M x 768 (K = 256, M from --pq-m; M = 8 is the
     documented configuration and the `value`), LUT distance kernel, one MI355X.  The reference does no
@@ -1245,7 +1257,7 @@ def run_c4(a, ctx):
     head_m = "M=192" if "M=192" in points else ("M=8" if "M=8" in points else next(iter(points)))
     head = points[head_m]["batch_%d" % nq]
     m_head = int(head_m.split("=")[1])
-    kernel = "k_greedy_search<PQDist>" if m_head * 256 * 4 <= 65536 else "k_greedy_search_pqw"
+    kernel = pq_walk_kernel(m_head)
     res = {
         "metric": "QPS, vectorVamana + product quantizer %dMx%d (K=256, %s), PQ-LUT distance kernel, batch=1024" %
                   (n // 1000000, d, head_m) if n >= 1000000 else

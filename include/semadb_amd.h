@@ -235,10 +235,11 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        euclidean uses) instead of the matrix cores
  *   SDB_TUNE_WIDE_HASH   != 0: searches over a quantized store keep their visited ids in 32-bit LDS cells (four
  *                        walks per CU) instead of the 16-bit cells used for stores of up to 2^24 rows (six)
- *   SDB_TUNE_PQ_NARROW   1: searches over a quantized store whose per-query table exceeds 64 KB (M = 128 .. 384 at
- *                        K = 256) stay on the one-wave kernel with the table in global memory (round 2) instead of the
- *                        four-wave walk that keeps it in LDS and registers; 2: M = 192 takes the four-wave variant with
- *                        one query per CU instead of two
+ *   SDB_TUNE_PQ_NARROW   1: every search over a quantized store stays on the one-wave kernel -- a per-query table of
+ *                        more than 64 KB (M = 128 .. 384 at K = 256) in global memory (round 2) instead of the four-wave
+ *                        walk that keeps it in LDS and registers, a table of up to 8 KB (M = 8 at K = 256) without the
+ *                        second wave that runs AddWithLimit (round 5); 2: M = 192 takes the four-wave variant with one
+ *                        query per CU instead of two
  *   SDB_TUNE_WIDE_WALK   the walk of calls with few queries (one REST request is one query, vamana.go:278-310): a
  *                        workgroup of sixteen waves per query -- one walks, all split every hop's rows and compute the
  *                        likely next hop's distances ahead -- instead of one wave per query (eight waves for 257 .. 512

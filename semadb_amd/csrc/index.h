@@ -177,7 +177,7 @@ struct sdb_index {
   bool tune_host_filters = false;  // filter ids are resolved to slots by the host's hash map even when the table's ids are consecutive
   uint32_t tune_wide_walk = 0;  // the workgroup-per-query walk of small calls: 0 = up to 256 queries, 1 = never, 2 = always
   bool tune_no_defer = false;  // A/B and parity tests: every back-edge re-prune runs in k_backedges (BuildArgs::def_*)
-  uint32_t tune_pq_narrow = 0;  // quantized searches never take the multi-wave walk (k_greedy_search_pqw): A/B and parity tests
+  uint32_t tune_pq_narrow = 0;  // 1: quantized searches never take a multi-wave walk (k_greedy_search_pqw, k_greedy_search_pq2): A/B and parity tests
   bool tune_no_mfma = false;  // exact scan of dot/cosine rows on the packed-FMA kernel instead of the matrix cores
   uint32_t tune_no_tile = 0;  // 0: LDS-tiled prune of new nodes, 1: one-wave kernel only, 2: tiled with 4 waves instead of 8, 3: tiled without the separate selection kernel (measurement)
   // a write that failed after it had started to change the graph leaves it unusable: every later call fails

@@ -453,6 +453,23 @@ bool search_uses_hash(const SearchArgs &a, uint32_t nq) {
   }
 }
 
+// The quantized walk with its table in LDS, on two waves per query (search_kernel.h k_greedy_search_pq2: the walker and
+// the merger): plain unfiltered searches of the reference's searchSize range; a build's searches (visit log), a start
+// node with an overflow list and SDB_TUNE_PQ_NARROW = 1 keep the one-wave kernel.
+static bool pq_two_waves(const SearchArgs &a, uint32_t nq) {
+  if (!a.pq_codes || !a.pq_lut_in_lds || (size_t)a.pq_M * a.pq_K > 2048 || a.pq_narrow == 1) return false;
+  if (a.filt_off || a.vis_slots || a.dcache || a.start_ext_n || a.search_size > 96) return false;
+  return search_uses_hash(a, nq);
+}
+template <uint32_t HCAP>
+static int launch_pq2(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
+  constexpr uint32_t vis = HCAP == kHash16 ? HashVisited16::kWords : HashVisited<HCAP == kHash16 ? 4u : HCAP>::kWords;
+  const size_t lds = ((size_t)vis + (((size_t)a.pq_M * a.pq_K + 3) & ~(size_t)3) + kPq2SharedWords) * sizeof(uint32_t);
+  hipLaunchKernelGGL((k_greedy_search_pq2<HCAP>), dim3(nq), dim3(128), lds, stream, a);
+  SDB_HIP(hipGetLastError());
+  return SDB_OK;
+}
+
 // HCAP: 0 = bitset, else the LDS hash set's capacity (it precedes the policy's own LDS of `lds` bytes)
 template <class Dist, uint32_t HCAP>
 static int launch_nreg(const SearchArgs &a, uint32_t nq, hipStream_t stream, size_t lds) {
@@ -574,6 +591,10 @@ int launch_greedy_search(const SearchArgs &a_in, uint32_t nq, hipStream_t stream
       default: break;
     }
     const size_t lds = a.pq_lut_in_lds ? (size_t)a.pq_M * a.pq_K * sizeof(float) : 0;
+    if (pq_two_waves(a, nq)) {
+      if ((uint64_t)a.words_per_query * 32 <= (1u << 24) && !a.wide_hash) return launch_pq2<kHash16>(a, nq, stream);
+      return launch_pq2<kHashCapPQ>(a, nq, stream);
+    }
     if (search_uses_hash(a, nq)) {
       // up to 2^24 rows: the 16-bit-cell set (16 KB, six walks per CU); beyond: 32-bit cells
       if ((uint64_t)a.words_per_query * 32 <= (1u << 24) && !a.wide_hash) return launch_nreg<PQDist, kHash16>(a, nq, stream, lds);

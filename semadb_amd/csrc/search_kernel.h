@@ -58,7 +58,7 @@ struct SearchArgs {
   const uint8_t *adj_codes;
   uint32_t adj_rows;  // rows of `adj` (what tells an adjacency row from a chunk of the start node's overflow list)
   uint32_t pq_lut_in_lds;  // != 0: the kernel copies its LUT into LDS first
-  uint32_t pq_narrow;      // 1: never the multi-wave walk (k_greedy_search_pqw); 2: its one-query-per-CU variant for M = 192
+  uint32_t pq_narrow;      // 1: never a multi-wave walk (k_greedy_search_pqw, k_greedy_search_pq2); 2: the one-query-per-CU variant of the former for M = 192
 
   // filtered search (search.go:33-51,93-95): per query CSR of seeds (<= searchSize slots, ascending id
   // order) and of the whole filter as ascending slots; rbitsets = the result set's own visited set
@@ -1831,6 +1831,313 @@ __global__ __launch_bounds__(64) void k_greedy_search(const SearchArgs a) {
       NoVisited rv;
       search_body<Dist, NREG, FILT>(a, q, lane, dist, bv, rv);
     }
+  }
+}
+
+// ---- the one-wave quantized walk on two waves -------------------------------------------------------------
+// A quantizer whose table sits in LDS beside the walk (M x K <= 2 048) makes a hop a matter of instructions, not of
+// bytes: at 10M x 768, M = 8 a hop is ~7 200 cycles of ONE wave's instruction stream -- 1 550 the row and its code
+// rows, 2 100 the visited-set test, 500 the table sums, 3 050 AddWithLimit (profiles/r05_stamps_c4.txt) -- and a batch
+// of 1 024 queries is four lone waves per CU.  Here a query is two waves, and the stream is cut where its only
+// dependency allows:
+//   * the WALKER (wave 0) fetches the row, runs the visited-set test and the sums -- and names the next hop's node
+//     itself, from one fact about the candidate array (its first unvisited entry F1 after the last insertions) and
+//     this hop's distances: a new point lands in front of F1 iff its distance is smaller (distset.go:196-198 moves a
+//     point left while it is `<` its neighbour, so it stops behind every entry `<=` it), the smallest such point --
+//     if it is the only one at that distance -- is then the array's first unvisited entry (it is always inserted: at
+//     its turn the array's tail is F1 or a point not smaller than it; nothing inserted later is in front of it or
+//     overwrites it), and if there is none F1 stays where it is;
+//   * the MERGER (wave 1) owns the candidate array: it takes the hop's (slot, distance) points from LDS, runs
+//     AddWithLimit exactly as the one-wave kernel does, marks the named node, and answers with the next F1 -- while the
+//     walker is already at the named node's row.
+// Nothing is guessed: whenever the rule above does not apply -- no unvisited entry left, a point equal to F1, two points
+// sharing the smallest distance, a NaN among
+// the distances now or earlier (a NaN entry stops every later point behind it, distset.go:197) -- the walker names nothing, waits for the
+// merge and is told the next node (or that the walk is over) by the merger.
+// a 64-bit LDS word read / written as ONE ds instruction (a volatile access through a generic pointer compiles to
+// flat_load / flat_store with system scope: the aperture check and the vector-memory path cost a mailbox poll ~600 cycles)
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64_t;
+__device__ __forceinline__ unsigned long long lds_load_u64(const void *p) {
+  return *(lds_u64_t *)p;
+}
+__device__ __forceinline__ void lds_store_u64(void *p, unsigned long long v) { *(lds_u64_t *)p = v; }
+
+struct Pq2Shared {
+  // Both mailboxes are written by one lane with plain LDS stores, the word that carries the sequence number last: a
+  // wave's LDS instructions are performed in the order it issued them, so whoever sees the number sees what was written
+  // before it -- no s_waitcnt on either side (a workgroup-scope fence would wait for every store the wave has in flight).
+  uint2 pts_word;  // x: the node the walker goes to next, or kNoSlot: the merger says; y: batches posted (monotonic)
+  uint2 pts_mask;  // lanes of the batch that hold a point
+  uint2 ans_word;  // x: pts_word.x == kNoSlot: the first unvisited entry after the insertions (marked now), kNoSlot: none left; y: batches merged
+  uint2 ans_f1;    // the first unvisited entry behind the node the walk goes to (x: slot or kNoSlot, y: its distance's bits)
+  uint32_t pad[8];
+  uint32_t pts_id[64];
+  float pts_d[64];
+};
+constexpr uint32_t kPq2SharedWords = sizeof(Pq2Shared) / 4;
+
+template <class Visited>
+__device__ __forceinline__ void pq2_walker(const SearchArgs &a, const uint32_t q, const int lane, PQDist &dist, Visited &vis,
+                                           Pq2Shared *sh) {
+  uint32_t n_dist = 0, n_hop = 0, n_edges = 0, seq = 0;
+  bool seen_nan = false;
+#ifdef SDB_PQ2_STATS
+  uint32_t n_slow = 0;
+  unsigned long long w_t0 = __builtin_amdgcn_s_memtime(), w_tot0 = w_t0, w_acc[4] = {0, 0, 0, 0};  // front part, wait, naming + post, told
+#define SDB_PQ2_W(i)                                          \
+  {                                                           \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    w_acc[i] += _t - w_t0;                                    \
+    w_t0 = _t;                                                \
+  }
+#else
+#define SDB_PQ2_W(i)
+#endif
+  // one batch of points to the merger; `named`: where the walk goes next, if the walker knows
+  auto post = [&](uint64_t pend, uint32_t id, float d, uint32_t named) {
+    if ((pend >> lane) & 1ull) sh->pts_id[lane] = id, sh->pts_d[lane] = d;
+    seq++;
+    if (lane == 0) sh->pts_mask = make_uint2((uint32_t)pend, (uint32_t)(pend >> 32));
+    wave_lds_sync();
+    if (lane == 0) lds_store_u64(&sh->pts_word, (unsigned long long)named | ((unsigned long long)seq << 32));
+  };
+  uint32_t told = kNoSlot;  // the merger's word on where to go (read by answered())
+  auto answered = [&]() {   // the merger is through with everything posted
+    unsigned long long w;
+    while (w = lds_load_u64(&sh->ans_word), (uint32_t)(w >> 32) != seq) __builtin_amdgcn_s_sleep(1);
+    told = (uint32_t)w;
+    wave_lds_sync();
+  };
+  // ---- searchSet.AddWithLimit(startNode)  search.go:57-61: a batch of one point, the merger names the first node
+  {
+    const uint32_t s = a.start_slot;
+    const bool snew = vis.test_and_set(lane == 0, s, lane);
+    const uint64_t pend = __ballot(snew);
+    float d = 0.0f;
+    if (pend) d = dist.one(a, s, lane), n_dist++;
+    seen_nan = d != d;
+    post(pend, s, d, kNoSlot);
+  }
+  answered();
+  uint32_t pid = told;
+  // ---- main loop search.go:65-98
+  while (pid != kNoSlot) {
+#ifndef SDB_PQ2_STATS
+    if (lane == 0 && a.tr_visit && n_hop < a.visit_cap) a.tr_visit[(size_t)q * a.visit_cap + n_hop] = a.ids[pid];  // :73
+#endif
+    n_hop++;
+    const uint32_t *__restrict__ rowp = a.adj + (size_t)pid * kAdjStride;
+    dist.begin_row(a, rowp, lane);
+    const uint32_t nb = rowp[lane];  // node.neighbours in edge order :77-91
+    const bool valid = nb != kNoSlot;
+    n_edges += (uint32_t)__popcll(__ballot(valid));
+    dist.prefetch(a, nb, valid);
+    const bool isnew = vis.test_and_set(valid, nb, lane);  // CheckAndVisit distset.go:174
+    const uint64_t pend = __ballot(isnew);
+    float mydist = 0.0f;
+    if (pend) {
+      n_dist += (uint32_t)__popcll(pend);
+      mydist = dist.hop(a, nb, pend, lane);
+    } else {
+      dist.skip(lane);
+    }
+    const bool mine = (pend >> lane) & 1ull;
+    seen_nan = seen_nan || (__ballot(mine && mydist != mydist) != 0ull);
+#ifdef SDB_PQ2_STATS
+    asm volatile("" ::"v"(mydist));
+#endif
+    SDB_PQ2_W(0)
+    // the array after the LAST hop's insertions (the merger has had this hop's fetch, test and sums for them)
+    answered();
+    SDB_PQ2_W(1)
+    const uint2 f1w = sh->ans_f1;
+    const uint32_t f1 = f1w.x;
+    const float f1d = __uint_as_float(f1w.y);
+    uint32_t named = kNoSlot;
+    // (a point EQUAL to F1 goes behind it -- unless F1 is the full array's tail, which the point overwrites before it
+    // moves, distset.go:189-194: rare enough to leave to the merger as well)
+    if (!seen_nan && f1 != kNoSlot && !__ballot(mine && mydist == f1d)) {
+      uint32_t b1 = f1;
+      float b1d = f1d, b2d = f1d;  // the two smallest distances in front of F1, edge order among equals
+      for (uint64_t t = __ballot(mine && mydist < f1d); t; t &= t - 1) {
+        const int j = __ffsll((unsigned long long)t) - 1;
+        const float dj = rlf(mydist, j);
+        if (dj < b1d) b2d = b1d, b1d = dj, b1 = rl(nb, j);
+        else if (dj < b2d) b2d = dj;
+      }
+      // two points share the smallest distance: the first in edge order is in front -- unless it is the full array's
+      // tail when the second arrives and is overwritten by it (distset.go:189-194); left to the merger
+      if (b1 == f1 || b2d != b1d) named = b1;
+    }
+    post(pend, nb, mydist, named);
+    SDB_PQ2_W(2)
+    if (named == kNoSlot) {
+#ifdef SDB_PQ2_STATS  // measurement builds: hops the merger named, reported in place of n_edges
+      n_slow++;
+#endif
+      answered();
+      named = told;
+      SDB_PQ2_W(3)
+    }
+    pid = named;
+  }
+  if (lane == 0) {
+    if (a.tr_ndist) a.tr_ndist[q] = n_dist;
+    if (a.tr_nhop) a.tr_nhop[q] = n_hop;
+#ifdef SDB_PQ2_STATS
+    if (a.tr_nedges) a.tr_nedges[q] = n_slow;
+    if (a.tr_visit && a.visit_cap >= 8) {
+      for (int i = 0; i < 4; i++) a.tr_visit[(size_t)q * a.visit_cap + i] = w_acc[i];
+      a.tr_visit[(size_t)q * a.visit_cap + 4] = __builtin_amdgcn_s_memtime() - w_tot0;
+    }
+#else
+    if (a.tr_nedges) a.tr_nedges[q] = n_edges;
+#endif
+    if (a.vis_count) a.vis_count[q] = n_hop;
+    if (a.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
+      unsigned long long *t = a.totals + (q & 63u) * 16u;
+      atomicAdd(t, (unsigned long long)n_dist), atomicAdd(t + 1, (unsigned long long)n_edges);
+    }
+  }
+}
+
+__device__ __forceinline__ void pq2_merger(const SearchArgs &a, const uint32_t q, const int lane, Pq2Shared *sh, uint32_t *scratch) {
+  constexpr int NREG = 2;
+  uint32_t cid[NREG];
+  float cd[NREG];
+#pragma unroll
+  for (int r = 0; r < NREG; r++) cid[r] = kNoSlot, cd[r] = 0.0f;
+  int len = 0;
+  const int cap = (int)a.search_size;
+#ifdef SDB_PQ2_STATS
+  unsigned long long m_t0 = __builtin_amdgcn_s_memtime(), m_acc[3] = {0, 0, 0};  // waiting for points, AddWithLimit, mark + answer
+#define SDB_PQ2_M(i)                                          \
+  {                                                           \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    m_acc[i] += _t - m_t0;                                    \
+    m_t0 = _t;                                                \
+  }
+#else
+#define SDB_PQ2_M(i)
+#endif
+  for (uint32_t seq = 1;; seq++) {
+    unsigned long long w;
+    while (w = lds_load_u64(&sh->pts_word), (uint32_t)(w >> 32) != seq) __builtin_amdgcn_s_sleep(1);
+    wave_lds_sync();
+    SDB_PQ2_M(0)
+    const uint32_t named = (uint32_t)w;
+    const uint2 pm = sh->pts_mask;
+    const uint64_t pend = (uint64_t)pm.x | ((uint64_t)pm.y << 32);
+    const bool mine = (pend >> lane) & 1ull;
+    const uint32_t id = mine ? sh->pts_id[lane] : kNoSlot;
+    const float d = mine ? sh->pts_d[lane] : 0.0f;
+    // AddWithLimit over the new neighbours, in edge order distset.go:184-198
+    if (pend) add_with_limit_merge(cid, cd, len, cap, id, d, pend, lane, scratch);
+#ifdef SDB_PQ2_STATS
+    asm volatile("" ::"v"(cd[0]));
+#endif
+    SDB_PQ2_M(1)
+    // the node the walk goes to -- named by the walker, or the first unvisited entry (search.go:66-71) -- is marked :74
+    uint64_t um[NREG];  // the array's unvisited entries, by position
+#pragma unroll
+    for (int r = 0; r < NREG; r++) um[r] = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
+    int sel = -1;
+    if (named != kNoSlot) {
+#pragma unroll
+      for (int r = 0; r < NREG; r++) {
+        const uint64_t m = __ballot((r * 64 + lane) < len && cid[r] == named);
+        if (m) sel = r * 64 + __ffsll((unsigned long long)m) - 1;
+      }
+    } else {
+#pragma unroll
+      for (int r = NREG - 1; r >= 0; r--)
+        if (um[r]) sel = r * 64 + __ffsll((unsigned long long)um[r]) - 1;
+    }
+    uint32_t next = kNoSlot;
+#pragma unroll
+    for (int r = 0; r < NREG; r++)
+      if (sel >= 0 && (sel >> 6) == r) {
+        next = rl(cid[r], sel & 63);
+        if (lane == (sel & 63)) cid[r] |= kVisBit;
+        um[r] &= ~(1ull << (sel & 63));
+      }
+    // the first unvisited entry behind it: what the walker names the hop after this one with
+    uint32_t f1 = kNoSlot;
+    float f1d = 0.0f;
+#pragma unroll
+    for (int r = NREG - 1; r >= 0; r--)
+      if (um[r]) {
+        const int s2 = __ffsll((unsigned long long)um[r]) - 1;
+        f1 = rl(cid[r], s2), f1d = rlf(cd[r], s2);
+      }
+    if (lane == 0) sh->ans_f1 = make_uint2(f1, __float_as_uint(f1d));
+    wave_lds_sync();
+    if (lane == 0) lds_store_u64(&sh->ans_word, (unsigned long long)next | ((unsigned long long)seq << 32));
+    SDB_PQ2_M(2)
+    if (named == kNoSlot && next == kNoSlot) break;  // no unvisited entry left :66-71 -- the walker has been waiting for this
+  }
+#ifdef SDB_PQ2_STATS
+  if (lane == 0 && a.tr_visit && a.visit_cap >= 8)
+    for (int i = 0; i < 3; i++) a.tr_visit[(size_t)q * a.visit_cap + 5 + i] = m_acc[i];
+#endif
+  // ---- IndexVamana.Search result copy vamana.go:293-307
+  if (a.out_ids) {
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+      const uint32_t s = cid[r] & ~kVisBit;
+      const bool ok = (r * 64 + lane) < len && s != a.start_slot;  // :294-296
+      const uint64_t m = __ballot(ok);
+      const int rank = base + __popcll(m & ((1ull << lane) - 1));
+      if (ok && rank < (int)a.limit) {  // :297-299
+        a.out_ids[(size_t)q * a.limit + rank] = a.ids[s];
+        a.out_dists[(size_t)q * a.limit + rank] = cd[r];
+      }
+      base += __popcll(m);
+    }
+    const int got = base < (int)a.limit ? base : (int)a.limit;
+    if (lane == 0) a.out_counts[q] = (uint32_t)got;
+    for (int i = got + lane; i < (int)a.limit; i += 64)
+      a.out_ids[(size_t)q * a.limit + i] = 0, a.out_dists[(size_t)q * a.limit + i] = 0.0f;
+  }
+}
+
+// Dynamic LDS: [visited set's table][the query's M x K table][Pq2Shared].  Unfiltered searches with searchSize <= 128,
+// no visit log for a build, no overflow list on the start node (index.hip launch_greedy_search decides).
+// (A workgroup of four waves with the walker on wave (blockIdx / 256) % 4 and the merger two SIMDs on -- the placement
+// trick of k_greedy_search_pqw -- was slower: 0.370 against 0.323 ms at 4M x 768.)
+template <uint32_t HCAP>
+__global__ __launch_bounds__(128) void k_greedy_search_pq2(const SearchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t q = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  __shared__ uint32_t s_scatter2[2 * 2 * 64];  // add_with_limit_merge scratch
+  constexpr uint32_t kVisWords = HCAP == kHash16 ? HashVisited16::kWords : HashVisited<HCAP == kHash16 ? 4u : HCAP>::kWords;
+  float *lut = lds_f + kVisWords;
+  Pq2Shared *sh = reinterpret_cast<Pq2Shared *>(lut + ((a.pq_M * a.pq_K + 3u) & ~3u));
+  uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
+  if (wave == 1) {
+    const float *g = a.pq_lut + (size_t)q * a.pq_M * a.pq_K;
+    for (uint32_t i = lane; i < a.pq_M * a.pq_K; i += 64) lut[i] = g[i];
+    if (lane == 0) sh->pts_word = make_uint2(kNoSlot, 0u), sh->ans_word = make_uint2(kNoSlot, 0u);
+    __syncthreads();  // table, visited set and mailbox in place
+    return pq2_merger(a, q, lane, sh, s_scatter2);
+  }
+  PQDist dist;
+  dist.lut = lut;
+  if constexpr (HCAP == kHash16) {
+    HashVisited16 hv;
+    hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
+    __syncthreads();
+    pq2_walker(a, q, lane, dist, hv, sh);
+  } else {
+    HashVisited<HCAP == kHash16 ? 4u : HCAP> hv;
+    hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
+    __syncthreads();
+    pq2_walker(a, q, lane, dist, hv, sh);
   }
 }
 

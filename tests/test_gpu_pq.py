@@ -147,6 +147,38 @@ def test_pq_search_parity(oracle, metric, d, M, K):
         g2 = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
         assert np.array_equal(g2[0], g_ids) and np.array_equal(bits(g2[1]), bits(g_d))
         assert np.array_equal(g2[3].visit_ids, tr.visit_ids)
+    # the default is the two-wave kernel (walker + merger, search_kernel.h k_greedy_search_pq2); the one-wave kernel
+    # (SDB_TUNE_PQ_NARROW = 1), also with the other visited sets, walks the same path
+    for key in ("pq_narrow", "wide_hash"):
+        ix.set_tuning(key, 1)
+        g2 = ix.search_batch(q, 10, 50, trace=True, visit_cap=512)
+        ix.set_tuning(key, 0)
+        assert np.array_equal(g2[0], g_ids) and np.array_equal(bits(g2[1]), bits(g_d)), key
+        assert np.array_equal(g2[3].visit_ids, tr.visit_ids) and np.array_equal(g2[3].n_dist, tr.n_dist), key
+        assert np.array_equal(g2[3].n_edges, tr.n_edges) and np.array_equal(g2[3].n_hop, tr.n_hop), key
+    # queries that make the table non-finite (a NaN component: every sum NaN; components that overflow: +-inf and NaN
+    # sums side by side) -- the walker names nothing then and the merger's insertions decide every hop (distset.go:184-198
+    # with NaN: `d > tail` is false, `d < items[i-1]` is false)
+    from tests.test_gpu_nonfinite import same_bits_or_both_nan  # (a NaN's payload is the one thing the machines do not share)
+    qn = q[:8].copy()
+    qn[0, 3] = np.nan
+    qn[1, :] = np.float32(3e38)
+    qn[2, ::2] = np.float32(-3e38)
+    qn[3, 0] = np.inf
+    qn[4, : d // 2] = np.float32(2e38)
+    with np.errstate(all="ignore"):
+        n_ids, n_d, n_c, n_tr = ix.search_batch(qn, 10, 50, trace=True, visit_cap=512)
+        for k in range(8):
+            o_ids, o_d, o_vis, o_tr = o.search(qn[k], 10, 50)
+            assert int(n_c[k]) == len(o_ids), k
+            assert np.array_equal(n_ids[k, :len(o_ids)], o_ids) and same_bits_or_both_nan(n_d[k, :len(o_ids)], o_d), k
+            assert int(n_tr.n_hop[k]) == o_tr.n_hop and int(n_tr.n_dist[k]) == o_tr.n_dist, k
+            assert np.array_equal(n_tr.visit_ids[k, :o_tr.n_hop], o_vis), k
+        ix.set_tuning("pq_narrow", 1)
+        n2 = ix.search_batch(qn, 10, 50, trace=True, visit_cap=512)
+        ix.set_tuning("pq_narrow", 0)
+        assert np.array_equal(n2[0], n_ids) and same_bits_or_both_nan(n2[1], n_d)
+        assert np.array_equal(n2[3].visit_ids, n_tr.visit_ids)
     # filtered search over the quantized store: seeds and result set use the LUT distance too
     filters = [set(int(v) for v in rng.choice(ids[1:], size=40, replace=False)) for _ in range(32)]
     f_ids, f_d, f_c, f_tr = ix.search_batch(q, 5, 50, filters=filters, trace=True, visit_cap=512)
@@ -348,9 +380,9 @@ def test_quantized_walk_is_the_same_under_every_visited_set(oracle):
     # hash16_probes 1 / 2: a key whose first (two) bucket(s) are full sends the walk to the bitset -- the `stuck` spill,
     # a one-in-ten-million event with the full budget of 15 buckets
     for key, value in [("wide_hash", 1), ("no_hash", 1), ("hash_limit", 40), ("hash_limit", 600), ("hash16_probes", 1),
-                       ("hash16_probes", 2)]:
+                       ("hash16_probes", 2), ("pq_narrow", 1)]:
         ix.set_tuning("wide_hash", 0), ix.set_tuning("no_hash", 0), ix.set_tuning("hash_limit", 0)
-        ix.set_tuning("hash16_probes", 0)
+        ix.set_tuning("hash16_probes", 0), ix.set_tuning("pq_narrow", 0)
         ix.set_tuning(key, value)
         got = ix.search_batch(q, 10, L, trace=True, visit_cap=1024)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), key
