@@ -23,7 +23,7 @@ cal = [v for k, v in per.items() if k.startswith("k_index_distance")][0][-1]
 factor = exp["calibration"]["bytes"] / (cal * 1024)   # FETCH_SIZE is in KB; the gfx950 correction comes out of the calibration
 res = {"M": M, "rows": exp["n"], "dim": exp["dim"], "fetch_correction_factor": round(factor, 3)}
 for k, v in per.items():
-    if k.startswith("k_greedy_search") and ("PQDist" in k or "pqw" in k) and len(v) >= 5:  # not the build's walks
+    if k.startswith("k_greedy_search") and ("PQDist" in k or "pqw" in k or "pq2" in k) and len(v) >= 5:  # not the build's walks
         last = v[-5:]
         rows = []
         for fs, e in zip(last, exp["search"]):
