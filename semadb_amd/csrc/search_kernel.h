@@ -784,6 +784,25 @@ struct PQDist {
     pre = make_uint2(0u, 0u);
     if (a.pq_M == 8 && valid && !row_codes) pre = *reinterpret_cast<const uint2 *>(a.pq_codes + (size_t)nb * 8);
   }
+  // M == 8 with the code row at hand (it came with the row of ids): the eight table entries can be asked for AHEAD of
+  // the visited-set test, whose first LDS round trip then covers theirs, and summed after it (k_greedy_search_pq2)
+  __device__ __forceinline__ bool ahead8(const SearchArgs &a) const { return a.pq_M == 8 && pre_ready; }
+  __device__ __forceinline__ void load8(const SearchArgs &a, bool valid, float (&t)[8]) const {
+    const uint32_t K = a.pq_K;
+    const uint32_t x = valid ? pre.x : 0u, y = valid ? pre.y : 0u;
+    t[0] = lut[0 * K + (x & 0xFF)], t[1] = lut[1 * K + ((x >> 8) & 0xFF)];
+    t[2] = lut[2 * K + ((x >> 16) & 0xFF)], t[3] = lut[3 * K + (x >> 24)];
+    t[4] = lut[4 * K + (y & 0xFF)], t[5] = lut[5 * K + ((y >> 8) & 0xFF)];
+    t[6] = lut[6 * K + ((y >> 16) & 0xFF)], t[7] = lut[7 * K + (y >> 24)];
+  }
+  __device__ __forceinline__ float sum8(const float (&t)[8], uint64_t pend, int lane) {
+    row_codes = nullptr, pre_ready = false;
+    if (!((pend >> lane) & 1ull)) return 0.0f;
+    float dist = 0.0f;  // the same sequential adds in index order (product.go:271-275)
+#pragma unroll
+    for (int i = 0; i < 8; i++) dist += t[i];
+    return dist;
+  }
   __device__ __forceinline__ float hop(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane) {
     const uint8_t *rc = row_codes;
     const bool ready = pre_ready;
@@ -1937,12 +1956,15 @@ __device__ __forceinline__ void pq2_walker(const SearchArgs &a, const uint32_t q
     const bool valid = nb != kNoSlot;
     n_edges += (uint32_t)__popcll(__ballot(valid));
     dist.prefetch(a, nb, valid);
+    const bool ahead8 = dist.ahead8(a);
+    float t8[8];
+    if (ahead8) dist.load8(a, valid, t8);
     const bool isnew = vis.test_and_set(valid, nb, lane);  // CheckAndVisit distset.go:174
     const uint64_t pend = __ballot(isnew);
     float mydist = 0.0f;
     if (pend) {
       n_dist += (uint32_t)__popcll(pend);
-      mydist = dist.hop(a, nb, pend, lane);
+      mydist = ahead8 ? dist.sum8(t8, pend, lane) : dist.hop(a, nb, pend, lane);
     } else {
       dist.skip(lane);
     }
