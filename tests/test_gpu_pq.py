@@ -526,3 +526,51 @@ def test_neighbour_code_rows_follow_the_graph(oracle, d, M, K):
     # and a second quantizer with another layout replaces the first
     ix.close()
     gpq.close()
+
+
+@pytest.mark.parametrize("metric,d,M,K", [("euclidean", 32, 8, 2), ("cosine", 32, 4, 4), ("dot", 48, 16, 16), ("euclidean", 24, 2, 3),
+                                          ("cosine", 64, 32, 8), ("euclidean", 40, 8, 256)])
+def test_two_wave_walk_names_what_the_array_says(metric, d, M, K):
+    """k_greedy_search_pq2's walker names the next node from the array's first unvisited entry and the hop's distances
+    instead of waiting for AddWithLimit.  The rule's edge is equal distances and the array's tail: a point equal to the
+    entry it is compared with, two points sharing the smallest distance, an entry that a full array drops.  Coarse
+    quantizers (K = 2 .. 16: a handful of distinct sums, ties in every hop) over every searchSize from a nearly empty
+    array to the reference's maximum, against the one-wave kernel (SDB_TUNE_PQ_NARROW = 1: AddWithLimit as written,
+    itself held to the oracle above): ids, distance bits, visit order, the three counters, query by query."""
+    from semadb_amd import vamana, vectorstore as vs
+    from tests.helpers import start_vector
+    rng = np.random.default_rng(7000 + 31 * M + K)
+    n = 6000
+    lat = rng.standard_normal((6, d)).astype(np.float32)
+    base = rng.standard_normal((n, 6)).astype(np.float32) @ lat + 0.1 * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    ix = vamana.NewIndexVamana("tw", vamana.IndexVectorVamanaParameters(d, metric, 64, 32, 1.2), strict=False)
+    ix.set_start(start_vector(np.random.default_rng(5), d))
+    ix.insert_batch(None, base)
+    pq = vs.ProductQuantizer(metric, vs.ProductQuantizerParameters(K, M), d)
+    pq.Fit(base[:1500].copy(), rng.integers(0, 1500, M), alias=True)
+    vs.attach(ix, pq)
+    q = base[rng.choice(n, 512, replace=False)] + 0.05 * rng.standard_normal((512, d)).astype(np.float32)
+    # (the two-wave kernel serves tables of up to 2 048 entries on graphs whose start node has no overflow list --
+    # index.hip pq_two_waves; rocprofv3 --kernel-trace of this test shows k_greedy_search_pq2 beside k_greedy_search<PQDist>)
+    assert M * K <= 2048
+    _, _, g_off, _ = ix.export(with_vectors=False)
+    assert int(g_off[1] - g_off[0]) <= 64
+    ties = 0
+    for L in (1, 2, 3, 5, 10, 17, 33, 64, 75, 96):
+        ix.set_tuning("pq_narrow", 0)
+        two = ix.search_batch(q, min(10, L), L, trace=True, visit_cap=512)
+        ix.set_tuning("pq_narrow", 1)
+        one = ix.search_batch(q, min(10, L), L, trace=True, visit_cap=512)
+        assert np.array_equal(two[2], one[2]), L
+        assert np.array_equal(two[0], one[0]) and np.array_equal(bits(two[1]), bits(one[1])), L
+        assert np.array_equal(two[3].visit_ids, one[3].visit_ids), L
+        for f in ("n_dist", "n_hop", "n_edges"):
+            assert np.array_equal(getattr(two[3], f), getattr(one[3], f)), (L, f)
+        dd = two[1][:, : min(10, L)]
+        ties += int((dd[:, 1:] == dd[:, :-1]).sum())
+    ix.set_tuning("pq_narrow", 0)
+    if K ** M <= 4096:  # a few hundred distinct sums at most
+        assert ties > 100, ties  # the case the test is about did occur: equal distances among the results themselves
+    ix.close()
+    pq.close()
