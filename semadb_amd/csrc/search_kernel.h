@@ -212,7 +212,10 @@ struct PlainDist {
   static constexpr bool kPointDistances = true;  // dist(query, row) is distFn between two stored vectors
   // search_body: nothing is worked ahead on between the hops.  (Round 5 tried the walker's naming of the next hop's row
   // here too -- its adjacency row asked for under AddWithLimit, a round trip less per hop in the batch's tail: 0.983
-  // against 0.975 ms per batch, the naming's ~300 instructions per hop cost a lone wave more than the hidden latency.)
+  // against 0.975 ms per batch, the naming's ~300 instructions per hop cost a lone wave more than the hidden latency.
+  // The cheap half -- no naming, only the adjacency row of the array's first unvisited entry asked for before
+  // AddWithLimit and taken from the register when the walk does go there -- made no difference at all: 0.955 / 0.958 /
+  // 0.957 against 0.957 / 0.954 / 0.973 ms in alternating runs; the batch walk is bound by bytes, not by a wave's round trips.)
   static constexpr bool kSpeculate = false;
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = UPAIRS ? UPAIRS : (NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4);
