@@ -239,7 +239,8 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        more than 64 KB (M = 128 .. 384 at K = 256) in global memory (round 2) instead of the four-wave
  *                        walk that keeps it in LDS and registers, a table of up to 8 KB (M = 8 at K = 256) without the
  *                        second wave that runs AddWithLimit (round 5); 2: M = 192 takes the four-wave variant with one
- *                        query per CU instead of two
+ *                        query per CU instead of two; 3: the four-wave walk of M = 128 / 192 keeps the candidate array in
+ *                        the walker instead of in the helper wave next to it
  *   SDB_TUNE_WIDE_WALK   the walk of calls with few queries (one REST request is one query, vamana.go:278-310): a
  *                        workgroup of sixteen waves per query -- one walks, all split every hop's rows and compute the
  *                        likely next hop's distances ahead -- instead of one wave per query (eight waves for 257 .. 512

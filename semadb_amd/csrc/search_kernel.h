@@ -848,10 +848,14 @@ struct PQDist {
 // Barriers per chunk (all four waves): B0 row published, B1 pending mask published, then one per wave's turn.
 struct PQWideShared {
   unsigned long long rowp;  // mode 1: the adjacency chunk to expand
-  uint32_t mode;            // 0: the walk is over, 1: expand rowp, 2: the single point `slot` (start node)
+  uint32_t mode;            // 0: the walk is over, 1: expand rowp, 2: the single point `slot` (start node), 3: (split form) the merger inserts what it holds and names the next node
   uint32_t slot;
   unsigned long long pend;  // lanes whose neighbour passed CheckAndVisit
-  uint32_t pad[2];
+  // the split form (k_greedy_search_pqw<..., SPLIT>: the candidate array lives in a helper wave, the merger)
+  uint32_t named;  // walker -> merger, with mode 1 / 3: the node the walk went to after the chunk the merger still holds, kNoSlot: the merger picks
+  uint32_t next;   // merger -> walker, mode 3: the node it picked (marked), kNoSlot: no unvisited entry left
+  uint32_t f1;     // merger -> walker: the first unvisited entry behind the node the walk went to, kNoSlot: none
+  float f1d;
   float psum[64];           // partial sums on their way from wave to wave, by lane
 };
 constexpr uint32_t kPqwSharedWords = sizeof(PQWideShared) / 4;
@@ -859,6 +863,13 @@ constexpr uint32_t kPqwSharedWords = sizeof(PQWideShared) / 4;
 // NL / RT: tables per wave in LDS / in registers (NL + RT a multiple of 16); W: waves per query, M = W (NL + RT).
 // W = 8 (two waves per SIMD, 256 registers each) carries M = 384 with the per-wave layout of M = 192: round 3's
 // four-wave form of it kept 64 tables = 256 registers per wave and spilled 80 more.
+template <int NREG>  // (defined with the candidate array's other operations below)
+__device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap, uint32_t idreg,
+                                                     float mydist, uint64_t pd, int lane, uint32_t *scratch
+#ifdef SDB_STAMPS
+                                                     , unsigned long long *mst
+#endif
+);
 template <int NL, int RT, int W = 4>
 struct PQWideDist {
   // Fetching ahead (search_body, Dist::kSpeculate) was built for this walk too -- every wave fetched the likely next
@@ -958,9 +969,17 @@ struct PQWideDist {
   // ---- the walker's side (wave 0): the policy interface search_body calls
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
+  uint32_t post_named = kNoSlot;  // split form: what begin_row tells the merger about the chunk before this one
   __device__ __forceinline__ void begin_row(const SearchArgs &, const uint32_t *rowp, int lane) {
-    if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u;
+    if (lane == 0) sh->rowp = reinterpret_cast<unsigned long long>(rowp), sh->mode = 1u, sh->named = post_named;
     __syncthreads();  // B0
+  }
+  // split form: the merger inserts the chunk it holds, picks the first unvisited entry and says which (B0, B1)
+  __device__ __forceinline__ uint32_t ask_next(int lane) {
+    if (lane == 0) sh->mode = 3u, sh->named = kNoSlot;
+    __syncthreads();  // B0
+    __syncthreads();  // B1: the answer is there
+    return sh->next;
   }
   __device__ __forceinline__ void prefetch(const SearchArgs &a, uint32_t nb, bool) { load_codes(a, nb); }
   __device__ __forceinline__ void skip(int lane) {
@@ -975,7 +994,7 @@ struct PQWideDist {
     return turns(val);
   }
   __device__ __forceinline__ float one(const SearchArgs &a, uint32_t s, int lane) {
-    if (lane == 0) sh->slot = s, sh->mode = 2u;
+    if (lane == 0) sh->slot = s, sh->mode = 2u, sh->named = kNoSlot;
     __syncthreads();  // B0
     load_codes(a, lane == 0 ? s : kNoSlot);
     return rlf(hop(a, s, 1ull, lane), 0);
@@ -985,11 +1004,76 @@ struct PQWideDist {
     __syncthreads();  // B0: the helpers leave
   }
   // ---- waves 1..3
-  __device__ __forceinline__ void serve(const SearchArgs &a, int lane) {
+  // MERGER (split form): this helper also owns the candidate array.  It keeps the chunk it has just helped to sum -- the
+  // row's slots, the finished sums, the pending mask: every wave has them -- and runs AddWithLimit over it one round
+  // LATER, after the next row's codes have been asked for and while the walker runs that row's visited-set test; then
+  // it marks the node the walker went to and leaves the first unvisited entry behind it in sh->f1 before B1, which is
+  // when the walker needs it: after that round's sums.  No polling: the walk's own barriers order every word.
+  template <bool MERGER = false>
+  __device__ __forceinline__ void serve(const SearchArgs &a, int lane, const uint32_t q = 0, uint32_t *scratch = nullptr) {
+    constexpr int NREG = 2;
+    uint32_t cid[MERGER ? NREG : 1];
+    float cd[MERGER ? NREG : 1];
+    int len = 0;
+    const int cap = (int)a.search_size;
+    uint32_t h_nb = kNoSlot;  // the chunk held back
+    float h_d = 0.0f;
+    uint64_t h_pend = 0;
+    bool held = false;
+    if constexpr (MERGER) {
+#pragma unroll
+      for (int r = 0; r < NREG; r++) cid[r] = kNoSlot, cd[r] = 0.0f;
+    }
+    // AddWithLimit over the chunk held back (distset.go:184-198), then the node the walk went to -- named by the walker,
+    // or the first unvisited entry (search.go:66-71) -- is marked :74; answers in sh->next / f1 / f1d
+    auto settle = [&](uint32_t named) {
+      if constexpr (MERGER) {
+        if (h_pend) add_with_limit_merge(cid, cd, len, cap, h_nb, h_d, h_pend, lane, scratch);
+        held = false, h_pend = 0;
+        uint64_t um[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; r++) um[r] = __ballot((r * 64 + lane) < len && !(cid[r] & kVisBit));
+        int sel = -1;
+        if (named != kNoSlot) {
+#pragma unroll
+          for (int r = 0; r < NREG; r++) {
+            const uint64_t m = __ballot((r * 64 + lane) < len && cid[r] == named);
+            if (m) sel = r * 64 + __ffsll((unsigned long long)m) - 1;
+          }
+        } else {
+#pragma unroll
+          for (int r = NREG - 1; r >= 0; r--)
+            if (um[r]) sel = r * 64 + __ffsll((unsigned long long)um[r]) - 1;
+        }
+        uint32_t next = kNoSlot;
+#pragma unroll
+        for (int r = 0; r < NREG; r++)
+          if (sel >= 0 && (sel >> 6) == r) {
+            next = rl(cid[r], sel & 63);
+            if (lane == (sel & 63)) cid[r] |= kVisBit;
+            um[r] &= ~(1ull << (sel & 63));
+          }
+        uint32_t f1 = kNoSlot;
+        float f1d = 0.0f;
+#pragma unroll
+        for (int r = NREG - 1; r >= 0; r--)
+          if (um[r]) {
+            const int s2 = __ffsll((unsigned long long)um[r]) - 1;
+            f1 = rl(cid[r], s2), f1d = rlf(cd[r], s2);
+          }
+        if (lane == 0) sh->next = next, sh->f1 = f1, sh->f1d = f1d;
+      }
+    };
     for (;;) {
       __syncthreads();  // B0
       const uint32_t mode = sh->mode;
-      if (mode == 0u) return;
+      if (mode == 0u) break;
+      if (mode == 3u) {
+        if constexpr (MERGER) settle(kNoSlot);
+        __syncthreads();  // B1
+        continue;
+      }
+      const uint32_t named = sh->named;
       uint32_t nb;
       if (mode == 1u) nb = reinterpret_cast<const uint32_t *>(sh->rowp)[lane];
       else nb = lane == 0 ? sh->slot : kNoSlot;
@@ -999,10 +1083,37 @@ struct PQWideDist {
       // walker's CheckAndVisit (1.59 -> 1.47 ms per batch at 1M x 768).  The two-per-CU variant has no registers to
       // keep 48 values across the barrier -- there it cost 1.38 -> 1.89 ms in spills -- and looks up after it.
       if constexpr (NL >= 16) lookups<0>(val);
+      if constexpr (MERGER)
+        if (held) settle(named);
       __syncthreads();  // B1
-      if (sh->pend == 0ull) continue;
+      const uint64_t pend = sh->pend;
+      if constexpr (MERGER) held = true, h_nb = nb, h_pend = pend, h_d = 0.0f;
+      if (pend == 0ull) continue;
       if constexpr (NL < 16) lookups<0>(val);
-      (void)turns(val);
+      const float sum = turns(val);
+      if constexpr (MERGER) h_d = sum;
+    }
+    if constexpr (MERGER) {
+      // ---- IndexVamana.Search result copy vamana.go:293-307
+      if (a.out_ids) {
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+          const uint32_t s = cid[r] & ~kVisBit;
+          const bool ok = (r * 64 + lane) < len && s != a.start_slot;  // :294-296
+          const uint64_t m = __ballot(ok);
+          const int rank = base + __popcll(m & ((1ull << lane) - 1));
+          if (ok && rank < (int)a.limit) {  // :297-299
+            a.out_ids[(size_t)q * a.limit + rank] = a.ids[s];
+            a.out_dists[(size_t)q * a.limit + rank] = cd[r];
+          }
+          base += __popcll(m);
+        }
+        const int got = base < (int)a.limit ? base : (int)a.limit;
+        if (lane == 0) a.out_counts[q] = (uint32_t)got;
+        for (int i = got + lane; i < (int)a.limit; i += 64)
+          a.out_ids[(size_t)q * a.limit + i] = 0, a.out_dists[(size_t)q * a.limit + i] = 0.0f;
+      }
     }
   }
 };
@@ -2182,6 +2293,79 @@ __global__ __launch_bounds__(128) void k_greedy_search_pq2(const SearchArgs a) {
   }
 }
 
+// The walker of the multi-wave quantized walk in its split form: k_greedy_search_pq2's division of labour inside
+// k_greedy_search_pqw.  The candidate array lives in a helper wave (PQWideDist::serve<true>, the merger), which inserts
+// a hop's points one round late, under the next row's code fetch and visited-set test; this wave names the next node
+// from the array's first unvisited entry and the hop's sums, by the rule and with the exceptions described above
+// pq2_walker -- when the rule does not apply it asks (a round of two barriers) and the merger picks.
+template <class Dist, class Visited>
+__device__ __forceinline__ void pqw_split_walker(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist, Visited &vis) {
+  uint32_t n_dist = 0, n_hop = 0, n_edges = 0;
+  bool seen_nan = false;
+  // ---- searchSet.AddWithLimit(startNode)  search.go:57-61
+  {
+    const uint32_t s = a.start_slot;
+    const bool snew = vis.test_and_set(lane == 0, s, lane);
+    if (__ballot(snew)) {
+      const float d = dist.one(a, s, lane);
+      n_dist++;
+      seen_nan = d != d;
+    }
+  }
+  uint32_t pid = dist.ask_next(lane);
+  dist.post_named = kNoSlot;
+  // ---- main loop search.go:65-98
+  while (pid != kNoSlot) {
+    if (lane == 0 && a.tr_visit && n_hop < a.visit_cap) a.tr_visit[(size_t)q * a.visit_cap + n_hop] = a.ids[pid];  // :73
+    n_hop++;
+    const uint32_t *__restrict__ rowp = a.adj + (size_t)pid * kAdjStride;
+    dist.begin_row(a, rowp, lane);
+    const uint32_t nb = rowp[lane];  // node.neighbours in edge order :77-91
+    const bool valid = nb != kNoSlot;
+    n_edges += (uint32_t)__popcll(__ballot(valid));
+    dist.prefetch(a, nb, valid);
+    const bool isnew = vis.test_and_set(valid, nb, lane);  // CheckAndVisit distset.go:174
+    const uint64_t pend = __ballot(isnew);
+    float mydist = 0.0f;
+    if (pend) {
+      n_dist += (uint32_t)__popcll(pend);
+      mydist = dist.hop(a, nb, pend, lane);
+    } else {
+      dist.skip(lane);
+    }
+    const bool mine = (pend >> lane) & 1ull;
+    seen_nan = seen_nan || (__ballot(mine && mydist != mydist) != 0ull);
+    // the array after the LAST hop's insertions and with this hop's node marked: written by the merger before this
+    // round's second barrier
+    const uint32_t f1 = dist.sh->f1;
+    const float f1d = dist.sh->f1d;
+    uint32_t named = kNoSlot;
+    if (!seen_nan && f1 != kNoSlot && !__ballot(mine && mydist == f1d)) {
+      uint32_t b1 = f1;
+      float b1d = f1d, b2d = f1d;  // the two smallest distances in front of F1, edge order among equals
+      for (uint64_t t = __ballot(mine && mydist < f1d); t; t &= t - 1) {
+        const int j = __ffsll((unsigned long long)t) - 1;
+        const float dj = rlf(mydist, j);
+        if (dj < b1d) b2d = b1d, b1d = dj, b1 = rl(nb, j);
+        else if (dj < b2d) b2d = dj;
+      }
+      if (b1 == f1 || b2d != b1d) named = b1;
+    }
+    dist.post_named = named;  // (with the next row; kNoSlot: the merger has settled by then)
+    pid = named != kNoSlot ? named : dist.ask_next(lane);
+  }
+  if (lane == 0) {
+    if (a.tr_ndist) a.tr_ndist[q] = n_dist;
+    if (a.tr_nhop) a.tr_nhop[q] = n_hop;
+    if (a.tr_nedges) a.tr_nedges[q] = n_edges;
+    if (a.vis_count) a.vis_count[q] = n_hop;
+    if (a.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
+      unsigned long long *t = a.totals + (q & 63u) * 16u;
+      atomicAdd(t, (unsigned long long)n_dist), atomicAdd(t + 1, (unsigned long long)n_edges);
+    }
+  }
+}
+
 // The multi-wave quantized walk: one query per workgroup of four waves (PQWideDist above).  Dynamic LDS: the visited
 // set's table, the command area, the LDS-resident tables [4][NL][K].
 // NL < 16: the variant meant to run two queries per CU (half the LDS each) -- its registers are capped accordingly
@@ -2189,7 +2373,8 @@ __global__ __launch_bounds__(128) void k_greedy_search_pq2(const SearchArgs a) {
 // (candidate array, visited set, ~100 registers) on top of what every wave holds; at eight waves per query (M = 384,
 // 256 registers per wave) that state plus 33 register tables plus the 48 looked-up values did not fit -- 43 registers
 // spilled.  There the walker takes 24 of its 48 tables from LDS and 24 from registers; the helpers keep 15 + 33.
-template <int NL, int RT, uint32_t HCAP, int W = 4, int NLW = NL>
+// SPLIT: the candidate array lives in the helper next to the walker (pqw_split_walker, PQWideDist::serve<true>)
+template <int NL, int RT, uint32_t HCAP, int W = 4, int NLW = NL, bool SPLIT = false>
 __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_search_pqw(const SearchArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2208,11 +2393,14 @@ __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_
   using Walker = PQWideDist<NLW, NL + RT - NLW, W>;
   using Helper = PQWideDist<NL, RT, W>;
   uint32_t *bits = a.bitsets + (size_t)q * a.words_per_query;
+  __shared__ uint32_t s_scatter_m[SPLIT ? 2 * 2 * 64 : 1];  // the merger's add_with_limit_merge scratch
   if (wave != walker) {
     Helper dist;
     // (NLW != NL: the walker is wave 0 and its NLW tables come first in the block)
     dist.init_wave(a, q, lane, wave, lut_lds, sh, NLW == NL ? (uint32_t)wave * NL : (uint32_t)(NLW + (wave - 1) * NL));
     __syncthreads();  // tables and visited set in place
+    if constexpr (SPLIT)
+      if (wave == ((walker + 1) & (W - 1))) return dist.template serve<true>(a, lane, q, s_scatter_m);
     return dist.serve(a, lane);
   }
   Walker dist;
@@ -2222,12 +2410,14 @@ __global__ __launch_bounds__(64 * W, (NL < 16 && W == 4) ? 2 : 1) void k_greedy_
     HashVisited16 hv;
     hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit, a.hash16_probes);
     __syncthreads();  // tables and visited set in place
-    search_body<Walker, 2, false>(a, q, lane, dist, hv, rv);
+    if constexpr (SPLIT) pqw_split_walker(a, q, lane, dist, hv);
+    else search_body<Walker, 2, false>(a, q, lane, dist, hv, rv);
   } else {
     HashVisited<HCAP == kHash16 ? 4u : HCAP> hv;
     hv.init_nosync(reinterpret_cast<uint32_t *>(lds_f), bits, a.words_per_query, lane, a.hash_limit);
     __syncthreads();
-    search_body<Walker, 2, false>(a, q, lane, dist, hv, rv);
+    if constexpr (SPLIT) pqw_split_walker(a, q, lane, dist, hv);
+    else search_body<Walker, 2, false>(a, q, lane, dist, hv, rv);
   }
   dist.finish(lane);
 }

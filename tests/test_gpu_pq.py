@@ -442,7 +442,8 @@ def test_multi_wave_quantized_walk_parity(oracle, metric, d, M, K):
         assert np.array_equal(bits(g_d[k, :len(o_ids)]), bits(o_d)), k
         assert int(tr.n_hop[k]) == o_tr.n_hop and int(tr.n_dist[k]) == o_tr.n_dist, k
         assert np.array_equal(tr.visit_ids[k, :o_tr.n_hop], o_vis), k
-    for key, value in [("pq_narrow", 1), ("pq_narrow", 2), ("hash_limit", 30), ("wide_hash", 1), ("no_hash", 1)]:
+    # (pq_narrow 3: the walker keeps the candidate array itself; the default for M = 192 is the split form, the array in a helper wave)
+    for key, value in [("pq_narrow", 1), ("pq_narrow", 2), ("pq_narrow", 3), ("hash_limit", 30), ("wide_hash", 1), ("no_hash", 1)]:
         for kk in ("pq_narrow", "hash_limit", "wide_hash", "no_hash"):
             ix.set_tuning(kk, 0)
         ix.set_tuning(key, value)

@@ -1,5 +1,5 @@
 """A/B harness for search-kernel variants: the library named by SEMADB_AMD_LIB (default: the built one) on
-(a) the headline shape 1M x 384, batch 1024 and (b) a quantized index ROWS_PQ x 768, M = 8; median kernel ms of 30
+(a) the headline shape 1M x 384, batch 1024 and (b) a quantized index ROWS_PQ x 768, M = PQ_M (8); median kernel ms of 30
 launches each, plus a checksum of the result ids so that variants can be seen to agree."""
 import hashlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,8 +19,9 @@ def run(n, d, with_pq):
         key, value = kv.split("=")
         ix.set_tuning(key, int(value))
     if with_pq:
-        pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(256, 8, 10000), d)
-        pq.Fit(base[:10000].cpu().numpy().copy(), np.arange(8) * 7, alias=True)
+        M = int(os.environ.get("PQ_M", 8))
+        pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(256, M, 10000), d)
+        pq.Fit(base[:10000].cpu().numpy().copy(), np.arange(M) * 7, alias=True)
         vs.attach(ix, pq)
     ix.set_profiling(True)
     h = hashlib.sha1()
@@ -38,6 +39,7 @@ def run(n, d, with_pq):
     return {"kernel_ms_median": round(float(np.median(ms)), 4), "kernel_ms_min": round(float(ms.min()), 4), "ids_sha1": h.hexdigest()[:12]}
 
 
-out["plain_1Mx384"] = run(1000000, 384, False)
-out["pq_%dx768_M8" % int(os.environ.get("ROWS_PQ", 4000000))] = run(int(os.environ.get("ROWS_PQ", 4000000)), 768, True)
+if not os.environ.get("SKIP_PLAIN"):
+    out["plain_1Mx384"] = run(1000000, 384, False)
+out["pq_%dx768_M%s" % (int(os.environ.get("ROWS_PQ", 4000000)), os.environ.get("PQ_M", "8"))] = run(int(os.environ.get("ROWS_PQ", 4000000)), 768, True)
 print(json.dumps(out))
