@@ -1009,6 +1009,8 @@ struct PQWideDist {
   // LATER, after the next row's codes have been asked for and while the walker runs that row's visited-set test; then
   // it marks the node the walker went to and leaves the first unvisited entry behind it in sh->f1 before B1, which is
   // when the walker needs it: after that round's sums.  No polling: the walk's own barriers order every word.
+  // (Pulling that entry's adjacency row through L2 here, as k_greedy_search_pq2's merger does, cost more than it hid:
+  // 1.027 against 0.989 ms per batch at 2M x 768, M = 192 -- this wave is the one the round's second barrier waits for.)
   template <bool MERGER = false>
   __device__ __forceinline__ void serve(const SearchArgs &a, int lane, const uint32_t q = 0, uint32_t *scratch = nullptr) {
     constexpr int NREG = 2;
