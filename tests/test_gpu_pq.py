@@ -113,7 +113,7 @@ def test_pq_parameter_errors():
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
-@pytest.mark.parametrize("d,M,K", [(32, 8, 16), (96, 8, 256), (64, 32, 64)])
+@pytest.mark.parametrize("d,M,K", [(32, 8, 16), (96, 8, 256), (64, 32, 64), (128, 64, 32)])  # (the last: code rows gathered by slot, M > 32)
 def test_pq_search_parity(oracle, metric, d, M, K):
     """greedy search over a quantized store: LUT distances (product.go:250-277) drive the same walk"""
     from semadb_amd import vamana, vectorstore as vs
