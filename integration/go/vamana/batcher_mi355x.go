@@ -224,7 +224,13 @@ func (b *searchBatcher) submit(ctx context.Context, vector []float32, limit, sea
 			b.rotateLocked(fb, uint32(b.maxBatch))
 			b.mu.Unlock()
 		} else if i == 0 {
-			b.cond.Signal() // a worker starts this batch's window
+			// a worker starts this batch's window.  Through the lock: a worker that has just read "no first request
+			// yet" under it is inside its Wait by the time the signal is sent (a signal between its look and its Wait
+			// would be lost and the batch would sit for the worker's poll instead of its window) -- found with the C++
+			// twin under the stress of tests/host/test_concurrency.cpp, fixed in both
+			b.mu.Lock()
+			b.mu.Unlock() //nolint:staticcheck // empty critical section on purpose
+			b.cond.Signal()
 		}
 		placed = true
 	}

@@ -28,6 +28,7 @@
 
 #include "exchange.h"
 #include "index.h"
+#include "turnstile.h"
 
 namespace sdb {
 
@@ -110,8 +111,10 @@ struct Group;
                        __LINE__);                                                                       \
   } while (0)
 
-struct sdb_cluster {
-  int rank = 0, world = 1, device = 0;
+// (the order of a rank's calls -- tickets, sequence numbers, ring-slot flags, its lock -- is sdb::OrderState /
+// sdb::SlotState of turnstile.h, which compile and are stress-tested without a GPU)
+struct sdb_cluster : sdb::OrderState {
+  int world = 1, device = 0;
   ncclComm_t comm = nullptr;    // RCCL transport
   sdb::Group *group = nullptr;  // shared-device transport
   hipStream_t xs = nullptr;       // the exchange stream
@@ -121,7 +124,7 @@ struct sdb_cluster {
   char *gathered = nullptr;  // [world][block bytes]
   size_t gathered_bytes = 0;
   static constexpr int kRing = SDB_CLUSTER_RING;  // exchanges one rank may have in flight
-  struct Slot {
+  struct Slot : sdb::SlotState {
     char *block = nullptr;  // the shard's result block (search_batch)
     size_t bytes = 0;
     char *stage = nullptr;  // host-memory callers: staged queries + merged outputs on the device ...
@@ -131,17 +134,7 @@ struct sdb_cluster {
     hipStream_t hs = nullptr;       // the stream a host-memory caller's search runs on
     hipEvent_t produced = nullptr;  // search stream -> exchange stream
     hipEvent_t done = nullptr;      // every read of the block, the merge and the copies back of this exchange have run
-    bool used = false;              // `done` has been recorded at least once
-    bool busy = false;              // a host-memory call still reads its staging
-    bool pending = false;           // shared transport: registered, the last rank has not enqueued it yet
   } ring[kRing];
-  unsigned next_slot = 0;
-  // order
-  uint64_t seq = 0;          // collectives this rank has entered
-  uint64_t next_ticket = 1;  // the ticket the turnstile lets in next
-  bool desync = false;       // a call left between taking its sequence number and entering the exchange
-  std::set<uint64_t> skipped;  // tickets the fan-out has declared lost on this rank (sdb_cluster_skip_ticket)
-  uint32_t deadline_ms = 30000;  // longest wait at the turnstile / for the peers (0: for ever)
   // verdicts of the exchanges in flight (pinned host memory, written by the merge kernels)
   static constexpr int kVerdicts = 64;
   sdb::ExchangeVerdict *verdicts = nullptr;
@@ -149,12 +142,6 @@ struct sdb_cluster {
   bool vused[kVerdicts] = {};
   bool vhost[kVerdicts] = {};  // a host-memory call in flight will read this one itself
   std::string sticky;  // first failure of a device-memory exchange since the last synchronize
-  // RCCL ranks lock their own mutex; the ranks of a shared-device group share the group's (the last rank to arrive
-  // enqueues on everybody's streams)
-  std::mutex own_mu;
-  std::condition_variable own_cv;
-  std::mutex *mu = &own_mu;
-  std::condition_variable *cv = &own_cv;
 };
 
 namespace sdb {
@@ -162,6 +149,7 @@ namespace sdb {
 // one exchange as a rank registered it with the group
 struct Arrival {
   sdb_cluster *c = nullptr;
+  OrderState *owner = nullptr;  // = c, as the rendezvous knows it
   sdb_cluster::Slot *slot = nullptr;
   const char *block = nullptr;
   hipEvent_t produced = nullptr;
@@ -176,13 +164,7 @@ struct Arrival {
   uint64_t seq = 0, ticket = 0;
 };
 
-struct Group {
-  std::mutex mu;
-  std::condition_variable cv;
-  int world = 0, device = 0, alive = 0;
-  int gone = -1;  // a rank of the group that has been destroyed: no exchange can complete any more
-  std::map<uint64_t, std::vector<Arrival>> rv;  // sequence number -> arrivals so far
-};
+struct Group : GroupState<Arrival> {};
 
 }  // namespace sdb
 
@@ -302,47 +284,6 @@ static int exchange_shared(std::vector<Arrival> &arr) {
   return rc;
 }
 
-// the ticket turnstile: a call enters in ticket order and ALWAYS gives the turn on when it leaves the locked section,
-// whatever happened in between -- otherwise its successors would wait forever.  A ticket that is never presented on
-// this rank (the fan-out's thread died, the request was cancelled before this rank was called) would wedge them all
-// the same: the wait has a deadline (sdb_cluster_set_deadline) after which the call fails having done NOTHING -- it
-// may be presented again --, and sdb_cluster_skip_ticket lets the fan-out declare a ticket lost.  The reference fails
-// one request and serves the next (cluster/actions.go:339-353).
-struct Turn {
-  sdb_cluster *c;
-  uint64_t ticket;
-  bool mine = false;
-  static void advance(sdb_cluster *c, uint64_t to) {  // lock held
-    c->next_ticket = to;
-    for (auto it = c->skipped.find(c->next_ticket); it != c->skipped.end(); it = c->skipped.find(c->next_ticket)) {
-      c->skipped.erase(it);
-      c->next_ticket++;
-    }
-    c->cv->notify_all();
-  }
-  int enter(std::unique_lock<std::mutex> &lk) {
-    if (!ticket) return SDB_OK;
-    if (ticket < c->next_ticket)
-      return fail(SDB_ERR_INVALID, "ticket %llu has already entered the exchange on rank %d (next is %llu)",
-                  (unsigned long long)ticket, c->rank, (unsigned long long)c->next_ticket);
-    if (c->skipped.count(ticket))
-      return fail(SDB_ERR_INVALID, "ticket %llu was skipped on rank %d (sdb_cluster_skip_ticket)", (unsigned long long)ticket, c->rank);
-    auto ready = [&] { return c->next_ticket == ticket; };
-    if (c->deadline_ms == 0) {
-      c->cv->wait(lk, ready);
-    } else if (!c->cv->wait_for(lk, std::chrono::milliseconds(c->deadline_ms), ready)) {
-      return fail(SDB_ERR_STATE, "ticket %llu waited %u ms on rank %d for ticket %llu, which has not been presented to this rank; "
-                  "the call did nothing (present it again once the missing ticket has been presented or skipped: sdb_cluster_skip_ticket)",
-                  (unsigned long long)ticket, c->deadline_ms, c->rank, (unsigned long long)c->next_ticket);
-    }
-    mine = true;
-    return SDB_OK;
-  }
-  ~Turn() {  // runs with the lock held (declared after the lock)
-    if (mine) advance(c, ticket + 1);
-  }
-};
-
 // hipEventSynchronize with the handle's deadline: 0 = the event has fired, 1 = deadline passed, -1 = the device failed
 static int wait_event(sdb_cluster *c, hipEvent_t ev) {
   if (c->deadline_ms == 0) return hipEventSynchronize(ev) == hipSuccess ? 0 : -1;
@@ -366,21 +307,6 @@ static int wait_event_or_fail(sdb_cluster *c, hipEvent_t ev, const char *what) {
   c->desync = true;  // something this rank enqueued never ran: a peer did not join its collective
   return fail(SDB_ERR_STATE, "rank %d waited %u ms for %s: a peer never joined that exchange; the cluster handle is out of "
               "step with its peers, recreate it", c->rank, c->deadline_ms, what);
-}
-
-// a free ring slot (may wait for one); lock held
-static sdb_cluster::Slot *take_slot(sdb_cluster *c, std::unique_lock<std::mutex> &lk) {
-  for (;;) {
-    // in ring order: the slot taken is the one whose last exchange lies furthest back, so that waiting for it to
-    // finish (below) only ever blocks a caller that has kRing exchanges in flight
-    for (int k = 0; k < sdb_cluster::kRing; k++) {
-      sdb_cluster::Slot &s = c->ring[(c->next_slot + k) % sdb_cluster::kRing];
-      if (s.busy || s.pending) continue;
-      c->next_slot = (c->next_slot + k + 1) % sdb_cluster::kRing;
-      return &s;
-    }
-    c->cv->wait(lk);
-  }
 }
 
 static int verdict_slot(sdb_cluster *c, uint64_t seq, int *vi) {
@@ -453,7 +379,7 @@ static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint6
   const OutLayout ol(nq, limit);
   // ---- buffers first: an allocation that fails here leaves this rank outside the exchange (its peers' only cure is
   // their own timeout), so nothing that can fail for another reason comes before the rank is sure to get in
-  sdb_cluster::Slot *slot = take_slot(c, lk);
+  sdb_cluster::Slot *slot = take_slot(c, c->ring, lk);
   if (slot->used) SDB_TRY(wait_event_or_fail(c, slot->done, "this ring slot's previous exchange"));  // staging, events
   int vi = 0;
   SDB_TRY(verdict_slot(c, c->seq, &vi));
@@ -486,7 +412,7 @@ static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint6
   // ---- from here on this rank WILL enter the exchange; a failure of its own goes into the tag
   // (the group's arrival list for this sequence number gets its room first: nothing between taking the number and
   // registering the arrival may need host memory -- a rank that took a number and then stayed out is out of step)
-  if (c->group) c->group->rv[c->seq].reserve((size_t)c->world);
+  if (c->group) c->group->reserve(c->seq);
   const uint64_t seq = c->seq++;
   prog.numbered = true, prog.slot = slot, prog.vi = vi;
   int local_rc = SDB_OK;
@@ -522,7 +448,7 @@ static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint6
     entered = false;
   if (entered && hipEventRecord(slot->produced, stream) != hipSuccess) entered = false;
   Arrival a;
-  a.c = c, a.slot = slot, a.block = block, a.produced = slot->produced, a.nq = nq, a.per_shard = per_shard, a.limit = limit;
+  a.c = c, a.owner = c, a.slot = slot, a.block = block, a.produced = slot->produced, a.nq = nq, a.per_shard = per_shard, a.limit = limit;
   a.host = host, a.vi = vi, a.seq = seq, a.ticket = ticket;
   a.copy_back = host && out_ids != nullptr;
   if (host) {
@@ -535,12 +461,8 @@ static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint6
   if (entered) {
     if (c->group) {
       slot->pending = true;
-      auto &arr = c->group->rv[seq];
-      arr.push_back(a);
-      if ((int)arr.size() == c->world) {
-        std::vector<Arrival> all;
-        all.swap(arr);
-        c->group->rv.erase(seq);
+      std::vector<Arrival> all;
+      if (c->group->arrive(seq, a, &all)) {  // the last rank enqueues for everybody
         if (exchange_shared(all) != SDB_OK) entered = false;
         c->cv->notify_all();
       }
@@ -566,10 +488,7 @@ static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint6
   // ---- host memory: give the turn on, let the next call of this rank enqueue, and wait for this exchange alone
   slot->busy = true;
   c->vhost[vi] = true;
-  if (turn.mine) {
-    turn.mine = false;
-    Turn::advance(c, ticket + 1);
-  }
+  turn.pass();
   // shared transport: until the last rank has enqueued it
   auto enqueued = [&] { return !slot->pending; };
   if (c->deadline_ms == 0) {
@@ -577,16 +496,9 @@ static int collective_impl(sdb_cluster *c, sdb_index *ix, uint64_t ticket, uint6
   } else if (!c->cv->wait_for(lk, std::chrono::milliseconds(c->deadline_ms), enqueued)) {
     // the peers never presented this request: take the arrival back.  Nothing of it is on any stream yet, so if it was
     // this rank's latest sequence number the handle is exactly where it was before the call
-    auto it = c->group->rv.find(seq);
-    if (it != c->group->rv.end()) {
-      auto &arr = it->second;
-      arr.erase(std::remove_if(arr.begin(), arr.end(), [&](const Arrival &x) { return x.c == c; }), arr.end());
-      if (arr.empty()) c->group->rv.erase(it);
-    }
+    c->group->withdraw(seq, c);
     slot->pending = false, slot->busy = false;
     c->vhost[vi] = false, c->verdicts[vi].state = kVerdictNone;
-    if (c->seq == seq + 1) c->seq = seq;
-    else c->desync = true;
     c->cv->notify_all();
     if (out_counts) memset(out_counts, 0, nq * 4);
     return fail(SDB_ERR_STATE, "shard exchange %llu (ticket %llu): the other ranks did not join within %u ms; the request was "
@@ -839,12 +751,7 @@ int sdb_cluster_skip_ticket(sdb_cluster *c, uint64_t ticket, uint64_t nq, uint32
   if (!ticket) return fail(SDB_ERR_INVALID, "ticket 0 is not a ticket");
   if (nq == 0) {  // no rank has entered or will enter for this ticket: the turn passes over it
     std::lock_guard<std::mutex> g(*c->mu);
-    if (ticket < c->next_ticket)
-      return fail(SDB_ERR_INVALID, "ticket %llu has already entered the exchange on rank %d (next is %llu)",
-                  (unsigned long long)ticket, c->rank, (unsigned long long)c->next_ticket);
-    if (ticket == c->next_ticket) Turn::advance(c, ticket + 1);
-    else c->skipped.insert(ticket);
-    return SDB_OK;
+    return skip_unentered(c, ticket);
   }
   // other ranks may be inside this request's exchange: stand in for it with an empty answer under an error flag
   return collective(c, nullptr, ticket, nq, nullptr, per_shard, nullptr, limit, 0, nullptr, nullptr, nullptr, nullptr,

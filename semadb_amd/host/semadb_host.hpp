@@ -313,6 +313,7 @@ class SearchBatcher {
   }
   uint64_t deviceBatches() const { return n_batches_.load(); }
   uint64_t queriesServed() const { return n_queries_.load(); }
+  uint64_t backpressureWaits() const { return n_backpressure_.load(); }  // submits that found every slab in use
 
   // enqueue; the request (and what it points to) must stay alive until r->done
   void submit(Request *r) {
@@ -323,6 +324,7 @@ class SearchBatcher {
     while (fast) {
       Batch *b = cur_.load(std::memory_order_acquire);
       if (!b) {  // every slab is in use (back-pressure) or a rotation is under way
+        n_backpressure_.fetch_add(1, std::memory_order_relaxed);
         std::unique_lock<std::mutex> lk(qmu_);
         fcv_.wait(lk, [&] { return cur_.load(std::memory_order_acquire) != nullptr || stop_; });
         if (stop_) {
@@ -354,7 +356,11 @@ class SearchBatcher {
         std::lock_guard<std::mutex> g(qmu_);
         rotateLocked(b, (uint32_t)max_batch_);
       } else if (i == 0) {
-        qcv_.notify_one();  // a worker starts this batch's window
+        // a worker starts this batch's window.  Through the lock: a worker that has just read "no first request
+        // yet" under it is inside its wait by the time this notify is sent (a notify between its look and its wait
+        // would be lost, and the batch would sit for the worker's 2 ms poll instead of its window)
+        { std::lock_guard<std::mutex> g(qmu_); }
+        qcv_.notify_one();
       }
       return;
     }
@@ -423,11 +429,13 @@ class SearchBatcher {
     qcv_.notify_one();
     fcv_.notify_all();
   }
-  // the 32-bit form of (limit << 32 | searchSize) that shares the slot atomic; parameters beyond 16 bits (the API's
-  // maxima are 75 and 75, models/search.go:287-297) take the queue
+  // the 32-bit form of (limit << 32 | searchSize) that shares the slot atomic; parameters beyond 16 bits and limits
+  // beyond the workers' result slabs (the API's maxima are 75 and 75, models/search.go:287-297) take the queue,
+  // whose calls size their own buffers -- so that a request's answer never depends on which path it took
+  static constexpr size_t kMaxLimit = 128;
   static bool tagOf(uint64_t key, uint32_t *tag) {
     const uint64_t limit = key >> 32, L = key & 0xFFFFFFFFull;
-    if (limit > 0xFFFF || L > 0xFFFF) return false;
+    if (limit > kMaxLimit || L > 0xFFFF) return false;
     *tag = (uint32_t)(limit << 16 | L);
     return true;
   }
@@ -500,7 +508,6 @@ class SearchBatcher {
 
   void loop() {
     // this worker's pinned result slabs, for the largest limit the API allows (models/search.go:287-297)
-    const size_t kMaxLimit = 128;
     // pinned when that can be had (the limit on locked memory), else ordinary pages: the device call then stages the
     // copies back, slower, same answers -- like the query slabs (newBatch)
     struct Slab {
@@ -580,7 +587,7 @@ class SearchBatcher {
     while (b->written.load(std::memory_order_acquire) < nq) std::this_thread::yield();  // the last copies in flight
     int rc;
     const char *why = nullptr;
-    if (limit > 128) rc = SDB_ERR_INVALID, why = "limit beyond the batcher's result slabs (128)";
+    if (limit > kMaxLimit) rc = SDB_ERR_INVALID, why = "limit beyond the batcher's result slabs (128)";
     else if (!ids || !dists || !counts) rc = SDB_ERR_DEVICE, why = "out of host memory for the batcher's result slabs";
     else rc = sdb_index_search_batch(h_, nq, b->queries, limit, L, nullptr, nullptr, ids, dists, counts, nullptr, SDB_MEM_HOST, nullptr);
     n_batches_++;
@@ -687,7 +694,7 @@ class SearchBatcher {
   bool stop_ = false;
   size_t max_batch_, cap_ = 0;
   std::chrono::microseconds window_;
-  std::atomic<uint64_t> n_batches_{0}, n_queries_{0};
+  std::atomic<uint64_t> n_batches_{0}, n_queries_{0}, n_backpressure_{0};
   std::atomic<int> busy_{0};  // workers inside a device call
 };
 
