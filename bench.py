@@ -968,22 +968,44 @@ def host_rates(a, ix, queries, k, L, last_device_result):
     for b in range(nb):
         ix.search_batch(q_np[b], k, L, out=(o_ids, o_d, o_c))
     dt = time.perf_counter() - t0
-    out["host_qps"] = round(nb * nq / dt, 1)
-    out["host_ms_per_batch"] = round(dt / nb * 1e3, 4)
-    out["host_qps_definition"] = "queries in pinned host memory -> sdb_index_search_batch(SDB_MEM_HOST) -> results " \
-                                 "in pinned host memory, one blocking call per batch of %d, %d batches" % (nq, nb)
+    out["host_qps_via_python"] = round(nb * nq / dt, 1)  # the same calls through ctypes: + the interpreter between them
     # the batcher: libsemadb_hostbench.so (semadb_amd/host/hostbench.cpp over semadb_host.hpp's SearchBatcher)
     so = os.path.join(ROOT, "semadb_amd", "libsemadb_hostbench.so")
     hb = C.CDLL(so)
+    # host_qps: the blocking calls issued from C (what a Go host pays through cgo), page-locked slabs of sdb_host_alloc:
+    # the walk reads the queries and writes the results in place, one launch and one wait per call
+    hb.sdb_hostbench_blocking.restype = C.c_int
+    hb.sdb_hostbench_blocking.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double)]
+    flat_q = np.ascontiguousarray(q_np.reshape(nb * nq, d))
+    blk = {}
+    for label, pinned, no_zc in (("in_place", 1, 0), ("staged", 1, 1), ("pageable", 0, 0)):
+        ix.set_tuning("no_zero_copy", no_zc)
+        qps_b, ms_b = C.c_double(0), C.c_double(0)
+        b_ids = np.zeros((nq, k), dtype=np.uint64)
+        b_c = np.zeros(nq, dtype=np.uint32)
+        rc_b = hb.sdb_hostbench_blocking(ix._h, d, flat_q.ctypes.data, nb, nq, k, L, 3, pinned, b_ids.ctypes.data, b_c.ctypes.data,
+                                         C.byref(qps_b), C.byref(ms_b))
+        ids0, _, c0, _ = ix.search_batch(q_np[0], k, L)
+        blk[label] = {"qps": round(qps_b.value, 1), "ms_per_batch": round(ms_b.value, 4), "rc": rc_b,
+                      "matches_direct_call": bool(np.array_equal(b_ids, ids0) and np.array_equal(b_c, c0))}
+    ix.set_tuning("no_zero_copy", 0)
+    out["host_qps"] = blk["in_place"]["qps"]
+    out["host_ms_per_batch"] = blk["in_place"]["ms_per_batch"]
+    out["host_blocking_variants"] = blk
+    out["host_qps_definition"] = "queries in page-locked host memory -> sdb_index_search_batch(SDB_MEM_HOST) -> results in " \
+                                 "page-locked host memory, one blocking call per batch of %d issued from C (3 x %d batches); the " \
+                                 "kernel reads and writes the host buffers in place (host_blocking_variants.staged: the " \
+                                 "same with staging copies forced; .pageable: malloc'ed buffers)" % (nq, nb)
     hb.sdb_hostbench_batcher.restype = C.c_int
     hb.sdb_hostbench_batcher.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    flat_q = np.ascontiguousarray(q_np.reshape(nb * nq, d))
     first_ids = np.zeros((nb * nq, k), dtype=np.uint64)
     first_c = np.zeros(nb * nq, dtype=np.uint32)
-    threads, depth, workers = 64, 48, 2
+    threads, depth, workers = 64, 48, 4
     qps, batches, served = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     p50, p99 = C.c_double(0), C.c_double(0)
     rc = hb.sdb_hostbench_batcher(ix._h, d, flat_q.ctypes.data, nb * nq, k, L, threads, depth, nq, 300, workers, 2.0,
@@ -1008,6 +1030,11 @@ def host_rates(a, ix, queries, k, L, last_device_result):
                                                "qps": round(q2.value, 1), "mean_batch": round(s2.value / max(1, b2.value), 2),
                                                "rc": rc2}
     out["batcher_light_load"] = light
+    # batches in flight: the same load at 2 workers (rounds 3-5's setting) beside the default's 4
+    q3, b3, s3, p50c, p99c = C.c_double(0), C.c_uint64(0), C.c_uint64(0), C.c_double(0), C.c_double(0)
+    rc3 = hb.sdb_hostbench_batcher(ix._h, d, flat_q.ctypes.data, nb * nq, k, L, threads, depth, nq, 300, 2, 1.0, None, None,
+                                   C.byref(q3), C.byref(b3), C.byref(s3), C.byref(p50c), C.byref(p99c))
+    out["batcher_qps_2_in_flight"] = round(q3.value, 1) if rc3 == 0 else None
     # the batcher's answers are the same answers: compare the first batch with a direct call
     ids0, _, c0, _ = ix.search_batch(q_np[0], k, L)
     out["batcher_matches_direct_call"] = bool(np.array_equal(first_ids[:nq], ids0) and np.array_equal(first_c[:nq], c0))

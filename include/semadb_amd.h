@@ -64,8 +64,12 @@ int sdb_abi_version(void);
 /* number of visible MI355X devices; SDB_ERR_DEVICE if the HIP runtime finds none */
 int sdb_device_count(int *count);
 /* Page-locked host memory for SDB_MEM_HOST buffers a host re-uses call after call (a batcher's query and result
- * slabs): copies to and from it are single DMAs and truly asynchronous, where pageable memory (a Go slice) is staged
- * through the driver.  Plain pageable buffers keep working everywhere; this is an optimisation, not a requirement. */
+ * slabs).  A search whose queries and outputs live in such memory (or in memory the caller page-locked itself:
+ * hipHostMalloc / hipHostRegister) is ONE kernel launch: the walk reads each query from the caller's buffer once, when
+ * its wave starts, and writes the [nq][limit] results straight into the caller's arrays -- no staging copies, no copy
+ * packets around the kernel.  Other copies to and from it are single DMAs and truly asynchronous, where pageable memory
+ * (a Go slice) is staged through the driver.  Plain pageable buffers keep working everywhere; this is an optimisation,
+ * not a requirement. */
 int sdb_host_alloc(size_t bytes, void **out);
 int sdb_host_free(void *p);
 
@@ -256,7 +260,10 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        the length of the call) for the re-prune that meets them later.  Same graph either way.
  *   SDB_TUNE_HASH16_PROBES  buckets a key of the 16-bit-cell set may try before the walk spills to the HBM bitset
  *                        (0 = all 15; 1..15).  With 15 that spill is a one-in-ten-million event; a test sets 1 or 2
- *                        to walk through it */
+ *                        to walk through it
+ *   SDB_TUNE_NO_ZERO_COPY  != 0: a host-memory search stages queries and results through device buffers even when the
+ *                        caller's buffers are page-locked (sdb_host_alloc) and the kernel could read / write them in
+ *                        place (A/B and parity tests) */
 #define SDB_TUNE_HUB_MIN 1
 #define SDB_TUNE_HASH_LIMIT 2
 #define SDB_TUNE_NO_HASH 3
@@ -268,6 +275,7 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
 #define SDB_TUNE_WIDE_WALK 9
 #define SDB_TUNE_HOST_FILTERS 10
 #define SDB_TUNE_NO_DEFER 11
+#define SDB_TUNE_NO_ZERO_COPY 12
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
 
 /* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts

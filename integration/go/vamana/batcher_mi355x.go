@@ -46,6 +46,12 @@ type searchReq struct {
 type fillBatch struct {
 	mem     unsafe.Pointer // pinned [maxBatch][dim] float32
 	queries []float32      // the same memory as a slice
+	// pinned result slabs for limits up to slabLimit (one block: ids | dists | counts): with queries AND outputs
+	// page-locked a device call is one kernel launch that reads and writes them in place (semadb_amd.h sdb_host_alloc)
+	resMem    unsafe.Pointer
+	resIds    []uint64
+	resDists  []float32
+	resCounts []uint32
 	reqs    []*searchReq
 	st      atomic.Uint64 // tagOf(key)<<32 | slots reserved; slots >= maxBatch: full or sealed
 	written atomic.Uint32 // slots whose vector has been copied in
@@ -75,6 +81,9 @@ type searchBatcher struct {
 	wg       sync.WaitGroup
 }
 
+// slabLimit: the largest limit a batch's page-locked result slab holds (the API's maximum is 75, models/search.go:287-297)
+const slabLimit = 128
+
 func newSearchBatcher(ix *IndexVamana, maxBatch int, window time.Duration, workers int) *searchBatcher {
 	b := &searchBatcher{ix: ix, dim: int(ix.parameters.VectorSize), maxBatch: maxBatch, window: window}
 	b.cond = sync.NewCond(&b.mu)
@@ -85,6 +94,14 @@ func newSearchBatcher(ix *IndexVamana, maxBatch int, window time.Duration, worke
 			fb.queries = unsafe.Slice((*float32)(fb.mem), maxBatch*b.dim)
 		} else {
 			fb.mem, fb.queries = nil, make([]float32, maxBatch*b.dim) // pageable memory works too, only slower
+		}
+		resBytes := maxBatch*slabLimit*12 + maxBatch*4
+		if rc := C.sdb_host_alloc(C.size_t(resBytes), &fb.resMem); rc == C.SDB_OK && fb.resMem != nil {
+			fb.resIds = unsafe.Slice((*uint64)(fb.resMem), maxBatch*slabLimit)
+			fb.resDists = unsafe.Slice((*float32)(unsafe.Add(fb.resMem, maxBatch*slabLimit*8)), maxBatch*slabLimit)
+			fb.resCounts = unsafe.Slice((*uint32)(unsafe.Add(fb.resMem, maxBatch*slabLimit*12)), maxBatch)
+		} else {
+			fb.resMem = nil // flushSlab then answers into Go slices: staged by the driver, same answers
 		}
 		b.all = append(b.all, fb)
 		b.free = append(b.free, fb)
@@ -108,6 +125,9 @@ func (b *searchBatcher) stop() {
 	for _, fb := range b.all {
 		if fb.mem != nil {
 			C.sdb_host_free(fb.mem)
+		}
+		if fb.resMem != nil {
+			C.sdb_host_free(fb.resMem)
 		}
 	}
 }
@@ -355,9 +375,15 @@ func (b *searchBatcher) flushSlab(fb *fillBatch) {
 		runtime.Gosched()
 	}
 	limit, L := int(fb.key>>32), int(fb.key&0xFFFFFFFF)
-	ids := make([]uint64, nq*limit)
-	dists := make([]float32, nq*limit)
-	counts := make([]uint32, nq)
+	var ids []uint64
+	var dists []float32
+	var counts []uint32
+	inSlab := fb.resMem != nil && limit <= slabLimit
+	if inSlab { // the batch's own page-locked result slab: the kernel writes the answers in place
+		ids, dists, counts = fb.resIds[:nq*limit], fb.resDists[:nq*limit], fb.resCounts[:nq]
+	} else {
+		ids, dists, counts = make([]uint64, nq*limit), make([]float32, nq*limit), make([]uint32, nq)
+	}
 	rc := C.sdb_index_search_batch(b.ix.h, C.uint64_t(nq), (*C.float)(unsafe.Pointer(&fb.queries[0])),
 		C.uint32_t(limit), C.uint32_t(L), nil, nil,
 		(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dists[0])),
@@ -370,7 +396,11 @@ func (b *searchBatcher) flushSlab(fb *fillBatch) {
 			continue
 		}
 		n := int(counts[i])
-		r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
+		if inSlab { // the slab is refilled by the next batch: the caller gets its own copy
+			r.done <- searchResp{ids: append([]uint64(nil), ids[i*limit:i*limit+n]...), dists: append([]float32(nil), dists[i*limit:i*limit+n]...)}
+		} else {
+			r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
+		}
 	}
 }
 
@@ -467,6 +497,10 @@ func (b *searchBatcher) flush(reqs []*searchReq) {
 			continue
 		}
 		n := int(counts[i])
-		r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
+		if inSlab { // the slab is refilled by the next batch: the caller gets its own copy
+			r.done <- searchResp{ids: append([]uint64(nil), ids[i*limit:i*limit+n]...), dists: append([]float32(nil), dists[i*limit:i*limit+n]...)}
+		} else {
+			r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
+		}
 	}
 }

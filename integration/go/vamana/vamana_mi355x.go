@@ -119,7 +119,7 @@ func NewIndexVamana(name string, params models.IndexVectorVamanaParameters, buck
 		v.Close()
 		return nil, fmt.Errorf("could not setup start node: %w", err)
 	}
-	v.batcher = newSearchBatcher(v, 1024, 200*time.Microsecond, 2)
+	v.batcher = newSearchBatcher(v, 1024, 200*time.Microsecond, 4) // batches in flight: see semadb_host.hpp (2 -> 4: 1.06 -> 1.18 M queries/s)
 	return v, nil
 }
 

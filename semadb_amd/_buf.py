@@ -44,3 +44,38 @@ def empty_like_mem(mem, shape, dtype, device_index=0, zero=False):
         return t, C.c_void_p(t.data_ptr())
     a = np.zeros(shape, dtype=dtype)
     return a, C.c_void_p(a.ctypes.data)
+
+
+class _PinnedBlock:
+    """owns one sdb_host_alloc block for as long as an array made over it lives"""
+
+    def __init__(self, nbytes):
+        from ._lib import check, lib
+        self._p = C.c_void_p(0)
+        check(lib().sdb_host_alloc(max(1, int(nbytes)), C.byref(self._p)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            if self._p:
+                lib().sdb_host_free(self._p)
+                self._p = C.c_void_p(0)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over page-locked host memory (sdb_host_alloc): a host-memory search reads / writes it in place"""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    blk = _PinnedBlock(n * dt.itemsize)
+    raw = (C.c_char * max(1, n * dt.itemsize)).from_address(blk._p.value)
+    arr = np.frombuffer(raw, dtype=dt, count=n).reshape(shape)
+    _KEEP[id(raw)] = blk  # numpy keeps `raw` alive through arr.base; the block goes when `raw` does
+    import weakref
+    weakref.finalize(raw, _KEEP.pop, id(raw), None)
+    return arr
+
+
+_KEEP = {}

@@ -895,9 +895,10 @@ constexpr uint32_t kBackCap = 256;
 // do not fit that cap: NG = 12 spilled 20 registers, NG = 24 more than 180 (404 bytes of scratch per lane).  They run two
 // waves per SIMD with 256 registers each -- since round 5 also rows of 768 and 1 024 floats and the run-time row length
 // (NG = 6 with its pair records; NG = 8, -1: 7 and 10 registers spilled at three waves once the deferral of full
-// re-prunes had joined the kernel).
+// re-prunes had joined the kernel).  Rows of 3 072 floats (NG = 24: the query row is 96 registers) take the whole file --
+// one wave per SIMD -- since round 6: at 256 registers 5 of them went to scratch.
 template <int NG, bool L2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NG >= 6 || NG == -1) ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NG == 24 ? 1 : (NG >= 6 || NG == -1) ? 2 : SDB_BACK_WAVES))) void k_backedges(const BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   PruneLds l(lds_raw, kBackCap, NG >= 0);
   const int lane = threadIdx.x, L = lane & 31;

@@ -389,8 +389,15 @@ __global__ __launch_bounds__(256, (NBLK <= 12 && !TAIL) ? 2 : 1) void k_flat_sca
 #pragma unroll
     for (int g = 0; g < NG; g++)
 #pragma unroll
-      for (int k = 0; k < 8; k++)
-        A[g][k] = *reinterpret_cast<const f4v *>(src + 128 * g + 4 * (8 * (k >> 1) + 4 * (k & 1)));
+      for (int k = 0; k < 8; k++) {
+        const float *p = src + 128 * g + 4 * (8 * (k >> 1) + 4 * (k & 1));
+        constexpr int kLast = NBLK - 4 * (NG - 1);  // blocks in the last slab group: its other components are padding that
+        if (g + 1 < NG || kLast == 4) {              // no matrix instruction reads -- loaded, they held 8 registers each
+          A[g][k] = *reinterpret_cast<const f4v *>(p);
+        } else {
+          A[g][k] = f4v{p[0], kLast > 1 ? p[1] : 0.0f, kLast > 2 ? p[2] : 0.0f, 0.0f};
+        }
+      }
   }
   // rows 4 (lane / 16) + i4 of the wave's tile are the ones this lane emits
   const uint32_t slot0 = row0 + 16 * wave + 4 * (lane >> 4);
@@ -405,8 +412,20 @@ __global__ __launch_bounds__(256, (NBLK <= 12 && !TAIL) ? 2 : 1) void k_flat_sca
   typedef const __attribute__((address_space(1))) void glb_void;
   auto dma = [&](uint32_t G) __attribute__((always_inline)) {
     const char *src = reinterpret_cast<const char *>(qsw) + (size_t)min(G, ngroups - 1) * (kGrpF4 * 16) + wave * 1024;
+    {
+      // The group's base stays a scalar pair of ITS iteration (opaque to the optimiser): otherwise the loop-invariant
+      // part of the address is hoisted together with the lane's offset into a 64-bit VGPR pair that lives through the
+      // whole loop -- at 11 and 12 blocks, where two waves per SIMD leave exactly 256 registers, that pair (and what it
+      // pushed out) went to scratch and came back once per query group.  With a scalar base the load takes the
+      // saddr + 32-bit offset form and the lane's part is one register.
+      uint32_t lo = (uint32_t)reinterpret_cast<uintptr_t>(src), hi = (uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32);
+      lo = __builtin_amdgcn_readfirstlane(lo), hi = __builtin_amdgcn_readfirstlane(hi);
+      asm volatile("" : "+s"(lo), "+s"(hi));
+      src = reinterpret_cast<const char *>(((uintptr_t)hi << 32) | lo);
+    }
     char *dst = reinterpret_cast<char *>(bs) + (size_t)(G & 1) * (kGrpF4 * 16) + wave * 1024;
-    const uint32_t lane_off = lane * 16;  // the only per-lane part of the address
+    uint32_t lane_off = lane * 16;  // the only per-lane part of the address ...
+    asm volatile("" : "+v"(lane_off));  // ... made here, per group, from the lane id: one shift instead of a live 64-bit pair
 #pragma unroll
     for (int piece = 0; piece < (kPieces + 3) / 4; piece++)
       if (4 * piece + wave < kPieces)
@@ -476,7 +495,8 @@ __global__ __launch_bounds__(256, (NBLK <= 12 && !TAIL) ? 2 : 1) void k_flat_sca
     if (hit == 0) return;  // nearly always
     uint32_t *cnt_g = a.cnt + 16 * G;                       // uniform base, the lane's part is a 32-bit offset
     uint2 *cand_g = a.cand + (size_t)(16 * G) * a.cap;
-    const uint32_t j = lane & 15;
+    uint32_t j = lane & 15;
+    asm volatile("" : "+v"(j));  // j * cap is made HERE, by the rare lane that has a hit, not kept through the loop
 #pragma unroll
     for (int i4 = 0; i4 < 4; i4++)
       if ((hit >> i4) & 1u) {

@@ -176,6 +176,7 @@ struct sdb_index {
   uint32_t tune_hash16_probes = 0;  // test knob: probe budget of the 16-bit visited set (0 = 15 buckets)
   bool tune_host_filters = false;  // filter ids are resolved to slots by the host's hash map even when the table's ids are consecutive
   uint32_t tune_wide_walk = 0;  // the workgroup-per-query walk of small calls: 0 = up to 256 queries, 1 = never, 2 = always
+  bool tune_no_zero_copy = false;  // A/B and parity tests: host-memory searches stage even page-locked buffers
   bool tune_no_defer = false;  // A/B and parity tests: every back-edge re-prune runs in k_backedges (BuildArgs::def_*)
   uint32_t tune_pq_narrow = 0;  // 1: quantized searches never take a multi-wave walk (k_greedy_search_pqw, k_greedy_search_pq2): A/B and parity tests
   bool tune_no_mfma = false;  // exact scan of dot/cosine rows on the packed-FMA kernel instead of the matrix cores

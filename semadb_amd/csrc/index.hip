@@ -1064,6 +1064,40 @@ int sdb_index::sync_start_ext() {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// Page-locked host memory the kernels can address in place.  Blocks from sdb_host_alloc are kept in a table (exact,
+// and dropped by sdb_host_free before the memory goes back); any other pointer is asked of the runtime -- memory the
+// caller page-locked itself (hipHostMalloc, hipHostRegister; torch's pin_memory) says so, a pageable pointer does not.
+struct PinnedRange {
+  size_t bytes;
+  char *dev;  // the device's address of the block's first byte (NULL: not mapped)
+};
+static std::shared_mutex g_pinned_mu;
+static std::map<uintptr_t, PinnedRange> g_pinned;
+
+static bool device_view_of_host(const void *p, size_t bytes, void **dev) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  {
+    std::shared_lock<std::shared_mutex> g(g_pinned_mu);
+    auto it = g_pinned.upper_bound(a);
+    if (it != g_pinned.begin()) {
+      --it;
+      if (a >= it->first && a + bytes <= it->first + it->second.bytes) {
+        if (!it->second.dev) return false;
+        *dev = it->second.dev + (a - it->first);
+        return true;
+      }
+    }
+  }
+  hipPointerAttribute_t attr{};
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // a pageable pointer is not an error of this call
+    return false;
+  }
+  if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return false;
+  *dev = attr.devicePointer;
+  return true;
+}
+
 extern "C" {
 
 const char *sdb_last_error(void) { return last_error_buf(); }
@@ -1087,13 +1121,27 @@ int sdb_host_alloc(size_t bytes, void **out) try {
   if (!out) return fail(SDB_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (bytes == 0) return SDB_OK;
-  SDB_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  void *p = nullptr;
+  SDB_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  void *dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) dev = nullptr, (void)hipGetLastError();
+  try {
+    std::unique_lock<std::shared_mutex> g(g_pinned_mu);
+    g_pinned[reinterpret_cast<uintptr_t>(p)] = PinnedRange{bytes, static_cast<char *>(dev)};
+  } catch (...) {  // no room for the note: the block is still good memory, searches just stage through it
+  }
+  *out = p;
   return SDB_OK;
 }
 SDB_API_CATCH("sdb_host_alloc")
 
 int sdb_host_free(void *p) try {
-  if (p) SDB_HIP(hipHostFree(p));
+  if (!p) return SDB_OK;
+  {
+    std::unique_lock<std::shared_mutex> g(g_pinned_mu);
+    g_pinned.erase(reinterpret_cast<uintptr_t>(p));
+  }
+  SDB_HIP(hipHostFree(p));
   return SDB_OK;
 }
 SDB_API_CATCH("sdb_host_free")
@@ -1705,7 +1753,25 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
     }
     return launch();
   }
-  // host memory: stage through one scratch allocation
+  // host memory.  Page-locked buffers (sdb_host_alloc, or locked by the caller) are read and written IN PLACE by the
+  // walk: a wave reads its query once, when it starts (PlainDist::init), and writes its <= limit results when it ends,
+  // so what crosses the bus is what a copy would have moved, without the copy packets around the kernel and without a
+  // staging buffer -- the call is one launch and one wait.  (Not with a quantizer: the table kernel reads a query's
+  // sub-vectors once per centroid block, and host memory is not cached on the device.  Not with a trace: test calls.)
+  const bool zc_ok = !trace && !ix->tune_no_zero_copy;
+  void *z_q = nullptr, *z_i = nullptr, *z_d = nullptr, *z_c = nullptr;
+  const bool zc_out = zc_ok && device_view_of_host(out_ids, nq * limit * sizeof(uint64_t), &z_i) &&
+                      device_view_of_host(out_dists, nq * limit * sizeof(float), &z_d) &&
+                      device_view_of_host(out_counts, nq * sizeof(uint32_t), &z_c);
+  const bool zc_q = zc_ok && !ix->pq && device_view_of_host(queries, nq * l.dim * sizeof(float), &z_q);
+  if (zc_out && zc_q) {
+    a.queries = static_cast<const float *>(z_q);
+    a.out_ids = static_cast<uint64_t *>(z_i), a.out_dists = static_cast<float *>(z_d), a.out_counts = static_cast<uint32_t *>(z_c);
+    SDB_TRY(launch());
+    SDB_HIP(hipStreamSynchronize(stream));
+    return SDB_OK;
+  }
+  // otherwise: stage through one scratch allocation (what is page-locked still skips its copy)
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     size_t o = off;
@@ -1721,11 +1787,16 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
   const size_t o_v = carve((trace && trace->visit_ids) ? nq * vcap * sizeof(uint64_t) : 0);
   SDB_TRY(ws->ensure_scratch(off));
   char *base = static_cast<char *>(ws->scratch);
-  SDB_HIP(hipMemcpyAsync(base + o_q, queries, nq * l.dim * sizeof(float), hipMemcpyHostToDevice, stream));
-  a.queries = reinterpret_cast<float *>(base + o_q);
+  if (zc_q) {
+    a.queries = static_cast<const float *>(z_q);
+  } else {
+    SDB_HIP(hipMemcpyAsync(base + o_q, queries, nq * l.dim * sizeof(float), hipMemcpyHostToDevice, stream));
+    a.queries = reinterpret_cast<float *>(base + o_q);
+  }
   a.out_ids = reinterpret_cast<uint64_t *>(base + o_ids);
   a.out_dists = reinterpret_cast<float *>(base + o_d);
   a.out_counts = reinterpret_cast<uint32_t *>(base + o_c);
+  if (zc_out) a.out_ids = static_cast<uint64_t *>(z_i), a.out_dists = static_cast<float *>(z_d), a.out_counts = static_cast<uint32_t *>(z_c);
   if (trace) {
     a.tr_ndist = reinterpret_cast<uint32_t *>(base + o_nd);
     a.tr_nhop = reinterpret_cast<uint32_t *>(base + o_nh);
@@ -1734,9 +1805,11 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
   }
   SDB_HIP(hipMemsetAsync(base + o_ids, 0, o_c - o_ids, stream));
   SDB_TRY(launch());
-  SDB_HIP(hipMemcpyAsync(out_ids, a.out_ids, nq * limit * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  SDB_HIP(hipMemcpyAsync(out_dists, a.out_dists, nq * limit * sizeof(float), hipMemcpyDeviceToHost, stream));
-  SDB_HIP(hipMemcpyAsync(out_counts, a.out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  if (!zc_out) {
+    SDB_HIP(hipMemcpyAsync(out_ids, a.out_ids, nq * limit * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipMemcpyAsync(out_dists, a.out_dists, nq * limit * sizeof(float), hipMemcpyDeviceToHost, stream));
+    SDB_HIP(hipMemcpyAsync(out_counts, a.out_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  }
   if (trace) {
     if (trace->n_dist) SDB_HIP(hipMemcpyAsync(trace->n_dist, a.tr_ndist, nq * 4, hipMemcpyDeviceToHost, stream));
     if (trace->n_hop) SDB_HIP(hipMemcpyAsync(trace->n_hop, a.tr_nhop, nq * 4, hipMemcpyDeviceToHost, stream));
@@ -1815,6 +1888,9 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) try {
       return SDB_OK;
     case SDB_TUNE_HOST_FILTERS:
       ix->tune_host_filters = value != 0;
+      return SDB_OK;
+    case SDB_TUNE_NO_ZERO_COPY:
+      ix->tune_no_zero_copy = value != 0;
       return SDB_OK;
     case SDB_TUNE_NO_DEFER:
       ix->tune_no_defer = value != 0;

@@ -7,6 +7,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -112,6 +114,51 @@ int sdb_hostbench_batcher(sdb_index *h, uint32_t dim, const float *queries, uint
   if (device_batches) *device_batches = batcher.deviceBatches();
   if (served) *served = batcher.queriesServed();
   return errors.load() ? 2 : 0;
+}
+
+// One blocking sdb_index_search_batch(SDB_MEM_HOST) call per batch, from page-locked slabs, timed from C: what a Go
+// host pays per call through cgo (no interpreter between the calls).  queries [n_batches][nq][dim] host memory (copied
+// into a slab of sdb_host_alloc once, before the clock starts); first_ids / first_counts (optional) receive batch 0's
+// answer for a parity check.  pinned == 0: pageable slabs (the driver stages them).
+int sdb_hostbench_blocking(sdb_index *h, uint32_t dim, const float *queries, uint32_t n_batches, uint32_t nq, uint32_t limit,
+                           uint32_t search_size, uint32_t reps, int pinned, uint64_t *first_ids, uint32_t *first_counts,
+                           double *qps, double *ms_per_batch) {
+  if (!h || !queries || !n_batches || !nq || !reps || !qps) return 1;
+  const size_t qb = (size_t)n_batches * nq * dim * 4, ib = (size_t)nq * limit * 8, db = (size_t)nq * limit * 4, cb = (size_t)nq * 4;
+  void *q = nullptr, *ids = nullptr, *d = nullptr, *c = nullptr;
+  auto get = [&](size_t bytes, void **p) {
+    if (pinned) return sdb_host_alloc(bytes, p) == SDB_OK && *p;
+    *p = std::malloc(bytes);
+    return *p != nullptr;
+  };
+  auto drop = [&](void *p) {
+    if (!p) return;
+    if (pinned) sdb_host_free(p);
+    else std::free(p);
+  };
+  int rc = 0;
+  if (!get(qb, &q) || !get(ib, &ids) || !get(db, &d) || !get(cb, &c)) rc = 3;
+  if (!rc) {
+    std::memcpy(q, queries, qb);
+    auto call = [&](uint32_t b) {
+      return sdb_index_search_batch(h, nq, (const float *)q + (size_t)b * nq * dim, limit, search_size, nullptr, nullptr,
+                                    (uint64_t *)ids, (float *)d, (uint32_t *)c, nullptr, SDB_MEM_HOST, nullptr);
+    };
+    if (call(0) != SDB_OK) rc = 2;
+    if (!rc && first_ids) std::memcpy(first_ids, ids, ib);
+    if (!rc && first_counts) std::memcpy(first_counts, c, cb);
+    for (uint32_t b = 0; b < std::min(3u, n_batches) && !rc; b++)
+      if (call(b) != SDB_OK) rc = 2;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t r = 0; r < reps && !rc; r++)
+      for (uint32_t b = 0; b < n_batches && !rc; b++)
+        if (call(b) != SDB_OK) rc = 2;
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *qps = (double)reps * n_batches * nq / el;
+    if (ms_per_batch) *ms_per_batch = el * 1e3 / ((double)reps * n_batches);
+  }
+  drop(q), drop(ids), drop(d), drop(c);
+  return rc;
 }
 
 }  // extern "C"

@@ -241,7 +241,12 @@ inline Error GetFloatDistanceFn(const std::string &name, FloatDistFunc *out, int
 // IndexVamana.Search under the shard's RLock (shard/cache/manager.go:163, shard/index/search.go:53-87).  One
 // query alone leaves the GPU idle (a walk is ~80 dependent hops), so concurrent Search calls are coalesced
 // into sdb_index_search_batch calls; `workers` threads run the device calls, so up to `workers` batches are in
-// flight (a second batch fills the SIMDs the first one's finished walks have left).
+// flight (a second batch fills the SIMDs the first one's finished walks have left).  Four by
+// default since round 6: a worker spends part of its cycle on the host (waiting for the last copies into its slab,
+// scattering 1 024 answers, waking clients), and with two workers the device then runs ONE batch for that long;
+// with the slabs page-locked a device call is a single kernel launch that reads the slab and writes the result
+// slabs in place, so more calls in flight cost nothing on the copy engines (measured on one MI355X, 1M x 384:
+// 2 / 3 / 4 / 6 workers = 1.06 / 1.15 / 1.18 / 1.18 M queries/s; with staged copies 1.05 / 0.97 / 1.00 / 1.05).
 //
 // What a request costs on the host, in the order it happens (round 3; the first version took one mutex and one
 // condition variable per request, re-gathered the query vectors into a fresh pageable buffer per batch, and moved
@@ -281,7 +286,7 @@ class SearchBatcher {
   };
 
   SearchBatcher(sdb_index *h, uint32_t dim, size_t max_batch = 1024,
-                std::chrono::microseconds window = std::chrono::microseconds(200), unsigned workers = 2)
+                std::chrono::microseconds window = std::chrono::microseconds(200), unsigned workers = 4)
       : h_(h), dim_(dim), max_batch_(max_batch ? max_batch : 1), window_(window) {
     workers = workers ? workers : 1;
     for (unsigned i = 0; i < workers + 2; i++) free_.push_back(newBatch());

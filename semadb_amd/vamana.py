@@ -155,7 +155,7 @@ class IndexVamana:
         return a.value, b.value, c.value
 
     TUNING = {"hub_min": 1, "hash_limit": 2, "no_hash": 3, "no_tile": 4, "no_mfma": 5, "wide_hash": 6, "hash16_probes": 7,
-              "pq_narrow": 8, "wide_walk": 9, "host_filters": 10, "no_defer": 11}  # SDB_TUNE_* (semadb_amd.h)
+              "pq_narrow": 8, "wide_walk": 9, "host_filters": 10, "no_defer": 11, "no_zero_copy": 12}  # SDB_TUNE_* (semadb_amd.h)
 
     def set_tuning(self, key, value):
         """test / measurement knobs of this index (sdb_index_set_tuning); none changes a result"""

@@ -229,3 +229,50 @@ def test_async_batches_on_two_streams(oracle):
         for i in range(len(qs)):
             assert torch.equal(outs[i], ref[i])
     ix.close()
+
+
+@pytest.mark.parametrize("d,nq", [(96, 40), (384, 300), (2112, 24)])
+def test_host_memory_search_in_place(oracle, d, nq):
+    """Queries and outputs in page-locked host memory (sdb_host_alloc): the walk reads and writes them in place, one
+    launch per call.  Same answers as the staged path (pageable buffers, or SDB_TUNE_NO_ZERO_COPY), bit for bit, plain
+    and filtered, also when only some of the buffers are page-locked, and the oracle's."""
+    from semadb_amd import _buf
+    rng = np.random.default_rng(d + nq)
+    base = unit_rows(rng, 1500, d)
+    o = build_oracle_index(oracle, base, "cosine", R=32, L=50)
+    ix = _gpu_index(o, d, "cosine", 32, 50)
+    queries = unit_rows(rng, nq, d)
+    k, L = 10, 50
+    ref_ids, ref_d, ref_c, _ = ix.search_batch(queries, k, L)  # pageable numpy: staged
+    for q in range(0, nq, 7):
+        o_ids, o_d, _, _ = o.search(queries[q], k, L)
+        assert np.array_equal(ref_ids[q, :len(o_ids)], o_ids) and np.array_equal(bits(ref_d[q, :len(o_ids)]), bits(o_d))
+    pq_ = _buf.pinned_empty((nq, d), "float32")
+    pq_[:] = queries
+    p_ids, p_d, p_c = _buf.pinned_empty((nq, k), "uint64"), _buf.pinned_empty((nq, k), "float32"), _buf.pinned_empty((nq,), "uint32")
+    filt = [set(int(v) for v in rng.choice(np.arange(2, 1502), size=int(rng.integers(0, 60)), replace=False)) for _ in range(nq)]
+    f_ids, f_d, f_c, _ = ix.search_batch(queries, k, L, filters=filt)
+    for no_zc in (0, 1, 0):
+        ix.set_tuning("no_zero_copy", no_zc)
+        for rep in range(3):  # the same slabs call after call, like a batcher's
+            p_ids[:] = 0xDEADBEEF
+            p_d[:] = -7.0
+            p_c[:] = 99
+            ix.search_batch(pq_, k, L, out=(p_ids, p_d, p_c))
+            assert np.array_equal(p_c, ref_c) and np.array_equal(p_ids, ref_ids) and np.array_equal(bits(p_d), bits(ref_d))
+        ix.search_batch(pq_, k, L, filters=filt, out=(p_ids, p_d, p_c))
+        assert np.array_equal(p_c, f_c) and np.array_equal(p_ids, f_ids) and np.array_equal(bits(p_d), bits(f_d))
+        # page-locked queries, pageable outputs -- and the other way round
+        m_ids, m_d, m_c, _ = ix.search_batch(pq_, k, L)
+        assert np.array_equal(m_ids, ref_ids) and np.array_equal(bits(m_d), bits(ref_d)) and np.array_equal(m_c, ref_c)
+        ix.search_batch(queries, k, L, out=(p_ids, p_d, p_c))
+        assert np.array_equal(p_ids, ref_ids) and np.array_equal(bits(p_d), bits(ref_d)) and np.array_equal(p_c, ref_c)
+        # a slice in the middle of a block: the device's view of it is the block's plus the offset
+        half = nq // 2
+        ix.search_batch(pq_[half:], k, L, out=(p_ids[half:], p_d[half:], p_c[half:]))
+        assert np.array_equal(p_ids[half:], ref_ids[half:]) and np.array_equal(p_c[half:], ref_c[half:])
+    ix.set_tuning("wide_walk", 1)  # the one-wave kernel for a small call, too
+    ix.search_batch(pq_, k, L, out=(p_ids, p_d, p_c))
+    assert np.array_equal(p_ids, ref_ids) and np.array_equal(bits(p_d), bits(ref_d))
+    ix.close()
+    del pq_, p_ids, p_d, p_c

@@ -79,8 +79,9 @@ def kernels(so=SO):
 
 
 def waves_per_simd(r):
-    # gfx950: 512 VGPRs per SIMD lane shared by arch + acc registers, allocation granule 8, at most 8 waves per SIMD
-    regs = r["vgpr_count"] + r["agpr_count"]
+    # gfx950: 512 VGPRs per SIMD lane shared by arch + acc registers, allocation granule 8, at most 8 waves per SIMD.
+    # .vgpr_count of a gfx90a+ code object is the unified total (arch registers up to the accumulation offset + AGPRs)
+    regs = r["vgpr_count"]
     regs = max(8, (regs + 7) // 8 * 8)
     return min(8, 512 // regs)
 
@@ -100,11 +101,11 @@ def offenders(rows):
 
 
 def markdown(rows):
-    lines = ["| kernel | VGPR | AGPR | SGPR | spilled VGPR | scratch B | static LDS B | max WG | waves/SIMD by registers |",
+    lines = ["| kernel | VGPR (of which AGPR) | SGPR | spilled VGPR | spilled SGPR | scratch B | static LDS B | max WG | waves/SIMD by registers |",
              "|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
-        lines.append("| `%s` | %d | %d | %d | %d | %d | %d | %d | %d |" % (
-            r["kernel"], r["vgpr_count"], r["agpr_count"], r["sgpr_count"], r["vgpr_spill_count"],
+        lines.append("| `%s` | %d (%d) | %d | %d | %d | %d | %d | %d | %d |" % (
+            r["kernel"], r["vgpr_count"], r["agpr_count"], r["sgpr_count"], r["vgpr_spill_count"], r["sgpr_spill_count"],
             r["private_segment_fixed_size"], r["group_segment_fixed_size"], r["max_flat_workgroup_size"], waves_per_simd(r)))
     return "\n".join(lines)
 
