@@ -557,7 +557,8 @@ int sdb_index_union_prune(sdb_index *ix, uint64_t id, uint64_t m, const uint64_t
 /* Centroid ids that do not come from encode(): the k-means labels productQuantizer.Fit leaves on
  * its training points (product.go:216-218) and the codes a bucket holds under NodeKey(id,'q')
  * (productQuantizedPoint.ReadFrom / WriteTo, product.go:349-383).  ids [n] u64, codes [n][M] u8,
- * host memory, on an index with an attached quantizer. */
+ * host memory, on an index with an attached quantizer.  Not inside a write transaction (SDB_ERR_STATE): code rows exist
+ * once, not per graph version, and could not be rolled back with it. */
 int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *ids, const uint8_t *codes);
 int sdb_index_get_codes(const sdb_index *ix, uint64_t n, const uint64_t *ids, uint8_t *codes);
 

@@ -1391,19 +1391,6 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
     SDB_HIP(hipMalloc(&def_dists, (size_t)def_cap * kTileMaxCand * 4));
     cleanup.ptrs.push_back(def_dists);
   }
-  // pair distances of appended edges (BuildArgs::pairc): 4 KB per row for the length of this call -- bulk builds only
-  // (a call that adds at least a quarter to the table); a cache, so no memory for it is no error
-  float *pairc = nullptr;
-  if (!pq && l.ng <= 6 && n >= 256 && n >= (uint64_t)n0 / 4 && !ix->tune_no_defer) {
-    const size_t bytes = (size_t)total_rows * kMaxDirty * 64 * sizeof(float);
-    if (hipMalloc(&pairc, bytes) == hipSuccess) {
-      cleanup.ptrs.push_back(pairc);
-      if (hipMemsetAsync(pairc, 0xFF, bytes, stream) != hipSuccess) pairc = nullptr;
-    } else {
-      (void)hipGetLastError();
-      pairc = nullptr;
-    }
-  }
   BigScratch big_scratch;
   // per new point: the (slot, distance) pairs its search evaluates, direct-mapped (SearchArgs::dcache)
   constexpr uint32_t kDcacheBits = SDB_DCACHE_BITS;  // 8 192 entries = 64 KB per point: ~4 000 evaluations, ~80 % survive
@@ -1411,6 +1398,26 @@ extern "C" int sdb_index_insert_batch(sdb_index *ix, uint64_t n, const uint64_t 
   if (!pq) {
     SDB_HIP(hipMalloc(&dcache, ((size_t)max_round << kDcacheBits) * sizeof(uint2)));
     cleanup.ptrs.push_back(dcache);
+  }
+  // pair distances of appended edges (BuildArgs::pairc): 4 KB per row for the length of this call -- bulk builds only
+  // (a call that adds at least a quarter to the table).  A CACHE: it is asked for LAST, after every buffer the call
+  // cannot do without, and only when it leaves the device room for what is allocated later -- the chip-wide prune's
+  // scratch and its radix sort (bigprune.inc, mid-build: a failure there leaves the handle unusable), the workspaces
+  // and quantizer tables of searches that run meanwhile: 4 GB or a sixteenth of the device, whichever is more (at
+  // 10M rows the cache is 41 GB; on a device near capacity it used to be taken first and starve the rest).
+  float *pairc = nullptr;
+  if (!pq && l.ng <= 6 && n >= 256 && n >= (uint64_t)n0 / 4 && !ix->tune_no_defer) {
+    const size_t bytes = (size_t)total_rows * kMaxDirty * 64 * sizeof(float);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = total_b = 0, (void)hipGetLastError();
+    const size_t headroom = std::max<size_t>((size_t)4 << 30, total_b / 16);
+    if (free_b >= bytes + headroom && hipMalloc(&pairc, bytes) == hipSuccess) {
+      cleanup.ptrs.push_back(pairc);
+      if (hipMemsetAsync(pairc, 0xFF, bytes, stream) != hipSuccess) pairc = nullptr;
+    } else {
+      (void)hipGetLastError();
+      pairc = nullptr;
+    }
   }
 
   // ---- from here on the call writes, into the writer's copy of the graph (index.h graph versions): searches

@@ -651,6 +651,19 @@ int sdb_index::reserve(uint32_t rows) {
       p.push_back(*out);
       return SDB_OK;
     }
+    // two buffers of a CACHE (the neighbours' code rows behind both adjacency copies): both or neither, and no room
+    // for them is no error -- the index works without (searches gather code rows by slot)
+    bool get_pair_if_room(void **a, void **b, size_t bytes) {
+      *a = *b = nullptr;
+      if (hipMalloc(a, bytes) == hipSuccess && hipMalloc(b, bytes) == hipSuccess) {
+        p.push_back(*a), p.push_back(*b);
+        return true;
+      }
+      (void)hipGetLastError();
+      if (*a) (void)hipFree(*a);
+      *a = *b = nullptr;
+      return false;
+    }
   } fresh;
   float *nslab = nullptr, *nad = nullptr;
   uint32_t *nadj = nullptr, *nradj = nullptr, *ndeg = nullptr, *nclean = nullptr, *ndc = nullptr;
@@ -668,11 +681,11 @@ int sdb_index::reserve(uint32_t rows) {
   SDB_TRY(fresh.get((void **)&ndc, (size_t)ncap * sizeof(uint32_t)));
   if (pq) SDB_TRY(fresh.get((void **)&ncodes, (size_t)ncap * pq->M));  // the code rows of a quantized store grow with it
   uint8_t *nacw = nullptr, *nacr = nullptr;  // ... and the neighbours' code rows behind both adjacency copies
-  const size_t ac_row = has_adjcodes() ? (size_t)kAdjStride * pq->M : 0;
-  if (ac_row) {
-    SDB_TRY(fresh.get((void **)&nacw, (size_t)ncap * ac_row));
-    SDB_TRY(fresh.get((void **)&nacr, (size_t)ncap * ac_row));
-  }
+  const bool had_ac = has_adjcodes();
+  size_t ac_row = had_ac ? (size_t)kAdjStride * pq->M : 0;
+  // (2 x 64 M bytes per row: 41 GB at 10M rows and M = 32, more than the vectors of d = 768.  A table that grows past
+  // the room for them drops them instead of failing the insert -- alloc_adjcodes treats them as optional the same way)
+  if (ac_row && !fresh.get_pair_if_room((void **)&nacw, (void **)&nacr, (size_t)ncap * ac_row)) ac_row = 0;
   // the old buffers are freed below: nothing may still be walking them (searches run on streams of their own)
   if (cap) SDB_HIP(hipDeviceSynchronize());
   SDB_HIP(hipMemset(nadj, 0xFF, (size_t)ncap * kAdjStride * sizeof(uint32_t)));
@@ -707,7 +720,7 @@ int sdb_index::reserve(uint32_t rows) {
                     (void *)r_ids, (void *)d_dirty, (void *)d_adjdist, (void *)d_dcount})
       if (p) (void)hipFree(p);
     if (pq && d_codes) (void)hipFree(d_codes);
-    if (ac_row) (void)hipFree(d_adjcodes), (void)hipFree(r_adjcodes), d_adjcodes = nacw, r_adjcodes = nacr;
+    if (had_ac) (void)hipFree(d_adjcodes), (void)hipFree(r_adjcodes), d_adjcodes = nacw, r_adjcodes = nacr;  // (NULL: dropped)
     d_slab = nslab, d_adj = nadj, r_adj = nradj, d_deg = ndeg, d_clean = nclean, d_ids = nids, r_ids = nrids;
     d_dirty = ndirty, d_adjdist = nad, d_dcount = ndc;
     if (pq) d_codes = ncodes;
@@ -929,6 +942,15 @@ int sdb_index::rollback() {
     hipLaunchKernelGGL(sdb::k_restore_rows, dim3((n + 3) / 4), dim3(256), 0, nullptr, r_adj, d_adj, r_ids, d_ids, d_deg,
                        d_clean, d_dcount, d_dirty, n, tx_n0);
   SDB_HIP(hipGetLastError());
+  // The writer's copy of the neighbours' code rows follows the restored adjacency rows.  commit() brings it to the
+  // transaction's state BEFORE the copies change hands, so a commit that failed after that step -- or a transaction that
+  // is simply aborted after its rows were written -- would leave restored rows carrying the transaction's code rows:
+  // edge e walked with another node's codes, silently.  All committed rows (a rollback is rare; 64 M bytes per row).
+  if (has_adjcodes() && tx_n0) {
+    hipLaunchKernelGGL(sdb::k_adjcodes_rows, dim3((tx_n0 + 3) / 4), dim3(256), 0, nullptr, d_adj, d_codes, d_adjcodes, nullptr,
+                       tx_n0, 0u, pq->M);
+    SDB_HIP(hipGetLastError());
+  }
   // the start node's overflow list as committed
   const uint32_t ext_n = view.start_ext_n, need = (ext_n + 63) / 64 * 64;
   h_start_ext.assign(ext_n, 0);
@@ -2097,10 +2119,24 @@ int sdb_index_compact(sdb_index *ix) try {
   SDB_TRY(nb.get((void **)&nrids, (size_t)cap * 8));
   if (M) SDB_TRY(nb.get((void **)&ncodes, (size_t)cap * M));
   uint8_t *nacw = nullptr, *nacr = nullptr;  // the neighbours' code rows follow the renumbered adjacency
-  if (ix->has_adjcodes()) {
-    SDB_TRY(nb.get((void **)&nacw, (size_t)cap * kAdjStride * M));
-    SDB_TRY(nb.get((void **)&nacr, (size_t)cap * kAdjStride * M));
+  const bool had_ac = ix->has_adjcodes();
+  if (had_ac && (hipMalloc((void **)&nacw, (size_t)cap * kAdjStride * M) != hipSuccess ||
+                 hipMalloc((void **)&nacr, (size_t)cap * kAdjStride * M) != hipSuccess)) {
+    // a cache (reserve, alloc_adjcodes): without room for its second copy the compacted index goes on without it
+    (void)hipGetLastError();
+    if (nacw) (void)hipFree(nacw);
+    nacw = nacr = nullptr;
   }
+  struct AcGuard {  // until they change hands below
+    uint8_t *&a, *&b;
+    bool keep = false;
+    ~AcGuard() {
+      if (!keep) {
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+      }
+    }
+  } ac_guard{nacw, nacr};
   SDB_TRY(tmp.get((void **)&d_live, (size_t)nn * 4 + 4));
   SDB_TRY(tmp.get((void **)&d_map, (size_t)n * 4));
   SDB_TRY(tmp.get((void **)&d_lost, 4));
@@ -2143,7 +2179,8 @@ int sdb_index_compact(sdb_index *ix) try {
                   (void *)ix->d_clean, (void *)ix->d_dcount, (void *)ix->d_ids, (void *)ix->r_ids})
     (void)hipFree(x);
   if (M) (void)hipFree(ix->d_codes);
-  if (nacw) (void)hipFree(ix->d_adjcodes), (void)hipFree(ix->r_adjcodes), ix->d_adjcodes = nacw, ix->r_adjcodes = nacr;
+  if (had_ac) (void)hipFree(ix->d_adjcodes), (void)hipFree(ix->r_adjcodes), ix->d_adjcodes = nacw, ix->r_adjcodes = nacr;  // (NULL: dropped)
+  ac_guard.keep = true;
   nb.keep = true;
   ix->d_slab = nslab, ix->d_adj = nadj, ix->r_adj = nradj, ix->d_adjdist = nad, ix->d_deg = ndeg, ix->d_clean = nclean;
   ix->d_dcount = ndc, ix->d_ids = nids, ix->r_ids = nrids;
@@ -2318,6 +2355,8 @@ SDB_API_CATCH("sdb_index_attach_pq")
 extern "C" int sdb_index_set_codes(sdb_index *ix, uint64_t n, const uint64_t *ids, const uint8_t *codes) try {
   if (!ix) return fail(SDB_ERR_INVALID, "index is NULL");
   if (!ix->pq) return fail(SDB_ERR_STATE, "no quantizer attached");
+  // (code rows exist once, not per graph version: rewritten inside a transaction they could not be rolled back with it)
+  if (ix->in_tx) return fail(SDB_ERR_STATE, "a write transaction is open: centroid ids are set outside it");
   if (n == 0) return SDB_OK;
   if (!ids || !codes) return fail(SDB_ERR_INVALID, "NULL argument");
   const uint32_t M = ix->pq->M;

@@ -52,6 +52,15 @@ __device__ __forceinline__ float dist_serial_metric(const float *x, const float 
 // elements in memory (sub_len % 32 of them), chained sequentially as the asm does.
 constexpr int kRegBlocksMax = 8;  // sub-vectors of up to 8 * 32 + 31 floats take the register path
 typedef float pq_f2v __attribute__((ext_vector_type(2)));
+typedef int pq_f16s __attribute__((ext_vector_type(16)));  // (an integer tuple: a float one is not accepted as a scalar asm operand)
+// 32 consecutive floats at a wave-uniform address + a constant byte offset, into two 16-register scalar tuples; the
+// caller waits (s_waitcnt lgkmcnt(0) tied to the tuples) before it reads them
+__device__ __forceinline__ void sload_block(uint64_t a, int byte_off, pq_f16s &lo, pq_f16s &hi) {
+  asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+               : "=&s"(lo), "=&s"(hi)
+               : "s"(a), "i"(byte_off), "i"(byte_off + 64)
+               : "memory");
+}
 template <bool L2, int NB, int TC = -1, typename UP = const float *__restrict__>  // TC >= 0: the tail's length, known at compile time
 __device__ __forceinline__ float dist_regs(const float *r, UP u, const float *__restrict__ rt, uint32_t tail_rt) {
   const uint32_t tail = TC >= 0 ? (uint32_t)TC : tail_rt;
@@ -60,18 +69,59 @@ __device__ __forceinline__ float dist_regs(const float *r, UP u, const float *__
   pq_f2v acc2[16];
 #pragma unroll
   for (int p = 0; p < 16; p++) acc2[p] = pq_f2v{0.0f, 0.0f};
+  if constexpr (NB >= 4 || (NB == 3 && TC < 0)) {  // (three blocks + a run-time tail: the same, its chain adds 31 scalars)
+    // Long sub-vectors (128 floats and more): `u` is wave-uniform and its elements arrive through scalar loads.  Left to
+    // the compiler ALL 32 NB of them are asked for before the first multiply -- 128 .. 256 scalars into ~100 SGPRs: up to
+    // 4 093 were spilled into VGPR lanes (two lane moves per scalar, against one packed FMA per two scalars), and at
+    // NB = 8 the lanes' registers pushed 32 VGPRs into scratch.  (Invariant loads carry no ordering a scheduling barrier
+    // could hold on to.)  So the loads are written out: one block = two s_load_dwordx16, the next block's issued when
+    // this one's have arrived and in flight while it is multiplied -- 64 scalars live, nothing spilled.
+    // (the address is uniform by construction -- a centroid's or a query's sub-vector -- but not always provably so: a
+    // centroid row index read from memory sits in a VGPR)
+    uint64_t ua = (uint64_t)(uintptr_t)(const void *)u;
+    const uint32_t ua_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ua);  // (the builtin returns a SIGNED int)
+    const uint32_t ua_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ua >> 32));
+    ua = ((uint64_t)ua_hi << 32) | ua_lo;
+    pq_f16s c0, c1;
+    sload_block(ua, 0, c0, c1);
 #pragma unroll
-  for (int b = 0; b < NB; b++)
+    for (int b = 0; b < NB; b++) {
+      // (the accumulators ride through the wait: the previous block's multiplies are thereby in front of it -- without
+      // that they sink behind ALL the loads, and every block's scalars are parked in VGPR lanes until then)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+s"(c0), "+s"(c1), "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]), "+v"(acc2[4]), "+v"(acc2[5]),
+                     "+v"(acc2[6]), "+v"(acc2[7]), "+v"(acc2[8]), "+v"(acc2[9]), "+v"(acc2[10]), "+v"(acc2[11]), "+v"(acc2[12]),
+                     "+v"(acc2[13]), "+v"(acc2[14]), "+v"(acc2[15]));
+      pq_f16s n0 = c0, n1 = c1;
+      if (b + 1 < NB) sload_block(ua, 128 * (b + 1), n0, n1);
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-      const pq_f2v x = {r[32 * b + 2 * p], r[32 * b + 2 * p + 1]}, y = {u[32 * b + 2 * p], u[32 * b + 2 * p + 1]};
-      if constexpr (L2) {
-        const pq_f2v d = x - y;
-        acc2[p] = __builtin_elementwise_fma(d, d, acc2[p]);
-      } else {
-        acc2[p] = __builtin_elementwise_fma(x, y, acc2[p]);
+      for (int p = 0; p < 16; p++) {
+        const pq_f2v x = {r[32 * b + 2 * p], r[32 * b + 2 * p + 1]};
+        const pq_f2v yy = p < 8 ? pq_f2v{__int_as_float(c0[2 * p]), __int_as_float(c0[2 * p + 1])}
+                                : pq_f2v{__int_as_float(c1[2 * p - 16]), __int_as_float(c1[2 * p - 15])};
+        if constexpr (L2) {
+          const pq_f2v d = x - yy;
+          acc2[p] = __builtin_elementwise_fma(d, d, acc2[p]);
+        } else {
+          acc2[p] = __builtin_elementwise_fma(x, yy, acc2[p]);
+        }
       }
+      c0 = n0, c1 = n1;
     }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        const pq_f2v x = {r[32 * b + 2 * p], r[32 * b + 2 * p + 1]}, y = {u[32 * b + 2 * p], u[32 * b + 2 * p + 1]};
+        if constexpr (L2) {
+          const pq_f2v d = x - y;
+          acc2[p] = __builtin_elementwise_fma(d, d, acc2[p]);
+        } else {
+          acc2[p] = __builtin_elementwise_fma(x, y, acc2[p]);
+        }
+      }
+  }
   float rr[4];
 #pragma unroll
   for (int l = 0; l < 4; l++) {
@@ -593,7 +643,8 @@ __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ quer
   // a fixed trip count: the sub-vectors of all kLutQT queries are wave-uniform scalar loads, and unrolled the compiler
   // issues them together instead of one query's, a wait, the next query's
   (void)q1;
-#pragma unroll
+  // (sub-vectors of 128 floats and more: one query at a time -- their scalars alone fill the SGPR file)
+#pragma unroll NB >= 4 ? 1 : (int)kLutQT
   for (uint32_t k = 0; k < kLutQT; k++) {
     const uint32_t q = q0 + k < nq ? q0 + k : nq - 1;  // past the end: the last query again (the same value is stored twice)
     const float *x = queries + (size_t)q * dim + (size_t)i * sub_len;

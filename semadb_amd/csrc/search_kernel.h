@@ -97,6 +97,17 @@ struct ChunkPairs {
   static constexpr int value = DEEP ? (NG == 3 ? SDB_DEEP3_PAIRS : 2 * base) : base;  // DEEP: 32 / 24 / 16 / 12 / 8 / 4 rows in flight
 };
 
+// The kernel's own arguments once more, through a pointer the optimiser cannot see through.  Every walk kernel takes
+// its SearchArgs by value as its first parameter, i.e. at offset 0 of the kernarg segment; a field read through `a` is
+// loaded in the kernel's first instructions and -- with ~60 fields against ~100 SGPRs -- parked in a VGPR lane until it
+// is used.  A field that only the epilogue reads is read through this view: one scalar load at the point of use.
+__device__ __forceinline__ const SearchArgs &cold_args(const SearchArgs &) {
+  typedef const __attribute__((address_space(4))) SearchArgs *kernarg_view;
+  uintptr_t p = (uintptr_t)(kernarg_view)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const SearchArgs *)p;
+}
+
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
@@ -1878,9 +1889,16 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
 #endif
 
   // ---- IndexVamana.Search result copy vamana.go:293-307 (from resultSet when filtered, search.go:36)
-  if (a.out_ids) {
+  // (what only this epilogue reads -- outputs, trace, counters -- comes through cold_args(): loaded here, once, instead
+  // of being carried, spilled into VGPR lanes, from the kernel's first instruction through the whole walk)
+  const SearchArgs &e = cold_args(a);
+  if (e.out_ids) {
     int base = 0;
     const int olen = FILT ? rlen : len;
+    const int limit = (int)e.limit;
+    uint64_t *const o_ids = e.out_ids + (size_t)q * limit;
+    float *const o_d = e.out_dists + (size_t)q * limit;
+    const uint64_t *const ids = e.ids;
 #pragma unroll
     for (int r = 0; r < NREG; r++) {
       const uint32_t s = (FILT ? rid[FILT ? r : 0] : cid[r]) & ~kVisBit;
@@ -1888,28 +1906,28 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       const bool ok = (r * 64 + lane) < olen && s != a.start_slot;  // :294-296
       const uint64_t m = __ballot(ok);
       const int rank = base + __popcll(m & ((1ull << lane) - 1));
-      if (ok && rank < (int)a.limit) {  // :297-299
-        a.out_ids[(size_t)q * a.limit + rank] = a.ids[s];
-        a.out_dists[(size_t)q * a.limit + rank] = dd;
+      if (ok && rank < limit) {  // :297-299
+        o_ids[rank] = ids[s];
+        o_d[rank] = dd;
       }
       base += __popcll(m);
     }
-    const int got = base < (int)a.limit ? base : (int)a.limit;
-    if (lane == 0) a.out_counts[q] = (uint32_t)got;
-    for (int i = got + lane; i < (int)a.limit; i += 64)  // rows shorter than `limit` end in zeros, not in
-      a.out_ids[(size_t)q * a.limit + i] = 0, a.out_dists[(size_t)q * a.limit + i] = 0.0f;  // whatever was there
+    const int got = base < limit ? base : limit;
+    if (lane == 0) e.out_counts[q] = (uint32_t)got;
+    for (int i = got + lane; i < limit; i += 64)  // rows shorter than `limit` end in zeros, not in
+      o_ids[i] = 0, o_d[i] = 0.0f;                // whatever was there
   }
   if (lane == 0) {
-    if (a.tr_ndist) a.tr_ndist[q] = n_dist;
-    if (a.tr_nhop) a.tr_nhop[q] = n_hop;
+    if (e.tr_ndist) e.tr_ndist[q] = n_dist;
+    if (e.tr_nhop) e.tr_nhop[q] = n_hop;
 #ifdef SDB_SPEC_STATS
-    if (a.tr_nedges) a.tr_nedges[q] = Dist::kSpeculate ? n_spec_hit : n_edges;
+    if (e.tr_nedges) e.tr_nedges[q] = Dist::kSpeculate ? n_spec_hit : n_edges;
 #else
-    if (a.tr_nedges) a.tr_nedges[q] = n_edges;
+    if (e.tr_nedges) e.tr_nedges[q] = n_edges;
 #endif
-    if (a.vis_count) a.vis_count[q] = n_hop;
-    if (a.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
-      unsigned long long *t = a.totals + (q & 63u) * 16u;
+    if (e.vis_count) e.vis_count[q] = n_hop;
+    if (e.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
+      unsigned long long *t = e.totals + (q & 63u) * 16u;
       atomicAdd(t, (unsigned long long)n_dist), atomicAdd(t + 1, (unsigned long long)n_edges);
     }
   }
@@ -2000,11 +2018,19 @@ __device__ __forceinline__ unsigned long long lds_load_u64(const void *p) {
   return *(lds_u64_t *)p;
 }
 __device__ __forceinline__ void lds_store_u64(void *p, unsigned long long v) { *(lds_u64_t *)p = v; }
+// the mailboxes' payload goes through volatile LDS accesses as well: the compiler keeps volatile accesses in program
+// order among themselves, so the payload's stores stay in front of the store of the word that carries the sequence
+// number and its loads stay behind the load that saw it -- the hardware performs one wave's LDS instructions in issue
+// order, and the emitted instructions are the same ds_read / ds_write as before
+typedef __attribute__((address_space(3))) volatile uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_load_u32(const void *p) { return *(lds_u32_t *)p; }
+__device__ __forceinline__ void lds_store_u32(void *p, uint32_t v) { *(lds_u32_t *)p = v; }
 
 struct Pq2Shared {
-  // Both mailboxes are written by one lane with plain LDS stores, the word that carries the sequence number last: a
-  // wave's LDS instructions are performed in the order it issued them, so whoever sees the number sees what was written
-  // before it -- no s_waitcnt on either side (a workgroup-scope fence would wait for every store the wave has in flight).
+  // Both mailboxes are written by one lane with volatile LDS stores, the word that carries the sequence number last: a
+  // wave's LDS instructions are performed in the order it issued them (and volatile accesses are issued in program
+  // order), so whoever sees the number sees what was written before it -- no s_waitcnt on either side (a workgroup-scope
+  // release would wait for every global load the walker has in flight: the next hop's rows).
   uint2 pts_word;  // x: the node the walker goes to next, or kNoSlot: the merger says; y: batches posted (monotonic)
   uint2 pts_mask;  // lanes of the batch that hold a point
   uint2 ans_word;  // x: pts_word.x == kNoSlot: the first unvisited entry after the insertions (marked now), kNoSlot: none left; y: batches merged
@@ -2035,9 +2061,9 @@ __device__ __forceinline__ void pq2_walker(const SearchArgs &a, const uint32_t q
 #endif
   // one batch of points to the merger; `named`: where the walk goes next, if the walker knows
   auto post = [&](uint64_t pend, uint32_t id, float d, uint32_t named) {
-    if ((pend >> lane) & 1ull) sh->pts_id[lane] = id, sh->pts_d[lane] = d;
+    if ((pend >> lane) & 1ull) lds_store_u32(&sh->pts_id[lane], id), lds_store_u32(&sh->pts_d[lane], __float_as_uint(d));
     seq++;
-    if (lane == 0) sh->pts_mask = make_uint2((uint32_t)pend, (uint32_t)(pend >> 32));
+    if (lane == 0) lds_store_u64(&sh->pts_mask, (unsigned long long)pend);
     wave_lds_sync();
     if (lane == 0) lds_store_u64(&sh->pts_word, (unsigned long long)named | ((unsigned long long)seq << 32));
   };
@@ -2093,7 +2119,8 @@ __device__ __forceinline__ void pq2_walker(const SearchArgs &a, const uint32_t q
     // the array after the LAST hop's insertions (the merger has had this hop's fetch, test and sums for them)
     answered();
     SDB_PQ2_W(1)
-    const uint2 f1w = sh->ans_f1;
+    const unsigned long long f1w64 = lds_load_u64(&sh->ans_f1);
+    const uint2 f1w = make_uint2((uint32_t)f1w64, (uint32_t)(f1w64 >> 32));
     const uint32_t f1 = f1w.x;
     const float f1d = __uint_as_float(f1w.y);
     uint32_t named = kNoSlot;
@@ -2171,11 +2198,12 @@ __device__ __forceinline__ void pq2_merger(const SearchArgs &a, const uint32_t q
     wave_lds_sync();
     SDB_PQ2_M(0)
     const uint32_t named = (uint32_t)w;
-    const uint2 pm = sh->pts_mask;
+    const unsigned long long pm64 = lds_load_u64(&sh->pts_mask);
+    const uint2 pm = make_uint2((uint32_t)pm64, (uint32_t)(pm64 >> 32));
     const uint64_t pend = (uint64_t)pm.x | ((uint64_t)pm.y << 32);
     const bool mine = (pend >> lane) & 1ull;
-    const uint32_t id = mine ? sh->pts_id[lane] : kNoSlot;
-    const float d = mine ? sh->pts_d[lane] : 0.0f;
+    const uint32_t id = mine ? lds_load_u32(&sh->pts_id[lane]) : kNoSlot;
+    const float d = mine ? __uint_as_float(lds_load_u32(&sh->pts_d[lane])) : 0.0f;
     // AddWithLimit over the new neighbours, in edge order distset.go:184-198
     if (pend) add_with_limit_merge(cid, cd, len, cap, id, d, pend, lane, scratch);
 #ifdef SDB_PQ2_STATS
@@ -2215,7 +2243,7 @@ __device__ __forceinline__ void pq2_merger(const SearchArgs &a, const uint32_t q
         const int s2 = __ffsll((unsigned long long)um[r]) - 1;
         f1 = rl(cid[r], s2), f1d = rlf(cd[r], s2);
       }
-    if (lane == 0) sh->ans_f1 = make_uint2(f1, __float_as_uint(f1d));
+    if (lane == 0) lds_store_u64(&sh->ans_f1, (unsigned long long)f1 | ((unsigned long long)__float_as_uint(f1d) << 32));
     wave_lds_sync();
     if (lane == 0) lds_store_u64(&sh->ans_word, (unsigned long long)next | ((unsigned long long)seq << 32));
     // That entry is where the walk goes next unless the hop under way finds a nearer point: its adjacency row and the

@@ -48,6 +48,10 @@ def test_kmeans_reference_kat():
                                      (64, 8, 32, 500), (128, 8, 64, 500), (96, 4, 16, 300), (96, 8, 16, 300),
                                      # sub-vector lengths 100 (3 blocks + tail), 256 (8 blocks), 320 (generic kernel)
                                      (200, 2, 16, 300), (512, 2, 8, 200), (640, 2, 8, 200),
+                                     # 4 .. 7 blocks, whole and with a tail: the scalar operands of these go block by block
+                                     # through hand-placed s_load_dwordx16 (pq.hip dist_regs, round 6)
+                                     (256, 2, 8, 200), (320, 2, 12, 200), (384, 2, 8, 150), (448, 2, 8, 150), (460, 2, 8, 150),
+                                     (270, 2, 8, 150),
                                      # whole 32-float blocks and K % 16 == 0: the LUT of dot / cosine is built on the matrix cores
                                      (256, 8, 256, 1300), (512, 2, 16, 300), (768, 8, 256, 1300)])
 def test_pq_matches_oracle(oracle, metric, d, M, K, n):
@@ -507,6 +511,13 @@ def test_neighbour_code_rows_follow_the_graph(oracle, d, M, K):
     same_walks("inside an open transaction")  # searches walk the committed copy
     ix.abort_write()
     same_walks("after abort")
+    # centroid ids exist once, not per graph version: they are not set inside a transaction (it could not take them back)
+    ix.begin_write()
+    from semadb_amd._lib import SemaDBError
+    with pytest.raises(SemaDBError):
+        vs.set_codes(ix, np.array(live[:3], dtype=np.uint64), np.zeros((3, M), dtype=np.uint8))
+    ix.abort_write()
+    same_walks("after a refused set_codes and an abort")
     # deletes (stragglers go onto the start node: rows change far from the deleted ones)
     dead = rng.choice(np.arange(2, n0 + 2 + n1, dtype=np.uint64), 120, replace=False)
     assert o.delete(dead) == 0
