@@ -198,6 +198,61 @@ class Exchange:
             self.cl.close()
 
 
+def rank_identity(dev_index, ex=None):
+    """What this rank is, for the N > 1 line's self-diagnosis (config.rccl): its device ordinal and PCI bus id as the
+    runtime reports them and -- when the library's communicator is up -- what sdb_cluster_info and
+    sdb_cluster_transport say about it.  Gathered from every rank with all_gather_object."""
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+          "device_ordinal": dev_index, "pci_bus_id": None, "pid": os.getpid()}
+    try:
+        props = torch.cuda.get_device_properties(dev_index)
+        if hasattr(props, "pci_bus_id"):
+            me["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id,
+                                                   getattr(props, "pci_device_id", 0))
+        me["device_name"] = props.name
+    except Exception:
+        pass
+    if ex is not None and getattr(ex, "native", False):
+        try:
+            from semadb_amd._lib import lib
+            r, w, dv = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+            lib().sdb_cluster_info(ex.cl._h, C.byref(r), C.byref(w), C.byref(dv))
+            me["cluster_rank"], me["cluster_world"], me["cluster_device"] = r.value, w.value, dv.value
+            me["transport"] = ex.cl.transport()
+        except Exception as e:
+            me["cluster_error"] = repr(e)
+    return me
+
+
+def judge_ranks(infos, world, native, shared_device_ok=False):
+    """-> (summary for config.rccl, reason the line is invalid or None).  Invalid: the ranks the communicator reports are
+    not exactly 0 .. N-1, a rank's communicator disagrees on the world size, or two ranks drive the same device (unless
+    the run is a functional one over gloo, where the ranks share a GPU on purpose)."""
+    import re
+    infos = sorted(infos, key=lambda r: r.get("rank", 0))
+    out = {"ranks": [{k: r.get(k) for k in ("rank", "local_rank", "device_ordinal", "pci_bus_id", "cluster_rank",
+                                            "cluster_world", "cluster_device")} for r in infos]}
+    bad = None
+    if [r.get("rank") for r in infos] != list(range(world)):
+        bad = "ranks gathered %s, expected 0..%d" % ([r.get("rank") for r in infos], world - 1)
+    if native:
+        seen = sorted(r.get("cluster_rank", -1) for r in infos)
+        out["ranks_seen_by_cluster_info"] = seen
+        if seen != list(range(world)):
+            bad = bad or "sdb_cluster_info reports ranks %s, expected 0..%d" % (seen, world - 1)
+        if any(r.get("cluster_world") != world for r in infos):
+            bad = bad or "a rank's communicator has %s ranks, expected %d" % ([r.get("cluster_world") for r in infos], world)
+        t = next((r.get("transport") for r in infos if r.get("transport")), None)
+        out["transport"] = t
+        m = re.search(r"rccl (\d+\.\d+\.\d+)", t or "")
+        out["nccl_version"] = m.group(1) if m else None
+    devs = [(r.get("pci_bus_id") or "ordinal %s" % r.get("device_ordinal")) for r in infos]
+    out["shared_device_ok"] = bool(shared_device_ok)
+    if len(set(devs)) != len(devs) and not shared_device_ok:
+        bad = bad or "two ranks drive the same device: %s" % devs
+    return out, bad
+
+
 def torchrun_command(gpus, argv, port=None):
     """The command line the driver itself uses for N > 1 (one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
     if port is None:
@@ -596,6 +651,38 @@ def measure_mode(a, ctx, mode, rows, primary):
     if split:
         result["config"]["exchange"] = "torch.distributed all_gather of the answers (%s); no merge" % ctx["backend"]
         result["config"]["ranks_seen"] = list(range(world))
+    if use_dist:
+        # the N > 1 line diagnoses itself (the first 8-GPU run will be the driver's, unattended): who the ranks are, what
+        # the communicator says, and what the exchange alone costs
+        infos = [None] * world
+        dist.all_gather_object(infos, rank_identity(dev_index, ex))
+        rccl, bad = judge_ranks(infos, world, bool(ex is not None and ex.native),
+                                shared_device_ok=(ctx["backend"] != "nccl" or os.environ.get("BENCH_FORCE_EXCHANGE") == "1"))
+        if ex is not None and not split:
+            try:  # the exchange alone: all-gather + merge of a block that is already there, per batch
+                from semadb_amd import cluster as _cl
+                per = _cl.shard_limit(k, world, 75)
+                blk = _cl.PackedTopK(nq, per, dev)
+                reps_x = 20
+                for i in range(reps_x + 3):
+                    if i == 3:
+                        torch.cuda.synchronize()
+                        barrier()
+                        t_x = time.perf_counter()
+                    if ex.native:
+                        ex.cl.allgather_merge(blk, k)
+                        ex.cl.synchronize()
+                    else:
+                        ex.seq += 1
+                        blk.exchange(k, seq=ex.seq, ticket=ex.seq, queries=None)
+                torch.cuda.synchronize()
+                rccl["allgather_merge_us_per_batch"] = round((time.perf_counter() - t_x) / reps_x * 1e6, 1)
+                rccl["allgather_bytes_per_rank"] = int(blk.buf.numel())
+            except Exception as e:
+                rccl["allgather_merge_error"] = repr(e)
+        result["config"]["rccl"] = rccl
+        if bad:
+            result["invalid"] = bad
     if ex is not None and not split:
         result["config"]["ranks_seen"] = sorted(ranks_seen)
         if ex.native:  # the library's own words: RCCL version, the librccl this process loaded, communicator size, rank
@@ -603,6 +690,8 @@ def measure_mode(a, ctx, mode, rows, primary):
         result["config"]["exchange"] = ("libsemadb_amd.so: sdb_cluster_search_batch (ncclAllGather on the library's stream)"
                                         if ex.native else "torch.distributed all_gather_into_tensor (%s) + sdb_cluster_merge_gathered (tag check + merge)%s" %
                                         (ctx["backend"], "; " + ex.note if ex.note else ""))
+    if ex is not None and not split and sorted(ranks_seen) != list(range(world)):
+        result["invalid"] = "the merged answers name shards %s, expected every one of 0..%d" % (sorted(ranks_seen), world - 1)
     if recall < 0.95:  # the metric is recall-gated: a line below the gate is not a measurement of it
         result["invalid"] = "recall@10 %.4f is below the metric's 0.95 gate" % recall
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -694,6 +783,15 @@ def flatten_summary(result):
             flat["%s_recall_at_10" % key] = rec["recall_at_10"]
             if "search_size_for_recall_0.95" in rec:
                 flat["%s_search_size_for_recall_0.95" % key] = rec["search_size_for_recall_0.95"]
+            if isinstance(rec.get("roofline"), dict):  # three datasets, three fractions (the headline's is roofline.frac)
+                flat["%s_roofline_frac" % key] = rec["roofline"].get("frac")
+                flat["%s_mean_n_dist" % key] = rec.get("mean_n_dist")
+                flat["%s_kernel_ms" % key] = rec.get("kernel_ms_avg")
+                flat["%s_algorithmic_bytes_per_launch" % key] = rec.get("algorithmic_bytes_per_launch")
+    hb = cfg.get("host_blocking_variants") or {}
+    for name in ("staged", "pageable"):
+        if isinstance(hb.get(name), dict):
+            flat["host_qps_%s" % name] = hb[name].get("qps")
     c4 = cfg.get("c4") or {}
     for mk, rec in c4.items():
         if mk.startswith("M=") and isinstance(rec, dict):
@@ -705,6 +803,12 @@ def flatten_summary(result):
                     flat["%s_%s" % (tag, dst)] = rec[src]
             if isinstance(rec.get("roofline"), dict):
                 flat["%s_roofline_frac" % tag] = rec["roofline"].get("frac")
+                flat["%s_roofline_bound" % tag] = rec["roofline"].get("bound")
+            if isinstance(rec.get("latency_roof"), dict):
+                flat["%s_latency_roof_frac" % tag] = rec["latency_roof"].get("frac")
+                flat["%s_dependent_fetch_ns" % tag] = (rec["latency_roof"].get("dependent_fetch_ns") or {}).get("loaded")
+            if rec.get("code_row_layout_bytes") is not None:
+                flat["%s_code_row_layout_bytes" % tag] = rec["code_row_layout_bytes"]
     if isinstance(c4.get("full_precision"), dict):
         flat["c4_full_precision_call_qps"] = c4["full_precision"].get("call_qps")
         flat["c4_full_precision_recall_at_10"] = c4["full_precision"].get("recall_at_10")
@@ -834,6 +938,26 @@ def latency_points(a, ix, queries):
     return out
 
 
+def dependent_fetch_ns(buf, walks):
+    """one dependent HBM round trip as a lone lane sees it (tools/probe chase_probe): a pointer chase over `buf`,
+    unloaded (one wave) and loaded (one chasing wave per walk of a batch).  None when the probe library is not there."""
+    try:
+        lib = C.CDLL(os.path.join(ROOT, "tools", "probe", "libgather_probe.so"))
+        lib.chase_probe.restype = C.c_double
+        lib.chase_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        nbytes = buf.numel() * buf.element_size()
+        torch.cuda.synchronize()
+        one = lib.chase_probe(buf.data_ptr(), nbytes, 2000, 1, None)
+        many = lib.chase_probe(buf.data_ptr(), nbytes, 2000, int(walks), None)
+        if one <= 0 or many <= 0:
+            return None
+        return {"unloaded": round(one, 1), "loaded": round(many, 1), "waves_loaded": int(walks),
+                "over_bytes": int(nbytes)}
+    except Exception as e:  # measurement aid only
+        log("dependent-fetch probe unavailable: %r" % (e,))
+        return None
+
+
 def c4_point(a, dev, dev_index):
     """BASELINE configs[3] (vectorVamana + product quantizer, d = 768, K = 256) inside the default line, at --c4-rows
     rows (1M by default so that the driver's run stays short; `--config c4` is the full 10M x 768 run).  Per M: whole-call
@@ -876,6 +1000,7 @@ def c4_point(a, dev, dev_index):
                 "kernel_qps": round(nq / kms * 1e3, 1), "recall_at_10": round(hits / (nbq * nq * k), 4),
                 "n_dist_per_batch": nd / nbq, "n_edges_per_batch": ne / nbq, "n_hop_per_batch": nh / nbq}
 
+    dep_ns = dependent_fetch_ns(base, nq)
     out = {"workload": "vectorVamana + product quantizer %dx%d %s, K=256, searchSize=%d degreeBound=%d, batch=%d" %
                        (n, d, a.metric, L, a.degree_bound, nq), "build_s": round(build_s, 2),
            "recall_note": "no re-ranking, like the reference (product.go:238-277): recall is the quantizer's"}
@@ -913,10 +1038,31 @@ def c4_point(a, dev, dev_index):
                 m["traffic_source"] = "profile-derived, not measured in this run: " + rec["source"]
         except Exception:
             pass
+        hbm_frac = round(alg / m["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4)
         m["roofline"] = {"bound": "hbm", "kernel": pq_walk_kernel(M),
                          "achieved": round(alg / m["kernel_ms"] / 1e6, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / m["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
                          "traffic": None}
+        # The roof that binds a quantized walk is not bytes: a hop cannot start before the previous hop has named its node,
+        # so a query's walk takes at least hops x (dependent fetches per hop) x one dependent HBM round trip -- measured here,
+        # on this box, by a one-lane pointer chase over the same 10M x 768 slab (tools/probe chase_probe; unloaded and
+        # with one chasing lane per walk of a batch).  latency_roof.frac = that floor / the kernel's time: the share of
+        # the batch's duration that is irreducible memory latency; the rest is the wave's own instruction stream.
+        fetches = 1 if M <= 32 else 2  # M <= 32: adjacency row + code rows in one fetch; else the code gather follows the row
+        hops = m["n_hop_per_batch"] / nq
+        if dep_ns:
+            floor_ms = hops * fetches * dep_ns["loaded"] * 1e-6
+            m["latency_roof"] = {"bound": "dependent-fetch latency", "hops_per_query": round(hops, 1),
+                                 "dependent_fetches_per_hop": fetches, "dependent_fetch_ns": dep_ns,
+                                 "floor_ms": round(floor_ms, 4), "kernel_ms": m["kernel_ms"],
+                                 "frac": round(floor_ms / m["kernel_ms"], 4),
+                                 "hop_us": round(m["kernel_ms"] * 1e3 / hops, 2)}
+            if m["latency_roof"]["frac"] > hbm_frac:  # what binds goes into the roofline object's own words
+                m["roofline"]["bound"] = "latency"
+                m["roofline"]["bound_note"] = ("hops x dependent-fetch latency: latency_roof.frac %.3f of the kernel's time "
+                                               "against %.3f of the HBM roof" % (m["latency_roof"]["frac"], hbm_frac))
+        if M <= 32:  # what the one-fetch-per-hop layout costs in HBM (counted in sdb_index_size_in_memory)
+            m["code_row_layout_bytes"] = int(2 * 64 * M * (n + 1))
         if M <= 32:
             # the neighbours' code rows sit behind the adjacency row (index.h d_adjcodes): a hop FETCHES 256 B of ids and
             # 64 M B of codes whatever the visited set then says -- the model of the bytes requested, beside the algorithmic ones
@@ -1061,14 +1207,35 @@ def secondary_points(a, dev, dev_index):
         for b in range(2, 4):
             ix.search_batch(queries[b], k, L)
         torch.cuda.synchronize()
+        ix.set_profiling(True)
+        ix.profile_read()
         t0 = time.perf_counter()
         reps = 12
         for r in range(reps):
             ix.search_batch(queries[2 + r % 4], k, L)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        kms = [float(v) for v in ix.profile_read()][-reps:]
+        ix.set_profiling(False)
+        # counter pass (B(q) = n_dist d 4 + edge ids read), the timed batches again with the trace on
+        alg = {}
+        nd_sum = nh_sum = 0.0
+        for b in range(2, 6):
+            _, _, _, tr = ix.search_batch(queries[b], k, L, trace=True)
+            nd = int(tr.n_dist.to(torch.int64).sum().item())
+            ne = int(tr.n_edges.to(torch.int64).sum().item())
+            alg[b] = nd * d * 4 + ne * 4
+            nd_sum += nd / nq
+            nh_sum += float(tr.n_hop.float().mean().item())
+        alg_total = sum(alg[2 + r % 4] for r in range(reps))
+        ach = alg_total / (sum(kms) * 1e-3) / 1e9 if kms else 0.0
         out[dist_name] = {"qps": round(reps * nq / dt, 1), "recall_at_10": round(hits / (2 * nq * k), 4),
-                          "build_s": round(build_s, 2), "passes_gate": hits / (2 * nq * k) >= 0.95}
+                          "build_s": round(build_s, 2), "passes_gate": hits / (2 * nq * k) >= 0.95,
+                          "mean_n_dist": round(nd_sum / 4, 1), "mean_n_hop": round(nh_sum / 4, 1),
+                          "algorithmic_bytes_per_launch": int(alg_total / reps),
+                          "kernel_ms_avg": round(float(np.mean(kms)), 4) if kms else None,
+                          "roofline": {"bound": "hbm", "kernel": "k_greedy_search", "achieved": round(ach, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}}
         if hits / (2 * nq * k) < 0.95:
             # "report the searchSize needed for recall 0.95 separately" -- the device walk takes searchSize up
             # to 512 (the API's maximum is 75, models/search.go:287-297)
@@ -1088,6 +1255,30 @@ def secondary_points(a, dev, dev_index):
         ix.close()
         del base, queries
         torch.cuda.empty_cache()
+    return out
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _cpu_affinity():
+    """what bounds the threads: CPUs visible, the process's affinity mask, the cgroup quota"""
+    out = {"cpus_online": os.cpu_count()}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except Exception:
+        pass
     return out
 
 
@@ -1131,6 +1322,9 @@ def cpu_baseline(a, ix, queries, k, L):
         "value": round(len(sample) / t_all, 1),
         "unit": "queries/s",
         "cores": threads,
+        # which host this was: the figure moved 20.2 k -> 14.8 k queries/s between two rounds' boxes with no code change
+        "cpu_model": _cpu_model(),
+        "affinity": _cpu_affinity(),
         "kind": "port",
         "sample": "%d queries (%d distinct batches of %d, x%d) on the same 1M graph; C restatement of "
                   "greedySearch with AVX2 transcription of distance/asm/dot.s; one query per thread" %

@@ -105,6 +105,14 @@ def test_fault_injection_program_compiles(tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib"])
 
 
+def test_device_fault_injection_program_compiles(tmp_path):
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_host_mirror import _device_faults_cmd
+    subprocess.check_call(_device_faults_cmd(str(tmp_path / "test_device_faults")))
+
+
 def test_hot_kernels_have_no_scratch():
     """tools/kernel_table.py reads the register / scratch figures from the built library's gfx950 code objects: NO
     kernel of the library may spill a VGPR or carry scratch memory (round 6: all 948), the kernels a BASELINE

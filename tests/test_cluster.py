@@ -1,6 +1,7 @@
 """Multi-shard path: the exchange step on 2 ranks over gloo (CPU), and the device merge kernel against
 the oracle's restatement of cluster/actions.go:357-376 (GPU)."""
 import os
+import sys
 import socket
 
 import numpy as np
@@ -232,6 +233,61 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch, capsys):
     assert not seen
 
 
+def _identity_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    infos = [None] * world
+    dist.all_gather_object(infos, bench.rank_identity(rank))  # (no GPU here: ordinal only, no PCI id, no communicator)
+    q.put((rank, bench.judge_ranks(infos, world, native=False)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_gpu_line_diagnoses_its_ranks(world):
+    """config.rccl of the N > 1 line (bench.rank_identity gathered over the process group, bench.judge_ranks): the keys
+    the unattended 8-GPU run will carry, and the conditions that make the line invalid instead of plausible."""
+    import torch.multiprocessing as mp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_identity_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        rccl, bad = got[r]
+        assert bad is None and [x["rank"] for x in rccl["ranks"]] == list(range(world))
+        assert [x["device_ordinal"] for x in rccl["ranks"]] == list(range(world))
+    # what a healthy RCCL run reports ...
+    tr = "rccl 2.22.3 (/opt/rocm/lib/librccl.so.1): ncclAllGather, communicator of %d ranks, this is rank 0 on GPU 0" % world
+    infos = [{"rank": r, "local_rank": r, "device_ordinal": r, "pci_bus_id": "0000:%02x:00" % (5 + r), "cluster_rank": r,
+              "cluster_world": world, "cluster_device": r, "transport": tr} for r in range(world)]
+    rccl, bad = bench.judge_ranks(infos, world, native=True)
+    assert bad is None and rccl["nccl_version"] == "2.22.3" and rccl["ranks_seen_by_cluster_info"] == list(range(world))
+    assert rccl["transport"] == tr
+    # ... and what must not pass for a measurement: a rank missing from the communicator, a communicator of another size,
+    # two ranks on one device
+    dup = [dict(i) for i in infos]
+    dup[1]["cluster_rank"] = 0
+    assert "sdb_cluster_info" in bench.judge_ranks(dup, world, native=True)[1]
+    small = [dict(i) for i in infos]
+    small[0]["cluster_world"] = world - 1
+    assert "communicator" in bench.judge_ranks(small, world, native=True)[1]
+    same = [dict(i) for i in infos]
+    same[1]["pci_bus_id"] = same[0]["pci_bus_id"]
+    assert "same device" in bench.judge_ranks(same, world, native=True)[1]
+    assert bench.judge_ranks(same, world, native=True, shared_device_ok=True)[1] is None
+    assert "ranks gathered" in bench.judge_ranks(infos[1:], world, native=True)[1]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
 def test_bench_without_a_launcher_runs_all_its_ranks(world):
@@ -255,6 +311,10 @@ def test_bench_without_a_launcher_runs_all_its_ranks(world):
     assert j["config"]["ranks_seen"] == list(range(world)) and "tag check" in j["config"]["exchange"]
     assert j["config"]["recall_at_10"] >= 0.95
     assert j["config"]["per_shard_limit"] == min(10, int(10 / world * 1.42 + 10))
+    # the line diagnoses itself: every rank's identity, what the exchange alone costs (round 6)
+    rccl = j["config"]["rccl"]
+    assert [r["rank"] for r in rccl["ranks"]] == list(range(world)) and rccl["shared_device_ok"] is True
+    assert all(r["device_ordinal"] == 0 for r in rccl["ranks"]) and rccl["allgather_merge_us_per_batch"] > 0
 
 
 @pytest.mark.gpu

@@ -80,3 +80,46 @@ extern "C" float gather_probe(const float *slab, uint32_t n_rows, uint32_t ld, u
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   return ms;
 }
+
+// ---- dependent-fetch probe: what ONE dependent HBM round trip costs a lone lane ------------------------------------
+// A graph walk's hop begins with a fetch whose address the previous hop produced.  Lane 0 of each wave chases through
+// `buf`: the next address is a hash of the word just loaded, so no two loads overlap.  One wave = the unloaded figure;
+// many waves = the same under the load of a batch.  Returns nanoseconds per dependent load (s_memtime, 100 MHz), < 0 on error.
+__global__ __launch_bounds__(64) void k_chase(const uint32_t *__restrict__ buf, uint64_t words, uint32_t steps,
+                                              unsigned long long *__restrict__ ticks, uint32_t *__restrict__ sink) {
+  if (threadIdx.x != 0) return;
+  uint64_t at = ((uint64_t)blockIdx.x * 0x9E3779B97F4A7C15ull) % words;
+  uint32_t acc = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (uint32_t i = 0; i < steps; i++) {
+    const uint32_t v = __builtin_nontemporal_load(buf + at);
+    acc += v;
+    uint64_t x = ((uint64_t)v << 32 | i) + at;
+    x ^= x >> 30, x *= 0xbf58476d1ce4e5b9ull, x ^= x >> 27, x *= 0x94d049bb133111ebull, x ^= x >> 31;
+    at = (x % words) & ~15ull;  // 64-byte aligned, anywhere in the buffer
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  ticks[blockIdx.x] = t1 - t0;
+  sink[blockIdx.x] = acc;
+}
+
+extern "C" double chase_probe(const void *buf, uint64_t bytes, uint32_t steps, uint32_t waves, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!buf || bytes < 4096 || !steps || !waves) return -2.0;
+  unsigned long long *ticks = nullptr;
+  uint32_t *sink = nullptr;
+  if (hipMalloc(&ticks, (size_t)waves * 8) != hipSuccess || hipMalloc(&sink, (size_t)waves * 4) != hipSuccess) return -1.0;
+  hipLaunchKernelGGL(k_chase, dim3(waves), dim3(64), 0, s, (const uint32_t *)buf, bytes / 4, steps, ticks, sink);
+  double ns = -1.0;
+  if (hipStreamSynchronize(s) == hipSuccess) {
+    unsigned long long *h = new unsigned long long[waves];
+    if (hipMemcpy(h, ticks, (size_t)waves * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum = 0;
+      for (uint32_t i = 0; i < waves; i++) sum += (double)h[i];
+      ns = sum / waves / steps * 10.0;  // s_memtime counts at 100 MHz
+    }
+    delete[] h;
+  }
+  (void)hipFree(ticks), (void)hipFree(sink);
+  return ns;
+}
