@@ -105,6 +105,21 @@ def test_fault_injection_program_compiles(tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib"])
 
 
+def test_design_register_table_is_generated_and_design_stays_short():
+    """DESIGN.md's per-kernel register figures are the tool's output for the BUILT library, not typed
+    (tools/kernel_table.py --design between the kernel_table markers), and the file stays under 60 KB: earlier rounds'
+    measurements live in HISTORY.md."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_table.py"), "--design"], capture_output=True,
+                         text=True, check=True).stdout.strip()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    begin, end = "<!-- kernel_table:begin", "<!-- kernel_table:end -->"
+    i, j = design.index(begin), design.index(end) + len(end)
+    assert design[i:j].strip() == out, "DESIGN.md's register table is stale: python3 tools/kernel_table.py --design"
+    assert len(design.encode()) <= 60 * 1024, "DESIGN.md has %d bytes" % len(design.encode())
+
+
 def test_device_fault_injection_program_compiles(tmp_path):
     import subprocess
     import sys

@@ -123,6 +123,27 @@ def markdown(rows):
     return "\n".join(lines)
 
 
+# the kernels DESIGN.md's register table shows: what the BASELINE configurations launch in their timed regions
+DESIGN = re.compile(
+    r"^sdb::(k_greedy_search<sdb::PlainDist<(3|6), false, true, 0>, 2, (false|true), 8192u>"
+    r"|k_greedy_search_wide<3, false, (8|16), false>|k_greedy_search_pq2<4294967295u>"
+    r"|k_greedy_search_pqw<15, 33, 4294967295u, 4, 15, true>|k_pq_lut_t<true, (3, 96|0, 4)>|k_pq_encode_t<true, 3, true>"
+    r"|k_pq_encode_pair<true, 4>|k_km_assign_t<(3, 96|0, 4)>|k_backedges<3, false>|k_prune_new<3, false>"
+    r"|k_prune_new_tiled<3, false, false, 8>|k_flat_scan_mfma<12, false>|k_flat_scan<false>|k_k1_stream_mfma<12>"
+    r"|k_k1_tile_mfma<12, false>|k_topk_merge)")
+BEGIN, END = "<!-- kernel_table:begin (python3 tools/kernel_table.py --design) -->", "<!-- kernel_table:end -->"
+
+
+def design_block(rows):
+    sel = [r for r in rows if DESIGN.match(r["kernel"])]
+    worst_t = max([r["sgpr_spill_count"] for r in rows if is_hot(r["kernel"]) and not FILTERED.match(r["kernel"])] or [0])
+    worst = max([r["sgpr_spill_count"] for r in rows] or [0])
+    head = ("%d kernels in the library; %d with spilled VGPRs or scratch memory; most spilled SGPRs: %d on a timed path, "
+            "%d anywhere.\n\n" % (len(rows), sum(1 for r in rows if r["vgpr_spill_count"] or r["private_segment_fixed_size"]),
+                                  worst_t, worst))
+    return BEGIN + "\n" + head + markdown(sel) + "\n" + END
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--so", default=SO)
@@ -130,8 +151,12 @@ def main():
     ap.add_argument("--match", default=None, help="regular expression on the demangled name")
     ap.add_argument("--json", default=None)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--design", action="store_true", help="the block DESIGN.md carries between its kernel_table markers")
     a = ap.parse_args()
     rows = kernels(a.so)
+    if a.design:
+        print(design_block(rows))
+        return 0
     if a.check:
         bad = offenders(rows)
         for r in bad:

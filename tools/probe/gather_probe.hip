@@ -84,13 +84,14 @@ extern "C" float gather_probe(const float *slab, uint32_t n_rows, uint32_t ld, u
 // ---- dependent-fetch probe: what ONE dependent HBM round trip costs a lone lane ------------------------------------
 // A graph walk's hop begins with a fetch whose address the previous hop produced.  Lane 0 of each wave chases through
 // `buf`: the next address is a hash of the word just loaded, so no two loads overlap.  One wave = the unloaded figure;
-// many waves = the same under the load of a batch.  Returns nanoseconds per dependent load (s_memtime, 100 MHz), < 0 on error.
+// many waves = the same under the load of a batch.  Returns nanoseconds per dependent load (s_memrealtime: the constant
+// 100 MHz counter -- s_memtime counts shader clocks on gfx950), < 0 on error.
 __global__ __launch_bounds__(64) void k_chase(const uint32_t *__restrict__ buf, uint64_t words, uint32_t steps,
                                               unsigned long long *__restrict__ ticks, uint32_t *__restrict__ sink) {
   if (threadIdx.x != 0) return;
   uint64_t at = ((uint64_t)blockIdx.x * 0x9E3779B97F4A7C15ull) % words;
   uint32_t acc = 0;
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (uint32_t i = 0; i < steps; i++) {
     const uint32_t v = __builtin_nontemporal_load(buf + at);
     acc += v;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(64) void k_chase(const uint32_t *__restrict__ buf, 
     x ^= x >> 30, x *= 0xbf58476d1ce4e5b9ull, x ^= x >> 27, x *= 0x94d049bb133111ebull, x ^= x >> 31;
     at = (x % words) & ~15ull;  // 64-byte aligned, anywhere in the buffer
   }
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
   ticks[blockIdx.x] = t1 - t0;
   sink[blockIdx.x] = acc;
 }
@@ -116,7 +117,7 @@ extern "C" double chase_probe(const void *buf, uint64_t bytes, uint32_t steps, u
     if (hipMemcpy(h, ticks, (size_t)waves * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       double sum = 0;
       for (uint32_t i = 0; i < waves; i++) sum += (double)h[i];
-      ns = sum / waves / steps * 10.0;  // s_memtime counts at 100 MHz
+      ns = sum / waves / steps * 10.0;  // 100 MHz
     }
     delete[] h;
   }
