@@ -807,6 +807,8 @@ def flatten_summary(result):
             if isinstance(rec.get("latency_roof"), dict):
                 flat["%s_latency_roof_frac" % tag] = rec["latency_roof"].get("frac")
                 flat["%s_dependent_fetch_ns" % tag] = (rec["latency_roof"].get("dependent_fetch_ns") or {}).get("loaded")
+            if isinstance(rec.get("encode_kernel_roofline"), dict) and "frac" in rec["encode_kernel_roofline"]:
+                flat["%s_encode_kernel_frac_of_fp32_vector_peak" % tag] = rec["encode_kernel_roofline"]["frac"]
             if rec.get("code_row_layout_bytes") is not None:
                 flat["%s_code_row_layout_bytes" % tag] = rec["code_row_layout_bytes"]
     if isinstance(c4.get("full_precision"), dict):
@@ -1025,6 +1027,24 @@ def c4_point(a, dev, dev_index):
         m = measure()
         enc_tflops = (n + 1) * d * 256 * 2.0 / enc_s / 1e12  # assignment is FP32-vector bound, 2 K flops per float
         m["fit_s"], m["encode_s"] = round(fit_s, 3), round(enc_s, 3)
+        # the encode KERNEL on its own (sdb_pq_encode over 2M resident rows, HIP events): the attach call above also
+        # allocates the code table and writes the neighbours' code rows, which hid the kernel's own fraction
+        try:
+            sub = base[:min(n, 2_000_000)]
+            pq.encode(sub[:1024])
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            pq.encode(sub)
+            ev1.record()
+            torch.cuda.synchronize()
+            k_ms = ev0.elapsed_time(ev1)
+            k_tf = sub.shape[0] * d * 256 * 2.0 / (k_ms * 1e-3) / 1e12
+            m["encode_kernel_roofline"] = {"bound": "fp32_vector", "kernel": "k_pq_encode_t" if M <= 24 else "k_pq_encode_pair",
+                                           "rows": int(sub.shape[0]), "ms": round(k_ms, 3), "achieved": round(k_tf, 2),
+                                           "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(k_tf / FP32_VECTOR_PEAK_TFLOPS, 4)}
+        except Exception as e:
+            m["encode_kernel_roofline"] = {"error": repr(e)}
         m["encode_roofline"] = {"bound": "fp32_vector", "kernel": "k_pq_encode_t", "achieved": round(enc_tflops, 2),
                                 "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(enc_tflops / FP32_VECTOR_PEAK_TFLOPS, 4),
