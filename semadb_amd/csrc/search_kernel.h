@@ -2066,6 +2066,10 @@ __device__ __forceinline__ void pq2_walker(const SearchArgs &a, const uint32_t q
     if (lane == 0) lds_store_u64(&sh->pts_mask, (unsigned long long)pend);
     wave_lds_sync();
     if (lane == 0) lds_store_u64(&sh->pts_word, (unsigned long long)named | ((unsigned long long)seq << 32));
+#ifdef SDB_PQ2_STATS  // hand-over timeline of query 0, sequence numbers 17 .. 24 (tools/pq2_stats.py, visit_cap >= 40)
+    if (q == 0 && lane == 0 && seq >= 17 && seq < 25 && a.tr_visit && a.visit_cap >= 40)
+      a.tr_visit[8 + (seq - 17) * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
   };
   uint32_t told = kNoSlot;  // the merger's word on where to go (read by answered())
   auto answered = [&]() {   // the merger is through with everything posted
@@ -2073,6 +2077,10 @@ __device__ __forceinline__ void pq2_walker(const SearchArgs &a, const uint32_t q
     while (w = lds_load_u64(&sh->ans_word), (uint32_t)(w >> 32) != seq) __builtin_amdgcn_s_sleep(1);
     told = (uint32_t)w;
     wave_lds_sync();
+#ifdef SDB_PQ2_STATS
+    if (q == 0 && lane == 0 && seq >= 17 && seq < 25 && a.tr_visit && a.visit_cap >= 40)
+      a.tr_visit[8 + (seq - 17) * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
   };
   // ---- searchSet.AddWithLimit(startNode)  search.go:57-61: a batch of one point, the merger names the first node
   {
@@ -2196,6 +2204,10 @@ __device__ __forceinline__ void pq2_merger(const SearchArgs &a, const uint32_t q
     unsigned long long w;
     while (w = lds_load_u64(&sh->pts_word), (uint32_t)(w >> 32) != seq) __builtin_amdgcn_s_sleep(1);
     wave_lds_sync();
+#ifdef SDB_PQ2_STATS
+    if (q == 0 && lane == 0 && seq >= 17 && seq < 25 && a.tr_visit && a.visit_cap >= 40)
+      a.tr_visit[8 + (seq - 17) * 4 + 2] = __builtin_amdgcn_s_memtime();
+#endif
     SDB_PQ2_M(0)
     const uint32_t named = (uint32_t)w;
     const unsigned long long pm64 = lds_load_u64(&sh->pts_mask);
@@ -2246,6 +2258,10 @@ __device__ __forceinline__ void pq2_merger(const SearchArgs &a, const uint32_t q
     if (lane == 0) lds_store_u64(&sh->ans_f1, (unsigned long long)f1 | ((unsigned long long)__float_as_uint(f1d) << 32));
     wave_lds_sync();
     if (lane == 0) lds_store_u64(&sh->ans_word, (unsigned long long)next | ((unsigned long long)seq << 32));
+#ifdef SDB_PQ2_STATS
+    if (q == 0 && lane == 0 && seq >= 17 && seq < 25 && a.tr_visit && a.visit_cap >= 40)
+      a.tr_visit[8 + (seq - 17) * 4 + 3] = __builtin_amdgcn_s_memtime();
+#endif
     // That entry is where the walk goes next unless the hop under way finds a nearer point: its adjacency row and the
     // code rows behind it are pulled through L2 now, a whole hop before the walker asks for them (the values are not
     // used; they are waited for one batch later, when they have long arrived): 0.321 -> 0.306 ms per batch at 4M x 768
