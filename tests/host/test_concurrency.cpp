@@ -356,7 +356,7 @@ static void test_turnstile_order() {
 
 static void test_turnstile_missing_ticket() {
   RawRank c;
-  c.deadline_ms = 60;
+  c.deadline_ms = 150;
   auto present = [&](uint64_t ticket) {
     std::unique_lock<std::mutex> lk(*c.mu);
     sdb::Turn turn{&c, ticket};
@@ -536,7 +536,7 @@ static void test_exchange_missing_rank() {
   std::vector<sdb_cluster *> ranks((size_t)kRanks, nullptr);
   std::vector<int> devs((size_t)kRanks, 0);
   CHECK(sdb_cluster_create_local(kRanks, devs.data(), ranks.data()) == SDB_OK, "create_local");
-  for (auto *c : ranks) sdb_cluster_set_deadline(c, 80);
+  for (auto *c : ranks) sdb_cluster_set_deadline(c, 400);  // (generous: a loaded CI box under TSan must not time a healthy request out)
   auto call = [&](int r, uint64_t ticket, int *rc_out) {
     std::vector<float> q(kDim, 0.f);
     q[0] = (float)ticket;

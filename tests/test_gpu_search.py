@@ -274,5 +274,21 @@ def test_host_memory_search_in_place(oracle, d, nq):
     ix.set_tuning("wide_walk", 1)  # the one-wave kernel for a small call, too
     ix.search_batch(pq_, k, L, out=(p_ids, p_d, p_c))
     assert np.array_equal(p_ids, ref_ids) and np.array_equal(bits(p_d), bits(ref_d))
+    ix.set_tuning("wide_walk", 0)
+    # a quantized store: the table kernel reads the queries from a staged copy (host memory is not cached on the device),
+    # the walk still writes its results in place
+    if d % 8 == 0:
+        from semadb_amd import vectorstore as vs
+        pq = vs.ProductQuantizer("cosine", vs.ProductQuantizerParameters(16, 8, 1000), d)
+        pq.Fit(base[:1000].copy(), np.arange(8) * 11, alias=False)
+        vs.attach(ix, pq)
+        q_ids, q_d, q_c, _ = ix.search_batch(queries, k, L)  # pageable: staged both ways
+        for no_zc in (0, 1):
+            ix.set_tuning("no_zero_copy", no_zc)
+            p_ids[:] = 7
+            p_d[:] = -1.0
+            p_c[:] = 99
+            ix.search_batch(pq_, k, L, out=(p_ids, p_d, p_c))
+            assert np.array_equal(p_c, q_c) and np.array_equal(p_ids, q_ids) and np.array_equal(bits(p_d), bits(q_d))
     ix.close()
     del pq_, p_ids, p_d, p_c
