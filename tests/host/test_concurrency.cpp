@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../semadb_amd/csrc/turnstile.h"
+#include "../../semadb_amd/csrc/view_mutex.h"
 #include "../../semadb_amd/host/semadb_host.hpp"
 #include "mock_sdb.h"
 
@@ -412,6 +413,50 @@ static void test_turnstile_missing_ticket() {
   CHECK(c.next_ticket == 12, "next %" PRIu64, c.next_ticket);
 }
 
+// the lock around an index's committed view (index.h view_mu): searches hold it shared back to back from several
+// batcher workers; a writer (commit, compact, table growth) must still get its turn -- and see a consistent view
+static void test_view_mutex_writer_gets_its_turn() {
+  sdb::ViewMutex mu;
+  struct View {
+    uint64_t a = 0, b = 0;  // a writer keeps a == b
+  } view;
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> reads{0}, torn{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < 8; t++)  // always-busy readers: as soon as one lets go another holds it
+    pool.emplace_back([&] {
+      while (!stop.load(std::memory_order_relaxed)) {
+        std::shared_lock<sdb::ViewMutex> g(mu);
+        const View v = view;
+        if (v.a != v.b) torn++;
+        reads++;
+      }
+    });
+  const int commits = scaled(300);
+  int64_t worst_ns = 0;
+  std::thread writer([&] {
+    for (int i = 0; i < commits; i++) {
+      const auto t0 = std::chrono::steady_clock::now();
+      {
+        std::unique_lock<sdb::ViewMutex> g(mu);
+        worst_ns = std::max<int64_t>(worst_ns, std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+        view.a++;
+        std::this_thread::yield();
+        view.b++;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  });
+  writer.join();
+  stop = true;
+  for (auto &t : pool) t.join();
+  CHECK(torn.load() == 0, "a reader saw half a commit");
+  CHECK(view.a == (uint64_t)commits && view.b == view.a, "commits lost");
+  CHECK(reads.load() > (uint64_t)commits, "the readers never ran");
+  CHECK(worst_ns < 2000000000ll, "a writer waited %.1f ms behind readers", worst_ns / 1e6);
+  std::printf("  view lock: %d commits among %" PRIu64 " reads, the longest wait of a writer %.2f ms\n", commits, reads.load(), worst_ns / 1e6);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // (c) the exchange through the C ABI: what GpuFanout drives
 static void expected_merge(const float *q, int shards, uint32_t limit, std::vector<uint64_t> *ids, std::vector<float> *d,
@@ -683,6 +728,7 @@ int main(int argc, char **argv) {
       {"batcher_destructor", test_batcher_destructor},
       {"turnstile_order", test_turnstile_order},
       {"turnstile_missing_ticket", test_turnstile_missing_ticket},
+      {"view_mutex_writer_gets_its_turn", test_view_mutex_writer_gets_its_turn},
       {"fanout", test_fanout},
       {"exchange_order", test_exchange_order},
       {"exchange_missing_rank", test_exchange_missing_rank},

@@ -60,8 +60,15 @@ def test_host_concurrency_under_sanitizer(kind, tmp_path):
         assert word not in out.stderr, "sanitizer report:\n" + tail
     for name in ("batcher_mixed", "batcher_backpressure", "batcher_window_race", "batcher_pageable",
                  "batcher_poll_and_reissue", "batcher_destructor", "turnstile_order", "turnstile_missing_ticket",
+                 "view_mutex_writer_gets_its_turn",
                  "fanout", "exchange_order", "exchange_missing_rank", "vamana_readers_and_writers"):
         assert "ok   " + name in out.stdout, tail
+
+
+def test_index_uses_the_tested_view_lock():
+    src = open(os.path.join(ROOT, "semadb_amd", "csrc", "index.h")).read()
+    assert '#include "view_mutex.h"' in src and "class ViewMutex" not in src
+    assert "mutable sdb::ViewMutex view_mu;" in src
 
 
 def test_cluster_source_uses_the_tested_turnstile():
