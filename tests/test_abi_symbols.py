@@ -120,6 +120,28 @@ def test_design_register_table_is_generated_and_design_stays_short():
     assert len(design.encode()) <= 60 * 1024, "DESIGN.md has %d bytes" % len(design.encode())
 
 
+def test_bench_traffic_constants_are_the_committed_profiles():
+    """bench.py labels roofline.traffic and config.c4.*.traffic_over_algorithmic as profile-derived: the constants it
+    reads (profiles/pmc_traffic.json, profiles/pmc_c4.json) must be the figures of the profile files they name."""
+    import json
+    import re
+    prof = os.path.join(ROOT, "profiles")
+    t = json.load(open(os.path.join(prof, "pmc_traffic.json")))
+    src = re.match(r"profiles/(\S+\.md)", t["source"]).group(1)
+    md = open(os.path.join(prof, src)).read()
+    read_b = float(re.search(r"corrected HBM read bytes / launch[^|]*\| ([0-9.e+]+) \|", md).group(1))
+    write_b = float(re.search(r"WRITE_SIZE / launch \(KB\) -> bytes \| [0-9.]+ -> ([0-9.e+]+) \|", md).group(1))
+    assert abs(t["read_bytes"] - read_b) <= 1e-3 * read_b and abs(t["write_bytes"] - write_b) <= 1e-2 * write_b
+    assert abs(t["hbm_bytes_per_launch"] - (read_b + write_b)) <= 1e-3 * read_b
+    c4 = json.load(open(os.path.join(prof, "pmc_c4.json")))
+    for M in (8, 192):
+        name = re.search(r"profiles/(\S*pmc_c4_M%d\.json)" % M, c4["source"]) or re.search(r"(r\d+\w*_pmc_c4_M%d\.json)" % M, c4["source"])
+        rec = json.load(open(os.path.join(prof, os.path.basename(name.group(1)))))
+        runs = [v for k, v in rec.items() if k.startswith("k_greedy_search")][0]
+        mean = sum(r["traffic_over_codes_and_edges"] for r in runs) / len(runs)
+        assert abs(c4["M=%d" % M]["traffic_over_codes_and_edges"] - mean) < 0.005, (M, mean)
+
+
 def test_device_fault_injection_program_compiles(tmp_path):
     import subprocess
     import sys
