@@ -497,10 +497,6 @@ func (b *searchBatcher) flush(reqs []*searchReq) {
 			continue
 		}
 		n := int(counts[i])
-		if inSlab { // the slab is refilled by the next batch: the caller gets its own copy
-			r.done <- searchResp{ids: append([]uint64(nil), ids[i*limit:i*limit+n]...), dists: append([]float32(nil), dists[i*limit:i*limit+n]...)}
-		} else {
-			r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
-		}
+		r.done <- searchResp{ids: ids[i*limit : i*limit+n], dists: dists[i*limit : i*limit+n]}
 	}
 }

@@ -267,3 +267,137 @@ def test_every_file_has_the_build_tag_and_balanced_braces():
         code = _go_code(text)
         for a, b in ["()", "{}", "[]"]:
             assert code.count(a) == code.count(b), "%s: unbalanced %s%s" % (os.path.basename(path), a, b)
+
+
+GO_BUILTIN = set("""break default func interface select case defer go map struct chan else goto package switch const
+fallthrough if range type continue for import return var append cap close complex copy delete imag len make new panic
+print println real recover bool byte complex64 complex128 error float32 float64 int int8 int16 int32 int64 rune
+string uint uint8 uint16 uint32 uint64 uintptr true false iota nil any min max clear _""".split())
+
+def _go_strip(text):
+    """comments -> nothing, string / rune literals -> "" / 0, one left-to-right scan (an apostrophe in a comment is not
+    a rune, a // in a string is not a comment)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        two = text[i:i + 2]
+        if two == "//":
+            i = text.find("\n", i)
+            i = n if i < 0 else i
+        elif two == "/*":
+            j = text.index("*/", i) + 2
+            out.append("\n" * text.count("\n", i, j))
+            i = j
+        elif text[i] == "`":
+            j = text.index("`", i + 1) + 1
+            out.append('""' + "\n" * text.count("\n", i, j))
+            i = j
+        elif text[i] in "\"'":
+            q, j = text[i], i + 1
+            while text[j] != q:
+                j += 2 if text[j] == "\\" else 1
+            out.append('""' if q == '"' else "0")
+            i = j + 1
+        else:
+            out.append(text[i])
+            i += 1
+    return "".join(out)
+
+def _go_funcs(text):
+    for m in re.finditer(r"^func\b", text, flags=re.M):
+        i = text.index("{", m.end())
+        # the body's brace: skip braces of interface{} / struct{} in the signature
+        depth = 0
+        j = m.end()
+        while True:
+            ch = text[j]
+            if ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+            elif ch == "{" and depth == 0 and not re.search(r"(interface|struct)\s*$", text[:j]):
+                break
+            j += 1
+        d, k = 0, j
+        while True:
+            if text[k] == "{": d += 1
+            elif text[k] == "}":
+                d -= 1
+                if d == 0: break
+            k += 1
+        yield text[m.start():j], text[j:k + 1]
+
+def _go_declared(sig, body):
+    names = set()
+    for m in re.finditer(r"([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)\s+(?:\.\.\.|\*|\[|<-|func\b|map\b|chan\b|[A-Za-z_])", sig):
+        names.update(x.strip() for x in m.group(1).split(","))
+    for m in re.finditer(r"([A-Za-z_][\w]*(?:\s*,\s*[A-Za-z_]\w*)*)\s*:=", body):
+        names.update(x.strip() for x in m.group(1).split(","))
+    for m in re.finditer(r"\b(?:var|const)\s+([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)", body):
+        names.update(x.strip() for x in m.group(1).split(","))
+    for m in re.finditer(r"\bfunc\s*\(([^)]*)\)", body):       # closures' parameters
+        for p in m.group(1).split(","):
+            p = p.strip().split()
+            if p: names.add(p[0])
+    for m in re.finditer(r"^\s*([A-Za-z_]\w*):\s*$", body, flags=re.M):   # labels
+        names.add(m.group(1))
+    return names
+
+def _go_package_names(texts):
+    names = set()
+    for t in texts:
+        for m in re.finditer(r"^func\s+(?:\([^)]*\)\s*)?([A-Za-z_]\w*)", t, flags=re.M): names.add(m.group(1))
+        for m in re.finditer(r"^(?:type|var|const)\s+([A-Za-z_]\w*)", t, flags=re.M): names.add(m.group(1))
+        for blk in re.finditer(r"^(?:var|const)\s*\((.*?)^\)", t, flags=re.M | re.S):
+            for m in re.finditer(r"^\s*([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)", blk.group(1), flags=re.M):
+                names.update(x.strip() for x in m.group(1).split(","))
+    return names
+
+def _go_imports(raw):
+    out = set()
+    blk = re.search(r"^import\s*\((.*?)^\)", raw, flags=re.M | re.S)
+    lines = blk.group(1).splitlines() if blk else re.findall(r'^import\s+(.*)$', raw, flags=re.M)
+    for ln in lines:
+        m = re.match(r'\s*(?:([A-Za-z_]\w*)\s+)?"([^"]+)"', ln)
+        if m:
+            parts = m.group(2).split("/")
+            if re.fullmatch(r"v\d+", parts[-1]) and len(parts) > 1:   # math/rand/v2 is package rand
+                parts.pop()
+            out.add(m.group(1) or parts[-1])
+    return out
+
+def _go_undeclared(pkgdir):
+    raws = {p: open(p).read() for p in sorted(glob.glob(pkgdir + "/*.go"))}
+    texts = {p: _go_strip(r) for p, r in raws.items()}
+    pk = _go_package_names(texts.values())
+    bad = []
+    for p, t in texts.items():
+        imp = _go_imports(raws[p]) | {"C"}
+        for sig, body in _go_funcs(t):
+            known = _go_declared(sig, body) | pk | imp | GO_BUILTIN
+            for m in re.finditer(r"(?<![\w.])([A-Za-z_]\w*)\b", body):
+                name = m.group(1)
+                if name in known: continue
+                if re.match(r"\s*:[^=]", body[m.end():m.end() + 3]):   # key of a composite literal
+                    continue
+                bad.append((os.path.basename(p), sig.strip()[:70], name))
+    return bad
+
+
+def test_every_name_a_function_uses_is_declared():
+    """No compiler here: a poor man's name resolution instead.  Every identifier in a function body (not a selector
+    after a dot, not the key of a composite literal) must be a parameter, result, local, closure parameter or label of
+    that function, a package-level name of the same package, an import of the file, or a Go builtin -- an edit that
+    leaves a function using another function's local (round 6: `inSlab` in flush()) fails here."""
+    bad = []
+    for d in sorted(glob.glob(os.path.join(ROOT, "integration", "go", "*"))):
+        bad += _go_undeclared(d)
+    assert not bad, "undeclared names in the Go shim:\n" + "\n".join("%s: %s: %s" % b for b in bad)
+
+
+def test_name_check_sees_a_planted_stray(tmp_path):
+    pkg = tmp_path / "p"
+    pkg.mkdir()
+    (pkg / "a.go").write_text('package p\n\nimport "fmt"\n\nvar table = map[string]int{}\n\n'
+                              'func a(x int) int {\n\t// it\'s a comment with "quotes\n\ty := x + table["k"]\n'
+                              '\treturn y\n}\n\nfunc b(x int) {\n\tif y > 0 {\n\t\tfmt.Println(x)\n\t}\n}\n')
+    assert [b[2] for b in _go_undeclared(str(pkg))] == ["y"]
