@@ -401,3 +401,23 @@ def test_name_check_sees_a_planted_stray(tmp_path):
                               'func a(x int) int {\n\t// it\'s a comment with "quotes\n\ty := x + table["k"]\n'
                               '\treturn y\n}\n\nfunc b(x int) {\n\tif y > 0 {\n\t\tfmt.Println(x)\n\t}\n}\n')
     assert [b[2] for b in _go_undeclared(str(pkg))] == ["y"]
+
+
+def test_no_unused_locals_or_imports():
+    """the two other things the Go compiler refuses and an edit here leaves behind easily"""
+    bad = []
+    for path, raw in go_sources().items():
+        code = _go_strip(raw)
+        for imp in _go_imports(raw) - {"C"}:
+            if not re.search(r"(?<![\w.])%s\." % re.escape(imp), code):
+                bad.append("%s: import %s is not used" % (os.path.basename(path), imp))
+        for sig, body in _go_funcs(code):
+            names = set()
+            for m in re.finditer(r"([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)\s*:=", body):
+                names.update(x.strip() for x in m.group(1).split(","))
+            for m in re.finditer(r"\bvar\s+([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)", body):
+                names.update(x.strip() for x in m.group(1).split(","))
+            for name in names - {"_"}:
+                if len(re.findall(r"(?<![\w.])%s\b" % re.escape(name), body)) < 2:
+                    bad.append("%s: %s: %s declared and not used" % (os.path.basename(path), sig.strip()[:70], name))
+    assert not bad, "\n".join(bad)
