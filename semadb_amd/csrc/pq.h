@@ -9,6 +9,7 @@ struct sdb_pq {
   int metric = 0;  // after the cosine -> euclidean swap (product.go:52-61)
   int device = 0;
   float *d_centroids = nullptr;  // flatCentroids [M][K][sub_len]  (product.go:37)
+  float *d_centroids_t = nullptr;  // the same, element-major [M][sub_len][K]: the table kernel's coalesced row loads
   float *d_cdists = nullptr;     // centroidDists [M][K][K]        (product.go:36)
   bool fitted = false;
 };

@@ -627,19 +627,22 @@ __global__ void k_pq_lut(const float *__restrict__ queries, uint32_t dim, const 
 constexpr uint32_t kLutQT = SDB_LUT_QT;
 template <bool L2, int NB, int SL = 0>  // SL: the sub-vector length when it is a usual short one (k_pq_encode_pair), 0 = any
 __global__ __launch_bounds__(256) void k_pq_lut_t(const float *__restrict__ queries, uint32_t nq, uint32_t dim,
-                                                  const float *__restrict__ cent, uint32_t M, uint32_t K,
+                                                  const float *__restrict__ cent_t /* [M][sub_len][K] */, uint32_t M, uint32_t K,
                                                   uint32_t sub_len_rt, int metric, float *__restrict__ lut) {
   const uint32_t sub_len = SL > 0 ? (uint32_t)SL : sub_len_rt;
   const uint32_t i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
   const uint32_t q0 = blockIdx.z * kLutQT, q1 = min(q0 + kLutQT, nq);
-  const float *row = cent + ((size_t)i * K + min(j, K - 1)) * sub_len;
+  // the thread's centroid row, from the element-major copy of the table (sdb_pq::d_centroids_t): element e of the 64
+  // centroids of a wave is one 256-byte line.  (From [K][sub_len] every load instruction of a 96-float row touched 64
+  // lines, 384 bytes apart -- the row loads were a fifth of the kernel at M = 8.)
+  const float *col = cent_t + (size_t)i * sub_len * K + min(j, K - 1);
   float r[NB > 0 ? NB * 32 : 1];
 #pragma unroll
-  for (int e = 0; e < NB * 32; e++) r[e] = row[e];
+  for (int e = 0; e < NB * 32; e++) r[e] = col[(size_t)e * K];
   const uint32_t tail = sub_len - NB * 32;
   float rt[31];
 #pragma unroll
-  for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? row[NB * 32 + e] : 0.0f;
+  for (int e = 0; e < 31; e++) rt[e] = (uint32_t)e < tail ? col[(size_t)(NB * 32 + e) * K] : 0.0f;
   // a fixed trip count: the sub-vectors of all kLutQT queries are wave-uniform scalar loads, and unrolled the compiler
   // issues them together instead of one query's, a wait, the next query's
   (void)q1;
@@ -736,10 +739,10 @@ static void launch_lut_t(const sdb_pq *pq, const float *d_queries, uint64_t nq, 
     constexpr int SL = decltype(sl)::value;
     if (pq->metric == SDB_METRIC_EUCLIDEAN)
       hipLaunchKernelGGL((k_pq_lut_t<true, NB, SL>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
-                         pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+                         pq->d_centroids_t, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
     else
       hipLaunchKernelGGL((k_pq_lut_t<false, NB, SL>), grid, dim3(256), 0, stream, d_queries, (uint32_t)nq, pq->dim,
-                         pq->d_centroids, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
+                         pq->d_centroids_t, pq->M, pq->K, pq->sub_len, pq->metric, d_lut);
   };
   if constexpr (NB > 0) {
     if (pq->sub_len == (uint32_t)NB * 32) {  // whole blocks, no tail chain at all (M = 8 at d = 768: 96 floats)
@@ -908,9 +911,20 @@ int pq_encode_device(const sdb_pq *pq, const float *d_vecs, uint64_t n, uint8_t 
   return SDB_OK;
 }
 
+// what is derived from a new codebook: the centroid-pair table (product.go:225-230) and the element-major copy the
+// table kernel reads its rows from
+__global__ void k_pq_transpose_cent(const float *__restrict__ cent, float *__restrict__ cent_t, uint32_t K, uint32_t sub_len) {
+  const uint32_t i = blockIdx.y;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // = e * K + j
+  if (t >= K * sub_len) return;
+  const uint32_t e = t / K, j = t % K;
+  cent_t[(size_t)i * sub_len * K + t] = cent[((size_t)i * K + j) * sub_len + e];
+}
 static int pq_fill_cdists(sdb_pq *pq, hipStream_t stream) {
   hipLaunchKernelGGL(k_pq_cdists, dim3(pq->K, pq->M), dim3(64), 0, stream, pq->d_centroids, pq->d_cdists, pq->M, pq->K,
                      pq->sub_len, pq->metric);
+  hipLaunchKernelGGL(k_pq_transpose_cent, dim3((pq->K * pq->sub_len + 255) / 256, pq->M), dim3(256), 0, stream, pq->d_centroids,
+                     pq->d_centroids_t, pq->K, pq->sub_len);
   SDB_HIP(hipGetLastError());
   return SDB_OK;
 }
@@ -998,9 +1012,11 @@ int sdb_pq_create(uint32_t dim, uint32_t metric, uint32_t num_subvectors, uint32
   pq->metric = metric == SDB_METRIC_COSINE ? SDB_METRIC_EUCLIDEAN : (int)metric;  // product.go:52-61
   pq->device = device;
   hipError_t e = hipMalloc(&pq->d_centroids, (size_t)pq->M * pq->K * pq->sub_len * 4);
+  if (e == hipSuccess) e = hipMalloc(&pq->d_centroids_t, (size_t)pq->M * pq->K * pq->sub_len * 4);
   if (e == hipSuccess) e = hipMalloc(&pq->d_cdists, (size_t)pq->M * pq->K * pq->K * 4);
   if (e != hipSuccess) {
     if (pq->d_centroids) (void)hipFree(pq->d_centroids);
+    if (pq->d_centroids_t) (void)hipFree(pq->d_centroids_t);
     delete pq;
     return fail(SDB_ERR_DEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
   }
@@ -1014,6 +1030,7 @@ int sdb_pq_destroy(sdb_pq *pq) try {
   DeviceGuard dg(pq->device);
   (void)hipDeviceSynchronize();
   if (pq->d_centroids) (void)hipFree(pq->d_centroids);
+  if (pq->d_centroids_t) (void)hipFree(pq->d_centroids_t);
   if (pq->d_cdists) (void)hipFree(pq->d_cdists);
   delete pq;
   return SDB_OK;

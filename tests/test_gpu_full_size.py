@@ -402,3 +402,27 @@ def test_c5_one_rank_at_size():
     assert np.array_equal(bits(k1f.cpu().numpy()), bits(f_d[:64].cpu().numpy()))
     ix.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_headline_protocol_on_the_reference_schedule_graph():
+    """tools/reference_schedule_graph.py at a size the suite can afford: the sequential device build (the reference's
+    insertSinglePoint loop, insert.go:16-68) equals the oracle's on a prefix of the bench's own rows edge for edge, and
+    the batched rounds' graph answers the same batches with the same recall and walk length as the sequential graph
+    (profiles/r06_refsched_1m.json is the same comparison at 1M x 384)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "reference_schedule_graph.py"), "--rows", "30000",
+                          "--prefix", "6000", "--chunk", "12000", "--timed-batches", "4"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["prefix"] == dict(j["prefix"], rows=6000, equal_to_oracle_edge_for_edge=True)
+    assert j["rows_reached"] == 30000
+    seq, bat = j["reference_schedule_graph"], j["batched_graph"]
+    assert seq["recall_at_10"] >= 0.95 and bat["recall_at_10"] >= 0.95
+    assert abs(seq["recall_at_10"] - bat["recall_at_10"]) <= 0.01
+    assert 0.95 <= bat["mean_n_dist"] / seq["mean_n_dist"] <= 1.05
+    assert 0.95 <= bat["mean_degree"] / seq["mean_degree"] <= 1.05
