@@ -1252,7 +1252,7 @@ def secondary_points(a, dev, dev_index):
         ix.set_profiling(False)
         # counter pass (B(q) = n_dist d 4 + edge ids read), the timed batches again with the trace on
         alg = {}
-        nd_sum = nh_sum = 0.0
+        nd_sum = nh_sum = tail_sum = 0.0
         for b in range(2, 6):
             _, _, _, tr = ix.search_batch(queries[b], k, L, trace=True)
             nd = int(tr.n_dist.to(torch.int64).sum().item())
@@ -1260,11 +1260,14 @@ def secondary_points(a, dev, dev_index):
             alg[b] = nd * d * 4 + ne * 4
             nd_sum += nd / nq
             nh_sum += float(tr.n_hop.float().mean().item())
+            ndq = tr.n_dist.float()  # a batch ends on its longest walk: how far that is from the mean
+            tail_sum += float(ndq.max().item() / ndq.mean().item())
         alg_total = sum(alg[2 + r % 4] for r in range(reps))
         ach = alg_total / (sum(kms) * 1e-3) / 1e9 if kms else 0.0
         out[dist_name] = {"qps": round(reps * nq / dt, 1), "recall_at_10": round(hits / (2 * nq * k), 4),
                           "build_s": round(build_s, 2), "passes_gate": hits / (2 * nq * k) >= 0.95,
                           "mean_n_dist": round(nd_sum / 4, 1), "mean_n_hop": round(nh_sum / 4, 1),
+                          "longest_walk_over_mean": round(tail_sum / 4, 3),
                           "algorithmic_bytes_per_launch": int(alg_total / reps),
                           "kernel_ms_avg": round(float(np.mean(kms)), 4) if kms else None,
                           "roofline": {"bound": "hbm", "kernel": "k_greedy_search", "achieved": round(ach, 1),
