@@ -801,6 +801,8 @@ def flatten_summary(result):
                 flat["%s_mean_n_dist" % key] = rec.get("mean_n_dist")
                 flat["%s_kernel_ms" % key] = rec.get("kernel_ms_avg")
                 flat["%s_algorithmic_bytes_per_launch" % key] = rec.get("algorithmic_bytes_per_launch")
+                flat["%s_longest_walk_over_mean" % key] = rec.get("longest_walk_over_mean")
+                flat["%s_two_batches_in_flight_frac" % key] = rec.get("two_batches_in_flight_frac")
     hb = cfg.get("host_blocking_variants") or {}
     for name in ("staged", "pageable"):
         if isinstance(hb.get(name), dict):
@@ -1264,10 +1266,26 @@ def secondary_points(a, dev, dev_index):
             tail_sum += float(ndq.max().item() / ndq.mean().item())
         alg_total = sum(alg[2 + r % 4] for r in range(reps))
         ach = alg_total / (sum(kms) * 1e-3) / 1e9 if kms else 0.0
+        # the same batches with two of them in flight (what the tail of a batch -- longest_walk_over_mean -- costs)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        for r in range(2):
+            with torch.cuda.stream(streams[r]):
+                ix.search_batch(queries[2 + r], k, L)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(4 * reps):  # (longer than the one-at-a-time loop: filling and draining the pair is not the point)
+            with torch.cuda.stream(streams[r % 2]):
+                ix.search_batch(queries[2 + r % 4], k, L)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / 4
         out[dist_name] = {"qps": round(reps * nq / dt, 1), "recall_at_10": round(hits / (2 * nq * k), 4),
                           "build_s": round(build_s, 2), "passes_gate": hits / (2 * nq * k) >= 0.95,
                           "mean_n_dist": round(nd_sum / 4, 1), "mean_n_hop": round(nh_sum / 4, 1),
                           "longest_walk_over_mean": round(tail_sum / 4, 3),
+                          "two_batches_in_flight_qps": round(reps * nq / dt2, 1),
+                          "two_batches_in_flight_frac": round(alg_total / dt2 / 1e9 / HBM_PEAK_GBS, 4),
                           "algorithmic_bytes_per_launch": int(alg_total / reps),
                           "kernel_ms_avg": round(float(np.mean(kms)), 4) if kms else None,
                           "roofline": {"bound": "hbm", "kernel": "k_greedy_search", "achieved": round(ach, 1),
