@@ -410,6 +410,7 @@ class SearchBatcher {
     r->client = &c;
     submit(r);
     waitFor(&c, 1);
+    r->client = nullptr;  // `c` ends here; the request may live on in the caller
   }
 
  private:
