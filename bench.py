@@ -704,6 +704,25 @@ def measure_mode(a, ctx, mode, rows, primary):
         except Exception:
             pass
 
+    # the same protocol on the graph the REFERENCE's sequential insert schedule builds from the same rows (415 s on the
+    # device: not part of this run) -- tools/reference_schedule_graph.py wrote the record; it is repeated here, labelled
+    ref = os.path.join(ROOT, "profiles", "r06_refsched_1m.json")
+    if os.path.exists(ref) and world == 1 and primary:
+        try:
+            rec = json.load(open(ref))
+            if rec.get("rows_reached") == n and a.dist in rec.get("workload", "") and "%d x %d" % (n, d) in rec["workload"]:
+                g = rec["reference_schedule_graph"]
+                result["config"]["reference_schedule_graph"] = {
+                    "source": "profile-derived, not measured in this run: profiles/r06_refsched_1m.json "
+                              "(tools/reference_schedule_graph.py; insert.go:16-68 one point after another, the first "
+                              "%d rows equal to the oracle's graph edge for edge)" % rec["prefix"]["rows"],
+                    "qps": g["qps"], "recall_at_10": g["recall_at_10"], "kernel_ms_avg": g["kernel_ms_avg"],
+                    "frac_of_hbm_peak": g["frac_of_hbm_peak"], "mean_n_dist": g["mean_n_dist"],
+                    "sequential_build_s": rec["sequential_build_s"],
+                    "batched_graph_same_process": {k: rec["batched_graph"][k] for k in ("qps", "recall_at_10", "frac_of_hbm_peak", "mean_n_dist")}}
+        except Exception:
+            pass
+
     if rank == 0 and world == 1 and primary and not ctx.get("rehearse"):
         cfg = result["config"]
         # the timed loop once more, the same way (a run checks itself: the driver's N = 1 figures of its BENCH and SCALE
@@ -788,6 +807,10 @@ def flatten_summary(result):
     flat = {}
     if "value_host" in result:
         flat["value_host"] = result["value_host"]  # SURVEY 8d's protocol figure (H2D + D2H inside the timed region)
+    rs = cfg.get("reference_schedule_graph")
+    if isinstance(rs, dict):  # profile-derived (labelled in the nested object)
+        flat["reference_schedule_graph_qps_from_profile"] = rs.get("qps")
+        flat["reference_schedule_graph_recall_at_10_from_profile"] = rs.get("recall_at_10")
     sec = cfg.get("secondary_datasets") or {}
     for name, rec in sec.items():
         if isinstance(rec, dict) and "qps" in rec:

@@ -163,3 +163,17 @@ def test_hot_kernels_have_no_scratch():
     import re
     m = re.search(r"most SGPRs spilled: (\d+) on a timed path, (\d+) anywhere", out.stdout)
     assert m and int(m.group(1)) <= 64 and int(m.group(2)) <= 160, out.stdout[-500:]
+
+
+def test_bench_repeats_the_reference_schedule_record_as_it_is():
+    """config.reference_schedule_graph is labelled profile-derived: what bench.py copies must be the committed file's
+    figures, and the file must say that its prefix equalled the oracle's graph."""
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_refsched_1m.json")))
+    assert rec["prefix"]["equal_to_oracle_edge_for_edge"] is True and rec["prefix"]["rows"] >= 20000
+    assert rec["rows_reached"] == 1000000 and "1000000 x 384" in rec["workload"] and "latent:24" in rec["workload"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'os.path.join(ROOT, "profiles", "r06_refsched_1m.json")' in src
+    assert "profile-derived, not measured in this run: profiles/r06_refsched_1m.json" in src
+    for key in ("qps", "recall_at_10", "kernel_ms_avg", "frac_of_hbm_peak", "mean_n_dist"):
+        assert key in rec["reference_schedule_graph"] and '"%s": g["%s"]' % (key, key) in src
