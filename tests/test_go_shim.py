@@ -421,3 +421,62 @@ def test_no_unused_locals_or_imports():
                 if len(re.findall(r"(?<![\w.])%s\b" % re.escape(name), body)) < 2:
                     bad.append("%s: %s: %s declared and not used" % (os.path.basename(path), sig.strip()[:70], name))
     assert not bad, "\n".join(bad)
+
+
+def _go_signature_arity(sig):
+    """'func (recv) name(params) results' -> (name, is_method, fewest, most arguments)"""
+    m = re.match(r"func\s*(\([^)]*\)\s*)?([A-Za-z_]\w*)\s*\(", sig)
+    if not m:
+        return None
+    start = m.end() - 1
+    plist = sig[start + 1:_balanced(sig, start) - 1].strip()
+    if not plist:
+        return m.group(2), bool(m.group(1)), 0, 0
+    parts = _split_top_level(plist)  # "a, b int" are two parameters: one per comma-separated part
+    variadic = "..." in parts[-1]
+    return m.group(2), bool(m.group(1)), len(parts) - 1 if variadic else len(parts), 10 ** 6 if variadic else len(parts)
+
+
+def _go_call_arity_mismatches(pkgdir):
+    """calls of the package's own functions and methods (a method by its name, when every method of that name in the
+    package takes the same number) whose argument count is not the declaration's; returns (mismatches, calls checked)"""
+    texts = {p: _go_strip(open(p).read()) for p in sorted(glob.glob(pkgdir + "/*.go"))}
+    funcs, methods = {}, {}
+    for t in texts.values():
+        for sig, _ in _go_funcs(t):
+            r = _go_signature_arity(sig)
+            if r:
+                (methods if r[1] else funcs).setdefault(r[0], set()).add((r[2], r[3]))
+    bad, checked = [], 0
+    for p, t in texts.items():
+        for sig, body in _go_funcs(t):
+            for pattern, table in ((r"(?<![\w.])([a-z][A-Za-z0-9_]*)\(", funcs), (r"\.([a-z][A-Za-z0-9_]*)\(", methods)):
+                for m in re.finditer(pattern, body):
+                    name = m.group(1)
+                    if name not in table or len(table[name]) != 1:
+                        continue
+                    args = body[m.end():_balanced(body, m.end() - 1) - 1].strip()
+                    n = len(_split_top_level(args)) if args else 0
+                    lo, hi = next(iter(table[name]))
+                    checked += 1
+                    if lo <= n <= hi or (n == 1 and re.match(r"^[\w.]+\(.*\)$", args, flags=re.S)):  # f(g()) spreads g's results
+                        continue
+                    bad.append("%s: %s: %s() called with %d arguments, declared with %s" %
+                               (os.path.basename(p), sig.strip()[:60], name, n, lo if lo == hi else "%d or more" % lo))
+    return bad, checked
+
+
+def test_calls_inside_the_packages_pass_the_declared_number_of_arguments(tmp_path):
+    total = 0
+    for d in sorted(glob.glob(os.path.join(ROOT, "integration", "go", "*"))):
+        bad, checked = _go_call_arity_mismatches(d)
+        assert not bad, "\n".join(bad)
+        total += checked
+    assert total > 50, total  # the check does see the calls
+    pkg = tmp_path / "p"
+    pkg.mkdir()
+    (pkg / "a.go").write_text("package p\n\ntype t struct{}\n\nfunc two(a, b int) int { return a + b }\n\n"
+                              "func (x *t) one(a int, rest ...int) int { return a }\n\n"
+                              "func use(x *t) int {\n\treturn two(1) + x.one() + two(1, 2) + x.one(1, 2, 3)\n}\n")
+    bad, checked = _go_call_arity_mismatches(str(pkg))
+    assert checked == 4 and len(bad) == 2 and "two() called with 1" in bad[0] and "one() called with 0" in bad[1]
