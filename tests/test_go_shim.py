@@ -480,3 +480,29 @@ def test_calls_inside_the_packages_pass_the_declared_number_of_arguments(tmp_pat
                               "func use(x *t) int {\n\treturn two(1) + x.one() + two(1, 2) + x.one(1, 2, 3)\n}\n")
     bad, checked = _go_call_arity_mismatches(str(pkg))
     assert checked == 4 and len(bad) == 2 and "two() called with 1" in bad[0] and "one() called with 0" in bad[1]
+
+
+def test_functions_with_results_end_in_a_terminating_statement():
+    """'missing return' is a compile error: a function with results must end in return / panic, an endless `for {`
+    or a `select {` / `switch` whose every branch ends that way (the last two are only recognised by their opener)."""
+    bad = []
+    for path, raw in go_sources().items():
+        for sig, body in _go_funcs(_go_strip(raw)):
+            m = re.match(r"func\s*(\([^)]*\)\s*)?([A-Za-z_]\w*)\s*\(", sig)
+            if not m or not sig[_balanced(sig, m.end() - 1):].strip():
+                continue  # no results
+            depth, opener, last = 0, "", ""
+            for line in body.strip()[1:-1].splitlines():
+                s = line.strip()
+                if not s:
+                    continue
+                after = depth + s.count("{") - s.count("}")
+                if depth == 0 or after == 0:  # a statement of the function's own block, or the brace that closes one
+                    last = s
+                    if depth == 0 and s.endswith("{"):
+                        opener = s
+                depth = after
+            ok = last.startswith(("return", "panic(")) or (last == "}" and re.match(r"^(for|select)\s*\{$", opener))
+            if not ok:
+                bad.append("%s: %s ends in %r" % (os.path.basename(path), sig.strip()[:70], last[:40]))
+    assert not bad, "\n".join(bad)
