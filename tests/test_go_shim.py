@@ -506,3 +506,84 @@ def test_functions_with_results_end_in_a_terminating_statement():
             if not ok:
                 bad.append("%s: %s ends in %r" % (os.path.basename(path), sig.strip()[:70], last[:40]))
     assert not bad, "\n".join(bad)
+
+
+def _go_structs_and_methods(texts):
+    structs, methods = {}, {}
+    for t in texts:
+        for m in re.finditer(r"^type\s+([A-Za-z_]\w*)\s+struct\s*\{(.*?)^\}", t, flags=re.M | re.S):
+            fields = set()
+            for line in m.group(2).splitlines():
+                line = line.strip()
+                mm = re.match(r"^([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)\s+\S", line)
+                if mm:
+                    fields.update(x.strip() for x in mm.group(1).split(","))
+                else:
+                    mm = re.match(r"^\*?(?:\w+\.)?([A-Za-z_]\w*)$", line)  # an embedded type
+                    if mm:
+                        fields.add(mm.group(1))
+            structs[m.group(1)] = fields
+        for sig, _ in _go_funcs(t):
+            mm = re.match(r"func\s*\(\s*\w+\s+\*?(\w+)\s*\)\s*(\w+)", sig)
+            if mm:
+                methods.setdefault(mm.group(1), set()).add(mm.group(2))
+    return structs, methods
+
+
+def _go_unknown_selectors(pkgdir):
+    """x.name where x is a receiver, a parameter or a local made from a composite literal of one of the package's own
+    struct types, and name is neither a field nor a method of that type; keys of the package's composite literals that
+    are not fields.  Returns (findings, selectors checked)."""
+    texts = {p: _go_strip(open(p).read()) for p in sorted(glob.glob(pkgdir + "/*.go"))}
+    structs, methods = _go_structs_and_methods(texts.values())
+    bad, checked = [], 0
+    for p, t in texts.items():
+        for sig, body in _go_funcs(t):
+            typed = {}
+            for m in re.finditer(r"([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)\s+\*?([A-Za-z_]\w*)\s*[,)]", sig):
+                if m.group(2) in structs:
+                    for name in m.group(1).split(","):
+                        typed[name.strip()] = m.group(2)
+            for m in re.finditer(r"(?<![\w.])([A-Za-z_]\w*)\s*:=\s*&?([A-Za-z_]\w*)\{", body):
+                if m.group(2) in structs:
+                    typed[m.group(1)] = m.group(2)
+            for var, typ in typed.items():
+                if len(re.findall(r"(?<![\w.])%s\s*(?::=|,\s*\w+\s*:=)" % re.escape(var), body)) > (1 if re.search(
+                        r"(?<![\w.])%s\s*:=\s*&?%s\{" % (re.escape(var), typ), body) else 0):
+                    continue  # re-declared with something else somewhere: not followed
+                for u in re.finditer(r"(?<![\w.])%s\.([A-Za-z_]\w*)" % re.escape(var), body):
+                    checked += 1
+                    if u.group(1) not in structs[typ] and u.group(1) not in methods.get(typ, set()):
+                        bad.append("%s: %s: %s.%s is neither a field nor a method of %s" %
+                                   (os.path.basename(p), sig.strip()[:50], var, u.group(1), typ))
+            for m in re.finditer(r"(?<![\w.])&?([A-Za-z_]\w*)\{", body):
+                if m.group(1) not in structs:
+                    continue
+                depth, i = 1, m.end()
+                while depth:
+                    depth += {"{": 1, "}": -1}.get(body[i], 0)
+                    i += 1
+                for part in _split_top_level(body[m.end():i - 1]):
+                    km = re.match(r"^\s*([A-Za-z_]\w*)\s*:[^=]", part)
+                    if km:
+                        checked += 1
+                        if km.group(1) not in structs[m.group(1)]:
+                            bad.append("%s: %s{%s: ...}: no such field" % (os.path.basename(p), m.group(1), km.group(1)))
+    return bad, checked
+
+
+def test_selectors_on_the_packages_own_structs_exist(tmp_path):
+    total = 0
+    for d in sorted(glob.glob(os.path.join(ROOT, "integration", "go", "*"))):
+        if os.path.isdir(d):
+            bad, checked = _go_unknown_selectors(d)
+            assert not bad, "\n".join(bad)
+            total += checked
+    assert total > 300, total
+    pkg = tmp_path / "p"
+    pkg.mkdir()
+    (pkg / "a.go").write_text("package p\n\ntype t struct {\n\ta, b int\n\tname string\n}\n\nfunc (x *t) get() int { return x.a + x.c }\n\n"
+                              "func mk(y *t) *t {\n\tz := &t{a: 1, d: 2}\n\tz.b = y.nam\n\treturn z\n}\n")
+    bad, _ = _go_unknown_selectors(str(pkg))
+    assert len(bad) == 3 and any("x.c is neither" in b for b in bad) and any("y.nam is neither" in b for b in bad) \
+        and any("t{d: ...}: no such field" in b for b in bad), bad
