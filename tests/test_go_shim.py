@@ -1,7 +1,9 @@
 """The cgo shim under integration/go/ cannot be compiled here (no Go toolchain in the image).  It is still held to
 the C ABI mechanically: every C.sdb_* call names a function include/semadb_amd.h declares and passes as many
 arguments as that declaration has parameters, every C.SDB_* constant exists, every helper the package calls is
-defined in it, and the exported surface SURVEY 8b lists is there with the reference's signatures."""
+defined in it, and the exported surface SURVEY 8b lists is there with the reference's signatures.  Since round 6 also
+a poor man's front end (names resolve, nothing unused, call arity inside the package, selectors on the package's own
+structs, terminating statements): the classes of error an edit leaves behind and a compiler would have refused."""
 import glob
 import os
 import re
