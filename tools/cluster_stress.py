@@ -1,3 +1,5 @@
+"""Stress of the shared-device shard exchange through the ctypes Fanout: four shards on one GPU, client threads racing
+requests of 1 .. 1 024 queries; every merged answer is compared with sdb_topk_merge of the shards' own answers."""
 import sys, threading, time
 sys.path.insert(0, "/root/repo")
 import numpy as np

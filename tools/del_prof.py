@@ -1,3 +1,5 @@
+"""Wall time of three sdb_index_delete_batch calls of 1 000 points each on the 1M x 384 bench graph (under rocprofv3:
+the delete path's kernel split)."""
 import sys, os, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch, bench

@@ -1,3 +1,5 @@
+"""Per-call times (enqueue / complete) of filtered searches on 200k x 384: 1 / 64 / 1 024 queries with 10 or 1 000 filter
+ids each -- where a filtered call's time goes on the host."""
 import sys, time, os
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
