@@ -263,7 +263,15 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        to walk through it
  *   SDB_TUNE_NO_ZERO_COPY  != 0: a host-memory search stages queries and results through device buffers even when the
  *                        caller's buffers are page-locked (sdb_host_alloc) and the kernel could read / write them in
- *                        place (A/B and parity tests) */
+ *                        place (A/B and parity tests)
+ *   SDB_TUNE_SKETCH      1: two-precision hop for batch searches of cosine / dot tables (rows of whole 32-float blocks,
+ *                        up to 768 floats; no quantizer, no filter): the index keeps a float16 copy of its rows (+ 50 %
+ *                        of their memory; rebuilt by every commit) and a hop reads a new neighbour's float32 row only
+ *                        when its float16 distance does not PROVE that AddWithLimit discards it (distset.go:184: the
+ *                        distance of a discarded neighbour is never used again).  Ids, distances, visit order and
+ *                        counters are the same bits either way.  2: the same, and every discarded neighbour is
+ *                        evaluated exactly as well; sdb_index_sketch_stats counts decisions the exact distance
+ *                        contradicts (must stay 0).  0: off, the copy is freed.  Off by default. */
 #define SDB_TUNE_HUB_MIN 1
 #define SDB_TUNE_HASH_LIMIT 2
 #define SDB_TUNE_NO_HASH 3
@@ -276,7 +284,12 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
 #define SDB_TUNE_HOST_FILTERS 10
 #define SDB_TUNE_NO_DEFER 11
 #define SDB_TUNE_NO_ZERO_COPY 12
+#define SDB_TUNE_SKETCH 13
 int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value);
+/* SDB_TUNE_SKETCH's counters since the knob was last set: out[0] = neighbours discarded on their float16 distance,
+ * out[1] = of those, the ones whose exact distance would have been kept (audit mode only; a non-zero value is a bug),
+ * out[2] = 1 when searches currently use the float16 copy (it exists and describes the committed rows), else 0. */
+int sdb_index_sketch_stats(sdb_index *ix, uint64_t out[3]);
 
 /* Counters of the most recent sdb_index_insert_batch call (the C3 roofline, SURVEY 8d: bytes = sum over inserts
  * of search bytes + prune pair-distance rows * d * 4).  out[0..n) with n = min(cap, SDB_BUILD_STATS):

@@ -63,6 +63,7 @@ SIGNATURES = {
     "sdb_index_distance_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p]),
     "sdb_index_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
+    "sdb_index_sketch_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "sdb_index_build_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "sdb_index_get_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdb_index_exists_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),

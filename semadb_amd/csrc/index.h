@@ -158,6 +158,18 @@ struct sdb_index {
   bool tune_host_filters = false;  // filter ids are resolved to slots by the host's hash map even when the table's ids are consecutive
   uint32_t tune_wide_walk = 0;  // the workgroup-per-query walk of small calls: 0 = up to 256 queries, 1 = never, 2 = always
   bool tune_no_zero_copy = false;  // A/B and parity tests: host-memory searches stage even page-locked buffers
+  // Two-precision hop (SDB_TUNE_SKETCH; search_kernel.h SearchArgs::sketch): a float16 copy of the slab's rows, an
+  // optional cache like d_adjcodes.  It describes the rows of the view published as number `sketch_gen`; a search
+  // uses it only while that is the current view, and commit / publish_full rebuild it behind the searches of the old one.
+  uint32_t tune_sketch = 0;  // 0 off, 1 on, 2 on + audit (every discarded neighbour is evaluated exactly as well and checked)
+  uint16_t *d_sketch = nullptr;
+  uint32_t sketch_cap = 0;   // rows d_sketch has room for
+  uint64_t sketch_gen = 0;   // view_gen the copy was built for (0: none)
+  float sk_emax = 0.0f, sk_ymax = 0.0f;
+  unsigned long long *d_sk_counters = nullptr;  // [0] neighbours discarded on their float16 distance, [1] contradicted (audit)
+  bool sketch_supported() const;               // cosine / dot rows of whole 32-float blocks, one of the walk's register layouts
+  int build_sketch(hipStream_t stream);        // (re)build for the rows as they are; failure to allocate leaves it off
+  void drop_sketch();
   bool tune_no_defer = false;  // A/B and parity tests: every back-edge re-prune runs in k_backedges (BuildArgs::def_*)
   uint32_t tune_pq_narrow = 0;  // 1: quantized searches never take a multi-wave walk (k_greedy_search_pqw, k_greedy_search_pq2): A/B and parity tests
   bool tune_no_mfma = false;  // exact scan of dot/cosine rows on the packed-FMA kernel instead of the matrix cores

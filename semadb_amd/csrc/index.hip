@@ -556,8 +556,18 @@ template <int NG, bool L2>
 static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   if constexpr (NG >= 1 && NG <= 8)
     if (wide_walk(a, nq)) return launch_wide<NG, L2>(a, nq, stream);
-  if (search_uses_hash(a, nq))
+  if (search_uses_hash(a, nq)) {
+    // the two-precision hop (SearchArgs::sketch): batch walks of cosine / dot rows, plain searches
+    if constexpr (!L2 && (NG == 1 || NG == 2 || NG == 3 || NG == 4 || NG == 6))
+      if (a.sketch && !a.filt_off && !a.vis_slots && !a.dcache && a.tail == 0 && a.search_size <= 128) {
+        using SkDist = PlainDist<NG, false, true, 0, true>;
+        hipLaunchKernelGGL((k_greedy_search<SkDist, 2, false, kHashCap>), dim3(nq), dim3(64),
+                           HashVisited<kHashCap>::kWords * sizeof(uint32_t) + SkDist::kLdsBytes, stream, a);
+        SDB_HIP(hipGetLastError());
+        return SDB_OK;
+      }
     return launch_nreg<PlainDist<NG, L2, true>, kHashCap>(a, nq, stream, PlainDist<NG, L2, true>::kLdsBytes);
+  }
   return launch_nreg<PlainDist<NG, L2, false>, 0>(a, nq, stream, PlainDist<NG, L2, false>::kLdsBytes);
 }
 
@@ -815,6 +825,73 @@ int sdb_index::begin_write() {
   return SDB_OK;
 }
 
+// ---- the float16 copy of the slab (two-precision hop) ----------------------------------------------------------
+namespace sdb {
+// one wave per row: element t of the row -> half t of the copy (sk_half: round to nearest, no denormals), and the
+// row's ||y - y16||, ||y16|| into the table-wide maxima (non-negative floats order like their bit patterns; a NaN's
+// pattern is above every number's, so a row with a NaN makes the bound NaN and the stage discards nothing)
+__global__ __launch_bounds__(256) void k_sketch_rows(const float *__restrict__ slab, uint16_t *__restrict__ sk, uint32_t n,
+                                                      uint32_t ld, uint32_t *__restrict__ stats) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float *s = slab + (size_t)row * ld;
+  uint16_t *d = sk + (size_t)row * ld;
+  double e2 = 0.0, n2 = 0.0;
+  for (uint32_t t = lane; t < ld; t += 64) {
+    const float v = s[t];
+    const _Float16 h = sk_half(v);
+    d[t] = __builtin_bit_cast(uint16_t, h);
+    const double dv = (double)v - (double)(float)h, hv = (double)(float)h;
+    e2 += dv * dv, n2 += hv * hv;
+  }
+  for (int o = 32; o; o >>= 1) e2 += __shfl_xor(e2, o), n2 += __shfl_xor(n2, o);
+  if (lane == 0) {
+    const float e = (float)(sqrt(e2) * 1.0001), y = (float)(sqrt(n2) * 1.0001);  // rounded up past their own rounding
+    atomicMax(stats, __float_as_uint(e < 0.0f ? 0.0f : e));
+    atomicMax(stats + 1, __float_as_uint(y < 0.0f ? 0.0f : y));
+  }
+}
+}  // namespace sdb
+
+bool sdb_index::sketch_supported() const {
+  if (P.metric == SDB_METRIC_EUCLIDEAN || lay.tail != 0 || pq) return false;
+  return lay.ng == 1 || lay.ng == 2 || lay.ng == 3 || lay.ng == 4 || lay.ng == 6;
+}
+
+void sdb_index::drop_sketch() {
+  if (d_sketch) (void)hipFree(d_sketch);
+  d_sketch = nullptr, sketch_cap = 0, sketch_gen = 0;
+}
+
+int sdb_index::build_sketch(hipStream_t stream) {
+  sketch_gen = 0;
+  if (!tune_sketch || !sketch_supported() || n == 0) return SDB_OK;
+  if (sketch_cap < cap) {
+    drop_sketch();
+    if (hipMalloc(&d_sketch, (size_t)cap * lay.ld * sizeof(uint16_t)) != hipSuccess) {  // a cache: without room for it the walk reads float32 rows
+      (void)hipGetLastError();
+      d_sketch = nullptr;
+      return SDB_OK;
+    }
+    sketch_cap = cap;
+  }
+  if (!d_sk_counters) {
+    SDB_HIP(hipMalloc(&d_sk_counters, 4 * sizeof(unsigned long long)));
+    SDB_HIP(hipMemset(d_sk_counters, 0, 4 * sizeof(unsigned long long)));
+  }
+  uint32_t *stats = reinterpret_cast<uint32_t *>(d_sk_counters + 2);
+  SDB_HIP(hipMemsetAsync(stats, 0, 8, stream));
+  hipLaunchKernelGGL(sdb::k_sketch_rows, dim3((n + 3) / 4), dim3(256), 0, stream, d_slab, d_sketch, n, lay.ld, stats);
+  SDB_HIP(hipGetLastError());
+  uint32_t h[2] = {0, 0};
+  SDB_HIP(hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, stream));
+  SDB_HIP(hipStreamSynchronize(stream));
+  memcpy(&sk_emax, &h[0], 4), memcpy(&sk_ymax, &h[1], 4);
+  sketch_gen = view_gen;
+  return SDB_OK;
+}
+
 int sdb_index::ensure_idmap(const View &vw, hipStream_t stream) const {
   std::lock_guard<std::mutex> g(idmap.mu);
   if (idmap.gen == view_gen) return SDB_OK;
@@ -932,6 +1009,9 @@ int sdb_index::commit(hipStream_t stream) {
     }
     SDB_HIP(hipMemcpyAsync(d_start_ext, r_start_ext, (size_t)need * 4, hipMemcpyDeviceToDevice, stream));
   }
+  // the float16 copy follows: on `stream`, which has waited for the searches of the old view (above); searches of the
+  // new one read float32 rows until sketch_gen says the copy is theirs
+  if (tune_sketch) SDB_TRY(build_sketch(stream));
   return SDB_OK;
 }
 
@@ -982,6 +1062,7 @@ int sdb_index::rollback() {
   }
   tx_deleted.clear();
   in_tx = false, tx_explicit = false, tx_dirty = false;
+  if (tune_sketch) SDB_TRY(build_sketch(nullptr));  // (exclusive lock held, device idle)
   return SDB_OK;
 }
 
@@ -1014,6 +1095,10 @@ int sdb_index::publish_full() {
   view_gen++;
   tx_deleted.clear();
   in_tx = false, tx_explicit = false, tx_dirty = false;
+  if (tune_sketch) {
+    SDB_HIP(hipDeviceSynchronize());  // searches that slipped in between the first wait and the lock
+    SDB_TRY(build_sketch(nullptr));
+  }
   return SDB_OK;
 }
 
@@ -1205,6 +1290,8 @@ int sdb_index_destroy(sdb_index *ix) try {
   DeviceGuard dg(ix->P.device);
   (void)hipDeviceSynchronize();
   if (ix->d_slab) (void)hipFree(ix->d_slab);
+  ix->drop_sketch();
+  if (ix->d_sk_counters) (void)hipFree(ix->d_sk_counters);
   if (ix->d_adj) (void)hipFree(ix->d_adj);
   if (ix->d_deg) (void)hipFree(ix->d_deg);
   if (ix->d_clean) (void)hipFree(ix->d_clean);
@@ -1738,6 +1825,10 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
   a.wide_hash = ix->tune_wide_hash ? 1u : 0u, a.hash16_probes = ix->tune_hash16_probes;
   a.pq_narrow = ix->tune_pq_narrow;
   a.wide_mode = ix->tune_wide_walk;
+  // two-precision hop: only with the float16 copy of exactly this view's rows, outside a write transaction
+  if (ix->tune_sketch && ix->d_sketch && ix->sketch_gen == ix->view_gen && !ix->in_tx && !filtered)
+    a.sketch = ix->d_sketch, a.sk_emax = ix->sk_emax, a.sk_ymax = ix->sk_ymax, a.sk_audit = ix->tune_sketch == 2 ? 1u : 0u,
+    a.sk_counters = ix->d_sk_counters;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
   auto launch = [&]() -> int {
@@ -1914,6 +2005,19 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) try {
     case SDB_TUNE_NO_ZERO_COPY:
       ix->tune_no_zero_copy = value != 0;
       return SDB_OK;
+    case SDB_TUNE_SKETCH: {
+      if (value > 2) return fail(SDB_ERR_INVALID, "sketch: 0 = off, 1 = on, 2 = on with audit");
+      DeviceGuard dg(ix->P.device);
+      std::unique_lock<sdb::ViewMutex> wl(ix->view_mu);
+      SDB_HIP(hipDeviceSynchronize());  // walks that read the copy
+      ix->tune_sketch = (uint32_t)value;
+      if (!value) {
+        ix->drop_sketch();
+        return SDB_OK;
+      }
+      if (ix->d_sk_counters) SDB_HIP(hipMemset(ix->d_sk_counters, 0, 2 * sizeof(unsigned long long)));
+      return ix->in_tx ? SDB_OK : ix->build_sketch(nullptr);  // inside a transaction: its commit builds it
+    }
     case SDB_TUNE_NO_DEFER:
       ix->tune_no_defer = value != 0;
       return SDB_OK;
@@ -1926,6 +2030,22 @@ int sdb_index_set_tuning(sdb_index *ix, int key, uint64_t value) try {
   }
 }
 SDB_API_CATCH("sdb_index_set_tuning")
+
+int sdb_index_sketch_stats(sdb_index *ix, uint64_t out[3]) try {
+  if (!ix || !out) return fail(SDB_ERR_INVALID, "NULL argument");
+  DeviceGuard dg(ix->P.device);
+  out[0] = out[1] = out[2] = 0;
+  std::shared_lock<sdb::ViewMutex> rl(ix->view_mu);
+  if (ix->d_sk_counters) {
+    SDB_HIP(hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    SDB_HIP(hipMemcpy(h, ix->d_sk_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0], out[1] = h[1];
+  }
+  out[2] = (ix->tune_sketch && ix->d_sketch && ix->sketch_gen == ix->view_gen && !ix->in_tx) ? 1 : 0;
+  return SDB_OK;
+}
+SDB_API_CATCH("sdb_index_sketch_stats")
 
 int sdb_index_build_stats(const sdb_index *ix, uint64_t *out, uint32_t cap) try {
   if (!ix || !out) return fail(SDB_ERR_INVALID, "NULL argument");
@@ -2208,6 +2328,7 @@ int sdb_index_compact(sdb_index *ix) try {
   ix->view.adj_codes = ix->r_adjcodes;
   ix->view_gen++;
   (void)hipDeviceSynchronize();
+  if (ix->tune_sketch) (void)ix->build_sketch(nullptr);  // rows have moved (a stale copy is never used: sketch_gen)
   return SDB_OK;
 }
 SDB_API_CATCH("sdb_index_compact")

@@ -83,6 +83,14 @@ struct SearchArgs {
   uint32_t hash_limit;     // ids the LDS hash set may hold before the query falls back to its bitset
   uint32_t wide_mode;      // the workgroup-per-query walk: 0 = calls of up to kWideMaxQueries queries, 1 = never, 2 = always
   uint32_t wide_pull;      // 2: that walk's other waves work ahead on the row the walk expands next (PlainWideDist); 0: they only share a hop's rows
+  // Two-precision hop (index.h d_sketch; SDB_TUNE_SKETCH): a float16 copy of the slab, same element order, rows of
+  // `ld` halves.  A neighbour whose float16 distance lies above the candidate array's last distance by more than the
+  // bound on |float16 distance - the reference's float32 distance| is discarded by AddWithLimit whatever its exact
+  // distance is (distset.go:184; the distance is never looked at again), so only the others are read in float32.
+  const uint16_t *sketch;
+  float sk_emax, sk_ymax;            // max over the rows of ||y - y16|| and of ||y16|| (k_sketch_rows), rounded up
+  uint32_t sk_audit;                 // != 0: evaluate everything exactly as well and count decisions the exact distance contradicts
+  unsigned long long *sk_counters;   // [0] += neighbours discarded on their float16 distance, [1] += contradicted ones (audit)
 };
 
 // pairs of candidate rows a wave keeps in flight per chunk.  DEEP (one wave per SIMD, the batch-search
@@ -217,8 +225,15 @@ __device__ __forceinline__ void chunk_dist_lds(const float *__restrict__ slab, u
 
 // Full-precision store.  NG >= 0: compile-time group count, query in registers.  NG == -1: run-time
 // ng, query tile in LDS.
-template <int NG, bool L2, bool DEEP = false, int UPAIRS = 0>  // UPAIRS != 0: that many pairs of rows per chunk
+typedef _Float16 sk_h2 __attribute__((ext_vector_type(2)));
+// float -> float16 as the sketch stores it: round to nearest, magnitudes below the smallest NORMAL half become 0 (no
+// denormal half is ever an operand of v_dot2_f32_f16, whatever the mode register says about them); what this loses is
+// part of the measured error ||v - v16||, not an assumption
+__device__ __forceinline__ _Float16 sk_half(float v) { return fabsf(v) < 6.103515625e-5f ? (_Float16)0.0f : (_Float16)v; }
+
+template <int NG, bool L2, bool DEEP = false, int UPAIRS = 0, bool SK = false>  // UPAIRS != 0: that many pairs of rows per chunk; SK: two-precision hop
 struct PlainDist {
+  static constexpr bool kSketch = SK;
   static constexpr bool kHasStamps = true;
   static constexpr bool kPointDistances = true;  // dist(query, row) is distFn between two stored vectors
   // search_body: nothing is worked ahead on between the hops.  (Round 5 tried the walker's naming of the next hop's row
@@ -232,15 +247,113 @@ struct PlainDist {
   static constexpr int U = UPAIRS ? UPAIRS : (NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4);
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
   // [kHopSlots], raw distances by rank [kHopSlots], a U-word dump
-  static constexpr uint32_t kHopSlots = 64 + U;  // ranks 0..63 and the overrun of the last half-wave run
-  static constexpr size_t kLdsBytes = NG >= 0 ? (2 * kHopSlots + U) * sizeof(uint32_t) : 0;
+  // (two-precision hop: pairs of float16 rows in flight per round -- all of a hop's new neighbours in ONE round where
+  // the registers allow it, 2 NG registers per row: a round is a dependent memory round trip of the hop)
+#ifndef SDB_SKETCH_ROWS
+#define SDB_SKETCH_ROWS 32  // measurement builds: tools/sketch_ab.py
+#endif
+  static constexpr int US = !SK ? U : (SDB_SKETCH_ROWS < 96 / NGR ? SDB_SKETCH_ROWS : 96 / NGR);
+  static constexpr int UX = U > US ? U : US;
+  static constexpr uint32_t kHopSlots = 64 + UX;  // ranks 0..63 and the overrun of the last half-wave run
+  static constexpr size_t kLdsBytes = NG >= 0 ? (2 * kHopSlots + UX) * sizeof(uint32_t) : 0;
   float4 xq[NGR];
   float xt;
   float *qs;
   uint32_t *hs;
+  sk_h2 qh[SK ? NGR : 1][2];  // the query in float16, in xq's element order
+  float sk_eps;               // bound on |float16 distance - the reference's float32 distance| for this query, any row
 #ifdef SDB_STAMPS
   unsigned long long st[3] = {0, 0, 0};  // issue, wait, compute
 #endif
+
+  // The bound.  With q16, y16 the float16 copies (exact in float32): q.y - q16.y16 = (q - q16).y16 + q.(y - y16), so
+  // |q.y - q16.y16| <= ||q - q16|| Ymax16 + ||q|| Emax (Cauchy-Schwarz; Emax, Ymax16 measured over all rows by
+  // k_sketch_rows, ||q - q16|| and ||q|| measured here).  The two computed sums differ from the exact ones by their
+  // rounding: the reference's 32 chains of NG x 4 / 32 ... fused multiply-adds and its 6-level tree, at most 4 NG + 6
+  // roundings of relative size 2^-24 on sums bounded by ||q|| ||y||; the sketch's 2 NG v_dot2_f32_f16 (products of
+  // halves are exact in float32, three additions each) and the same tree: 6 NG + 6.  For NG <= 8 that is below
+  // 110 x 2^-24 = 6.6e-6; 2e-5 ||q|| (Ymax16 + Emax) is charged.  Norms are inflated by 1e-4 for their own rounding; the
+  // final 1 - dot / -dot and the subtraction of the bound are covered per comparison (sketch_keep).  A query or a table
+  // with a non-finite or float16-overflowing element makes the bound infinite or NaN: nothing is discarded then.
+  __device__ __forceinline__ void init_sketch(const SearchArgs &a, int lane) {
+    float e2 = 0.0f, n2 = 0.0f;
+#pragma unroll
+    for (int g = 0; g < NGR; g++) {
+      const float v[4] = {xq[g].x, xq[g].y, xq[g].z, xq[g].w};
+      _Float16 h[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        h[k] = sk_half(v[k]);
+        const float dv = v[k] - (float)h[k];
+        e2 = __builtin_fmaf(dv, dv, e2), n2 = __builtin_fmaf(v[k], v[k], n2);
+      }
+      qh[g][0] = sk_h2{h[0], h[1]}, qh[g][1] = sk_h2{h[2], h[3]};
+    }
+    // (both halves of the wave hold the same query: the sum over one half's 32 lanes)
+    e2 = rlf(asm_reduce(e2, 0.0f, lane), 0), n2 = rlf(asm_reduce(n2, 0.0f, lane), 0);
+    const float qerr = __builtin_sqrtf(e2) * 1.0001f, qn = __builtin_sqrtf(n2) * 1.0001f;
+    sk_eps = (qerr * a.sk_ymax + qn * a.sk_emax + 2e-5f * qn * (a.sk_ymax + a.sk_emax)) * 1.0001f;
+  }
+
+  // float16 dot products of the pending rows by rank, two rows per wave instruction like rows_range
+  __device__ __forceinline__ void sketch_range(const SearchArgs &a, const uint32_t *s_slot, float *s_res, int cnt, int lane) {
+    const int L = lane & 31, half = lane >> 5;
+    const char *baseL = reinterpret_cast<const char *>(a.sketch) + L * 8;
+    const uint32_t row_bytes = a.ld * 2u;
+    for (int c0 = 0; c0 < cnt; c0 += 2 * US) {
+      const int m = cnt - c0 < 2 * US ? cnt - c0 : 2 * US;
+      const int h0 = (m + 1) >> 1;
+      const int base = c0 + (half ? h0 : 0);
+      uint32_t sl[US];
+#pragma unroll
+      for (int u = 0; u < US; u++) sl[u] = s_slot[base + u];
+      uint2 y[US][NGR];
+#pragma unroll
+      for (int u = 0; u < US; u++)
+        if (u < h0) {
+          const char *r = baseL + (uint64_t)sl[u] * row_bytes;
+#pragma unroll
+          for (int g = 0; g < NG; g++) y[u][g] = *reinterpret_cast<const uint2 *>(r + g * 256);
+        }
+      float *wp = (L == 0) ? s_res + base : s_res + kHopSlots;  // the other lanes write to a dump
+#pragma unroll
+      for (int u = 0; u < US; u++)
+        if (u < h0) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(sk_h2, y[u][g].x), qh[g][0], acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(sk_h2, y[u][g].y), qh[g][1], acc, false);
+          }
+          wp[u] = asm_reduce(acc, 0.0f, lane);
+        }
+    }
+  }
+
+  // the pending neighbours that AddWithLimit may keep: `out` gets the ones whose float16 distance is above `tail_d` by
+  // more than the bound (every comparison with a NaN is false: such a neighbour is kept for the exact evaluation)
+  __device__ __forceinline__ uint64_t sketch_keep(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane, float tail_d,
+                                                  uint64_t &out) {
+    const int cnt = __popcll(pend);
+    const bool mine = (pend >> lane) & 1ull;
+    const uint32_t rank =
+        __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+    uint32_t *s_slot = hs;
+    float *s_res = reinterpret_cast<float *>(hs + kHopSlots);
+    if (mine) {
+      s_slot[rank] = nb;
+      if ((int)rank == cnt - 1) s_slot[cnt] = nb;  // the spare entry
+    }
+    wave_lds_sync();
+    sketch_range(a, s_slot, s_res, cnt, lane);
+    wave_lds_sync();
+    const float d16 = mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
+    // (1 - dot, -dot and the subtraction below round once each: 3 x 2^-24 of magnitudes below 1 + |d16| + eps)
+    const float slack = sk_eps + 4e-7f * (1.0f + fabsf(d16) + sk_eps);
+    out = __ballot(mine && (d16 - slack > tail_d));
+    wave_lds_sync();  // hop() compacts into the same scratch
+    return pend & ~out;
+  }
 
   __device__ __forceinline__ void init(const SearchArgs &a, uint32_t q, int lane, float *lds) {
     const int L = lane & 31;
@@ -255,6 +368,7 @@ struct PlainDist {
                             q_elem(qv, a.nblk, g, 2, L), q_elem(qv, a.nblk, g, 3, L));
       if (NG == 0) xq[0] = make_float4(0.f, 0.f, 0.f, 0.f);
       xt = (a.tail && (uint32_t)L < a.tail) ? qv[a.nblk * 32 + L] : 0.0f;
+      if constexpr (SK) init_sketch(a, lane);
     } else {
       for (uint32_t i = lane; i < a.ng * 128; i += 64) {
         uint32_t g = i / 128, r = i % 128;
@@ -1607,6 +1721,12 @@ struct NoVisited {
 // (4 KB) next to the search set's; past 750 ids it spills to its HBM bitset like the big one does.
 constexpr uint32_t kHashCapResult = 1024;
 
+// does the distance policy have the two-precision stage (PlainDist<..., SK = true>)?
+template <class D, class = void>
+struct sketch_policy { static constexpr bool value = false; };
+template <class D>
+struct sketch_policy<D, decltype((void)D::kSketch)> { static constexpr bool value = D::kSketch; };
+
 // greedySearch for one query by one wavefront.  RVis: the visited set of the filtered search's result set.
 template <class Dist, int NREG, bool FILT, class Visited, class RVis>
 __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t q, const int lane, Dist &dist,
@@ -1618,6 +1738,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
   int len = 0;
   const int cap = (int)a.search_size;
   uint32_t n_dist = 0, n_hop = 0, n_edges = 0;
+  uint32_t n_sk_out = 0;  // two-precision hop: neighbours discarded on their float16 distance
   __shared__ uint32_t s_scatter[2 * NREG * 64];  // add_with_limit_merge scratch
 
   // filtered search (search.go:33-51): resultSet = DistSet(cap k) with its own visited set
@@ -1790,11 +1911,28 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       bool isnew;
       if (Dist::kSpeculate && have_marks && first_chunk) isnew = (mark_mask >> lane) & 1ull;
       else isnew = vis.test_and_set(valid, nb, lane);
-      const uint64_t pend = __ballot(isnew);
+      uint64_t pend = __ballot(isnew);
       SDB_STAMP(st_atom)
       if (pend) {
         n_dist += (uint32_t)__popcll(pend);
-        const float mydist = dist.hop(a, nb, pend, lane);  // lane j: distance of edge j
+        if constexpr (sketch_policy<Dist>::value) {
+          // two-precision hop: with the array full, the neighbours whose float16 distance is provably above its last
+          // distance -- as it is NOW: it only falls while this row's points are inserted -- are discarded here;
+          // AddWithLimit would discard them one by one (distset.go:184) and nothing else ever reads their distance
+          if (len == cap) {
+            const float tail_d = list_tail(cd, cap);
+            uint64_t out = 0;
+            const uint64_t keep = dist.sketch_keep(a, nb, pend, lane, tail_d, out);
+            if (a.sk_audit) {  // (rare path: counted at once, not carried in a register through the walk)
+              const float dx = dist.hop(a, nb, pend, lane);
+              const uint64_t bad = __ballot(((out >> lane) & 1ull) && !(dx > tail_d));
+              if (bad && lane == 0 && a.sk_counters) atomicAdd(a.sk_counters + 1, (unsigned long long)__popcll(bad));
+            }
+            n_sk_out += (uint32_t)__popcll(out);
+            pend = keep;
+          }
+        }
+        const float mydist = pend ? dist.hop(a, nb, pend, lane) : 0.0f;  // lane j: distance of edge j
         if constexpr (Dist::kPointDistances)
           if (a.dcache && ((pend >> lane) & 1ull))
             a.dcache[((size_t)q << (32 - a.dcache_shift)) + ((nb * 2654435761u) >> a.dcache_shift)] =
@@ -1835,12 +1973,14 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
           }
         }
         // AddWithLimit over the new neighbours, in edge order distset.go:184-198
-        if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
+        if (!sketch_policy<Dist>::value || pend) {  // (the two-precision hop may have discarded every new neighbour)
+          if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
 #ifdef SDB_STAMPS
-        else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter, st_m);
+          else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter, st_m);
 #else
-        else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
+          else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
 #endif
+        }
         SDB_STAMP(st_ins)
       } else {
         dist.skip(lane);
@@ -1926,6 +2066,8 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
     if (e.tr_nedges) e.tr_nedges[q] = n_edges;
 #endif
     if (e.vis_count) e.vis_count[q] = n_hop;
+    if constexpr (sketch_policy<Dist>::value)
+      if (e.sk_counters && n_sk_out) atomicAdd(e.sk_counters, (unsigned long long)n_sk_out);
     if (e.totals) {  // one of 64 copies of the counters (index.h kStatCopies)
       unsigned long long *t = e.totals + (q & 63u) * 16u;
       atomicAdd(t, (unsigned long long)n_dist), atomicAdd(t + 1, (unsigned long long)n_edges);

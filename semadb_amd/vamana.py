@@ -155,7 +155,14 @@ class IndexVamana:
         return a.value, b.value, c.value
 
     TUNING = {"hub_min": 1, "hash_limit": 2, "no_hash": 3, "no_tile": 4, "no_mfma": 5, "wide_hash": 6, "hash16_probes": 7,
-              "pq_narrow": 8, "wide_walk": 9, "host_filters": 10, "no_defer": 11, "no_zero_copy": 12}  # SDB_TUNE_* (semadb_amd.h)
+              "pq_narrow": 8, "wide_walk": 9, "host_filters": 10, "no_defer": 11, "no_zero_copy": 12,
+              "sketch": 13}  # SDB_TUNE_* (semadb_amd.h)
+
+    def sketch_stats(self):
+        """(neighbours discarded on their float16 distance, contradicted by the exact distance [audit], copy in use)"""
+        out = (C.c_uint64 * 3)()
+        check(lib().sdb_index_sketch_stats(self._h, out))
+        return int(out[0]), int(out[1]), bool(out[2])
 
     def set_tuning(self, key, value):
         """test / measurement knobs of this index (sdb_index_set_tuning); none changes a result"""
