@@ -738,6 +738,11 @@ def measure_mode(a, ctx, mode, rows, primary):
             cfg["value_passes_agree_within_3pct"] = bool(abs(v2 - result["value"]) <= 0.03 * result["value"])
         except Exception as e:
             cfg["value_second_pass"] = repr(e)
+        # not the metric's default path: the two-precision hop (SDB_TUNE_SKETCH) on the same batches, checked against it
+        try:
+            cfg["two_precision_hop"] = two_precision_point(a, ix, queries, tb, k, L, d, nq, result)
+        except Exception as e:
+            cfg["two_precision_hop"] = {"error": repr(e)}
         # not the metric (one batch at a time): the same batches with two of them in flight on two streams, the way a
         # serving process (the host batcher) runs -- a second batch fills the SIMDs the first one's finished walks left
         try:
@@ -800,6 +805,74 @@ def measure_mode(a, ctx, mode, rows, primary):
     return result
 
 
+def two_precision_point(a, ix, queries, tb, k, L, d, nq, result):
+    """The timed loop again with SDB_TUNE_SKETCH = 1 (include/semadb_amd.h): the index keeps a float16 copy of its rows
+    and a hop reads a new neighbour's float32 row only when the float16 distance does not prove that AddWithLimit
+    discards it (distset.go:184).  Every answer of every timed batch is compared with the default walk's, bit for bit;
+    a separate pass in audit mode evaluates every discarded neighbour exactly as well and counts contradictions."""
+    distinct = sorted(set(tb[a.warmup:]))
+    ref = {}
+    for b in distinct:
+        ids, dd, cnt, tr = ix.search_batch(queries[b], k, L, trace=True)
+        ref[b] = (ids.clone(), dd.clone().view(torch.int32), cnt.clone(), tr.n_dist.clone(), tr.n_hop.clone())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ix.set_tuning("sketch", 1)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    out = {"knob": "SDB_TUNE_SKETCH = 1 (off by default): float16 copy of the rows, + 50 % of their memory, rebuilt by every commit",
+           "copy_build_s": round(build_s, 4), "in_use": ix.sketch_stats()[2]}
+    try:
+        for b in range(2):
+            ix.search_batch(queries[b], k, L)
+        torch.cuda.synchronize()
+        ix.set_profiling(True)
+        ix.profile_read()
+        t1 = time.perf_counter()
+        for s_ in range(a.steps):
+            ix.search_batch(queries[tb[a.warmup + s_]], k, L)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        kms = [float(v) for v in ix.profile_read()][-a.steps:]
+        ix.set_profiling(False)
+        same = True
+        n_dist = 0
+        for b in distinct:
+            ids, dd, cnt, tr = ix.search_batch(queries[b], k, L, trace=True)
+            r = ref[b]
+            same &= bool(torch.equal(ids, r[0]) and torch.equal(dd.view(torch.int32), r[1]) and torch.equal(cnt, r[2]) and
+                         torch.equal(tr.n_dist, r[3]) and torch.equal(tr.n_hop, r[4]))
+            n_dist += int(tr.n_dist.to(torch.int64).sum().item())
+        discarded_all = ix.sketch_stats()[0]
+        ix.set_tuning("sketch", 2)  # audit: counters start at zero
+        for b in distinct:
+            ix.search_batch(queries[b], k, L)
+        discarded, contradicted, _ = ix.sketch_stats()
+        qps = nq * a.steps / dt
+        per_launch_nd = n_dist / len(distinct)
+        bytes_read = per_launch_nd * d * 2 + (per_launch_nd - discarded / len(distinct)) * d * 4  # (float16 rows: an upper bound)
+        kavg = float(np.mean(kms)) if kms else 0.0
+        out.update({"qps": round(qps, 1), "ms_per_step": round(dt / a.steps * 1e3, 4), "kernel_ms_avg": round(kavg, 4),
+                    "speedup_over_value": round(qps / result["value"], 3),
+                    "identical_to_the_default_walk": same,
+                    "compared": "%d distinct timed batches: ids, distance bits, counts, n_dist, n_hop" % len(distinct),
+                    "discarded_frac_of_evaluated": round(discarded / max(1, n_dist), 4),
+                    "audit_contradicted": int(contradicted),
+                    "row_bytes_read_per_launch_upper_bound": int(bytes_read),
+                    "roofline": {"bound": "hbm", "kernel": "k_greedy_search<PlainDist<..., SK>>",
+                                 "achieved": round(bytes_read / (kavg * 1e-3) / 1e9, 1) if kavg else None, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(bytes_read / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kavg else None,
+                                 "note": "bytes actually read (float16 row of every evaluated neighbour + float32 row of "
+                                         "the kept ones), not SURVEY 8d's n_dist x d x 4: the walk is no longer bound by HBM"}})
+        if not same or contradicted:
+            out["invalid"] = "the two-precision hop disagrees with the default walk"
+        _ = discarded_all
+    finally:
+        ix.set_profiling(False)
+        ix.set_tuning("sketch", 0)
+    return out
+
+
 def flatten_summary(result):
     """The driver's record keeps the scalars of `config` and drops nested objects: the figures a reader of that record
     needs are repeated as scalars (the nested objects stay for whoever reads the full line)."""
@@ -807,6 +880,11 @@ def flatten_summary(result):
     flat = {}
     if "value_host" in result:
         flat["value_host"] = result["value_host"]  # SURVEY 8d's protocol figure (H2D + D2H inside the timed region)
+    tp = cfg.get("two_precision_hop")
+    if isinstance(tp, dict) and "qps" in tp:
+        flat["two_precision_hop_qps"] = tp["qps"]
+        flat["two_precision_hop_identical_to_the_default_walk"] = tp["identical_to_the_default_walk"]
+        flat["two_precision_hop_kernel_ms"] = tp["kernel_ms_avg"]
     rs = cfg.get("reference_schedule_graph")
     if isinstance(rs, dict):  # profile-derived (labelled in the nested object)
         flat["reference_schedule_graph_qps_from_profile"] = rs.get("qps")

@@ -2164,7 +2164,8 @@ int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) try {
   // slab row + adjacency row + its distance cache + degree / clean / cached counters + id (+ code row)
   // (+ the second adjacency / id copy of the graph versions, + the neighbours' code rows behind both adjacency copies)
   *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + 3 * kAdjStride * 4 + 3 * 4 + 2 * 8 + (ix->pq ? ix->pq->M : 0) +
-                               (ix->has_adjcodes() ? 2 * kAdjStride * ix->pq->M : 0));
+                               (ix->has_adjcodes() ? 2 * kAdjStride * ix->pq->M : 0)) +
+           (int64_t)ix->sketch_cap * ix->lay.ld * 2;  // (+ the float16 copy of the rows, SDB_TUNE_SKETCH)
   return SDB_OK;
 }
 SDB_API_CATCH("sdb_index_size_in_memory")

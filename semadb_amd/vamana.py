@@ -6,6 +6,7 @@ IndexVamana.Search (vamana.go:278), InsertUpdateDelete (vamana.go:127), SizeInMe
 The index state lives in HBM; this module only marshals.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -111,11 +112,19 @@ class IndexVamana:
         h = C.c_void_p()
         check(lib().sdb_index_create(C.byref(p), C.byref(h)))
         self._h = h
+        # test harness only (the library itself never reads the environment): run a whole suite with the two-precision
+        # hop switched on -- 2 = with its audit -- on every index this mirror creates, and have close() check the audit
+        self._forced_sketch = int(os.environ.get("SEMADB_AMD_TEST_SKETCH", "0") or 0)
+        if self._forced_sketch:
+            self.set_tuning("sketch", self._forced_sketch)
 
     def close(self):
         if getattr(self, "_h", None):
+            bad = self.sketch_stats()[1] if getattr(self, "_forced_sketch", 0) else 0
             lib().sdb_index_destroy(self._h)
             self._h = None
+            if bad:
+                raise AssertionError("two-precision hop: %d discarded neighbours had an exact distance that would have been kept" % bad)
 
     def __del__(self):
         try:
