@@ -835,6 +835,22 @@ def two_precision_point(a, ix, queries, tb, k, L, d, nq, result):
         dt = time.perf_counter() - t1
         kms = [float(v) for v in ix.profile_read()][-a.steps:]
         ix.set_profiling(False)
+        # ... and with two batches in flight, like two_batches_in_flight_qps does for the default walk
+        dev = queries.device
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        reps = max(a.steps, 20)
+        for i in range(4):
+            with torch.cuda.stream(streams[i % 2]):
+                ix.search_batch(queries[tb[i % len(tb)]], k, L)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(reps):
+            with torch.cuda.stream(streams[i % 2]):
+                ix.search_batch(queries[tb[a.warmup + i % a.steps]], k, L)
+        torch.cuda.synchronize()
+        out["two_batches_in_flight_qps"] = round(nq * reps / (time.perf_counter() - t2), 1)
         same = True
         n_dist = 0
         for b in distinct:

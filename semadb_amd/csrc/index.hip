@@ -560,7 +560,8 @@ static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
     // the two-precision hop (SearchArgs::sketch): batch walks of cosine / dot rows, plain searches
     if constexpr (!L2 && (NG == 1 || NG == 2 || NG == 3 || NG == 4 || NG == 6))
       if (a.sketch && !a.filt_off && !a.vis_slots && !a.dcache && a.tail == 0 && a.search_size <= 128) {
-        using SkDist = PlainDist<NG, false, true, 0, true>;
+        // (few float32 rows survive the first stage: four pairs of them in flight per round leave the registers to the float16 rows)
+        using SkDist = PlainDist<NG, false, true, 4, true>;
         hipLaunchKernelGGL((k_greedy_search<SkDist, 2, false, kHashCap>), dim3(nq), dim3(64),
                            HashVisited<kHashCap>::kWords * sizeof(uint32_t) + SkDist::kLdsBytes, stream, a);
         SDB_HIP(hipGetLastError());

@@ -262,6 +262,17 @@ struct PlainDist {
   uint32_t *hs;
   sk_h2 qh[SK ? NGR : 1][2];  // the query in float16, in xq's element order
   float sk_eps;               // bound on |float16 distance - the reference's float32 distance| for this query, any row
+  // Rows of up to 384 floats: the float16 rows of ALL 64 edges of an adjacency row fit the register file (2 NG registers
+  // per pair of rows), so they are asked for as soon as the edge ids are there -- BEFORE the visited-set test, whose
+  // LDS round trips (~2 100 cycles) then run under the rows' flight instead of in front of it.  Rows of edges that turn
+  // out to be visited already were read for nothing (a quarter more float16 bytes; the walk is not bound by bytes).
+#ifndef SDB_SKETCH_AHEAD
+#define SDB_SKETCH_AHEAD 1  // measurement builds: 0 = rows asked for after the test, compacted (tools/sketch_ab.py)
+#endif
+  static constexpr bool kSketchAhead = SK && SDB_SKETCH_AHEAD && NG >= 1 && NG <= 3;
+  uint2 sky[kSketchAhead ? 32 : 1][kSketchAhead ? NGR : 1];  // pair u: edge 2u (lanes 0..31) and edge 2u + 1 (lanes 32..63)
+  bool sk_go = false;        // search_body: this hop's rows are asked for ahead (the array is full, the copy is there)
+  bool sk_loaded = false;
 #ifdef SDB_STAMPS
   unsigned long long st[3] = {0, 0, 0};  // issue, wait, compute
 #endif
@@ -334,6 +345,32 @@ struct PlainDist {
   // more than the bound (every comparison with a NaN is false: such a neighbour is kept for the exact evaluation)
   __device__ __forceinline__ uint64_t sketch_keep(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane, float tail_d,
                                                   uint64_t &out) {
+    if constexpr (kSketchAhead) {
+      if (sk_loaded) {  // the rows are in registers, by edge position: sums of the pairs with a pending edge, by position
+        float *s_res = reinterpret_cast<float *>(hs + kHopSlots);
+        const int L = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+          // (every pair, pending or not: 32 independent chains the scheduler can interleave -- skipping the pairs without
+          // a pending edge puts each chain into a basic block of its own)
+          float acc = 0.0f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(sk_h2, sky[u][g].x), qh[g][0], acc, false);
+            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(sk_h2, sky[u][g].y), qh[g][1], acc, false);
+          }
+          const float r = asm_reduce(acc, 0.0f, lane);
+          (L == 0 ? s_res + 2 * u + half : s_res + kHopSlots)[0] = r;  // the other lanes write to the dump
+        }
+        wave_lds_sync();
+        const bool mine = (pend >> lane) & 1ull;
+        const float d16 = mine ? metric_finish(s_res[lane], a.metric) : 0.0f;
+        const float slack = sk_eps + 4e-7f * (1.0f + fabsf(d16) + sk_eps);
+        out = __ballot(mine && (d16 - slack > tail_d));
+        wave_lds_sync();  // hop() compacts into the same scratch
+        return pend & ~out;
+      }
+    }
     const int cnt = __popcll(pend);
     const bool mine = (pend >> lane) & 1ull;
     const uint32_t rank =
@@ -399,7 +436,26 @@ struct PlainDist {
     return metric_finish(rlf(res[0], 0), a.metric);
   }
 
-  __device__ __forceinline__ void prefetch(const SearchArgs &, uint32_t, bool) {}  // rows are fetched in hop()
+  __device__ __forceinline__ void prefetch(const SearchArgs &a, uint32_t nb, bool valid) {  // float32 rows are fetched in hop()
+    if constexpr (kSketchAhead) {
+      sk_loaded = false;
+      if (!sk_go) return;
+      const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const int L = lane & 31;
+      const bool hi = lane >= 32;
+      const char *baseL = reinterpret_cast<const char *>(a.sketch) + L * 8;
+      const uint32_t row_bytes = a.ld * 2u;
+      const uint32_t safe = valid ? nb : a.start_slot;  // an edge that is not there: any row (its result is not looked at)
+#pragma unroll
+      for (int u = 0; u < 32; u++) {
+        const uint32_t s0 = rl(safe, 2 * u), s1 = rl(safe, 2 * u + 1);
+        const char *r = baseL + (uint64_t)(hi ? s1 : s0) * row_bytes;
+#pragma unroll
+        for (int g = 0; g < NG; g++) sky[u][g] = *reinterpret_cast<const uint2 *>(r + g * 256);
+      }
+      sk_loaded = true;
+    }
+  }
   __device__ __forceinline__ void speculation(bool, const uint32_t *) {}
   __device__ __forceinline__ void ahead(const SearchArgs &, const uint32_t *, int, bool) {}
   // hooks of the multi-wave quantized walk (PQWideDist); nothing to do for a one-wave policy
@@ -988,11 +1044,11 @@ constexpr uint32_t kPqwSharedWords = sizeof(PQWideShared) / 4;
 // NL / RT: tables per wave in LDS / in registers (NL + RT a multiple of 16); W: waves per query, M = W (NL + RT).
 // W = 8 (two waves per SIMD, 256 registers each) carries M = 384 with the per-wave layout of M = 192: round 3's
 // four-wave form of it kept 64 tables = 256 registers per wave and spilled 80 more.
-template <int NREG>  // (defined with the candidate array's other operations below)
+template <int NREG, int FEW = 2>  // (defined with the candidate array's other operations below)
 __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap, uint32_t idreg,
                                                      float mydist, uint64_t pd, int lane, uint32_t *scratch
 #ifdef SDB_STAMPS
-                                                     , unsigned long long *mst
+                                                     , unsigned long long *mst = nullptr
 #endif
 );
 template <int NL, int RT, int W = 4>
@@ -1312,13 +1368,14 @@ __device__ __forceinline__ void add_with_limit_lanes(uint32_t (&cid)[NREG], floa
 // order -- so that state is computed directly: every array entry moves up by the number of points below
 // it, every point lands at (#entries below it + #points below it), entries pushed past `cap` vanish.  The
 // scatter goes through a 2*NREG*64-word LDS scratch.  Any tie, NaN, or a not-yet-full array falls back to
-// the one-by-one replay, which is the specification.
-template <int NREG>
+// the one-by-one replay, which is the specification.  FEW: fewer candidates than this are replayed one by one as well
+// (the two-precision hop hands over ~5 points per hop, not ~50: the scatter's fixed cost is not worth it then).
+template <int NREG, int FEW>
 __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], float (&cd)[NREG], int &len, int cap,
                                                      uint32_t idreg, float mydist, uint64_t pd, int lane,
                                                      uint32_t *scratch
 #ifdef SDB_STAMPS
-                                                     , unsigned long long *mst = nullptr
+                                                     , unsigned long long *mst
 #endif
 ) {
 #ifdef SDB_STAMPS
@@ -1340,7 +1397,7 @@ __device__ __forceinline__ void add_with_limit_merge(uint32_t (&cid)[NREG], floa
   const float tail0 = list_tail(cd, cap);
   const uint64_t cm = __ballot(!(mydist > tail0)) & pd;  // the points the replay would look at first
   SDB_MST(0)
-  if (__popcll(cm) < 2 || (__ballot(mydist != mydist) & pd)) {
+  if (__popcll(cm) < FEW || (__ballot(mydist != mydist) & pd)) {
     add_with_limit_lanes(cid, cd, len, cap, idreg, mydist, pd, lane);
 #ifdef SDB_STAMPS
     asm volatile("" ::"v"(cd[0]));
@@ -1906,6 +1963,7 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
       if (!Dist::kSpeculate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the adjacency round trip to st_adj
 #endif
       SDB_STAMP(st_adj)
+      if constexpr (sketch_policy<Dist>::value) dist.sk_go = len == cap && a.sketch != nullptr;
       dist.prefetch(a, nb, valid);
       // CheckAndVisit distset.go:174 -- marks before any distance test
       bool isnew;
@@ -1975,10 +2033,13 @@ __device__ __forceinline__ void search_body(const SearchArgs &a, const uint32_t 
         // AddWithLimit over the new neighbours, in edge order distset.go:184-198
         if (!sketch_policy<Dist>::value || pend) {  // (the two-precision hop may have discarded every new neighbour)
           if constexpr (FILT) add_with_limit_lanes(cid, cd, len, cap, nb, mydist, pend, lane);  // array may be unsorted
+#ifndef SDB_SKETCH_FEW
+#define SDB_SKETCH_FEW 2  // measurement builds (tools/sketch_ab.py): 7 measured 0.756 against 0.729 ms
+#endif
 #ifdef SDB_STAMPS
-          else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter, st_m);
+          else add_with_limit_merge<NREG, sketch_policy<Dist>::value ? SDB_SKETCH_FEW : 2>(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter, st_m);
 #else
-          else add_with_limit_merge(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
+          else add_with_limit_merge<NREG, sketch_policy<Dist>::value ? SDB_SKETCH_FEW : 2>(cid, cd, len, cap, nb, mydist, pend, lane, s_scatter);
 #endif
         }
         SDB_STAMP(st_ins)
