@@ -738,11 +738,6 @@ def measure_mode(a, ctx, mode, rows, primary):
             cfg["value_passes_agree_within_3pct"] = bool(abs(v2 - result["value"]) <= 0.03 * result["value"])
         except Exception as e:
             cfg["value_second_pass"] = repr(e)
-        # not the metric's default path: the two-precision hop (SDB_TUNE_SKETCH) on the same batches, checked against it
-        try:
-            cfg["two_precision_hop"] = two_precision_point(a, ix, queries, tb, k, L, d, nq, result)
-        except Exception as e:
-            cfg["two_precision_hop"] = {"error": repr(e)}
         # not the metric (one batch at a time): the same batches with two of them in flight on two streams, the way a
         # serving process (the host batcher) runs -- a second batch fills the SIMDs the first one's finished walks left
         try:
@@ -784,6 +779,12 @@ def measure_mode(a, ctx, mode, rows, primary):
                 result["cpu_baseline"] = cpu_baseline(a, ix, queries[:nb_recall], k, L)
             except Exception as e:  # never lose the GPU line to a host-side problem
                 result["cpu_baseline"] = {"error": repr(e)}
+        # not the metric's default path: the two-precision hop (SDB_TUNE_SKETCH) on the same batches, checked against it.
+        # (Last on this index: its streams and its copy of the rows must not disturb the figures above.)
+        try:
+            cfg["two_precision_hop"] = two_precision_point(a, ix, queries, tb, k, L, d, nq, result)
+        except Exception as e:
+            cfg["two_precision_hop"] = {"error": repr(e)}
     ix.close()
     del base
     torch.cuda.empty_cache()

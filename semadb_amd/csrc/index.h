@@ -168,7 +168,7 @@ struct sdb_index {
   float sk_emax = 0.0f, sk_ymax = 0.0f;
   unsigned long long *d_sk_counters = nullptr;  // [0] neighbours discarded on their float16 distance, [1] contradicted (audit)
   bool sketch_supported() const;               // cosine / dot rows of whole 32-float blocks, one of the walk's register layouts
-  int build_sketch(hipStream_t stream);        // (re)build for the rows as they are; failure to allocate leaves it off
+  int build_sketch(hipStream_t stream, uint32_t from = 0);  // (re)build for the rows as they are (from > 0: only the rows from there on); failure to allocate leaves it off
   void drop_sketch();
   bool tune_no_defer = false;  // A/B and parity tests: every back-edge re-prune runs in k_backedges (BuildArgs::def_*)
   uint32_t tune_pq_narrow = 0;  // 1: quantized searches never take a multi-wave walk (k_greedy_search_pqw, k_greedy_search_pq2): A/B and parity tests

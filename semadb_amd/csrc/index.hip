@@ -865,7 +865,12 @@ void sdb_index::drop_sketch() {
   d_sketch = nullptr, sketch_cap = 0, sketch_gen = 0;
 }
 
-int sdb_index::build_sketch(hipStream_t stream) {
+// `from` > 0: the copy is current for rows [0, from) -- a Vamana table never rewrites a committed row, it appends
+// (updates are delete + insert, vamana.go:170-251) -- and only the rows behind them are converted; the two maxima
+// carry on from their values (they stay upper bounds when rows are deleted).
+int sdb_index::build_sketch(hipStream_t stream, uint32_t from) {
+  const bool carry = from > 0 && from <= n && d_sketch && sketch_cap >= cap && sketch_gen != 0;
+  if (!carry) from = 0;
   sketch_gen = 0;
   if (!tune_sketch || !sketch_supported() || n == 0) return SDB_OK;
   if (sketch_cap < cap) {
@@ -882,10 +887,13 @@ int sdb_index::build_sketch(hipStream_t stream) {
     SDB_HIP(hipMemset(d_sk_counters, 0, 4 * sizeof(unsigned long long)));
   }
   uint32_t *stats = reinterpret_cast<uint32_t *>(d_sk_counters + 2);
-  SDB_HIP(hipMemsetAsync(stats, 0, 8, stream));
-  hipLaunchKernelGGL(sdb::k_sketch_rows, dim3((n + 3) / 4), dim3(256), 0, stream, d_slab, d_sketch, n, lay.ld, stats);
-  SDB_HIP(hipGetLastError());
   uint32_t h[2] = {0, 0};
+  if (from) memcpy(&h[0], &sk_emax, 4), memcpy(&h[1], &sk_ymax, 4);
+  SDB_HIP(hipMemcpyAsync(stats, h, 8, hipMemcpyHostToDevice, stream));
+  if (n > from)
+    hipLaunchKernelGGL(sdb::k_sketch_rows, dim3((n - from + 3) / 4), dim3(256), 0, stream, d_slab + (size_t)from * lay.ld,
+                       d_sketch + (size_t)from * lay.ld, n - from, lay.ld, stats);
+  SDB_HIP(hipGetLastError());
   SDB_HIP(hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, stream));
   SDB_HIP(hipStreamSynchronize(stream));
   memcpy(&sk_emax, &h[0], 4), memcpy(&sk_ymax, &h[1], 4);
@@ -963,6 +971,7 @@ int sdb_index::rebuild_adjcodes(hipStream_t stream) {
 
 int sdb_index::commit(hipStream_t stream) {
   if (!in_tx) return SDB_OK;
+  const bool sk_current = d_sketch && sketch_gen == view_gen && sketch_cap >= cap;  // the float16 copy describes the rows below tx_n0
   const uint32_t need = (uint32_t)((h_start_ext.size() + 63) / 64 * 64);
   const uint32_t ac_bytes = has_adjcodes() ? kAdjStride * pq->M : 0;
   if (ac_bytes && n) {
@@ -1012,7 +1021,7 @@ int sdb_index::commit(hipStream_t stream) {
   }
   // the float16 copy follows: on `stream`, which has waited for the searches of the old view (above); searches of the
   // new one read float32 rows until sketch_gen says the copy is theirs
-  if (tune_sketch) SDB_TRY(build_sketch(stream));
+  if (tune_sketch) SDB_TRY(build_sketch(stream, sk_current && start_slot >= 0 ? tx_n0 : 0));
   return SDB_OK;
 }
 

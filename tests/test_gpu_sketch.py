@@ -112,6 +112,12 @@ def test_copy_follows_the_committed_rows(oracle):
     ix.insert_batch(np.arange(1502, 2602, dtype=np.uint64), base[1500:2600])  # grows the table: the copy is rebuilt at the new size
     b = both()
     assert not _same(a, b)  # the new rows are found
+    # small commits: only the appended rows are converted (the maxima carry on), one point at a time and with an update
+    more = unit_rows(rng, 12, d)
+    for i in range(10):
+        ix.insert_batch(np.array([5000 + i], dtype=np.uint64), more[i:i + 1], round_size=1)
+    ix.InsertUpdateDelete([vamana.IndexVectorChange(5003, more[10].tolist()), vamana.IndexVectorChange(5004, None)])
+    b = both()
     # an open transaction: searches walk the committed view with float32 rows only; abort: the copy is current again
     ix.begin_write()
     assert ix.sketch_stats()[2] is False
