@@ -783,6 +783,13 @@ def measure_mode(a, ctx, mode, rows, primary):
         # (Last on this index: its streams and its copy of the rows must not disturb the figures above.)
         try:
             cfg["two_precision_hop"] = two_precision_point(a, ix, queries, tb, k, L, d, nq, result)
+            tp = cfg["two_precision_hop"]
+            if tp.get("identical_to_the_default_walk") and not tp.get("audit_contradicted") and "invalid" not in tp:
+                result["value_two_precision"] = tp["qps"]
+                result["value_two_precision_definition"] = (
+                    "the same timed loop with SDB_TUNE_SKETCH = 1 (off by default; a float16 copy of the rows read first, "
+                    "float32 rows only for neighbours AddWithLimit may keep): every answer of every timed batch compared "
+                    "with the default walk's, bit for bit -- `value` is the default walk")
         except Exception as e:
             cfg["two_precision_hop"] = {"error": repr(e)}
     ix.close()

@@ -883,7 +883,12 @@ int sdb_index::build_sketch(hipStream_t stream, uint32_t from) {
     sketch_cap = cap;
   }
   if (!d_sk_counters) {
-    SDB_HIP(hipMalloc(&d_sk_counters, 4 * sizeof(unsigned long long)));
+    if (hipMalloc(&d_sk_counters, 4 * sizeof(unsigned long long)) != hipSuccess) {  // (the copy is optional: so is this)
+      (void)hipGetLastError();
+      d_sk_counters = nullptr;
+      drop_sketch();
+      return SDB_OK;
+    }
     SDB_HIP(hipMemset(d_sk_counters, 0, 4 * sizeof(unsigned long long)));
   }
   uint32_t *stats = reinterpret_cast<uint32_t *>(d_sk_counters + 2);

@@ -117,6 +117,8 @@ class IndexVamana:
         self._forced_sketch = int(os.environ.get("SEMADB_AMD_TEST_SKETCH", "0") or 0)
         if self._forced_sketch:
             self.set_tuning("sketch", self._forced_sketch)
+            if os.environ.get("SEMADB_AMD_TEST_WIDE_WALK"):  # ... and the batch walk (which has the stage) for small calls too
+                self.set_tuning("wide_walk", int(os.environ["SEMADB_AMD_TEST_WIDE_WALK"]))
 
     def close(self):
         if getattr(self, "_h", None):
