@@ -600,6 +600,66 @@ int main() {
                 "sdb_cluster_search_batch", injected, recreated);
     for (auto *s : sh) OK(sdb_index_destroy(s));
   }
+  // ---- 8. the two-precision hop's float16 copy of the rows (SDB_TUNE_SKETCH): an optional cache -- switching it on, and
+  // a commit that has to grow it, without room for it must leave searches on float32 rows with the same answers
+  {
+    LeakCheck lc("SDB_TUNE_SKETCH");
+    auto cos_index = [&](uint64_t capacity) {
+      sdb_index_params p{};
+      p.dim = D, p.metric = SDB_METRIC_COSINE, p.search_size = L, p.degree_bound = 32, p.alpha = 1.2f, p.device = 0;
+      p.capacity = capacity;
+      sdb_index *x = nullptr;
+      OK(sdb_index_create(&p, &x));
+      OK(sdb_index_set_tuning(x, SDB_TUNE_WIDE_WALK, 1));  // the batch walk has the stage
+      OK(sdb_index_set_start(x, start.data(), SDB_MEM_HOST));
+      OK(sdb_index_insert_batch(x, N, base_ids.data(), base.data(), SDB_MEM_HOST, 0, nullptr));
+      return x;
+    };
+    sdb_index *cref = cos_index(8192);
+    Answer c0, c1;
+    OK(search(cref, queries, &c0));
+    OK(sdb_index_insert_batch(cref, NEXTRA, extra_ids.data(), extra.data(), SDB_MEM_HOST, 0, nullptr));
+    OK(search(cref, queries, &c1));
+    OK(sdb_index_destroy(cref));
+    sdb_index *ix = nullptr;
+    Answer a;
+    auto fresh = [&] {
+      if (ix) OK(sdb_index_destroy(ix));
+      ix = cos_index(4096);  // (the extra inserts below push the table past this capacity)
+    };
+    sweep(
+        "set_tuning(SDB_TUNE_SKETCH)", fresh, [&] { return sdb_index_set_tuning(ix, SDB_TUNE_SKETCH, 2); },
+        [&](long, int) { CHECK(false); },  // nothing here may fail the call: the copy is optional
+        [&] {
+          OK(search(ix, queries, &a));
+          CHECK(a == c0);
+          uint64_t st[3] = {0, 0, 0};
+          OK(sdb_index_sketch_stats(ix, st));
+          CHECK(st[1] == 0);
+        });
+    auto fresh_on = [&] {
+      fresh();
+      OK(sdb_index_set_tuning(ix, SDB_TUNE_SKETCH, 2));
+    };
+    sweep(
+        "insert_batch with the copy", fresh_on,
+        [&] { return sdb_index_insert_batch(ix, NEXTRA, extra_ids.data(), extra.data(), SDB_MEM_HOST, 0, nullptr); },
+        [&](long, int) {  // as it was, or unusable and said so (section 4's contract)
+          if (!is_broken(ix, queries)) {
+            Answer b;
+            OK(search(ix, queries, &b));
+            CHECK(b == c0);
+          }
+        },
+        [&] {
+          OK(search(ix, queries, &a));
+          CHECK(a == c1);
+          uint64_t st[3] = {0, 0, 0};
+          OK(sdb_index_sketch_stats(ix, st));
+          CHECK(st[1] == 0);
+        });
+    if (ix) OK(sdb_index_destroy(ix));
+  }
   OK(sdb_pq_destroy(pq));
   std::printf("%s (%d failures)\n", g_fail ? "FAILED" : "all device-memory faults ended in a status", g_fail);
   return g_fail ? 1 : 0;
