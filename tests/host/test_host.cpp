@@ -447,6 +447,54 @@ static void test_cluster_fanout() {
 
 // a write that cannot go through must not wedge the index (sdb_index_abort_write): a bad point after good ones, then
 // the same index takes the next write
+static void test_two_precision_search_switch() {
+  // setTwoPrecisionSearch (SDB_TUNE_SKETCH) through the mirror: the batch walk of a cosine table answers with the same
+  // bits with and without the float16 copy, the copy stays current through later writes, and its audit finds nothing
+  std::mt19937 rng(11);
+  std::normal_distribution<float> N01;
+  const int d = 64, n = 1500;
+  models::IndexVectorVamanaParameters p;
+  p.VectorSize = d, p.DistanceMetric = "cosine", p.SearchSize = 40, p.DegreeBound = 32, p.Alpha = 1.2f;
+  std::vector<vamana::IndexVectorChange> pts;
+  for (int i = 0; i < n; i++) {
+    std::vector<float> v(d);
+    float s = 0;
+    for (auto &x : v) x = N01(rng), s += x * x;
+    for (auto &x : v) x /= std::sqrt(s);
+    pts.push_back({(uint64_t)(i + 2), v});
+  }
+  diskstore::MemBucket bucket;
+  auto [inv, err] = vamana::NewIndexVamana("test", p, &bucket);
+  CHECK(!err && !inv->InsertUpdateDelete(std::vector<vamana::IndexVectorChange>(pts.begin(), pts.begin() + 1000)));
+  CHECK(sdb_index_set_tuning(inv->handle(), SDB_TUNE_WIDE_WALK, 1) == SDB_OK);  // the batch walk for this small call too
+  const uint32_t nq = 64, k = 10;
+  std::vector<float> q(nq * d);
+  for (auto &x : q) x = N01(rng);
+  auto ask = [&](std::vector<uint64_t> &ids, std::vector<float> &dd, std::vector<uint32_t> &cc) {
+    ids.assign(nq * k, 0), dd.assign(nq * k, 0.f), cc.assign(nq, 0);
+    return sdb_index_search_batch(inv->handle(), nq, q.data(), k, 40, nullptr, nullptr, ids.data(), dd.data(), cc.data(), nullptr,
+                                  SDB_MEM_HOST, nullptr);
+  };
+  std::vector<uint64_t> i0, i1;
+  std::vector<float> d0, d1;
+  std::vector<uint32_t> c0, c1;
+  CHECK(ask(i0, d0, c0) == SDB_OK);
+  CHECK(!inv->setTwoPrecisionSearch(true));
+  CHECK(sdb_index_set_tuning(inv->handle(), SDB_TUNE_SKETCH, 2) == SDB_OK);  // (the same switch with its audit)
+  uint64_t st[3] = {0, 0, 0};
+  CHECK(sdb_index_sketch_stats(inv->handle(), st) == SDB_OK && st[2] == 1);
+  CHECK(ask(i1, d1, c1) == SDB_OK);
+  CHECK(i0 == i1 && c0 == c1 && std::memcmp(d0.data(), d1.data(), d0.size() * 4) == 0);
+  CHECK(!inv->InsertUpdateDelete(std::vector<vamana::IndexVectorChange>(pts.begin() + 1000, pts.end())));  // commit keeps the copy current
+  CHECK(sdb_index_sketch_stats(inv->handle(), st) == SDB_OK && st[2] == 1);
+  CHECK(ask(i1, d1, c1) == SDB_OK);
+  CHECK(!inv->setTwoPrecisionSearch(false));
+  CHECK(ask(i0, d0, c0) == SDB_OK);
+  CHECK(i0 == i1 && c0 == c1 && std::memcmp(d0.data(), d1.data(), d0.size() * 4) == 0);
+  CHECK(!inv->setTwoPrecisionSearch(true));
+  CHECK(sdb_index_sketch_stats(inv->handle(), st) == SDB_OK && st[1] == 0);
+}
+
 static void test_failed_write_leaves_the_index_writable() {
   auto [inv, err] = vamana::NewIndexVamana("test", vamanaParams(), nullptr);
   CHECK(!err);
@@ -504,6 +552,7 @@ int main() {
   test_create_update_delete();
   test_quantized_index();
   test_flat_index();
+  test_two_precision_search_switch();
   test_failed_write_leaves_the_index_writable();
   test_cluster_fanout();
   if (g_fail) {
