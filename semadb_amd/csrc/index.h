@@ -164,7 +164,7 @@ struct sdb_index {
   uint32_t tune_sketch = 0;  // 0 off, 1 on, 2 on + audit (every discarded neighbour is evaluated exactly as well and checked)
   uint16_t *d_sketch = nullptr;
   uint32_t sketch_cap = 0;   // rows d_sketch has room for
-  uint64_t sketch_gen = 0;   // view_gen the copy was built for (0: none)
+  std::atomic<uint64_t> sketch_gen{0};  // view_gen the copy was built for (0: none); written last by build_sketch, read by searches under the shared view lock
   float sk_emax = 0.0f, sk_ymax = 0.0f;
   unsigned long long *d_sk_counters = nullptr;  // [0] neighbours discarded on their float16 distance, [1] contradicted (audit)
   bool sketch_supported() const;               // cosine / dot rows of whole 32-float blocks, one of the walk's register layouts
