@@ -242,7 +242,15 @@ struct PlainDist {
   // The cheap half -- no naming, only the adjacency row of the array's first unvisited entry asked for before
   // AddWithLimit and taken from the register when the walk does go there -- made no difference at all: 0.955 / 0.958 /
   // 0.957 against 0.957 / 0.954 / 0.973 ms in alternating runs; the batch walk is bound by bytes, not by a wave's round trips.)
-  static constexpr bool kSpeculate = false;
+#ifndef SDB_SKETCH_SPECULATE
+#define SDB_SKETCH_SPECULATE 0  // measurement builds (tools/sketch_ab.py): 1 measured 0.716 against 0.722 ms (min of 10) -- within the noise, off
+#endif
+  // ... with the two-precision hop the walk IS bound by its round trips; naming the next hop's adjacency row and asking
+  // for it before AddWithLimit runs (search_body's kSpeculate path without the small-call kernel's marker wave) was
+  // measured there too and moved the kernel by 1 %: the naming costs about what the hidden round trip saves
+  static constexpr bool kSpeculate = SK && SDB_SKETCH_SPECULATE;
+  static constexpr bool marked = false;  // (no marker wave: nothing is tested ahead)
+  __device__ __forceinline__ void take_marks(int, uint64_t &, uint32_t &) {}
   static constexpr int NGR = NG > 0 ? NG : 1;
   static constexpr int U = UPAIRS ? UPAIRS : (NG >= 0 ? ChunkPairs<NG, DEEP>::value : 4);
   // dynamic LDS of the policy: NG == -1 the query tile; NG >= 0 the hop scratch -- pending slots by rank
