@@ -928,6 +928,7 @@ def flatten_summary(result):
                 flat["%s_algorithmic_bytes_per_launch" % key] = rec.get("algorithmic_bytes_per_launch")
                 flat["%s_longest_walk_over_mean" % key] = rec.get("longest_walk_over_mean")
                 flat["%s_two_batches_in_flight_frac" % key] = rec.get("two_batches_in_flight_frac")
+                flat["%s_two_precision_hop_qps" % key] = rec.get("two_precision_hop_qps")
     hb = cfg.get("host_blocking_variants") or {}
     for name in ("staged", "pageable"):
         if isinstance(hb.get(name), dict):
@@ -1391,6 +1392,27 @@ def secondary_points(a, dev, dev_index):
             tail_sum += float(ndq.max().item() / ndq.mean().item())
         alg_total = sum(alg[2 + r % 4] for r in range(reps))
         ach = alg_total / (sum(kms) * 1e-3) / 1e9 if kms else 0.0
+        # the two-precision hop on this dataset too (config.two_precision_hop is the headline's): same answers, its rate
+        two_p = {}
+        try:
+            ref = [ix.search_batch(queries[b], k, L)[:3] for b in range(2, 6)]
+            ref = [(r[0].clone(), r[1].clone().view(torch.int32), r[2].clone()) for r in ref]
+            ix.set_tuning("sketch", 1)
+            same = True
+            for i, b in enumerate(range(2, 6)):
+                ids, dd, cnt, _ = ix.search_batch(queries[b], k, L)
+                same &= bool(torch.equal(ids, ref[i][0]) and torch.equal(dd.view(torch.int32), ref[i][1]) and torch.equal(cnt, ref[i][2]))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for r in range(reps):
+                ix.search_batch(queries[2 + r % 4], k, L)
+            torch.cuda.synchronize()
+            two_p = {"two_precision_hop_qps": round(reps * nq / (time.perf_counter() - t0), 1),
+                     "two_precision_hop_identical_to_the_default_walk": same}
+        except Exception as e:
+            two_p = {"two_precision_hop_error": repr(e)}
+        finally:
+            ix.set_tuning("sketch", 0)
         # the same batches with two of them in flight (what the tail of a batch -- longest_walk_over_mean -- costs)
         streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
         for st in streams:
@@ -1415,6 +1437,7 @@ def secondary_points(a, dev, dev_index):
                           "kernel_ms_avg": round(float(np.mean(kms)), 4) if kms else None,
                           "roofline": {"bound": "hbm", "kernel": "k_greedy_search", "achieved": round(ach, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}}
+        out[dist_name].update(two_p)
         if hits / (2 * nq * k) < 0.95:
             # "report the searchSize needed for recall 0.95 separately" -- the device walk takes searchSize up
             # to 512 (the API's maximum is 75, models/search.go:287-297)
