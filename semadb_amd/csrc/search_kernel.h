@@ -354,28 +354,44 @@ struct PlainDist {
   __device__ __forceinline__ uint64_t sketch_keep(const SearchArgs &a, uint32_t nb, uint64_t pend, int lane, float tail_d,
                                                   uint64_t &out) {
     if constexpr (kSketchAhead) {
-      if (sk_loaded) {  // the rows are in registers, by edge position: sums of the pairs with a pending edge, by position
-        float *s_res = reinterpret_cast<float *>(hs + kHopSlots);
-        const int L = lane & 31, half = lane >> 5;
+      if (sk_loaded) {  // the rows are in registers, by edge position
+        // 32 sums per half-wave (pair u: edge 2u in lanes 0..31, edge 2u + 1 in lanes 32..63), each spread over the 32
+        // lanes.  Instead of 32 reductions that each end in one lane (and a trip through LDS to get edge j's sum to lane
+        // j), one transposing butterfly: at stride s a lane keeps the rows whose bit s equals its own and hands the
+        // others to lane ^ s -- 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 5, and lane L of a half ends with the
+        // complete sum of pair L.  One ds_bpermute then puts edge j's sum into lane j.  (Any order of additions is within
+        // the bound; no LDS memory is touched.)
+        float w[32];
 #pragma unroll
         for (int u = 0; u < 32; u++) {
-          // (every pair, pending or not: 32 independent chains the scheduler can interleave -- skipping the pairs without
-          // a pending edge puts each chain into a basic block of its own)
           float acc = 0.0f;
 #pragma unroll
           for (int g = 0; g < NG; g++) {
             acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(sk_h2, sky[u][g].x), qh[g][0], acc, false);
             acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(sk_h2, sky[u][g].y), qh[g][1], acc, false);
           }
-          const float r = asm_reduce(acc, 0.0f, lane);
-          (L == 0 ? s_res + 2 * u + half : s_res + kHopSlots)[0] = r;  // the other lanes write to the dump
+          w[u] = acc;
         }
-        wave_lds_sync();
+#define SDB_SK_STAGE(S)                                                                                         \
+  {                                                                                                             \
+    const bool up = (lane & (S)) != 0;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < (S); i++) {                                                           \
+      const float keep = up ? w[i + (S)] : w[i], send = up ? w[i] : w[i + (S)];                                 \
+      w[i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), ((S) << 10) | 0x1F));      \
+    }                                                                                                           \
+  }
+        SDB_SK_STAGE(16)
+        SDB_SK_STAGE(8)
+        SDB_SK_STAGE(4)
+        SDB_SK_STAGE(2)
+        SDB_SK_STAGE(1)
+#undef SDB_SK_STAGE
+        // lane 32 h + L holds edge 2 L + h: lane j takes its own from lane 32 (j & 1) + (j >> 1)
+        const float mysum = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 1) * 32 + (lane >> 1)) * 4, __float_as_int(w[0])));
         const bool mine = (pend >> lane) & 1ull;
-        const float d16 = mine ? metric_finish(s_res[lane], a.metric) : 0.0f;
+        const float d16 = mine ? metric_finish(mysum, a.metric) : 0.0f;
         const float slack = sk_eps + 4e-7f * (1.0f + fabsf(d16) + sk_eps);
         out = __ballot(mine && (d16 - slack > tail_d));
-        wave_lds_sync();  // hop() compacts into the same scratch
         return pend & ~out;
       }
     }
