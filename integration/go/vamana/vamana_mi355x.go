@@ -93,7 +93,7 @@ func randomUnitVector(d int) []float32 {
 // TwoPrecisionSearch switches SDB_TUNE_SKETCH on for every index created afterwards (a server sets it once from its
 // configuration): the device keeps a float16 copy of the rows (+ 50 % of their memory) and a batch search reads a
 // neighbour's float32 row only when its float16 distance does not prove that AddWithLimit discards it
-// (distset.go:184).  Same answers, bit for bit; 1.44 M against 1.07 M queries/s at 1M x 384.  Off like in the library.
+// (distset.go:184).  Same answers, bit for bit; 1.50 M against 1.07 M queries/s at 1M x 384.  Off like in the library.
 var TwoPrecisionSearch = false
 
 func NewIndexVamana(name string, params models.IndexVectorVamanaParameters, bucket diskstore.Bucket) (*IndexVamana, error) {
