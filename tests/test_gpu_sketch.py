@@ -144,3 +144,27 @@ def test_shapes_without_the_stage_are_untouched(oracle):
         ix.set_tuning("sketch", 1)
         assert ix.sketch_stats()[2] is False and _same(ref, _answers(ix, q, 5, 25))
         ix.close()
+
+
+@pytest.mark.parametrize("noise", [1e-3, 1e-4, 1e-5, 0.0])
+def test_near_ties_around_the_threshold(oracle, noise):
+    """rows in tight clusters: the candidate array's last distance sits inside a crowd of neighbours whose distances
+    differ by less than the bound (or not at all) -- the stage must leave every such neighbour to the exact evaluation"""
+    d, n, L = 128, 2400, 30
+    rng = np.random.default_rng(int(noise * 1e6) + 17)
+    centers = unit_rows(rng, 12, d)
+    base = centers[rng.integers(0, 12, n)] + np.float32(noise) * rng.standard_normal((n, d)).astype(np.float32)
+    base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
+    o = build_oracle_index(oracle, base, "cosine", R=24, L=L)
+    ix = _gpu_index(o, d, "cosine", 24, L)
+    queries = np.vstack([centers, base[:20], unit_rows(rng, 16, d)])
+    ref = _answers(ix, queries, 10, L)
+    ix.set_tuning("sketch", 2)
+    got = _answers(ix, queries, 10, L)
+    discarded, contradicted, in_use = ix.sketch_stats()
+    assert in_use and contradicted == 0 and _same(ref, got)
+    for q in range(0, queries.shape[0], 5):
+        o_ids, o_d, o_vis, o_tr = o.search(queries[q], 10, L)
+        assert np.array_equal(got[0][q, :len(o_ids)], o_ids) and np.array_equal(got[1][q, :len(o_ids)], bits(o_d))
+        assert int(got[3][q]) == o_tr.n_dist and np.array_equal(got[6][q, :o_tr.n_hop], o_vis)
+    ix.close()
