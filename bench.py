@@ -828,7 +828,7 @@ def two_precision_point(a, ix, queries, tb, k, L, d, nq, result):
     ix.set_tuning("sketch", 1)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
-    out = {"knob": "SDB_TUNE_SKETCH = 1 (off by default): float16 copy of the rows, + 50 % of their memory, rebuilt by every commit",
+    out = {"knob": "SDB_TUNE_SKETCH = 1 (off by default): float16 copy of the rows, + 50 % of their memory, kept current by every commit",
            "copy_build_s": round(build_s, 4), "in_use": ix.sketch_stats()[2]}
     try:
         for b in range(2):

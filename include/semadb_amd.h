@@ -266,7 +266,7 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *                        place (A/B and parity tests)
  *   SDB_TUNE_SKETCH      1: two-precision hop for batch searches of cosine / dot tables (rows of whole 32-float blocks,
  *                        up to 768 floats; no quantizer, no filter): the index keeps a float16 copy of its rows (+ 50 %
- *                        of their memory; rebuilt by every commit) and a hop reads a new neighbour's float32 row only
+ *                        of their memory; a commit converts the rows it appended) and a hop reads a new neighbour's float32 row only
  *                        when its float16 distance does not PROVE that AddWithLimit discards it (distset.go:184: the
  *                        distance of a discarded neighbour is never used again).  Ids, distances, visit order and
  *                        counters are the same bits either way.  2: the same, and every discarded neighbour is
