@@ -929,6 +929,10 @@ def flatten_summary(result):
                 flat["%s_longest_walk_over_mean" % key] = rec.get("longest_walk_over_mean")
                 flat["%s_two_batches_in_flight_frac" % key] = rec.get("two_batches_in_flight_frac")
                 flat["%s_two_precision_hop_qps" % key] = rec.get("two_precision_hop_qps")
+    c4tp = (cfg.get("c4") or {}).get("full_precision_two_precision_hop") if isinstance(cfg.get("c4"), dict) else None
+    if isinstance(c4tp, dict) and "call_qps" in c4tp:
+        flat["c4_full_precision_two_precision_hop_qps"] = c4tp["call_qps"]
+        flat["c4_full_precision_two_precision_hop_recall_at_10"] = c4tp["recall_at_10"]
     hb = cfg.get("host_blocking_variants") or {}
     for name in ("staged", "pageable"):
         if isinstance(hb.get(name), dict):
@@ -1150,6 +1154,26 @@ def c4_point(a, dev, dev_index):
     full = measure()
     full["GB/s"] = round((full["n_dist_per_batch"] * d * 4 + full["n_edges_per_batch"] * 4) / full["kernel_ms"] / 1e6, 1)
     out["full_precision"] = full
+    # the full-precision walk with the two-precision hop (SDB_TUNE_SKETCH; a float16 copy of the rows beside them): the same
+    # answers -- compared on every batch -- without a quantizer's loss of recall
+    try:
+        ref = [tuple(t.clone() for t in ix.search_batch(queries[b], k, L)[:3]) for b in range(nbq)]
+        ix.set_tuning("sketch", 1)
+        if ix.sketch_stats()[2]:
+            same = True
+            for b in range(nbq):
+                got = ix.search_batch(queries[b], k, L)[:3]
+                same &= bool(torch.equal(got[0], ref[b][0]) and torch.equal(got[1].view(torch.int32), ref[b][1].view(torch.int32)) and
+                             torch.equal(got[2], ref[b][2]))
+            tp = measure()
+            out["full_precision_two_precision_hop"] = {"call_qps": tp["call_qps"], "call_ms": tp["call_ms"], "kernel_ms": tp["kernel_ms"],
+                                                       "recall_at_10": tp["recall_at_10"], "identical_to_the_default_walk": same}
+        else:
+            out["full_precision_two_precision_hop"] = {"note": "no room for the float16 copy"}
+    except Exception as e:
+        out["full_precision_two_precision_hop"] = {"error": repr(e)}
+    finally:
+        ix.set_tuning("sketch", 0)
     keep = []
     for M in [int(x) for x in a.pq_m.split(",")]:
         if d % M:
