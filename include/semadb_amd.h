@@ -264,7 +264,7 @@ int sdb_index_distance_batch(sdb_index *ix, uint64_t nq, const float *queries, u
  *   SDB_TUNE_NO_ZERO_COPY  != 0: a host-memory search stages queries and results through device buffers even when the
  *                        caller's buffers are page-locked (sdb_host_alloc) and the kernel could read / write them in
  *                        place (A/B and parity tests)
- *   SDB_TUNE_SKETCH      1: two-precision hop for batch searches of cosine / dot tables (rows of whole 32-float blocks,
+ *   SDB_TUNE_SKETCH      1: two-precision hop for batch searches of plain tables, any metric (rows of whole 32-float blocks,
  *                        up to 768 floats; no quantizer, no filter): the index keeps a float16 copy of its rows (+ 50 %
  *                        of their memory; a commit converts the rows it appended) and a hop reads a new neighbour's float32 row only
  *                        when its float16 distance does not PROVE that AddWithLimit discards it (distset.go:184: the

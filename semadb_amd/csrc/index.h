@@ -163,6 +163,7 @@ struct sdb_index {
   // uses it only while that is the current view, and commit / publish_full rebuild it behind the searches of the old one.
   uint32_t tune_sketch = 0;  // 0 off, 1 on, 2 on + audit (every discarded neighbour is evaluated exactly as well and checked)
   uint16_t *d_sketch = nullptr;
+  float *d_sketch_norm = nullptr;  // [sketch_cap] ||y16||^2 per row (the euclidean form of the first stage)
   uint32_t sketch_cap = 0;   // rows d_sketch has room for
   std::atomic<uint64_t> sketch_gen{0};  // view_gen the copy was built for (0: none); written last by build_sketch, read by searches under the shared view lock
   float sk_emax = 0.0f, sk_ymax = 0.0f;

@@ -557,11 +557,11 @@ static int launch_plain(const SearchArgs &a, uint32_t nq, hipStream_t stream) {
   if constexpr (NG >= 1 && NG <= 8)
     if (wide_walk(a, nq)) return launch_wide<NG, L2>(a, nq, stream);
   if (search_uses_hash(a, nq)) {
-    // the two-precision hop (SearchArgs::sketch): batch walks of cosine / dot rows, plain searches
-    if constexpr (!L2 && (NG == 1 || NG == 2 || NG == 3 || NG == 4 || NG == 6))
+    // the two-precision hop (SearchArgs::sketch): batch walks, plain searches
+    if constexpr (NG == 1 || NG == 2 || NG == 3 || NG == 4 || NG == 6)
       if (a.sketch && !a.filt_off && !a.vis_slots && !a.dcache && a.tail == 0 && a.search_size <= 128) {
         // (few float32 rows survive the first stage: four pairs of them in flight per round leave the registers to the float16 rows)
-        using SkDist = PlainDist<NG, false, true, 4, true>;
+        using SkDist = PlainDist<NG, L2, true, 4, true>;
         hipLaunchKernelGGL((k_greedy_search<SkDist, 2, false, kHashCap>), dim3(nq), dim3(64),
                            HashVisited<kHashCap>::kWords * sizeof(uint32_t) + SkDist::kLdsBytes, stream, a);
         SDB_HIP(hipGetLastError());
@@ -831,8 +831,9 @@ namespace sdb {
 // one wave per row: element t of the row -> half t of the copy (sk_half: round to nearest, no denormals), and the
 // row's ||y - y16||, ||y16|| into the table-wide maxima (non-negative floats order like their bit patterns; a NaN's
 // pattern is above every number's, so a row with a NaN makes the bound NaN and the stage discards nothing)
-__global__ __launch_bounds__(256) void k_sketch_rows(const float *__restrict__ slab, uint16_t *__restrict__ sk, uint32_t n,
-                                                      uint32_t ld, uint32_t *__restrict__ stats) {
+__global__ __launch_bounds__(256) void k_sketch_rows(const float *__restrict__ slab, uint16_t *__restrict__ sk,
+                                                      float *__restrict__ sk_norm, uint32_t n, uint32_t ld,
+                                                      uint32_t *__restrict__ stats) {
   const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -848,6 +849,7 @@ __global__ __launch_bounds__(256) void k_sketch_rows(const float *__restrict__ s
   }
   for (int o = 32; o; o >>= 1) e2 += __shfl_xor(e2, o), n2 += __shfl_xor(n2, o);
   if (lane == 0) {
+    sk_norm[row] = (float)n2;  // ||y16||^2 (the sum in double: one rounding)
     const float e = (float)(sqrt(e2) * 1.0001), y = (float)(sqrt(n2) * 1.0001);  // rounded up past their own rounding
     atomicMax(stats, __float_as_uint(e < 0.0f ? 0.0f : e));
     atomicMax(stats + 1, __float_as_uint(y < 0.0f ? 0.0f : y));
@@ -856,13 +858,14 @@ __global__ __launch_bounds__(256) void k_sketch_rows(const float *__restrict__ s
 }  // namespace sdb
 
 bool sdb_index::sketch_supported() const {
-  if (P.metric == SDB_METRIC_EUCLIDEAN || lay.tail != 0 || pq) return false;
+  if (lay.tail != 0 || pq) return false;
   return lay.ng == 1 || lay.ng == 2 || lay.ng == 3 || lay.ng == 4 || lay.ng == 6;
 }
 
 void sdb_index::drop_sketch() {
   if (d_sketch) (void)hipFree(d_sketch);
-  d_sketch = nullptr, sketch_cap = 0, sketch_gen = 0;
+  if (d_sketch_norm) (void)hipFree(d_sketch_norm);
+  d_sketch = nullptr, d_sketch_norm = nullptr, sketch_cap = 0, sketch_gen = 0;
 }
 
 // `from` > 0: the copy is current for rows [0, from) -- a Vamana table never rewrites a committed row, it appends
@@ -875,9 +878,10 @@ int sdb_index::build_sketch(hipStream_t stream, uint32_t from) {
   if (!tune_sketch || !sketch_supported() || n == 0) return SDB_OK;
   if (sketch_cap < cap) {
     drop_sketch();
-    if (hipMalloc(&d_sketch, (size_t)cap * lay.ld * sizeof(uint16_t)) != hipSuccess) {  // a cache: without room for it the walk reads float32 rows
+    if (hipMalloc(&d_sketch, (size_t)cap * lay.ld * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc(&d_sketch_norm, (size_t)cap * sizeof(float)) != hipSuccess) {  // a cache: without room for it the walk reads float32 rows
       (void)hipGetLastError();
-      d_sketch = nullptr;
+      drop_sketch();
       return SDB_OK;
     }
     sketch_cap = cap;
@@ -897,7 +901,7 @@ int sdb_index::build_sketch(hipStream_t stream, uint32_t from) {
   SDB_HIP(hipMemcpyAsync(stats, h, 8, hipMemcpyHostToDevice, stream));
   if (n > from)
     hipLaunchKernelGGL(sdb::k_sketch_rows, dim3((n - from + 3) / 4), dim3(256), 0, stream, d_slab + (size_t)from * lay.ld,
-                       d_sketch + (size_t)from * lay.ld, n - from, lay.ld, stats);
+                       d_sketch + (size_t)from * lay.ld, d_sketch_norm + from, n - from, lay.ld, stats);
   SDB_HIP(hipGetLastError());
   SDB_HIP(hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, stream));
   SDB_HIP(hipStreamSynchronize(stream));
@@ -1842,7 +1846,7 @@ static int search_batch_impl(sdb_index *ix, uint64_t nq, const float *queries, u
   a.wide_mode = ix->tune_wide_walk;
   // two-precision hop: only with the float16 copy of exactly this view's rows, outside a write transaction
   if (ix->tune_sketch && ix->d_sketch && ix->sketch_gen == ix->view_gen && !ix->in_tx && !filtered)
-    a.sketch = ix->d_sketch, a.sk_emax = ix->sk_emax, a.sk_ymax = ix->sk_ymax, a.sk_audit = ix->tune_sketch == 2 ? 1u : 0u,
+    a.sketch = ix->d_sketch, a.sketch_norm = ix->d_sketch_norm, a.sk_emax = ix->sk_emax, a.sk_ymax = ix->sk_ymax, a.sk_audit = ix->tune_sketch == 2 ? 1u : 0u,
     a.sk_counters = ix->d_sk_counters;
 
   const uint32_t vcap = trace ? trace->visit_cap : 0;
@@ -2180,7 +2184,7 @@ int sdb_index_size_in_memory(const sdb_index *ix, int64_t *bytes) try {
   // (+ the second adjacency / id copy of the graph versions, + the neighbours' code rows behind both adjacency copies)
   *bytes = (int64_t)ix->cap * (ix->lay.ld * 4 + 3 * kAdjStride * 4 + 3 * 4 + 2 * 8 + (ix->pq ? ix->pq->M : 0) +
                                (ix->has_adjcodes() ? 2 * kAdjStride * ix->pq->M : 0)) +
-           (int64_t)ix->sketch_cap * ix->lay.ld * 2;  // (+ the float16 copy of the rows, SDB_TUNE_SKETCH)
+           (int64_t)ix->sketch_cap * (ix->lay.ld * 2 + 4);  // (+ the float16 copy of the rows and their norms, SDB_TUNE_SKETCH)
   return SDB_OK;
 }
 SDB_API_CATCH("sdb_index_size_in_memory")

@@ -88,6 +88,7 @@ struct SearchArgs {
   // bound on |float16 distance - the reference's float32 distance| is discarded by AddWithLimit whatever its exact
   // distance is (distset.go:184; the distance is never looked at again), so only the others are read in float32.
   const uint16_t *sketch;
+  const float *sketch_norm;          // [rows] ||y16||^2 of every row (euclidean tables: d16 = ||q16||^2 + ||y16||^2 - 2 q16.y16)
   float sk_emax, sk_ymax;            // max over the rows of ||y - y16|| and of ||y16|| (k_sketch_rows), rounded up
   uint32_t sk_audit;                 // != 0: evaluate everything exactly as well and count decisions the exact distance contradicts
   unsigned long long *sk_counters;   // [0] += neighbours discarded on their float16 distance, [1] += contradicted ones (audit)
@@ -260,7 +261,8 @@ struct PlainDist {
 #ifndef SDB_SKETCH_ROWS
 #define SDB_SKETCH_ROWS 32  // measurement builds: tools/sketch_ab.py
 #endif
-  static constexpr int US = !SK ? U : (SDB_SKETCH_ROWS < 96 / NGR ? SDB_SKETCH_ROWS : 96 / NGR);
+  static constexpr int kSkBudget = L2 ? 72 : 96;  // (the euclidean exact stage holds differences as well)
+  static constexpr int US = !SK ? U : (SDB_SKETCH_ROWS < kSkBudget / NGR ? SDB_SKETCH_ROWS : kSkBudget / NGR);
   static constexpr int UX = U > US ? U : US;
   static constexpr uint32_t kHopSlots = 64 + UX;  // ranks 0..63 and the overrun of the last half-wave run
   static constexpr size_t kLdsBytes = NG >= 0 ? (2 * kHopSlots + UX) * sizeof(uint32_t) : 0;
@@ -270,6 +272,8 @@ struct PlainDist {
   uint32_t *hs;
   sk_h2 qh[SK ? NGR : 1][2];  // the query in float16, in xq's element order
   float sk_eps;               // bound on |float16 distance - the reference's float32 distance| for this query, any row
+  float sk_qq, sk_delta;      // euclidean: ||q16||^2, and ||q - q16|| + max ||y - y16|| (rounded up)
+  float sk_yy;                // euclidean, rows asked for ahead: ||y16||^2 of this lane's edge
   // Rows of up to 384 floats: the float16 rows of ALL 64 edges of an adjacency row fit the register file (2 NG registers
   // per pair of rows), so they are asked for as soon as the edge ids are there -- BEFORE the visited-set test, whose
   // LDS round trips (~2 100 cycles) then run under the rows' flight instead of in front of it.  Rows of edges that turn
@@ -312,6 +316,38 @@ struct PlainDist {
     e2 = rlf(asm_reduce(e2, 0.0f, lane), 0), n2 = rlf(asm_reduce(n2, 0.0f, lane), 0);
     const float qerr = __builtin_sqrtf(e2) * 1.0001f, qn = __builtin_sqrtf(n2) * 1.0001f;
     sk_eps = (qerr * a.sk_ymax + qn * a.sk_emax + 2e-5f * qn * (a.sk_ymax + a.sk_emax)) * 1.0001f;
+    if constexpr (L2) {
+      float hh = 0.0f;
+#pragma unroll
+      for (int g = 0; g < NGR; g++) {
+        const float h0 = (float)qh[g][0][0], h1 = (float)qh[g][0][1], h2 = (float)qh[g][1][0], h3 = (float)qh[g][1][1];
+        hh = __builtin_fmaf(h0, h0, hh), hh = __builtin_fmaf(h1, h1, hh), hh = __builtin_fmaf(h2, h2, hh), hh = __builtin_fmaf(h3, h3, hh);
+      }
+      sk_qq = rlf(asm_reduce(hh, 0.0f, lane), 0);
+      sk_delta = (qerr + a.sk_emax) * 1.0001f;
+    }
+  }
+
+  // Squared euclidean distance.  With D16 = ||q16 - y16||^2 (exact) and delta >= ||q - q16|| + ||y - y16||:
+  // | sqrt(D) - sqrt(D16) | <= delta, so D >= D16 - 2 delta sqrt(D16) (when sqrt(D16) < delta the right side is
+  // negative and proves nothing, as it should).  D16 is computed as ||q16||^2 + ||y16||^2 - 2 q16.y16 from three rounded
+  // sums: its error is below 1e-5 (||q16||^2 + ||y16||^2 + 2 |q16.y16|) (the same roundings as the dot form, 2^-24 each for
+  // the two norms, three more for the combination -- well under 100 x 2^-24 = 6e-6).  The reference's own sum of rounded
+  // squares of rounded differences is within (NG x 4 + 10) x 2^-24 < 1e-5 of D, relatively (all terms are >= 0).
+  __device__ __forceinline__ bool sketch_out(const SearchArgs &a, float sum16, float yy, float tail_d) const {
+    if constexpr (L2) {
+      const float d16 = (sk_qq + yy) - 2.0f * sum16;
+      const float err = 1e-5f * (sk_qq + yy + 2.0f * fabsf(sum16)) + 1e-30f;
+      const float up = d16 + err;  // D16 <= up
+      const float root = __builtin_sqrtf(up > 0.0f ? up : 0.0f) * 1.00001f;  // >= sqrt(D16)
+      const float lower = ((d16 - err) - 2.0f * sk_delta * root) * (1.0f - 2e-5f);  // <= the reference's distance, rounding of this line included below
+      return lower - 1e-6f * (fabsf(d16) + err + sk_delta * root) > tail_d;  // (the roundings of the two lines above; a NaN anywhere: false)
+    } else {
+      const float d16 = metric_finish(sum16, a.metric);
+      // (1 - dot, -dot and the subtraction below round once each: 3 x 2^-24 of magnitudes below 1 + |d16| + eps)
+      const float slack = sk_eps + 4e-7f * (1.0f + fabsf(d16) + sk_eps);
+      return d16 - slack > tail_d;
+    }
   }
 
   // float16 dot products of the pending rows by rank, two rows per wave instruction like rows_range
@@ -389,14 +425,15 @@ struct PlainDist {
         // lane 32 h + L holds edge 2 L + h: lane j takes its own from lane 32 (j & 1) + (j >> 1)
         const float mysum = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 1) * 32 + (lane >> 1)) * 4, __float_as_int(w[0])));
         const bool mine = (pend >> lane) & 1ull;
-        const float d16 = mine ? metric_finish(mysum, a.metric) : 0.0f;
-        const float slack = sk_eps + 4e-7f * (1.0f + fabsf(d16) + sk_eps);
-        out = __ballot(mine && (d16 - slack > tail_d));
+        out = __ballot(mine && sketch_out(a, mysum, L2 ? sk_yy : 0.0f, tail_d));
         return pend & ~out;
       }
     }
     const int cnt = __popcll(pend);
     const bool mine = (pend >> lane) & 1ull;
+    float yy_me = 0.0f;
+    if constexpr (L2)
+      if (mine) yy_me = a.sketch_norm[nb];  // (in flight while the rows are summed)
     const uint32_t rank =
         __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
     uint32_t *s_slot = hs;
@@ -408,10 +445,7 @@ struct PlainDist {
     wave_lds_sync();
     sketch_range(a, s_slot, s_res, cnt, lane);
     wave_lds_sync();
-    const float d16 = mine ? metric_finish(s_res[rank], a.metric) : 0.0f;
-    // (1 - dot, -dot and the subtraction below round once each: 3 x 2^-24 of magnitudes below 1 + |d16| + eps)
-    const float slack = sk_eps + 4e-7f * (1.0f + fabsf(d16) + sk_eps);
-    out = __ballot(mine && (d16 - slack > tail_d));
+    out = __ballot(mine && sketch_out(a, s_res[rank], yy_me, tail_d));
     wave_lds_sync();  // hop() compacts into the same scratch
     return pend & ~out;
   }
@@ -470,6 +504,7 @@ struct PlainDist {
       const char *baseL = reinterpret_cast<const char *>(a.sketch) + L * 8;
       const uint32_t row_bytes = a.ld * 2u;
       const uint32_t safe = valid ? nb : a.start_slot;  // an edge that is not there: any row (its result is not looked at)
+      if constexpr (L2) sk_yy = a.sketch_norm[safe];
 #pragma unroll
       for (int u = 0; u < 32; u++) {
         const uint32_t s0 = rl(safe, 2 * u), s1 = rl(safe, 2 * u + 1);

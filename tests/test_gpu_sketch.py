@@ -29,7 +29,7 @@ def _same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("metric", ["cosine", "dot", "euclidean"])
 @pytest.mark.parametrize("d,n,L", [(96, 1500, 25), (128, 1500, 40), (256, 1200, 30), (384, 1500, 25), (512, 800, 25), (768, 700, 25)])
 def test_two_precision_hop_is_the_default_walk_bit_for_bit(oracle, metric, d, n, L):
     rng = np.random.default_rng(d + n)
@@ -74,17 +74,18 @@ def test_hostile_rows_discard_nothing_wrongly(oracle):
     }
     for name, rows in variants.items():
         rows = np.ascontiguousarray(rows, dtype=np.float32)
-        o = build_oracle_index(oracle, rows, "dot", R=16, L=L)
-        ix = _gpu_index(o, d, "dot", 16, L)
-        ref = _answers(ix, queries, 10, L)
-        ix.set_tuning("sketch", 2)
-        got = _answers(ix, queries, 10, L)
-        discarded, contradicted, in_use = ix.sketch_stats()
-        assert in_use and _same(ref, got), name
-        assert contradicted == 0, name
-        if name in ("float16 overflow", "a NaN row"):
-            assert discarded == 0, name  # an unbounded error proves nothing
-        ix.close()
+        for metric in ("dot", "euclidean"):
+            o = build_oracle_index(oracle, rows, metric, R=16, L=L)
+            ix = _gpu_index(o, d, metric, 16, L)
+            ref = _answers(ix, queries, 10, L)
+            ix.set_tuning("sketch", 2)
+            got = _answers(ix, queries, 10, L)
+            discarded, contradicted, in_use = ix.sketch_stats()
+            assert in_use and _same(ref, got), (name, metric)
+            assert contradicted == 0, (name, metric)
+            if name in ("float16 overflow", "a NaN row"):
+                assert discarded == 0, (name, metric)  # an unbounded error proves nothing
+            ix.close()
 
 
 def test_copy_follows_the_committed_rows(oracle):
@@ -135,7 +136,7 @@ def test_copy_follows_the_committed_rows(oracle):
 
 def test_shapes_without_the_stage_are_untouched(oracle):
     rng = np.random.default_rng(3)
-    for d, metric in ((128, "euclidean"), (100, "cosine")):  # no bound for euclidean rows here; a tail chain
+    for d, metric in ((100, "euclidean"), (100, "cosine")):  # rows with a tail chain (d % 32 != 0)
         base = unit_rows(rng, 600, d)
         o = build_oracle_index(oracle, base, metric, R=16, L=25)
         ix = _gpu_index(o, d, metric, 16, 25)
@@ -146,8 +147,9 @@ def test_shapes_without_the_stage_are_untouched(oracle):
         ix.close()
 
 
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
 @pytest.mark.parametrize("noise", [1e-3, 1e-4, 1e-5, 0.0])
-def test_near_ties_around_the_threshold(oracle, noise):
+def test_near_ties_around_the_threshold(oracle, noise, metric):
     """rows in tight clusters: the candidate array's last distance sits inside a crowd of neighbours whose distances
     differ by less than the bound (or not at all) -- the stage must leave every such neighbour to the exact evaluation"""
     d, n, L = 128, 2400, 30
@@ -155,8 +157,8 @@ def test_near_ties_around_the_threshold(oracle, noise):
     centers = unit_rows(rng, 12, d)
     base = centers[rng.integers(0, 12, n)] + np.float32(noise) * rng.standard_normal((n, d)).astype(np.float32)
     base = (base / np.linalg.norm(base, axis=1, keepdims=True)).astype(np.float32)
-    o = build_oracle_index(oracle, base, "cosine", R=24, L=L)
-    ix = _gpu_index(o, d, "cosine", 24, L)
+    o = build_oracle_index(oracle, base, metric, R=24, L=L)
+    ix = _gpu_index(o, d, metric, 24, L)
     queries = np.vstack([centers, base[:20], unit_rows(rng, 16, d)])
     ref = _answers(ix, queries, 10, L)
     ix.set_tuning("sketch", 2)
