@@ -767,7 +767,7 @@ class IndexVamana {
   bool quantized() const { return pq_fitted_; }
   // seed of the k-means first-centroid draws in Fit (kmeans.go:61-63 uses the global RNG); tests pin it
   void setFitSeed(uint64_t s) { fit_seed_ = s; }
-  // SDB_TUNE_SKETCH (include/semadb_amd.h): batch searches of cosine / dot rows read a float16 copy of the rows first
+  // SDB_TUNE_SKETCH (include/semadb_amd.h): batch searches of plain tables read a float16 copy of the rows first
   // and a neighbour's float32 row only when AddWithLimit may keep it -- same answers, + 50 % of the rows' memory.
   // (The Go twin is the package variable TwoPrecisionSearch, integration/go/vamana/vamana_mi355x.go.)
   Error setTwoPrecisionSearch(bool on) {
